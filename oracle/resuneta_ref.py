@@ -1,0 +1,396 @@
+"""PyTorch-CPU fp32 restatement of the reference ResUnet-a graph, losses and train step.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Parity unpinned by reference tests;
+pinned by KATs, the independent numpy restatement (oracle/naive_ops.py) and goldens.
+
+Follows, by file:line of /root/reference:
+  * graph            ResUnet_a/model2.py:14-193  (variant "model2", what the CLI trains)
+                     ResUnet_a/model.py:14-171   (variant "model")
+  * Tanimoto         multitasking_utils.py:38-85
+  * weighted CE      utils.py:466-491
+  * compile/step     train_ISPRS.py:404-461, 131/148 (train_on_batch), 167/186 (test_on_batch)
+
+Keras defaults restated (TF 2.2-2.3 era, not vendored in the reference):
+  Conv2D: kernel HWIO glorot_uniform, zero bias, padding 'valid' unless given, 'same' with
+          dilation d pads d on each side (stride 1).  strides=(2,2) + 1x1 + valid = pixels 0,2,4..
+  BatchNormalization: axis=-1, momentum=0.99, epsilon=1e-3, gamma=1, beta=0, moving_mean=0,
+          moving_variance=1; training: batch mean / biased variance normalise; moving stats
+          updated with the (fused-kernel) Bessel-corrected batch variance.
+  MaxPooling2D(k, strides=k, valid); UpSampling2D nearest; Concatenate on channels.
+  Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+1e-7).  SGD(momentum=.8):
+          v = mu*v - lr*g; theta += v.
+  Loss reduction: mean over every element the loss function returns (SUM_OVER_BATCH_SIZE).
+Tensors cross this module's API as float32 NHWC numpy arrays (the reference's layout).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3
+BN_MOMENTUM = 0.99
+KERAS_EPS = 1e-7
+
+
+@dataclass
+class RefConfig:
+    input_shape: Tuple[int, int, int] = (256, 256, 3)   # (H, W, C) as Resunet_a(input_shape,...)
+    num_classes: int = 5
+    multitasking: bool = False
+    variant: str = "model2"        # "model2" (CLI default, train_ISPRS.py:4) or "model"
+    width: int = 32                # first-stage filters (reference: 32)
+    depth: int = 6                 # encoder ResBlocks (reference: 6; 7 = build-defined d7)
+
+    def levels(self):
+        dil = [[1, 3, 15, 31], [1, 3, 15, 31], [1, 3, 15], [1, 3, 15], [1], [1], [1]]
+        return [(self.width * (2 ** i), dil[i]) for i in range(self.depth)]
+
+
+def _glorot(rng: np.random.Generator, shape):
+    kh, kw, cin, cout = shape
+    limit = math.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+class _Net:
+    """Walks the architecture once; in 'init' mode creates Keras-named parameters, in 'run'
+    mode applies them.  Auto names follow Keras creation order (conv2d, conv2d_1, ...)."""
+
+    def __init__(self, cfg: RefConfig, params=None, rng=None, training=True, new_stats=None):
+        self.cfg = cfg
+        self.params = params if params is not None else {}
+        self.init = params is None
+        self.rng = rng
+        self.training = training
+        self.new_stats = new_stats if new_stats is not None else {}
+        self.n_conv = 0
+        self.n_bn = 0
+        self.order: List[str] = []
+        self.taps: Dict[str, torch.Tensor] = {}
+
+    # -- layers -----------------------------------------------------------------------
+    def conv(self, x, nf, k, stride=1, dil=1, padding="valid", name=None):
+        if name is None:
+            name = "conv2d" if self.n_conv == 0 else f"conv2d_{self.n_conv}"
+            self.n_conv += 1
+        cin = x.shape[1]
+        if self.init:
+            self.params[name + "/kernel"] = torch.from_numpy(_glorot(self.rng, (k, k, cin, nf)))
+            self.params[name + "/bias"] = torch.zeros(nf)
+            self.order += [name + "/kernel", name + "/bias"]
+        w = self.params[name + "/kernel"].permute(3, 2, 0, 1)          # HWIO -> OIHW
+        pad = dil * (k // 2) if padding == "same" else 0
+        return F.conv2d(x, w, self.params[name + "/bias"], stride=stride, padding=pad, dilation=dil)
+
+    def bn(self, x):
+        name = "batch_normalization" if self.n_bn == 0 else f"batch_normalization_{self.n_bn}"
+        self.n_bn += 1
+        c = x.shape[1]
+        if self.init:
+            self.params[name + "/gamma"] = torch.ones(c)
+            self.params[name + "/beta"] = torch.zeros(c)
+            self.params[name + "/moving_mean"] = torch.zeros(c)
+            self.params[name + "/moving_variance"] = torch.ones(c)
+            self.order += [name + "/gamma", name + "/beta"]
+        g, b = self.params[name + "/gamma"], self.params[name + "/beta"]
+        if self.training:
+            mean = x.mean(dim=(0, 2, 3))
+            var = ((x - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))      # biased
+            n = x.numel() // c
+            with torch.no_grad():
+                unb = var * (n / max(n - 1, 1))
+                mm, mv = self.params[name + "/moving_mean"], self.params[name + "/moving_variance"]
+                self.new_stats[name + "/moving_mean"] = mm * BN_MOMENTUM + mean * (1 - BN_MOMENTUM)
+                self.new_stats[name + "/moving_variance"] = mv * BN_MOMENTUM + unb * (1 - BN_MOMENTUM)
+        else:
+            mean, var = self.params[name + "/moving_mean"], self.params[name + "/moving_variance"]
+        inv = torch.rsqrt(var + BN_EPS)
+        return (x - mean[None, :, None, None]) * (inv * g)[None, :, None, None] + b[None, :, None, None]
+
+    # -- blocks (model2.py:15-94 / model.py:15-70) ------------------------------------
+    def resblock(self, x, nf, dils):
+        v2 = self.cfg.variant == "model2"
+        outs = [x] if v2 else []
+        for d in dils:
+            y = self.conv(torch.relu(self.bn(x)), nf, 3, dil=d, padding="same")
+            y = self.conv(torch.relu(self.bn(y)), nf, 3, dil=d, padding="same")
+            outs.append(y)
+        out = outs[0]
+        for o in outs[1:]:
+            out = out + o
+        return out
+
+    def conv2dn(self, x, nf):
+        x = self.conv(x, nf, 1)
+        return self.bn(x)
+
+    def psp(self, x, nf):
+        v2 = self.cfg.variant == "model2"
+        w = self.cfg.input_shape[1]
+        ks = [1, 2] + ([4] if w >= 128 else []) + ([8] if w >= 256 else [])
+        pooled = [F.max_pool2d(x, k, k) if k > 1 else x for k in ks]
+        up = lambda t, k: t.repeat_interleave(k, 2).repeat_interleave(k, 3) if k > 1 else t
+        if v2:   # pool -> upsample -> conv+BN     (model2.py:47-68)
+            ups = [up(p, k) for p, k in zip(pooled, ks)]
+            br = [self.conv2dn(u, nf // 4) for u in ups]
+        else:    # pool -> conv -> upsample        (model.py:40-57)
+            cs = [self.conv(p, nf // 4, 1) for p in pooled]
+            br = [up(c, k) for c, k in zip(cs, ks)]
+        cat = torch.cat(br + [x], dim=1)
+        return self.conv2dn(cat, nf) if v2 else self.conv(cat, nf, 1)
+
+    def combine(self, x1, x2, nf):
+        x = torch.cat([torch.relu(x1), x2], dim=1)
+        x = self.conv(x, nf, 1)
+        return self.bn(x) if self.cfg.variant == "model2" else x
+
+    def upsampling(self, x, nf_skip):
+        up = lambda t: t.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        if self.cfg.variant == "model2":       # up -> conv(nf/2) -> BN   (model2.py:89-94)
+            return self.bn(self.conv(up(x), nf_skip // 2, 1))
+        return up(self.conv(x, nf_skip, 1))    # conv(nf) -> up           (model.py:93-94)
+
+    # -- full graph ---------------------------------------------------------------------
+    def forward(self, x):
+        cfg = self.cfg
+        v2 = cfg.variant == "model2"
+        lv = cfg.levels()
+        x = self.conv(x, lv[0][0], 1)
+        c1 = x
+        skips = []
+        for i, (nf, dils) in enumerate(lv):
+            if i > 0:
+                x = self.conv(x, nf, 1, stride=2)
+            x = self.resblock(x, nf, dils)
+            skips.append(x)
+        x = self.psp(x, lv[-1][0])
+        if v2:
+            x = torch.relu(x)
+        for i in range(len(lv) - 2, -1, -1):
+            nf, dils = lv[i]
+            x = self.upsampling(x, nf)
+            x = self.combine(x, skips[i], nf)
+            x = self.resblock(x, nf, dils)
+        x_comb = self.combine(x, c1, lv[0][0])
+        x_psp = self.psp(x_comb, lv[0][0])
+        if v2:
+            x_psp = torch.relu(x_psp)
+        C = cfg.num_classes
+        w0 = lv[0][0]
+        if not cfg.multitasking:
+            z = self.conv(x_psp, C, 1)
+            self.taps["logits"] = z
+            return torch.softmax(z, dim=1)
+        s = torch.relu(self.conv(x_psp, w0, 3, padding="same", name="seg1"))
+        s = torch.relu(self.conv(s, w0, 3, padding="same", name="seg2"))
+        zs = self.conv(s, C, 1, name="seg3")
+        b = torch.relu(self.conv(x_psp, w0, 3, padding="same"))
+        zb = self.conv(b, C, 1)
+        d = torch.relu(self.conv(x_comb, w0, 3, padding="same"))
+        d = torch.relu(self.conv(d, w0, 3, padding="same"))
+        zd = self.conv(d, C, 1)
+        zc = self.conv(x_comb, 3, 1, name="color")
+        self.taps.update({"seg_logits": zs, "bound_logits": zb, "dist_logits": zd, "color_logits": zc})
+        return {"seg": torch.softmax(zs, 1), "bound": torch.sigmoid(zb),
+                "dist": torch.softmax(zd, 1), "color": torch.sigmoid(zc)}
+
+
+# ---------------------------------------------------------------------------------------
+def init_params(cfg: RefConfig, seed: int = 0):
+    """Glorot-uniform kernels (numpy default_rng(seed)), zero biases, BN gamma=1 beta=0.
+    Returns (params dict name->torch tensor in Keras layout, trainable names in creation order)."""
+    net = _Net(cfg, params=None, rng=np.random.default_rng(seed), training=False)
+    h, w, c = cfg.input_shape
+    with torch.no_grad():
+        net.forward(torch.zeros(1, c, h, w))
+    return net.params, net.order
+
+
+def count_params(params) -> int:
+    return int(sum(v.numel() for v in params.values()))
+
+
+def forward(cfg: RefConfig, params, x_nhwc: np.ndarray, training: bool = False, want_taps=False):
+    """Model forward on float32 NHWC input.  Returns NHWC numpy output (array or dict)."""
+    net = _Net(cfg, params=params, training=training)
+    with torch.no_grad():
+        out = net.forward(torch.from_numpy(np.ascontiguousarray(x_nhwc)).permute(0, 3, 1, 2))
+    to_np = lambda t: t.permute(0, 2, 3, 1).contiguous().numpy()
+    res = {k: to_np(v) for k, v in out.items()} if isinstance(out, dict) else to_np(out)
+    if want_taps:
+        return res, {k: to_np(v) for k, v in net.taps.items()}
+    return res
+
+
+# ---- losses (operate on NCHW torch tensors; class axis = 1) ---------------------------
+def tanimoto_loss(label, pred):
+    """multitasking_utils.py:38-68 — note the (label, pred) argument order."""
+    smooth = 1e-5
+    vli = label.sum(dim=(2, 3)).mean(dim=0)
+    wli = 1.0 / (vli ** 2)
+    isinf = torch.isinf(wli)
+    new_w = torch.where(isinf, torch.zeros_like(wli), wli)
+    wli = torch.where(isinf, torch.ones_like(wli) * new_w.max(), wli)
+    sum_square = (pred ** 2 + label ** 2).sum(dim=(2, 3))
+    sum_product = (pred * label).sum(dim=(2, 3))
+    num = (wli * sum_product).sum(dim=-1)
+    den = (wli * (sum_square - sum_product)).sum(dim=-1)
+    return (num + smooth) / (den + smooth)
+
+
+def tanimoto_dual_loss(label, pred):
+    """multitasking_utils.py:71-85 — first term called with swapped arguments."""
+    loss1 = tanimoto_loss(pred, label)
+    loss2 = tanimoto_loss(1.0 - label, 1.0 - pred)
+    return 1.0 - 0.5 * (loss1 + loss2)          # shape (B,)
+
+
+def weighted_cce(weights):
+    w = torch.as_tensor(np.asarray(weights, dtype=np.float32))
+
+    def loss(y_true, y_pred):                  # utils.py:481-490; returns (B,H,W)
+        p = y_pred / y_pred.sum(dim=1, keepdim=True)
+        p = torch.clamp(p, KERAS_EPS, 1 - KERAS_EPS)
+        return -(y_true * torch.log(p) * w[None, :, None, None]).sum(dim=1)
+    return loss
+
+
+def categorical_ce_logits(y_true, logits):      # Keras CategoricalCrossentropy on a Softmax op
+    return -(y_true * torch.log_softmax(logits, dim=1)).sum(dim=1)
+
+
+def binary_ce_logits(y_true, logits):           # Keras BinaryCrossentropy on a Sigmoid op
+    l = torch.clamp(logits, min=0) - logits * y_true + torch.log1p(torch.exp(-logits.abs()))
+    return l.mean(dim=1)
+
+
+def mse(y_true, y_pred):
+    return ((y_true - y_pred) ** 2).mean(dim=1)
+
+
+@dataclass
+class CompileSpec:
+    """What train_ISPRS.py:404-461 passes to model.compile."""
+    loss: str = "weighted_cross_entropy"           # --loss choice
+    class_weights: Optional[List[float]] = None    # for weighted_cross_entropy
+    loss_weights: Dict[str, float] = field(default_factory=lambda: {"seg": 1.0, "bound": 1.0, "dist": 1.0, "color": 1.0})
+    optimizer: str = "adam"
+    lr: float = 1e-3
+    beta_1: float = 0.9
+    beta_2: float = 0.999
+    momentum: float = 0.8
+
+
+HEADS = ["seg", "bound", "dist", "color"]
+
+
+def _head_loss(spec: CompileSpec, head: str, y_true, y_pred, logits):
+    if spec.loss == "tanimoto":
+        return tanimoto_dual_loss(y_true, y_pred).mean()
+    if head == "seg":
+        if spec.loss == "weighted_cross_entropy":
+            return weighted_cce(spec.class_weights)(y_true, y_pred).mean()
+        return categorical_ce_logits(y_true, logits).mean()
+    if head == "bound":
+        return binary_ce_logits(y_true, logits).mean()
+    return mse(y_true, y_pred).mean()
+
+
+def _metrics(y_true, y_pred):
+    """accuracy (categorical), TP, FP, TN, FN at threshold 0.5 over all elements
+    (train_ISPRS.py:446-449; Keras metric defaults)."""
+    acc = (y_true.argmax(1) == y_pred.argmax(1)).float().mean().item()
+    t = y_true > 0.5
+    p = y_pred > 0.5
+    return [acc, float((t & p).sum()), float((~t & p).sum()), float((~t & ~p).sum()), float((t & ~p).sum())]
+
+
+class RefTrainer:
+    """Keras Model.compile + train_on_batch / test_on_batch restated (single replica)."""
+
+    def __init__(self, cfg: RefConfig, params, order, spec: CompileSpec):
+        self.cfg, self.params, self.order, self.spec = cfg, params, order, spec
+        self.t = 0
+        self.m = {k: torch.zeros_like(params[k]) for k in order}
+        self.v = {k: torch.zeros_like(params[k]) for k in order}
+        self.last_grads: Dict[str, torch.Tensor] = {}
+        self.last_taps: Dict[str, np.ndarray] = {}
+
+    def _losses(self, x, y, training):
+        cfg, spec = self.cfg, self.spec
+        net = _Net(cfg, params=self.params, training=training)
+        xt = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
+        out = net.forward(xt)
+        nchw = lambda a: torch.from_numpy(np.ascontiguousarray(a)).permute(0, 3, 1, 2)
+        if cfg.multitasking:
+            per = {h: _head_loss(spec, h, nchw(y[h]), out[h], net.taps[h + "_logits"]) for h in HEADS}
+            total = sum(spec.loss_weights[h] * per[h] for h in HEADS)
+            mets = _metrics(nchw(y["seg"]), out["seg"].detach())
+            vals = [total] + [per[h] for h in HEADS]
+        else:
+            yt = nchw(y)
+            total = _head_loss(spec, "seg", yt, out, net.taps["logits"])
+            mets = _metrics(yt, out.detach())
+            vals = [total]
+        self.last_taps = {k: v.detach().permute(0, 2, 3, 1).contiguous().numpy() for k, v in net.taps.items()}
+        return total, vals, mets, net
+
+    def test_on_batch(self, x, y):
+        with torch.no_grad():
+            _, vals, mets, _ = self._losses(x, y, training=False)
+        return [float(v) for v in vals] + mets
+
+    def train_on_batch(self, x, y):
+        for k in self.order:
+            self.params[k].requires_grad_(True)
+            self.params[k].grad = None
+        total, vals, mets, net = self._losses(x, y, training=True)
+        total.backward()
+        sp = self.spec
+        self.t += 1
+        with torch.no_grad():
+            for k in self.order:
+                p = self.params[k]
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                self.last_grads[k] = g.detach().clone()
+                if sp.optimizer == "adam":
+                    self.m[k].mul_(sp.beta_1).add_(g, alpha=1 - sp.beta_1)
+                    self.v[k].mul_(sp.beta_2).addcmul_(g, g, value=1 - sp.beta_2)
+                    lr_t = sp.lr * math.sqrt(1 - sp.beta_2 ** self.t) / (1 - sp.beta_1 ** self.t)
+                    p.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + KERAS_EPS))
+                else:
+                    self.m[k].mul_(sp.momentum).sub_(g, alpha=sp.lr)
+                    p.add_(self.m[k])
+                p.requires_grad_(False)
+                p.grad = None
+            for k, v in net.new_stats.items():
+                self.params[k] = v.detach().clone()
+        return [float(v) for v in vals] + mets
+
+
+# ---- analytic work model (conv MACs only) -------------------------------
+def forward_macs(cfg: RefConfig) -> int:
+    """Counts conv multiply-accumulates of one forward pass per patch by tracing shapes."""
+    macs = 0
+    orig = F.conv2d
+
+    def counting(x, w, b=None, stride=1, padding=0, dilation=1):
+        nonlocal macs
+        y = orig(x, w, b, stride=stride, padding=padding, dilation=dilation)
+        macs += y.shape[2] * y.shape[3] * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
+        return y
+    params, _ = init_params(cfg, 0)
+    F.conv2d = counting
+    try:
+        h, w, c = cfg.input_shape
+        net = _Net(cfg, params=params, training=False)
+        with torch.no_grad():
+            net.forward(torch.zeros(1, c, h, w))
+    finally:
+        F.conv2d = orig
+    return macs
