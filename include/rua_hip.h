@@ -1,0 +1,172 @@
+/* librua_hip.so — C ABI of the MI355X (gfx950) ResUnet-a training-path kernels.
+ *
+ * The reference (thimabru1010/ResUnet-a_mltsk_keras) has NO native/FFI interface: its hot
+ * path is the list of Keras layer call sites that TensorFlow executes.  Every entry point
+ * below therefore cites the reference call site(s) (file:line under /root/reference) whose
+ * arithmetic it replaces.  All tensors are channels-last (NHWC, the reference's own layout,
+ * train_ISPRS.py:73-92) in device memory owned by the caller; `dtype` selects the storage
+ * type of activations (RUA_F32 or RUA_BF16); accumulation is always fp32 (statistics fp64).
+ * Every function returns 0 on success or a negative code (text via rua_last_error()), takes
+ * the HIP stream as its last argument (`void*` = hipStream_t), allocates nothing and keeps no
+ * global state.  Nothing here depends on PyTorch.
+ */
+#ifndef RUA_HIP_H
+#define RUA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RUA_F32 0
+#define RUA_BF16 1
+#define RUA_MAX_SEG 6
+#define RUA_MAX_BRANCH 4
+
+#define RUA_OK 0
+#define RUA_ERR_ARG (-1)      /* shape/alignment precondition violated */
+#define RUA_ERR_LAUNCH (-2)   /* HIP launch error */
+
+int rua_version(void);
+const char* rua_last_error(void);
+int rua_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ---- segmented implicit-GEMM convolution (MFMA) --------------------------------------
+ * y[n,h,w,co] = sum over segments s, taps t, channels c of
+ *               src_s[n, (h*stride+dy_t*dil_s)>>up_s, (w*stride+dx_t*dil_s)>>up_s, c] * w_s[t][co][c]
+ * Replaces: KL.Conv2D 3x3 dilated 'same' (model2.py:19-24), 1x1 / strided 1x1 (:101-111),
+ * Concatenate+Conv2D of PSPPooling/combine (:73-78,:83-85) with the concat never
+ * materialised, UpSampling2D-nearest folded into the read (:55-60,:91), the n-ary Add of the
+ * ResBlock (:27-31) as the `aux` residual, and — with transposed/flipped weights — the
+ * data-gradient of all of them.  Channel counts must be multiples of 8 (bf16) / 4 (f32). */
+typedef struct rua_conv_seg {
+  const void* x;       /* source activations [N][Hs][Ws][C] */
+  const void* w;       /* weights [taps][Cout][C], same dtype as activations */
+  int32_t C, Hs, Ws;
+  int32_t up_shift;    /* nearest upsample by 2^up_shift folded into the read */
+  int32_t dil;         /* dilation of the 3x3 taps */
+  int32_t taps;        /* 1 or 9 */
+} rua_conv_seg;
+
+typedef struct rua_conv_desc {
+  rua_conv_seg seg[RUA_MAX_SEG];
+  int32_t nseg;
+  int32_t N, H, W, Cout;       /* logical output grid (GEMM rows = N*H*W) */
+  int32_t stride;              /* input coordinate = output coordinate * stride */
+  int32_t dtype;
+  const float* bias;           /* [Cout] or NULL */
+  const void* aux;             /* [N][H][W][Cout] or NULL */
+  int32_t aux_mode;            /* 0 none, 1 y += aux (residual), 2 y *= (mscale*aux+mshift > 0) (ReLU mask), 3 statistics only */
+  const float* mscale;         /* per-channel, NULL => 1 */
+  const float* mshift;         /* per-channel, NULL => 0 */
+  int32_t out_relu;
+  int32_t accumulate;          /* y += result instead of y = result */
+  void* y;                     /* [N][OH][OW][Cout], written at (h*out_stride, w*out_stride) */
+  int32_t out_stride, OH, OW;
+  double* stats;               /* [2][Cout] atomically accumulated, or NULL */
+  int32_t stats_mode;          /* 1: sum v, sum v^2   2: sum v, sum v*aux */
+} rua_conv_desc;
+int rua_conv_fwd(const rua_conv_desc* d, void* stream);
+int rua_conv_smem_bytes(const rua_conv_desc* d);
+
+/* ---- weight gradient (MFMA, split over pixels, fp32 atomic accumulation) ----------------
+ * dW[t][co][c] += sum_pixels dy[n,h,w,co] * a[n, h*stride+dy_t*dil, w*stride+dx_t*dil, c]
+ * Replaces the kernel-gradient of every KL.Conv2D above (Keras autodiff inside
+ * train_on_batch, train_ISPRS.py:131,148). */
+typedef struct rua_wgrad_desc {
+  const void* a;  int32_t C, Hs, Ws;        /* conv input  [N][Hs][Ws][C]  */
+  const void* dy; int32_t Cout, H, W;       /* out-gradient [N][H][W][Cout] */
+  int32_t N, stride, dil, taps, dtype;
+  float* dw;                                /* [taps][Cout][C] fp32 */
+} rua_wgrad_desc;
+int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream);
+
+/* Master fp32 weights [taps][Cout][C] -> activation-dtype copies: forward layout (same) and
+ * data-gradient layout [taps reversed][C][Cout].  One launch for the whole parameter table. */
+typedef struct rua_wprep_item { int64_t src_off, dst_off; int32_t taps, Cout, C, pad; } rua_wprep_item;
+int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev,
+                    int n_items, int max_elems, int dtype, void* stream);
+
+/* ---- few-channel 1x1 convolutions (VALU; the stem and the heads) -------------------------
+ * stem: KL.Conv2D(32,(1,1)) on the 3/6/7-band input (model2.py:101).  x fp32 [M][Cin<=16]. */
+int rua_stem_fwd(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, void* stream);
+int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db, int64_t M, int Cin, int Cout, int dtype, void* stream);
+/* heads: Conv2D(num_classes,(1,1)) + softmax / sigmoid (model2.py:145-146,160-162,169-171,181-183,186-188).
+ * act: 0 none, 1 softmax over channels, 2 sigmoid.  z (logits) and p are fp32 [M][Cout<=8]. */
+int rua_head_fwd(const void* x, const float* w, const float* b, float* z, float* p, int64_t M, int Cin, int Cout, int act, int dtype, void* stream);
+int rua_head_bwd(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db,
+                 int64_t M, int Cin, int Cout, int dtype, void* stream);
+
+/* ---- BatchNormalization (model2.py:17,21,38,86,93; Keras eps 1e-3, momentum .99) -------- */
+/* per-channel sum / sum of squares over all rows of x [M][C] -> stats[2][C] (fp64, accumulated) */
+int rua_col_stats(const void* x, int64_t M, int C, double* stats, int dtype, void* stream);
+/* sum g*m and sum g*m*x with m = (mscale*x+mshift > 0) when masked, else 1 */
+int rua_col_stats2(const void* g, const void* x, const float* mscale, const float* mshift, int masked,
+                   int64_t M, int C, double* stats, int dtype, void* stream);
+/* training: stats -> scale/shift (+ mean, rstd, moving-stat update with the Bessel factor
+ * bessel_n/(bessel_n-1), bessel_n = element count Keras sees, i.e. after nearest upsampling);
+ * inference: moving stats -> scale/shift */
+int rua_bn_finalize(const double* stats, double count, double bessel_n, const float* gamma, const float* beta,
+                    float* moving_mean, float* moving_var, float momentum, float eps, int training,
+                    float* scale, float* shift, float* mean, float* rstd, int C, void* stream);
+/* (float)stats[c] -> n (<=4) fp32 vectors: bias gradients from per-channel sums of dy */
+int rua_stats_to_f32(const double* stats, int C, float* const* dst, int n, void* stream);
+/* out_b = [relu](scale_b * x + shift_b) for b < nb (all branches of a ResBlock read x once) */
+int rua_bn_apply(const void* x, int nb, const float* const* scale, const float* const* shift, int relu,
+                 void* const* out, int64_t M, int C, int dtype, void* stream);
+/* backward statistics -> dgamma, dbeta and the coefficients A,B,Cc of dx = A*g + B*x + Cc */
+int rua_bn_bwd_finalize(const double* stats2, double count, const float* gamma, const float* mean, const float* rstd,
+                        float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC, int C, void* stream);
+/* dx (=|+=) [dskip] + sum_b (A_b * g_b * m_b + B_b * x + C_b),  m_b = ReLU mask of branch b (or 1) */
+int rua_bn_bwd_apply(int nb, const void* const* g, const float* const* coefA, const float* const* coefB,
+                     const float* const* coefC, const float* const* mscale, const float* const* mshift, int masked,
+                     const void* x, const void* dskip, void* dx, int accumulate, int64_t M, int C, int dtype, void* stream);
+
+/* ---- pooling / resampling (PSPPooling model2.py:47-60; decoder model2.py:91) ---------- */
+int rua_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int k, int dtype, void* stream);
+int rua_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int accumulate, int N, int H, int W, int C, int k, int dtype, void* stream);
+/* y[n,h,w,c] = sum over the k x k block (adjoint of nearest upsampling) */
+int rua_sumpool(const void* x, void* y, int N, int H, int W, int C, int k, int dtype, void* stream);
+int rua_upsample_nearest(const void* x, void* y, int N, int H, int W, int C, int k, int dtype, void* stream);
+
+/* ---- elementwise ------------------------------------------------------------------------- */
+int rua_add_n(int n, const void* const* in, void* out, int accumulate, int64_t elems, int dtype, void* stream);
+int rua_relu_mask(void* dy, const void* y, int64_t elems, int dtype, void* stream);   /* dy *= (y>0) */
+int rua_relu(const void* x, void* y, int64_t elems, int dtype, void* stream);
+int rua_cast_f32_to(const float* x, void* y, int64_t elems, int dtype, void* stream);
+int rua_cast_to_f32(const void* x, float* y, int64_t elems, int dtype, void* stream);
+int rua_fill_zero(void* p, int64_t bytes, void* stream);
+
+/* ---- losses and metrics (multitasking_utils.py:38-85, utils.py:466-491, train_ISPRS.py:411-461)
+ * p, y, z, dz are fp32 [B][HW][C]. */
+#define RUA_LOSS_TANIMOTO 0
+#define RUA_LOSS_WCE 1
+#define RUA_LOSS_CE_LOGITS 2
+#define RUA_LOSS_BCE_LOGITS 3
+#define RUA_LOSS_MSE 4
+#define RUA_ACT_NONE 0
+#define RUA_ACT_SOFTMAX 1
+#define RUA_ACT_SIGMOID 2
+/* six moments per (sample, class): sum p, sum (1-l), sum p*l, sum p^2+l^2, sum (1-p)(1-l), sum (1-p)^2+(1-l)^2 */
+int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t HW, int C, double* sums, void* stream);
+/* loss_out[0] = mean_n Tanimoto_dual ; coef[B][C][3] : dLoss/dp = c0 + c1*p + c2*l (already * grad_scale) */
+int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef, void* stream);
+/* loss_out[0] += sum over pixels of the per-pixel loss of kind 1..4 (caller divides) */
+int rua_pixel_loss(int kind, const float* p, const float* z, const float* y, const float* class_w,
+                   int64_t M, int C, double* loss_out, void* stream);
+/* dz = d(total)/d(logits) for every loss kind; coef only for Tanimoto; grad_scale = loss_weight/denominator */
+int rua_head_dz(int kind, int act, const float* p, const float* y, const float* coef, const float* class_w,
+                float grad_scale, int B, int64_t HW, int C, float* dz, void* stream);
+/* out[5] += {#argmax matches, TP, FP, TN, FN at threshold .5} */
+int rua_seg_metrics(const float* p, const float* y, int64_t M, int C, double* out, void* stream);
+
+/* ---- optimizers on the flat parameter buffer (train_ISPRS.py:404-407) --------------------- */
+/* Keras Adam: theta -= lr_t * m / (sqrt(v) + eps); g is read as g*grad_scale and zeroed if zero_grad */
+int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                  float eps, float grad_scale, int zero_grad, void* stream);
+int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, float momentum, float grad_scale,
+                 int zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,124 @@
+"""ctypes binding of librua_hip.so (include/rua_hip.h).  There is NO fallback: if the library
+is missing or a call fails, the product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librua_hip.so")
+
+RUA_F32, RUA_BF16 = 0, 1
+RUA_MAX_SEG, RUA_MAX_BRANCH = 6, 4
+LOSS_TANIMOTO, LOSS_WCE, LOSS_CE_LOGITS, LOSS_BCE_LOGITS, LOSS_MSE = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SOFTMAX, ACT_SIGMOID = 0, 1, 2
+
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+
+class ConvSeg(C.Structure):
+    _fields_ = [("x", vp), ("w", vp), ("C", i32), ("Hs", i32), ("Ws", i32), ("up_shift", i32), ("dil", i32), ("taps", i32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("seg", ConvSeg * RUA_MAX_SEG), ("nseg", i32), ("N", i32), ("H", i32), ("W", i32), ("Cout", i32),
+                ("stride", i32), ("dtype", i32), ("bias", vp), ("aux", vp), ("aux_mode", i32), ("mscale", vp),
+                ("mshift", vp), ("out_relu", i32), ("accumulate", i32), ("y", vp), ("out_stride", i32), ("OH", i32),
+                ("OW", i32), ("stats", vp), ("stats_mode", i32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("a", vp), ("C", i32), ("Hs", i32), ("Ws", i32), ("dy", vp), ("Cout", i32), ("H", i32), ("W", i32),
+                ("N", i32), ("stride", i32), ("dil", i32), ("taps", i32), ("dtype", i32), ("dw", vp)]
+
+
+class WprepItem(C.Structure):
+    _fields_ = [("src_off", i64), ("dst_off", i64), ("taps", i32), ("Cout", i32), ("C", i32), ("pad", i32)]
+
+
+PP = C.POINTER(vp)
+
+_SIGS = {
+    "rua_version": ([], i32),
+    "rua_device_info": ([C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32], i32),
+    "rua_conv_fwd": ([C.POINTER(ConvDesc), vp], i32),
+    "rua_conv_smem_bytes": ([C.POINTER(ConvDesc)], i32),
+    "rua_conv_wgrad": ([C.POINTER(WgradDesc), vp], i32),
+    "rua_weight_prep": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    "rua_stem_fwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
+    "rua_stem_bwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
+    "rua_head_fwd": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp], i32),
+    "rua_head_bwd": ([vp, vp, vp, vp, i32, vp, vp, i64, i32, i32, i32, vp], i32),
+    "rua_col_stats": ([vp, i64, i32, vp, i32, vp], i32),
+    "rua_col_stats2": ([vp, vp, vp, vp, i32, i64, i32, vp, i32, vp], i32),
+    "rua_bn_finalize": ([vp, f64, f64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, vp], i32),
+    "rua_bn_apply": ([vp, i32, PP, PP, i32, PP, i64, i32, i32, vp], i32),
+    "rua_bn_bwd_finalize": ([vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp], i32),
+    "rua_bn_bwd_apply": ([i32, PP, PP, PP, PP, PP, PP, i32, vp, vp, vp, i32, i64, i32, i32, vp], i32),
+    "rua_stats_to_f32": ([vp, i32, PP, i32, vp], i32),
+    "rua_maxpool_fwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "rua_maxpool_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "rua_sumpool": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "rua_upsample_nearest": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "rua_add_n": ([i32, PP, vp, i32, i64, i32, vp], i32),
+    "rua_relu_mask": ([vp, vp, i64, i32, vp], i32),
+    "rua_relu": ([vp, vp, i64, i32, vp], i32),
+    "rua_cast_f32_to": ([vp, vp, i64, i32, vp], i32),
+    "rua_cast_to_f32": ([vp, vp, i64, i32, vp], i32),
+    "rua_fill_zero": ([vp, i64, vp], i32),
+    "rua_tanimoto_sums": ([vp, vp, i32, i64, i32, vp, vp], i32),
+    "rua_tanimoto_finalize": ([vp, i32, i64, i32, f32, vp, vp, vp], i32),
+    "rua_pixel_loss": ([i32, vp, vp, vp, vp, i64, i32, vp, vp], i32),
+    "rua_head_dz": ([i32, i32, vp, vp, vp, vp, f32, i32, i64, i32, vp, vp], i32),
+    "rua_seg_metrics": ([vp, vp, i64, i32, vp, vp], i32),
+    "rua_adam_step": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp], i32),
+    "rua_sgd_step": ([vp, vp, vp, i64, f32, f32, f32, i32, vp], i32),
+}
+
+EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["rua_last_error"])
+
+
+class RuaError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise RuaError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -m resunet_a_mltsk_keras_amd.build` (needs hipcc). There is no CPU fallback.")
+        self.dll = C.CDLL(LIB_PATH)
+        self.dll.rua_last_error.restype = C.c_char_p
+        self.dll.rua_last_error.argtypes = []
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(self.dll, name)
+            fn.argtypes = args
+            fn.restype = res
+            setattr(self, "_" + name, fn)
+
+    def raw(self, name):
+        return getattr(self, "_" + name)
+
+    def check(self, rc, name):
+        if rc != 0:
+            raise RuaError(f"{name} failed ({rc}): {self.dll.rua_last_error().decode()}")
+
+    def call(self, name, *args):
+        self.check(getattr(self, "_" + name)(*args), name)
+
+
+_lib = None
+
+
+def lib() -> _Lib:
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib
+
+
+def ptr_array(ptrs):
+    """ctypes void*[n] from a list of ints (kept alive by the caller)."""
+    arr = (vp * len(ptrs))(*[vp(p) for p in ptrs])
+    return arr

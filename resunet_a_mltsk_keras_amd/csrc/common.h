@@ -1,0 +1,57 @@
+// Shared device/host helpers for the gfx950 kernels (wave64, MFMA, LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/rua_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+void rua_set_error(const char* fmt, ...);
+#define RUA_CHECK_ARG(cond, ...) do { if (!(cond)) { rua_set_error(__VA_ARGS__); return RUA_ERR_ARG; } } while (0)
+#define RUA_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    rua_set_error("%s: %s", name, hipGetErrorString(e_)); return RUA_ERR_LAUNCH; } } while (0)
+
+// ---- element traits: a "piece" is one 16-byte vector of VEC channels -------------------
+template <typename T> struct ET;
+template <> struct ET<float> {
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  }
+};
+template <> struct ET<bf16_t> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ uint32_t pk(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    bf2 r; r[0] = (__bf16)a; r[1] = (__bf16)b;      // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+    return __builtin_bit_cast(uint32_t, r);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(pk(f[0], f[1]), pk(f[2], f[3]), pk(f[4], f[5]), pk(f[6], f[7]));
+  }
+};
+
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void stg16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int rua_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

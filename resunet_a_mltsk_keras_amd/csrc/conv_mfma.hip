@@ -1,0 +1,607 @@
+// Segmented implicit-GEMM convolution on MFMA (gfx950), channels-last.
+//
+// GEMM view: rows = output pixels (n,h,w), cols = output channels, K = (segment, tap, channel).
+// A "unit" is 32 channels of one tap of one segment; a stage stages KU units of the A tile
+// (128 pixels x 32 ch) and the B tile (BN couts x 32 ch) through LDS with the global loads of
+// stage s+1 in flight under the MFMAs of stage s (issue-early / write-late).  Nothing is
+// im2col'ed: a tap is an address offset, zero padding is a predicated load, nearest upsampling
+// is a right shift of the source coordinate, channel concatenation is a list of segments.
+// Epilogue: accumulators -> LDS fp32 tile -> 8-channel pieces per thread: bias, residual /
+// ReLU-mask from `aux`, per-channel statistics (fp32 partials, fp64 atomics), 16-byte stores.
+#include "common.h"
+
+struct SegK { const unsigned char* x; const unsigned char* w; int C, Hs, Ws, up, dil, taps, nchunk, ubegin; };
+struct ConvK {
+  SegK seg[RUA_MAX_SEG];
+  int nseg, nunits;
+  int N, H, W, Cout, stride;
+  long long M;
+  const float* bias; const unsigned char* aux; int aux_mode; const float* mscale; const float* mshift;
+  int out_relu, accumulate; unsigned char* y; int out_stride, OH, OW; double* stats; int stats_mode;
+  int nbn;
+};
+
+template <typename T> __device__ __forceinline__ void load8(const unsigned char* base, size_t elem_off, float* f) {
+  if constexpr (sizeof(T) == 2) {
+    ET<T>::unpack(ldg16(base + elem_off * 2), f);
+  } else {
+    ET<T>::unpack(ldg16(base + elem_off * 4), f);
+    ET<T>::unpack(ldg16(base + elem_off * 4 + 16), f + 4);
+  }
+}
+template <typename T> __device__ __forceinline__ void store8(unsigned char* base, size_t elem_off, const float* f) {
+  if constexpr (sizeof(T) == 2) {
+    stg16(base + elem_off * 2, ET<T>::pack(f));
+  } else {
+    stg16(base + elem_off * 4, ET<T>::pack(f));
+    stg16(base + elem_off * 4 + 16, ET<T>::pack(f + 4));
+  }
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
+  constexpr int BM = 128, KU = 2;
+  constexpr int VEC = ET<T>::VEC, ES = sizeof(T);
+  constexpr int PPR = 32 / VEC;
+  constexpr int ROWB = (ES == 2) ? 80 : 132;
+  constexpr int RPP = 256 / PPR;
+  constexpr int APASS = BM / RPP;
+  constexpr int BPIECES = BN * PPR;
+  constexpr int BPASS = (BPIECES + 255) / 256;
+  constexpr int WN = (BN >= 64) ? 2 : 1, WM = 4 / WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int CSTR = BN + 4;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + KU * BM * ROWB;
+  float* sC = reinterpret_cast<float*>(smem);
+
+  // XCD-aware, bijective remap: blocks b and b+8 share an XCD (and its L2), so give each XCD a
+  // contiguous run of tiles; the BN-tiles of one pixel tile then hit the same L2.
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bn_i = vid % p.nbn, bm_i = vid / p.nbn;
+  const long long m0 = (long long)bm_i * BM;
+  const int n0 = bn_i * BN;
+
+  const int tid = threadIdx.x;
+  const int aq = tid % PPR, ar = tid / PPR;
+  const int HW = p.H * p.W;
+  int an[APASS], ah[APASS], aw[APASS];
+  bool av[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    long long m = m0 + ar + i * RPP;
+    av[i] = m < p.M;
+    int mm = av[i] ? (int)m : 0;
+    int n = mm / HW, rem = mm - n * HW, h = rem / p.W;
+    an[i] = n; ah[i] = h * p.stride; aw[i] = (rem - h * p.W) * p.stride;
+  }
+
+  uint4 ra[KU][APASS], rb[KU][BPASS];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto load_stage = [&](int st) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int unit = st * KU + u;
+      if (unit < p.nunits) {
+        int s = 0;
+        while (s + 1 < p.nseg && unit >= p.seg[s + 1].ubegin) ++s;
+        const SegK sg = p.seg[s];
+        const int loc = unit - sg.ubegin;
+        const int tap = loc / sg.nchunk, chunk = loc - tap * sg.nchunk;
+        int dh = 0, dw = 0;
+        if (sg.taps == 9) { dh = (tap / 3 - 1) * sg.dil; dw = (tap % 3 - 1) * sg.dil; }
+        const unsigned HL = (unsigned)(sg.Hs << sg.up), WL = (unsigned)(sg.Ws << sg.up);
+        const int c = chunk * 32 + aq * VEC;
+        const bool cok = c < sg.C;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+          const int hs = ah[i] + dh, ws = aw[i] + dw;
+          const bool ok = av[i] && cok && (unsigned)hs < HL && (unsigned)ws < WL;
+          uint4 v = zero4;
+          if (ok) {
+            const size_t off = ((size_t)(an[i] * sg.Hs + (hs >> sg.up)) * sg.Ws + (ws >> sg.up)) * sg.C + c;
+            v = ldg16(sg.x + off * ES);
+          }
+          ra[u][i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+          const int piece = tid + j * 256;
+          uint4 v = zero4;
+          if (piece < BPIECES) {
+            const int row = piece / PPR, qq = piece % PPR;
+            const int co = n0 + row, cc = chunk * 32 + qq * VEC;
+            if (co < p.Cout && cc < sg.C) {
+              const size_t off = ((size_t)tap * p.Cout + co) * sg.C + cc;
+              v = ldg16(sg.w + off * ES);
+            }
+          }
+          rb[u][j] = v;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) ra[u][i] = zero4;
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) rb[u][j] = zero4;
+      }
+    }
+  };
+
+  auto write_stage = [&]() {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        unsigned char* dst = sA + (u * BM + ar + i * RPP) * ROWB + aq * 16;
+        if constexpr (ES == 2) {
+          *reinterpret_cast<uint4*>(dst) = ra[u][i];
+        } else {
+          uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+          d[0] = ra[u][i].x; d[1] = ra[u][i].y; d[2] = ra[u][i].z; d[3] = ra[u][i].w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j) {
+        const int piece = tid + j * 256;
+        if (piece < BPIECES) {
+          unsigned char* dst = sB + (u * BN + piece / PPR) * ROWB + (piece % PPR) * 16;
+          if constexpr (ES == 2) {
+            *reinterpret_cast<uint4*>(dst) = rb[u][j];
+          } else {
+            uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+            d[0] = rb[u][j].x; d[1] = rb[u][j].y; d[2] = rb[u][j].z; d[3] = rb[u][j].w;
+          }
+        }
+      }
+    }
+  };
+
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  const int nstages = (p.nunits + KU - 1) / KU;
+  load_stage(0);
+  for (int st = 0; st < nstages; ++st) {
+    __syncthreads();
+    write_stage();
+    __syncthreads();
+    if (st + 1 < nstages) load_stage(st + 1);
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (st * KU + u < p.nunits) {
+        const unsigned char* pa = sA + (u * BM + wm * (BM / WM) + lr) * ROWB;
+        const unsigned char* pb = sB + (u * BN + wn * (BN / WN) + lr) * ROWB;
+        if constexpr (ES == 2) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(pa + a * 32 * ROWB + ks * 32 + lh * 16);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(pb + b * 32 * ROWB + ks * 32 + lh * 16);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+              for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const float*>(pa + a * 32 * ROWB + (ks * 2 + lh) * 4);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const float*>(pb + b * 32 * ROWB + (ks * 2 + lh) * 4);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+              for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = wm * (BM / WM) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        const int col = wn * (BN / WN) + b * 32 + lr;
+        sC[row * CSTR + col] = acc[a][b][i];
+      }
+  __syncthreads();
+
+  constexpr int CG = BN / 8;
+  constexpr int ROWS_PP = 256 / CG;
+  constexpr int EP = BM / ROWS_PP;
+  const int cg = tid % CG, r0 = tid / CG;
+  const int co = n0 + cg * 8;
+  const bool cok = co < p.Cout;
+  float s1[8], s2[8], bias8[8], ms8[8], mt8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; bias8[j] = 0.f; ms8[j] = 1.f; mt8[j] = 0.f; }
+  if (cok) {
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bias8[j] = p.bias[co + j];
+    }
+    if (p.aux_mode == 2) {
+      if (p.mscale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ms8[j] = p.mscale[co + j];
+      }
+      if (p.mshift) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mt8[j] = p.mshift[co + j];
+      }
+    }
+  }
+  const bool plain_out = (p.out_stride == 1 && p.OH == p.H && p.OW == p.W);
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    const int row = r0 + e * ROWS_PP;
+    const long long m = m0 + row;
+    if (m < p.M && cok) {
+      float v[8];
+      const float4 t0 = *reinterpret_cast<const float4*>(&sC[row * CSTR + cg * 8]);
+      const float4 t1 = *reinterpret_cast<const float4*>(&sC[row * CSTR + cg * 8 + 4]);
+      v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+      size_t ooff;
+      if (plain_out) {
+        ooff = (size_t)m * p.Cout + co;
+      } else {
+        const int mm = (int)m;
+        const int n = mm / HW, rem = mm - n * HW, h = rem / p.W, w = rem - h * p.W;
+        ooff = ((size_t)(n * p.OH + h * p.out_stride) * p.OW + w * p.out_stride) * p.Cout + co;
+      }
+      if (p.accumulate) {
+        float o[8];
+        load8<T>(p.y, ooff, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += o[j];
+      }
+      float a8[8];
+      if (p.aux_mode != 0) {
+        load8<T>(p.aux, (size_t)m * p.Cout + co, a8);
+        if (p.aux_mode == 1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += a8[j];
+        } else if (p.aux_mode == 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (fmaf(ms8[j], a8[j], mt8[j]) > 0.f) ? v[j] : 0.f;
+        }
+      }
+      if (p.out_relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (p.stats_mode == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+      } else if (p.stats_mode == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], a8[j], s2[j]); }
+      }
+      store8<T>(p.y, ooff, v);
+    }
+  }
+  if (p.stats_mode != 0) {
+    float* sred = sC + BM * CSTR;                 // [4 waves][CG][16]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int o = CG; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    if (lane < CG) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sred[(wid * CG + lane) * 16 + j] = s1[j]; sred[(wid * CG + lane) * 16 + 8 + j] = s2[j]; }
+    }
+    __syncthreads();
+    if (tid < CG * 16) {
+      const int g = tid / 16, k = tid % 16;
+      const float t = sred[(0 * CG + g) * 16 + k] + sred[(1 * CG + g) * 16 + k] + sred[(2 * CG + g) * 16 + k] + sred[(3 * CG + g) * 16 + k];
+      const int c = n0 + g * 8 + (k & 7);
+      if (c < p.Cout) atomicAdd(&p.stats[(k >> 3) * p.Cout + c], (double)t);
+    }
+  }
+}
+
+template <typename T, int BN> static constexpr int conv_smem() {
+  constexpr int ROWB = (sizeof(T) == 2) ? 80 : 132;
+  constexpr int a = 2 * (128 + BN) * ROWB;
+  constexpr int b = 128 * (BN + 4) * 4 + 4 * (BN / 8) * 16 * 4;
+  return a > b ? a : b;
+}
+
+template <typename T, int BN> static int launch_conv(const ConvK& k, int nbm, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int smem = conv_smem<T, BN>();
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm<T, BN>), dim3(nbm * k.nbn), dim3(256), smem, st, k);
+  RUA_LAUNCH_CHECK("conv_igemm");
+  return RUA_OK;
+}
+
+static int pick_bn(const rua_conv_desc* d, long long M) {
+  if (d->Cout <= 32) return 32;
+  if (d->Cout <= 64) return 64;
+  const long long nbm = (M + 127) / 128;
+  if (nbm * ((d->Cout + 127) / 128) < 512) return 64;   // small maps: more, smaller tiles
+  return 128;
+}
+
+extern "C" int rua_conv_smem_bytes(const rua_conv_desc* d) {
+  const long long M = (long long)d->N * d->H * d->W;
+  const int bn = pick_bn(d, M);
+  if (d->dtype == RUA_BF16) return bn == 32 ? conv_smem<bf16_t, 32>() : bn == 64 ? conv_smem<bf16_t, 64>() : conv_smem<bf16_t, 128>();
+  return bn == 32 ? conv_smem<float, 32>() : bn == 64 ? conv_smem<float, 64>() : conv_smem<float, 128>();
+}
+
+extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
+  RUA_CHECK_ARG(d && d->nseg >= 1 && d->nseg <= RUA_MAX_SEG, "rua_conv_fwd: nseg out of range");
+  RUA_CHECK_ARG(d->dtype == RUA_F32 || d->dtype == RUA_BF16, "rua_conv_fwd: bad dtype");
+  const int vec = d->dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(d->Cout > 0 && d->Cout % 8 == 0, "rua_conv_fwd: Cout=%d must be a multiple of 8", d->Cout);
+  RUA_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->stride >= 1, "rua_conv_fwd: bad output grid");
+  RUA_CHECK_ARG(d->y != nullptr, "rua_conv_fwd: null output");
+  RUA_CHECK_ARG(d->out_stride >= 1 && d->OH >= (d->H - 1) * d->out_stride + 1 && d->OW >= (d->W - 1) * d->out_stride + 1,
+                "rua_conv_fwd: output tensor smaller than the strided grid");
+  RUA_CHECK_ARG((long long)d->N * d->H * d->W < (1ll << 31), "rua_conv_fwd: too many pixels");
+  RUA_CHECK_ARG(d->aux_mode == 0 || d->aux != nullptr, "rua_conv_fwd: aux_mode without aux");
+  RUA_CHECK_ARG(d->stats_mode == 0 || d->stats != nullptr, "rua_conv_fwd: stats_mode without stats");
+  RUA_CHECK_ARG(d->stats_mode != 2 || d->aux != nullptr, "rua_conv_fwd: stats_mode 2 needs aux");
+  ConvK k;
+  k.nseg = d->nseg;
+  int units = 0;
+  for (int s = 0; s < d->nseg; ++s) {
+    const rua_conv_seg& g = d->seg[s];
+    RUA_CHECK_ARG(g.x && g.w, "rua_conv_fwd: null segment pointer");
+    RUA_CHECK_ARG(g.C > 0 && g.C % vec == 0, "rua_conv_fwd: segment C=%d not a multiple of %d", g.C, vec);
+    RUA_CHECK_ARG(g.taps == 1 || g.taps == 9, "rua_conv_fwd: taps must be 1 or 9");
+    RUA_CHECK_ARG(g.up_shift >= 0 && g.up_shift <= 4 && g.dil >= 1, "rua_conv_fwd: bad up_shift/dil");
+    // every centre-tap read must be in range: (H-1)*stride < Hs<<up
+    RUA_CHECK_ARG((long long)(d->H - 1) * d->stride < ((long long)g.Hs << g.up_shift) &&
+                  (long long)(d->W - 1) * d->stride < ((long long)g.Ws << g.up_shift),
+                  "rua_conv_fwd: segment %d source %dx%d (up %d) too small for output %dx%d stride %d", s, g.Hs, g.Ws, g.up_shift, d->H, d->W, d->stride);
+    RUA_CHECK_ARG((long long)d->N * g.Hs * g.Ws < (1ll << 31), "rua_conv_fwd: source too large");
+    SegK& o = k.seg[s];
+    o.x = (const unsigned char*)g.x; o.w = (const unsigned char*)g.w;
+    o.C = g.C; o.Hs = g.Hs; o.Ws = g.Ws; o.up = g.up_shift; o.dil = g.dil; o.taps = g.taps;
+    o.nchunk = (g.C + 31) / 32; o.ubegin = units;
+    units += g.taps * o.nchunk;
+  }
+  k.nunits = units;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.Cout = d->Cout; k.stride = d->stride;
+  k.M = (long long)d->N * d->H * d->W;
+  k.bias = d->bias; k.aux = (const unsigned char*)d->aux; k.aux_mode = d->aux_mode;
+  k.mscale = d->mscale; k.mshift = d->mshift; k.out_relu = d->out_relu; k.accumulate = d->accumulate;
+  k.y = (unsigned char*)d->y; k.out_stride = d->out_stride; k.OH = d->OH; k.OW = d->OW;
+  k.stats = d->stats; k.stats_mode = d->stats_mode;
+  const int bn = pick_bn(d, k.M);
+  k.nbn = (d->Cout + bn - 1) / bn;
+  const int nbm = (int)((k.M + 127) / 128);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == RUA_BF16) {
+    if (bn == 32) return launch_conv<bf16_t, 32>(k, nbm, st);
+    if (bn == 64) return launch_conv<bf16_t, 64>(k, nbm, st);
+    return launch_conv<bf16_t, 128>(k, nbm, st);
+  }
+  if (bn == 32) return launch_conv<float, 32>(k, nbm, st);
+  if (bn == 64) return launch_conv<float, 64>(k, nbm, st);
+  return launch_conv<float, 128>(k, nbm, st);
+}
+
+// =========================================================================================
+// Weight gradient: dW[t][co][c] += sum_pix dy[pix][co] * a[src(pix,t)][c]
+// GEMM rows = co, cols = c, K = pixels.  Both operands are pixel-major in HBM, so the K index is
+// the LDS row: bf16 fragments are gathered with the transposing LDS read (ds_read_b64_tr_b16),
+// fp32 fragments (32x32x2 MFMA) are single dwords.  Split over pixels across blocks, fp32 atomics.
+struct WgK {
+  const unsigned char* a; const unsigned char* dy; float* dw;
+  int C, Hs, Ws, Cout, H, W, N, stride, dil, taps;
+  long long M; int pix_per_block, ntc, nti, ksplit;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
+  constexpr int VEC = ET<T>::VEC, ES = sizeof(T);
+  constexpr int TP = 64;                         // pixels per stage
+  constexpr int PPR = 64 / VEC;                  // pieces per 64-channel row
+  constexpr int ROWB = (ES == 2) ? 192 : 260;    // 64 ch + pad (bank-conflict-free tr reads / b32 reads)
+  constexpr int PASS = TP * PPR / 256;           // bf16: 2, f32: 4
+  __shared__ __attribute__((aligned(16))) unsigned char sD[TP * ROWB];   // dy tile  [pix][co]
+  __shared__ __attribute__((aligned(16))) unsigned char sX[TP * ROWB];   // a  tile  [pix][ci]
+
+  int b = blockIdx.x;
+  const int ks = b % p.ksplit; b /= p.ksplit;
+  const int ti = b % p.nti; b /= p.nti;
+  const int tc = b % p.ntc; b /= p.ntc;
+  const int tap = b;
+  const int co0 = tc * 64, ci0 = ti * 64;
+  int dh = 0, dw = 0;
+  if (p.taps == 9) { dh = (tap / 3 - 1) * p.dil; dw = (tap % 3 - 1) * p.dil; }
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int pq = tid % PPR, pr = tid / PPR;      // piece column / row within pass
+  constexpr int RPP = 256 / PPR;
+  const int HW = p.H * p.W;
+  const long long k_begin = (long long)ks * p.pix_per_block;
+  long long k_end = k_begin + p.pix_per_block;
+  if (k_end > p.M) k_end = p.M;
+
+  const int wr = wid >> 1, wc = wid & 1;         // wave -> 32x32 tile (co half, ci half)
+  const bool active = (co0 + wr * 32 < p.Cout) && (ci0 + wc * 32 < p.C);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  uint4 rd[PASS], rx[PASS];
+  auto load_stage = [&](long long k0) {
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const long long m = k0 + pr + i * RPP;
+      uint4 vd = zero4, vx = zero4;
+      if (m < k_end) {
+        const int co = co0 + pq * VEC;
+        if (co < p.Cout) vd = ldg16(p.dy + ((size_t)m * p.Cout + co) * ES);
+        const int ci = ci0 + pq * VEC;
+        const int mm = (int)m;
+        const int n = mm / HW, rem = mm - n * HW, h = rem / p.W, w = rem - h * p.W;
+        const int hs = h * p.stride + dh, ws = w * p.stride + dw;
+        if (ci < p.C && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws)
+          vx = ldg16(p.a + (((size_t)(n * p.Hs + hs)) * p.Ws + ws) * p.C * ES + (size_t)ci * ES);
+      }
+      rd[i] = vd; rx[i] = vx;
+    }
+  };
+  auto write_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const int row = pr + i * RPP;
+      if constexpr (ES == 2) {
+        *reinterpret_cast<uint4*>(sD + row * ROWB + pq * 16) = rd[i];
+        *reinterpret_cast<uint4*>(sX + row * ROWB + pq * 16) = rx[i];
+      } else {
+        uint32_t* d = reinterpret_cast<uint32_t*>(sD + row * ROWB + pq * 16);
+        d[0] = rd[i].x; d[1] = rd[i].y; d[2] = rd[i].z; d[3] = rd[i].w;
+        uint32_t* x = reinterpret_cast<uint32_t*>(sX + row * ROWB + pq * 16);
+        x[0] = rx[i].x; x[1] = rx[i].y; x[2] = rx[i].z; x[3] = rx[i].w;
+      }
+    }
+  };
+
+  if (k_begin < k_end) load_stage(k_begin);
+  for (long long k0 = k_begin; k0 < k_end; k0 += TP) {
+    __syncthreads();
+    write_stage();
+    __syncthreads();
+    if (k0 + TP < k_end) load_stage(k0 + TP);
+    if (active) {
+      if constexpr (ES == 2) {
+        // transposing read: 16-lane group g reads a 4(pixel) x 16(channel) block; lane 4q+p of the
+        // group addresses row q, channels 4p..4p+3; lane i receives channel i of the 4 pixels.
+        const int li = lane & 15, g = lane >> 4;
+        const int q = li >> 2, pp = li & 3;
+        const int chan = 16 * (g & 1) + 4 * pp;        // channel offset inside the wave's 32
+        const int hrow = 8 * (g >> 1) + q;             // pixel row inside the 16-pixel k-step
+#pragma unroll
+        for (int kk = 0; kk < TP / 16; ++kk) {
+          const unsigned char* ad = sD + (kk * 16 + hrow) * ROWB + (wr * 32 + chan) * 2;
+          const unsigned char* ax = sX + (kk * 16 + hrow) * ROWB + (wc * 32 + chan) * 2;
+          typedef s16x4 __attribute__((address_space(3))) * lds4;
+          const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ad));
+          const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ad + 4 * ROWB));
+          const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ax));
+          const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ax + 4 * ROWB));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 fa = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+          const s16x8 fb = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll 8
+        for (int kk = 0; kk < TP / 2; ++kk) {
+          const float fa = *reinterpret_cast<const float*>(sD + (kk * 2 + lh) * ROWB + (wr * 32 + lr) * 4);
+          const float fb = *reinterpret_cast<const float*>(sX + (kk * 2 + lh) * ROWB + (wc * 32 + lr) * 4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (active) {
+    const int ci = ci0 + wc * 32 + lr;
+    if (ci < p.C) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = co0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        if (co < p.Cout) unsafeAtomicAdd(&p.dw[((size_t)tap * p.Cout + co) * p.C + ci], acc[i]);
+      }
+    }
+  }
+}
+
+extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
+  RUA_CHECK_ARG(d && d->a && d->dy && d->dw, "rua_conv_wgrad: null pointer");
+  RUA_CHECK_ARG(d->dtype == RUA_F32 || d->dtype == RUA_BF16, "rua_conv_wgrad: bad dtype");
+  const int vec = d->dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(d->C % vec == 0 && d->Cout % vec == 0, "rua_conv_wgrad: C=%d Cout=%d must be multiples of %d", d->C, d->Cout, vec);
+  RUA_CHECK_ARG(d->taps == 1 || d->taps == 9, "rua_conv_wgrad: taps must be 1 or 9");
+  RUA_CHECK_ARG((long long)(d->H - 1) * d->stride < d->Hs && (long long)(d->W - 1) * d->stride < d->Ws,
+                "rua_conv_wgrad: input %dx%d too small for gradient %dx%d stride %d", d->Hs, d->Ws, d->H, d->W, d->stride);
+  WgK k;
+  k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.dw = d->dw;
+  k.C = d->C; k.Hs = d->Hs; k.Ws = d->Ws; k.Cout = d->Cout; k.H = d->H; k.W = d->W; k.N = d->N;
+  k.stride = d->stride; k.dil = d->dil; k.taps = d->taps;
+  k.M = (long long)d->N * d->H * d->W;
+  RUA_CHECK_ARG(k.M < (1ll << 31) && (long long)d->N * d->Hs * d->Ws < (1ll << 31), "rua_conv_wgrad: too many pixels");
+  k.ntc = (d->Cout + 63) / 64; k.nti = (d->C + 63) / 64;
+  const long long tiles = (long long)k.ntc * k.nti * d->taps;
+  long long want = 2048 / tiles; if (want < 1) want = 1;
+  long long stages = (k.M + 63) / 64;
+  if (want > stages) want = stages;
+  long long spb = (stages + want - 1) / want;          // stages per block
+  k.pix_per_block = (int)(spb * 64);
+  k.ksplit = (int)((k.M + k.pix_per_block - 1) / k.pix_per_block);
+  const long long grid = tiles * k.ksplit;
+  RUA_CHECK_ARG(grid < (1ll << 31), "rua_conv_wgrad: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == RUA_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((wgrad_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, k);
+  RUA_LAUNCH_CHECK("wgrad_kernel");
+  return RUA_OK;
+}
+
+// =========================================================================================
+// Weight preparation: fp32 master [taps][Cout][C] -> dtype copies (forward layout, dgrad layout).
+template <typename T>
+__global__ void wprep_kernel(const float* __restrict__ master, T* __restrict__ wf, T* __restrict__ wd,
+                             const rua_wprep_item* __restrict__ items) {
+  const rua_wprep_item it = items[blockIdx.y];
+  const int per = it.Cout * it.C;
+  const int total = it.taps * per;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const float v = master[it.src_off + i];
+    wf[it.dst_off + i] = (T)v;
+    const int tap = i / per, r = i - tap * per, co = r / it.C, ci = r - co * it.C;
+    wd[it.dst_off + (size_t)(it.taps - 1 - tap) * per + (size_t)ci * it.Cout + co] = (T)v;
+  }
+}
+
+extern "C" int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev,
+                               int n_items, int max_elems, int dtype, void* stream) {
+  RUA_CHECK_ARG(master && w_fwd && w_dgrad && items_dev && n_items > 0, "rua_weight_prep: bad arguments");
+  int gx = rua_div_up(max_elems, 256 * 8); if (gx < 1) gx = 1; if (gx > 512) gx = 512;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((wprep_kernel<bf16_t>), dim3(gx, n_items), dim3(256), 0, st, master, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, items_dev);
+  else hipLaunchKernelGGL((wprep_kernel<float>), dim3(gx, n_items), dim3(256), 0, st, master, (float*)w_fwd, (float*)w_dgrad, items_dev);
+  RUA_LAUNCH_CHECK("wprep_kernel");
+  return RUA_OK;
+}

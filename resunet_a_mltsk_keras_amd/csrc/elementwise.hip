@@ -1,0 +1,545 @@
+// HBM-bound kernels: BatchNorm statistics / apply / backward, pooling, resampling, n-ary add.
+// All tensors are channels-last [M][C]; every thread moves 16-byte pieces (8 bf16 / 4 fp32
+// channels), per-channel coefficient tables are staged in LDS once per block.
+#include "common.h"
+
+static inline int grid_for(int64_t pieces) {
+  int64_t g = (pieces + 255) / 256;
+  if (g > 2048) g = 2048;          // 256 CUs x 8 blocks; grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-channel statistics
+struct StatsK { const unsigned char* x; const unsigned char* g; const float* ms; const float* mt; int masked;
+                long long M; int C, CG, TX, TY, rows_per_block; double* stats; };
+
+template <typename T, int MODE>   // MODE 1: sum x, sum x^2 ; MODE 2: sum g*m, sum g*m*x
+__global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
+  constexpr int VEC = ET<T>::VEC;
+  __shared__ float sred[256 * 2 * VEC];
+  const int tid = threadIdx.x;
+  const int tx = tid % p.TX, ty = tid / p.TX;
+  const int cp = blockIdx.y * p.TX + tx;
+  float s1[VEC], s2[VEC], ms[VEC], mt[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; ms[j] = 1.f; mt[j] = 0.f; }
+  if (cp < p.CG) {
+    if (MODE == 2 && p.masked) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { if (p.ms) ms[j] = p.ms[cp * VEC + j]; if (p.mt) mt[j] = p.mt[cp * VEC + j]; }
+    }
+    long long r = (long long)blockIdx.x * p.rows_per_block + ty;
+    long long rend = (long long)(blockIdx.x + 1) * p.rows_per_block;
+    if (rend > p.M) rend = p.M;
+    for (; r < rend; r += p.TY) {
+      float xv[VEC];
+      ET<T>::unpack(ldg16(p.x + ((size_t)r * p.CG + cp) * 16), xv);
+      if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { s1[j] += xv[j]; s2[j] = fmaf(xv[j], xv[j], s2[j]); }
+      } else {
+        float gv[VEC];
+        ET<T>::unpack(ldg16(p.g + ((size_t)r * p.CG + cp) * 16), gv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float m = (!p.masked || fmaf(ms[j], xv[j], mt[j]) > 0.f) ? gv[j] : 0.f;
+          s1[j] += m; s2[j] = fmaf(m, xv[j], s2[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sred[(tid * 2) * VEC + j] = s1[j]; sred[(tid * 2 + 1) * VEC + j] = s2[j]; }
+  __syncthreads();
+  // threads with ty == 0 fold the TY partials of their column piece (fixed order => deterministic per block)
+  if (ty == 0 && cp < p.CG) {
+    for (int k = 1; k < p.TY; ++k) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s1[j] += sred[((k * p.TX + tx) * 2) * VEC + j]; s2[j] += sred[((k * p.TX + tx) * 2 + 1) * VEC + j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      atomicAdd(&p.stats[cp * VEC + j], (double)s1[j]);
+      atomicAdd(&p.stats[p.C + cp * VEC + j], (double)s2[j]);
+    }
+  }
+}
+
+template <int MODE>
+static int launch_stats(const void* g, const void* x, const float* ms, const float* mt, int masked,
+                        int64_t M, int C, double* stats, int dtype, void* stream, const char* name) {
+  RUA_CHECK_ARG(x && stats && M > 0, "%s: bad arguments", name);
+  RUA_CHECK_ARG(dtype == RUA_F32 || dtype == RUA_BF16, "%s: bad dtype", name);
+  const int vec = dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(C % vec == 0, "%s: C=%d not a multiple of %d", name, C, vec);
+  StatsK k;
+  k.x = (const unsigned char*)x; k.g = (const unsigned char*)g; k.ms = ms; k.mt = mt; k.masked = masked;
+  k.M = M; k.C = C; k.CG = C / vec;
+  int tx = 1; while (tx * 2 <= k.CG && tx < 256) tx *= 2;
+  k.TX = tx; k.TY = 256 / tx;
+  const int gy = (k.CG + tx - 1) / tx;
+  int64_t target_blocks = 2048 / gy; if (target_blocks < 1) target_blocks = 1;
+  int64_t rpb = (M + target_blocks - 1) / target_blocks;
+  if (rpb < k.TY * 4) rpb = k.TY * 4;
+  k.rows_per_block = (int)rpb;
+  k.stats = stats;
+  const int gx = (int)((M + rpb - 1) / rpb);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((col_stats_kernel<bf16_t, MODE>), dim3(gx, gy), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((col_stats_kernel<float, MODE>), dim3(gx, gy), dim3(256), 0, st, k);
+  RUA_LAUNCH_CHECK(name);
+  return RUA_OK;
+}
+
+extern "C" int rua_col_stats(const void* x, int64_t M, int C, double* stats, int dtype, void* stream) {
+  return launch_stats<1>(nullptr, x, nullptr, nullptr, 0, M, C, stats, dtype, stream, "rua_col_stats");
+}
+extern "C" int rua_col_stats2(const void* g, const void* x, const float* mscale, const float* mshift, int masked,
+                              int64_t M, int C, double* stats, int dtype, void* stream) {
+  RUA_CHECK_ARG(g != nullptr, "rua_col_stats2: null g");
+  return launch_stats<2>(g, x, mscale, mshift, masked, M, C, stats, dtype, stream, "rua_col_stats2");
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* stats, double count, double bessel_n, const float* gamma, const float* beta,
+                                   float* mmean, float* mvar, float momentum, float eps, int training,
+                                   float* scale, float* shift, float* mean_o, float* rstd_o, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean, var;
+  if (training) {
+    mean = stats[c] / count;
+    var = stats[C + c] / count - mean * mean;
+    if (var < 0) var = 0;
+    if (mmean) {
+      const double unb = bessel_n > 1 ? var * (bessel_n / (bessel_n - 1)) : var;
+      mmean[c] = (float)((double)mmean[c] * momentum + mean * (1.0 - momentum));
+      mvar[c] = (float)((double)mvar[c] * momentum + unb * (1.0 - momentum));
+    }
+  } else {
+    mean = mmean[c]; var = mvar[c];
+  }
+  const double r = 1.0 / sqrt(var + (double)eps);
+  const double s = (double)gamma[c] * r;
+  scale[c] = (float)s;
+  shift[c] = (float)((double)beta[c] - mean * s);
+  if (mean_o) mean_o[c] = (float)mean;
+  if (rstd_o) rstd_o[c] = (float)r;
+}
+
+extern "C" int rua_bn_finalize(const double* stats, double count, double bessel_n, const float* gamma, const float* beta,
+                               float* moving_mean, float* moving_var, float momentum, float eps, int training,
+                               float* scale, float* shift, float* mean, float* rstd, int C, void* stream) {
+  RUA_CHECK_ARG(gamma && beta && scale && shift && C > 0, "rua_bn_finalize: bad arguments");
+  RUA_CHECK_ARG(training ? (stats != nullptr && count > 0) : (moving_mean && moving_var), "rua_bn_finalize: missing statistics");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(rua_div_up(C, 128)), dim3(128), 0, (hipStream_t)stream,
+                     stats, count, bessel_n, gamma, beta, moving_mean, moving_var, momentum, eps, training, scale, shift, mean, rstd, C);
+  RUA_LAUNCH_CHECK("rua_bn_finalize");
+  return RUA_OK;
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* st2, double count, const float* gamma, const float* mean, const float* rstd,
+                                       float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = st2[c], sgx = st2[C + c];
+  const double mu = mean[c], r = rstd[c], gm = gamma[c];
+  const double dbe = sg;
+  const double dga = r * (sgx - mu * sg);
+  const double s = gm * r;
+  if (dgamma) dgamma[c] = (float)dga;
+  if (dbeta) dbeta[c] = (float)dbe;
+  cA[c] = (float)s;
+  cB[c] = (float)(-s * r * dga / count);
+  cC[c] = (float)(-s * dbe / count + s * r * mu * dga / count);
+}
+
+extern "C" int rua_bn_bwd_finalize(const double* stats2, double count, const float* gamma, const float* mean, const float* rstd,
+                                   float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC, int C, void* stream) {
+  RUA_CHECK_ARG(stats2 && gamma && mean && rstd && coefA && coefB && coefC && C > 0 && count > 0, "rua_bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rua_div_up(C, 128)), dim3(128), 0, (hipStream_t)stream,
+                     stats2, count, gamma, mean, rstd, dgamma, dbeta, coefA, coefB, coefC, C);
+  RUA_LAUNCH_CHECK("rua_bn_bwd_finalize");
+  return RUA_OK;
+}
+
+// per-channel sums (fp64) -> n fp32 destinations (bias gradients: d b = sum over pixels of dy)
+__global__ void stats_to_f32_kernel(const double* stats, int C, float* d0, float* d1, float* d2, float* d3, int n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float v = (float)stats[c];
+  d0[c] = v; if (n > 1) d1[c] = v; if (n > 2) d2[c] = v; if (n > 3) d3[c] = v;
+}
+extern "C" int rua_stats_to_f32(const double* stats, int C, float* const* dst, int n, void* stream) {
+  RUA_CHECK_ARG(stats && dst && n >= 1 && n <= 4 && C > 0, "rua_stats_to_f32: bad arguments");
+  for (int i = 0; i < n; ++i) RUA_CHECK_ARG(dst[i], "rua_stats_to_f32: null destination");
+  hipLaunchKernelGGL(stats_to_f32_kernel, dim3(rua_div_up(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, C,
+                     dst[0], n > 1 ? dst[1] : nullptr, n > 2 ? dst[2] : nullptr, n > 3 ? dst[3] : nullptr, n);
+  RUA_LAUNCH_CHECK("rua_stats_to_f32");
+  return RUA_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+struct ApplyK { const unsigned char* x; int nb; const float* scale[RUA_MAX_BRANCH]; const float* shift[RUA_MAX_BRANCH];
+                unsigned char* out[RUA_MAX_BRANCH]; int relu; long long pieces; int C, CG; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyK p) {
+  constexpr int VEC = ET<T>::VEC;
+  extern __shared__ float tab[];                       // [nb][2][C]
+  for (int i = threadIdx.x; i < p.nb * p.C; i += 256) {
+    const int b = i / p.C, c = i - b * p.C;
+    tab[(b * 2) * p.C + c] = p.scale[b][c];
+    tab[(b * 2 + 1) * p.C + c] = p.shift[b][c];
+  }
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.pieces; i += stride) {
+    const int c = (int)(i % p.CG) * VEC;
+    float xv[VEC];
+    ET<T>::unpack(ldg16(p.x + i * 16), xv);
+    for (int b = 0; b < p.nb; ++b) {
+      float o[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        o[j] = fmaf(tab[(b * 2) * p.C + c + j], xv[j], tab[(b * 2 + 1) * p.C + c + j]);
+        if (p.relu) o[j] = fmaxf(o[j], 0.f);
+      }
+      stg16(p.out[b] + i * 16, ET<T>::pack(o));
+    }
+  }
+}
+
+extern "C" int rua_bn_apply(const void* x, int nb, const float* const* scale, const float* const* shift, int relu,
+                            void* const* out, int64_t M, int C, int dtype, void* stream) {
+  RUA_CHECK_ARG(x && scale && shift && out && nb >= 1 && nb <= RUA_MAX_BRANCH && M > 0, "rua_bn_apply: bad arguments");
+  const int vec = dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(C % vec == 0, "rua_bn_apply: C=%d not a multiple of %d", C, vec);
+  ApplyK k;
+  k.x = (const unsigned char*)x; k.nb = nb; k.relu = relu; k.C = C; k.CG = C / vec; k.pieces = M * k.CG;
+  for (int b = 0; b < nb; ++b) { k.scale[b] = scale[b]; k.shift[b] = shift[b]; k.out[b] = (unsigned char*)out[b];
+    RUA_CHECK_ARG(scale[b] && shift[b] && out[b], "rua_bn_apply: null branch pointer"); }
+  const size_t smem = (size_t)nb * 2 * C * 4;
+  RUA_CHECK_ARG(smem <= 64 * 1024, "rua_bn_apply: coefficient table too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid_for(k.pieces)), dim3(256), smem, st, k);
+  else hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid_for(k.pieces)), dim3(256), smem, st, k);
+  RUA_LAUNCH_CHECK("rua_bn_apply");
+  return RUA_OK;
+}
+
+struct BwdApplyK { int nb; const unsigned char* g[RUA_MAX_BRANCH]; const float* cA[RUA_MAX_BRANCH]; const float* cB[RUA_MAX_BRANCH];
+                   const float* cC[RUA_MAX_BRANCH]; const float* ms[RUA_MAX_BRANCH]; const float* mt[RUA_MAX_BRANCH]; int masked;
+                   const unsigned char* x; const unsigned char* dskip; unsigned char* dx; int accumulate; long long pieces; int C, CG; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyK p) {
+  constexpr int VEC = ET<T>::VEC;
+  extern __shared__ float tab[];                       // [nb][3][C] : A, ms, mt ; then [2][C] : sumB, sumC
+  float* tB = tab + p.nb * 3 * p.C;
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float sb = 0.f, sc = 0.f;
+    for (int b = 0; b < p.nb; ++b) {
+      tab[(b * 3) * p.C + c] = p.cA[b][c];
+      tab[(b * 3 + 1) * p.C + c] = (p.masked && p.ms[b]) ? p.ms[b][c] : 1.f;
+      tab[(b * 3 + 2) * p.C + c] = (p.masked && p.mt[b]) ? p.mt[b][c] : 0.f;
+      sb += p.cB[b][c]; sc += p.cC[b][c];
+    }
+    tB[c] = sb; tB[p.C + c] = sc;
+  }
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.pieces; i += stride) {
+    const int c = (int)(i % p.CG) * VEC;
+    float xv[VEC], acc[VEC];
+    ET<T>::unpack(ldg16(p.x + i * 16), xv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(tB[c + j], xv[j], tB[p.C + c + j]);
+    if (p.dskip) {
+      float d[VEC];
+      ET<T>::unpack(ldg16(p.dskip + i * 16), d);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += d[j];
+    }
+    if (p.accumulate) {
+      float d[VEC];
+      ET<T>::unpack(ldg16(p.dx + i * 16), d);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += d[j];
+    }
+    for (int b = 0; b < p.nb; ++b) {
+      float gv[VEC];
+      ET<T>::unpack(ldg16(p.g[b] + i * 16), gv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const bool on = !p.masked || fmaf(tab[(b * 3 + 1) * p.C + c + j], xv[j], tab[(b * 3 + 2) * p.C + c + j]) > 0.f;
+        acc[j] = fmaf(tab[(b * 3) * p.C + c + j], on ? gv[j] : 0.f, acc[j]);
+      }
+    }
+    stg16(p.dx + i * 16, ET<T>::pack(acc));
+  }
+}
+
+extern "C" int rua_bn_bwd_apply(int nb, const void* const* g, const float* const* coefA, const float* const* coefB,
+                                const float* const* coefC, const float* const* mscale, const float* const* mshift, int masked,
+                                const void* x, const void* dskip, void* dx, int accumulate, int64_t M, int C, int dtype, void* stream) {
+  RUA_CHECK_ARG(nb >= 1 && nb <= RUA_MAX_BRANCH && g && coefA && coefB && coefC && x && dx && M > 0, "rua_bn_bwd_apply: bad arguments");
+  const int vec = dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(C % vec == 0, "rua_bn_bwd_apply: C=%d not a multiple of %d", C, vec);
+  BwdApplyK k;
+  k.nb = nb; k.masked = masked; k.x = (const unsigned char*)x; k.dskip = (const unsigned char*)dskip; k.dx = (unsigned char*)dx;
+  k.accumulate = accumulate; k.C = C; k.CG = C / vec; k.pieces = M * k.CG;
+  for (int b = 0; b < nb; ++b) {
+    RUA_CHECK_ARG(g[b] && coefA[b] && coefB[b] && coefC[b], "rua_bn_bwd_apply: null branch pointer");
+    k.g[b] = (const unsigned char*)g[b]; k.cA[b] = coefA[b]; k.cB[b] = coefB[b]; k.cC[b] = coefC[b];
+    k.ms[b] = mscale ? mscale[b] : nullptr; k.mt[b] = mshift ? mshift[b] : nullptr;
+  }
+  const size_t smem = (size_t)(nb * 3 + 2) * C * 4;
+  RUA_CHECK_ARG(smem <= 64 * 1024, "rua_bn_bwd_apply: coefficient table too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid_for(k.pieces)), dim3(256), smem, st, k);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid_for(k.pieces)), dim3(256), smem, st, k);
+  RUA_LAUNCH_CHECK("rua_bn_bwd_apply");
+  return RUA_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// pooling / resampling: one thread per output (or input) piece
+template <typename T>
+__global__ void maxpool_fwd_kernel(const unsigned char* x, unsigned char* y, uint8_t* idx, int N, int H, int W, int CG, int k) {
+  constexpr int VEC = ET<T>::VEC;
+  const int Ho = H / k, Wo = W / k;
+  const long long total = (long long)N * Ho * Wo * CG;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cp = (int)(i % CG); long long r = i / CG;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); const int n = (int)(r / Ho);
+    float best[VEC]; int bi[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    for (int a = 0; a < k; ++a)
+      for (int b = 0; b < k; ++b) {
+        float v[VEC];
+        ET<T>::unpack(ldg16(x + ((((size_t)n * H + ho * k + a) * W + wo * k + b) * CG + cp) * 16), v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) if (v[j] > best[j]) { best[j] = v[j]; bi[j] = a * k + b; }   // first maximum wins
+      }
+    stg16(y + i * 16, ET<T>::pack(best));
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) idx[i * VEC + j] = (uint8_t)bi[j];
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const unsigned char* dy, const uint8_t* idx, unsigned char* dx, int accumulate,
+                                   int N, int H, int W, int CG, int k) {
+  constexpr int VEC = ET<T>::VEC;
+  const int Ho = H / k, Wo = W / k;
+  const long long total = (long long)N * H * W * CG;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cp = (int)(i % CG); long long r = i / CG;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H); const int n = (int)(r / H);
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+    if (accumulate) ET<T>::unpack(ldg16(dx + i * 16), o);
+    if (h / k < Ho && w / k < Wo) {
+      const size_t pi = (((size_t)n * Ho + h / k) * Wo + w / k) * CG + cp;
+      float g[VEC];
+      ET<T>::unpack(ldg16(dy + pi * 16), g);
+      const int pos = (h % k) * k + (w % k);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) if (idx[pi * VEC + j] == pos) o[j] += g[j];
+    }
+    stg16(dx + i * 16, ET<T>::pack(o));
+  }
+}
+
+template <typename T>
+__global__ void sumpool_kernel(const unsigned char* x, unsigned char* y, int N, int H, int W, int CG, int k) {
+  constexpr int VEC = ET<T>::VEC;
+  const int Ho = H / k, Wo = W / k;
+  const long long total = (long long)N * Ho * Wo * CG;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cp = (int)(i % CG); long long r = i / CG;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); const int n = (int)(r / Ho);
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    for (int a = 0; a < k; ++a)
+      for (int b = 0; b < k; ++b) {
+        float v[VEC];
+        ET<T>::unpack(ldg16(x + ((((size_t)n * H + ho * k + a) * W + wo * k + b) * CG + cp) * 16), v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[j] += v[j];
+      }
+    stg16(y + i * 16, ET<T>::pack(s));
+  }
+}
+
+template <typename T>
+__global__ void upsample_kernel(const unsigned char* x, unsigned char* y, int N, int H, int W, int CG, int k) {
+  const int Ho = H * k, Wo = W * k;
+  const long long total = (long long)N * Ho * Wo * CG;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cp = (int)(i % CG); long long r = i / CG;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); const int n = (int)(r / Ho);
+    stg16(y + i * 16, ldg16(x + ((((size_t)n * H + ho / k) * W + wo / k) * CG + cp) * 16));
+  }
+}
+
+#define POOL_ARGS_CHECK(name) \
+  RUA_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && k >= 1, name ": bad arguments"); \
+  RUA_CHECK_ARG(dtype == RUA_F32 || dtype == RUA_BF16, name ": bad dtype"); \
+  const int vec = dtype == RUA_BF16 ? 8 : 4; \
+  RUA_CHECK_ARG(C % vec == 0, name ": C=%d not a multiple of %d", C, vec); \
+  const int CG = C / vec; hipStream_t st = (hipStream_t)stream;
+
+extern "C" int rua_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int k, int dtype, void* stream) {
+  POOL_ARGS_CHECK("rua_maxpool_fwd");
+  RUA_CHECK_ARG(idx && H % k == 0 && W % k == 0 && k * k <= 256, "rua_maxpool_fwd: H,W must be divisible by k");
+  const int g = grid_for((int64_t)N * (H / k) * (W / k) * CG);
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, idx, N, H, W, CG, k);
+  else hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, idx, N, H, W, CG, k);
+  RUA_LAUNCH_CHECK("rua_maxpool_fwd");
+  return RUA_OK;
+}
+extern "C" int rua_maxpool_bwd(const void* x, const uint8_t* idx, void* y, int accumulate, int N, int H, int W, int C, int k, int dtype, void* stream) {
+  POOL_ARGS_CHECK("rua_maxpool_bwd");
+  RUA_CHECK_ARG(idx && H % k == 0 && W % k == 0, "rua_maxpool_bwd: H,W must be divisible by k");
+  const int g = grid_for((int64_t)N * H * W * CG);
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, idx, (unsigned char*)y, accumulate, N, H, W, CG, k);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, idx, (unsigned char*)y, accumulate, N, H, W, CG, k);
+  RUA_LAUNCH_CHECK("rua_maxpool_bwd");
+  return RUA_OK;
+}
+extern "C" int rua_sumpool(const void* x, void* y, int N, int H, int W, int C, int k, int dtype, void* stream) {
+  POOL_ARGS_CHECK("rua_sumpool");
+  RUA_CHECK_ARG(H % k == 0 && W % k == 0, "rua_sumpool: H,W must be divisible by k");
+  const int g = grid_for((int64_t)N * (H / k) * (W / k) * CG);
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((sumpool_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, N, H, W, CG, k);
+  else hipLaunchKernelGGL((sumpool_kernel<float>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, N, H, W, CG, k);
+  RUA_LAUNCH_CHECK("rua_sumpool");
+  return RUA_OK;
+}
+extern "C" int rua_upsample_nearest(const void* x, void* y, int N, int H, int W, int C, int k, int dtype, void* stream) {
+  POOL_ARGS_CHECK("rua_upsample_nearest");
+  const int g = grid_for((int64_t)N * H * k * W * k * CG);
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((upsample_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, N, H, W, CG, k);
+  else hipLaunchKernelGGL((upsample_kernel<float>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, N, H, W, CG, k);
+  RUA_LAUNCH_CHECK("rua_upsample_nearest");
+  return RUA_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+struct AddK { int n; const unsigned char* in[8]; unsigned char* out; int accumulate; long long pieces; };
+template <typename T>
+__global__ void add_n_kernel(const AddK p) {
+  constexpr int VEC = ET<T>::VEC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.pieces; i += (long long)gridDim.x * blockDim.x) {
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    if (p.accumulate) ET<T>::unpack(ldg16(p.out + i * 16), s);
+    for (int b = 0; b < p.n; ++b) {
+      float v[VEC];
+      ET<T>::unpack(ldg16(p.in[b] + i * 16), v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += v[j];
+    }
+    stg16(p.out + i * 16, ET<T>::pack(s));
+  }
+}
+extern "C" int rua_add_n(int n, const void* const* in, void* out, int accumulate, int64_t elems, int dtype, void* stream) {
+  RUA_CHECK_ARG(n >= 1 && n <= 8 && in && out && elems > 0, "rua_add_n: bad arguments");
+  const int vec = dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(elems % vec == 0, "rua_add_n: element count must be a multiple of %d", vec);
+  AddK k; k.n = n; k.out = (unsigned char*)out; k.accumulate = accumulate; k.pieces = elems / vec;
+  for (int b = 0; b < n; ++b) { RUA_CHECK_ARG(in[b], "rua_add_n: null input"); k.in[b] = (const unsigned char*)in[b]; }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((add_n_kernel<bf16_t>), dim3(grid_for(k.pieces)), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((add_n_kernel<float>), dim3(grid_for(k.pieces)), dim3(256), 0, st, k);
+  RUA_LAUNCH_CHECK("rua_add_n");
+  return RUA_OK;
+}
+
+template <typename T, int MODE>   // 0: dy *= (y>0) in place ; 1: out = relu(x)
+__global__ void relu_kernel(unsigned char* a, const unsigned char* b, long long pieces) {
+  constexpr int VEC = ET<T>::VEC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pieces; i += (long long)gridDim.x * blockDim.x) {
+    float u[VEC], v[VEC];
+    ET<T>::unpack(ldg16(b + i * 16), v);
+    if (MODE == 0) {
+      ET<T>::unpack(ldg16(a + i * 16), u);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) u[j] = v[j] > 0.f ? u[j] : 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) u[j] = fmaxf(v[j], 0.f);
+    }
+    stg16(a + i * 16, ET<T>::pack(u));
+  }
+}
+extern "C" int rua_relu_mask(void* dy, const void* y, int64_t elems, int dtype, void* stream) {
+  RUA_CHECK_ARG(dy && y && elems > 0, "rua_relu_mask: bad arguments");
+  const int vec = dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(elems % vec == 0, "rua_relu_mask: element count must be a multiple of %d", vec);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((relu_kernel<bf16_t, 0>), dim3(grid_for(elems / vec)), dim3(256), 0, st, (unsigned char*)dy, (const unsigned char*)y, (long long)(elems / vec));
+  else hipLaunchKernelGGL((relu_kernel<float, 0>), dim3(grid_for(elems / vec)), dim3(256), 0, st, (unsigned char*)dy, (const unsigned char*)y, (long long)(elems / vec));
+  RUA_LAUNCH_CHECK("rua_relu_mask");
+  return RUA_OK;
+}
+extern "C" int rua_relu(const void* x, void* y, int64_t elems, int dtype, void* stream) {
+  RUA_CHECK_ARG(x && y && elems > 0, "rua_relu: bad arguments");
+  const int vec = dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(elems % vec == 0, "rua_relu: element count must be a multiple of %d", vec);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((relu_kernel<bf16_t, 1>), dim3(grid_for(elems / vec)), dim3(256), 0, st, (unsigned char*)y, (const unsigned char*)x, (long long)(elems / vec));
+  else hipLaunchKernelGGL((relu_kernel<float, 1>), dim3(grid_for(elems / vec)), dim3(256), 0, st, (unsigned char*)y, (const unsigned char*)x, (long long)(elems / vec));
+  RUA_LAUNCH_CHECK("rua_relu");
+  return RUA_OK;
+}
+
+__global__ void cast_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = (bf16_t)x[i];
+}
+__global__ void cast_from_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+extern "C" int rua_cast_f32_to(const float* x, void* y, int64_t elems, int dtype, void* stream) {
+  RUA_CHECK_ARG(x && y && elems > 0, "rua_cast_f32_to: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) {
+    hipLaunchKernelGGL(cast_to_bf16_kernel, dim3(grid_for(elems)), dim3(256), 0, st, x, (bf16_t*)y, (long long)elems);
+    RUA_LAUNCH_CHECK("rua_cast_f32_to");
+    return RUA_OK;
+  }
+  hipError_t e = hipMemcpyAsync(y, x, elems * 4, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { rua_set_error("rua_cast_f32_to: %s", hipGetErrorString(e)); return RUA_ERR_LAUNCH; }
+  return RUA_OK;
+}
+extern "C" int rua_cast_to_f32(const void* x, float* y, int64_t elems, int dtype, void* stream) {
+  RUA_CHECK_ARG(x && y && elems > 0, "rua_cast_to_f32: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) {
+    hipLaunchKernelGGL(cast_from_bf16_kernel, dim3(grid_for(elems)), dim3(256), 0, st, (const bf16_t*)x, y, (long long)elems);
+    RUA_LAUNCH_CHECK("rua_cast_to_f32");
+    return RUA_OK;
+  }
+  hipError_t e = hipMemcpyAsync(y, x, elems * 4, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { rua_set_error("rua_cast_to_f32: %s", hipGetErrorString(e)); return RUA_ERR_LAUNCH; }
+  return RUA_OK;
+}
+extern "C" int rua_fill_zero(void* p, int64_t bytes, void* stream) {
+  RUA_CHECK_ARG(p && bytes >= 0, "rua_fill_zero: bad arguments");
+  if (bytes == 0) return RUA_OK;
+  hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
+  if (e != hipSuccess) { rua_set_error("rua_fill_zero: %s", hipGetErrorString(e)); return RUA_ERR_LAUNCH; }
+  return RUA_OK;
+}

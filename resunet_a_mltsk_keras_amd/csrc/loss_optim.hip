@@ -1,0 +1,333 @@
+// Loss heads, metrics and optimizers.  Everything here is fp32 on [B][HW][C] probabilities and
+// labels with fp64 accumulators; per-pixel work is HBM-bound, reductions are wavefront
+// shuffles + one fp64 atomic per block and value.
+#include "common.h"
+
+__device__ __forceinline__ void block_atomic_add(double* dst, float v, float* sh /*[4]*/, int slot) {
+  // every thread calls; wave shuffle -> LDS -> one fp64 atomic
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sh[slot * 4 + wid] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dst, (double)sh[slot * 4 + 0] + (double)sh[slot * 4 + 1] + (double)sh[slot * 4 + 2] + (double)sh[slot * 4 + 3]);
+  __syncthreads();
+}
+
+// ---- Tanimoto with complement (multitasking_utils.py:38-85) ------------------------------
+// sums[n][c][6] = { sum p, sum (1-l), sum p*l, sum p^2+l^2, sum (1-p)(1-l), sum (1-p)^2+(1-l)^2 }
+__global__ __launch_bounds__(256) void tanimoto_sums_kernel(const float* __restrict__ p, const float* __restrict__ y, long long HW, int C,
+                                                            int pix_per_block, double* sums) {
+  __shared__ float sh[4 * 48];
+  const int n = blockIdx.y;
+  float acc[8][6];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[c][k] = 0.f;
+  long long i = (long long)blockIdx.x * pix_per_block + threadIdx.x;
+  long long iend = (long long)(blockIdx.x + 1) * pix_per_block; if (iend > HW) iend = HW;
+  for (; i < iend; i += 256) {
+    const float* pp = p + ((size_t)n * HW + i) * C;
+    const float* yy = y + ((size_t)n * HW + i) * C;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c < C) {
+        const float a = pp[c], l = yy[c], q = 1.f - a, m = 1.f - l;
+        acc[c][0] += a; acc[c][1] += m; acc[c][2] = fmaf(a, l, acc[c][2]);
+        acc[c][3] += a * a + l * l; acc[c][4] = fmaf(q, m, acc[c][4]); acc[c][5] += q * q + m * m;
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float v = wave_sum(acc[c][k]);
+      if (lane == 0) sh[wid * 48 + c * 6 + k] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 48) {
+    const int c = threadIdx.x / 6, k = threadIdx.x % 6;
+    if (c < C) {
+      const double t = (double)sh[threadIdx.x] + (double)sh[48 + threadIdx.x] + (double)sh[96 + threadIdx.x] + (double)sh[144 + threadIdx.x];
+      atomicAdd(&sums[((size_t)n * C + c) * 6 + k], t);
+    }
+  }
+}
+
+extern "C" int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t HW, int C, double* sums, void* stream) {
+  RUA_CHECK_ARG(p && y && sums && B > 0 && HW > 0, "rua_tanimoto_sums: bad arguments");
+  RUA_CHECK_ARG(C >= 1 && C <= 8, "rua_tanimoto_sums: C=%d must be in 1..8", C);
+  int64_t ppb = (HW + 127) / 128; if (ppb < 1024) ppb = 1024;
+  ppb = (ppb + 255) / 256 * 256;
+  const int gx = (int)((HW + ppb - 1) / ppb);
+  hipLaunchKernelGGL(tanimoto_sums_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, p, y, (long long)HW, C, (int)ppb, sums);
+  RUA_LAUNCH_CHECK("rua_tanimoto_sums");
+  return RUA_OK;
+}
+
+// One block.  Follows Tanimoto_dual_loss: loss1 = T(label:=pred, pred:=label) so the class weights of
+// the first term come from the PREDICTION volumes (and carry gradient); loss2 = T(1-label, 1-pred).
+__global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B, int C, float grad_scale, double* loss_out, float* coef) {
+  __shared__ double w1[8], w2[8], v1[8], kap[8];
+  __shared__ double E1[256], F1[256], E2[256], F2[256];
+  __shared__ int inf1[8];
+  const int t = threadIdx.x;
+  const double smooth = 1e-5;
+  if (t < C) {
+    double a = 0, b = 0;
+    for (int n = 0; n < B; ++n) { a += sums[((size_t)n * C + t) * 6 + 0]; b += sums[((size_t)n * C + t) * 6 + 1]; }
+    a /= B; b /= B;
+    // the reference squares and takes the reciprocal in float32: overflow to inf happens only at V == 0
+    v1[t] = a;
+    const float a2 = (float)a * (float)a, b2 = (float)b * (float)b;
+    w1[t] = a2 == 0.f ? INFINITY : 1.0 / (a * a);
+    w2[t] = b2 == 0.f ? INFINITY : 1.0 / (b * b);
+  }
+  __syncthreads();
+  if (t == 0) {
+    double m1 = 0, m2 = 0;
+    for (int c = 0; c < C; ++c) { if (!isinf(w1[c]) && w1[c] > m1) m1 = w1[c]; if (!isinf(w2[c]) && w2[c] > m2) m2 = w2[c]; }
+    for (int c = 0; c < C; ++c) {
+      inf1[c] = isinf(w1[c]);
+      if (isinf(w1[c])) w1[c] = m1;
+      if (isinf(w2[c])) w2[c] = m2;
+    }
+  }
+  __syncthreads();
+  double lsum = 0;
+  for (int n = t; n < B; n += blockDim.x) {
+    double N1 = 0, D1 = 0, N2 = 0, D2 = 0;
+    for (int c = 0; c < C; ++c) {
+      const double* s = &sums[((size_t)n * C + c) * 6];
+      N1 += w1[c] * s[2]; D1 += w1[c] * (s[3] - s[2]);
+      N2 += w2[c] * s[4]; D2 += w2[c] * (s[5] - s[4]);
+    }
+    E1[n] = D1 + smooth; F1[n] = N1 + smooth; E2[n] = D2 + smooth; F2[n] = N2 + smooth;
+    lsum += 1.0 - 0.5 * (F1[n] / E1[n] + F2[n] / E2[n]);
+  }
+  // block sum of lsum (B <= 256, blockDim 64: one wave)
+  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
+  if (t == 0) loss_out[0] = lsum / B;
+  __syncthreads();
+  if (t < C) {
+    // d loss1[n] / d w1_c = [Spl (D1+e) - (N1+e)(SS - Spl)] / (D1+e)^2 ; d w1_c / d p = -2 / (V^3 B)
+    double R = 0;
+    for (int n = 0; n < B; ++n) {
+      const double* s = &sums[((size_t)n * C + t) * 6];
+      R += (s[2] * E1[n] - F1[n] * (s[3] - s[2])) / (E1[n] * E1[n]);
+    }
+    kap[t] = inf1[t] ? 0.0 : (-2.0 / (v1[t] * v1[t] * v1[t] * B)) * R;
+  }
+  __syncthreads();
+  const double sc = -0.5 * (double)grad_scale;      // d(1 - .5(l1+l2)); grad_scale = loss_weight / B
+  for (int i = t; i < B * C; i += blockDim.x) {
+    const int n = i / C, c = i - n * C;
+    const double a1 = w1[c] / (E1[n] * E1[n]), a2 = w2[c] / (E2[n] * E2[n]);
+    const double c0 = kap[c] + a2 * (F2[n] - E2[n]);
+    const double c1 = -2.0 * a1 * F1[n] - 2.0 * a2 * F2[n];
+    const double c2 = a1 * (E1[n] + F1[n]) + a2 * (E2[n] + F2[n]);
+    coef[i * 3 + 0] = (float)(sc * c0); coef[i * 3 + 1] = (float)(sc * c1); coef[i * 3 + 2] = (float)(sc * c2);
+  }
+}
+
+extern "C" int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef, void* stream) {
+  RUA_CHECK_ARG(sums && loss_out && coef && B > 0 && B <= 256, "rua_tanimoto_finalize: B must be in 1..256");
+  RUA_CHECK_ARG(C >= 1 && C <= 8, "rua_tanimoto_finalize: C=%d must be in 1..8", C);
+  (void)HW;
+  hipLaunchKernelGGL(tanimoto_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, B, C, grad_scale, loss_out, coef);
+  RUA_LAUNCH_CHECK("rua_tanimoto_finalize");
+  return RUA_OK;
+}
+
+// ---- per-pixel losses (utils.py:481-490; Keras CategoricalCrossentropy / BinaryCrossentropy /
+// MeanSquaredError as train_ISPRS.py:411-428 selects them) -----------------------------------
+#define KERAS_EPS 1e-7f
+__global__ __launch_bounds__(256) void pixel_loss_kernel(int kind, const float* __restrict__ p, const float* __restrict__ z,
+                                                         const float* __restrict__ y, const float* __restrict__ cw,
+                                                         long long M, int C, double* out) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+    float l = 0.f;
+    if (kind == RUA_LOSS_WCE) {
+      float S = 0.f;
+      for (int c = 0; c < C; ++c) S += p[m * C + c];
+      for (int c = 0; c < C; ++c) {
+        const float u = fminf(fmaxf(p[m * C + c] / S, KERAS_EPS), 1.f - KERAS_EPS);
+        l -= y[m * C + c] * logf(u) * cw[c];
+      }
+    } else if (kind == RUA_LOSS_CE_LOGITS) {
+      float mx = -INFINITY;
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[m * C + c]);
+      float s = 0.f;
+      for (int c = 0; c < C; ++c) s += expf(z[m * C + c] - mx);
+      const float lse = mx + logf(s);
+      for (int c = 0; c < C; ++c) l -= y[m * C + c] * (z[m * C + c] - lse);
+    } else if (kind == RUA_LOSS_BCE_LOGITS) {
+      for (int c = 0; c < C; ++c) {
+        const float zz = z[m * C + c];
+        l += fmaxf(zz, 0.f) - zz * y[m * C + c] + log1pf(expf(-fabsf(zz)));
+      }
+      l /= C;
+    } else {
+      for (int c = 0; c < C; ++c) { const float d = y[m * C + c] - p[m * C + c]; l = fmaf(d, d, l); }
+      l /= C;
+    }
+    acc += l;
+  }
+  block_atomic_add(out, acc, sh, 0);
+}
+
+extern "C" int rua_pixel_loss(int kind, const float* p, const float* z, const float* y, const float* class_w,
+                              int64_t M, int C, double* loss_out, void* stream) {
+  RUA_CHECK_ARG(p && y && loss_out && M > 0 && C >= 1 && C <= 64, "rua_pixel_loss: bad arguments");
+  RUA_CHECK_ARG(kind >= RUA_LOSS_WCE && kind <= RUA_LOSS_MSE, "rua_pixel_loss: kind %d is not a per-pixel loss", kind);
+  RUA_CHECK_ARG(kind != RUA_LOSS_WCE || class_w, "rua_pixel_loss: weighted CE needs class weights");
+  RUA_CHECK_ARG((kind != RUA_LOSS_CE_LOGITS && kind != RUA_LOSS_BCE_LOGITS) || z, "rua_pixel_loss: logits needed");
+  int64_t g = (M + 255) / 256; if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(pixel_loss_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, kind, p, z, y, class_w, (long long)M, C, loss_out);
+  RUA_LAUNCH_CHECK("rua_pixel_loss");
+  return RUA_OK;
+}
+
+// d(total loss)/d(logits), one thread per pixel
+__global__ __launch_bounds__(256) void head_dz_kernel(int kind, int act, const float* __restrict__ p, const float* __restrict__ y,
+                                                      const float* __restrict__ coef, const float* __restrict__ cw, float gs,
+                                                      long long HW, long long M, int C, float* dz) {
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+    float pv[8], yv[8], g[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { pv[c] = c < C ? p[m * C + c] : 0.f; yv[c] = c < C ? y[m * C + c] : 0.f; g[c] = 0.f; }
+    if (kind == RUA_LOSS_CE_LOGITS) {
+      float sy = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sy += yv[c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = (pv[c] * sy - yv[c]) * gs;
+      continue;
+    }
+    if (kind == RUA_LOSS_BCE_LOGITS) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = (pv[c] - yv[c]) * gs / C;
+      continue;
+    }
+    if (kind == RUA_LOSS_TANIMOTO) {
+      const int n = (int)(m / HW);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < C) { const float* k = coef + ((size_t)n * C + c) * 3; g[c] = fmaf(k[1], pv[c], fmaf(k[2], yv[c], k[0])); }
+    } else if (kind == RUA_LOSS_WCE) {
+      float S = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) S += pv[c];
+      float h[8], hu = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        h[c] = 0.f;
+        if (c < C) {
+          const float u = pv[c] / S;
+          const bool inside = u >= KERAS_EPS && u <= 1.f - KERAS_EPS;     // clip_by_value passes gradient inside only
+          h[c] = inside ? -yv[c] * cw[c] / u : 0.f;
+          hu = fmaf(h[c], u, hu);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) g[c] = (h[c] - hu) / S * gs;
+    } else {   // MSE
+#pragma unroll
+      for (int c = 0; c < 8; ++c) g[c] = 2.f * (pv[c] - yv[c]) * gs / C;
+    }
+    if (act == RUA_ACT_SOFTMAX) {
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) dot = fmaf(g[c], pv[c], dot);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = pv[c] * (g[c] - dot);
+    } else if (act == RUA_ACT_SIGMOID) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = g[c] * pv[c] * (1.f - pv[c]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = g[c];
+    }
+  }
+}
+
+extern "C" int rua_head_dz(int kind, int act, const float* p, const float* y, const float* coef, const float* class_w,
+                           float grad_scale, int B, int64_t HW, int C, float* dz, void* stream) {
+  RUA_CHECK_ARG(p && y && dz && B > 0 && HW > 0, "rua_head_dz: bad arguments");
+  RUA_CHECK_ARG(C >= 1 && C <= 8, "rua_head_dz: C=%d must be in 1..8", C);
+  RUA_CHECK_ARG(kind >= 0 && kind <= 4 && act >= 0 && act <= 2, "rua_head_dz: bad kind/act");
+  RUA_CHECK_ARG(kind != RUA_LOSS_TANIMOTO || coef, "rua_head_dz: Tanimoto needs coefficients");
+  RUA_CHECK_ARG(kind != RUA_LOSS_WCE || class_w, "rua_head_dz: weighted CE needs class weights");
+  const int64_t M = (int64_t)B * HW;
+  int64_t g = (M + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(head_dz_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, kind, act, p, y, coef, class_w, grad_scale,
+                     (long long)HW, (long long)M, C, dz);
+  RUA_LAUNCH_CHECK("rua_head_dz");
+  return RUA_OK;
+}
+
+// accuracy + TP/FP/TN/FN (Keras 'accuracy' = categorical accuracy; confusion counts at .5)
+__global__ __launch_bounds__(256) void seg_metrics_kernel(const float* __restrict__ p, const float* __restrict__ y, long long M, int C, double* out) {
+  __shared__ float sh[5 * 4];
+  float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+    int ip = 0, iy = 0; float bp = p[m * C], by = y[m * C];
+    for (int c = 0; c < C; ++c) {
+      const float pv = p[m * C + c], yv = y[m * C + c];
+      if (pv > bp) { bp = pv; ip = c; }
+      if (yv > by) { by = yv; iy = c; }
+      const bool t = yv > 0.5f, q = pv > 0.5f;
+      a[1] += (t && q); a[2] += (!t && q); a[3] += (!t && !q); a[4] += (t && !q);
+    }
+    a[0] += (ip == iy);
+  }
+  for (int k = 0; k < 5; ++k) block_atomic_add(&out[k], a[k], sh, k);
+}
+
+extern "C" int rua_seg_metrics(const float* p, const float* y, int64_t M, int C, double* out, void* stream) {
+  RUA_CHECK_ARG(p && y && out && M > 0 && C >= 1, "rua_seg_metrics: bad arguments");
+  int64_t g = (M + 255) / 256; if (g > 512) g = 512;
+  hipLaunchKernelGGL(seg_metrics_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p, y, (long long)M, C, out);
+  RUA_LAUNCH_CHECK("rua_seg_metrics");
+  return RUA_OK;
+}
+
+// ---- optimizers on the flat parameter buffer ---------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ th, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   long long n, float lr_t, float b1, float b2, float eps, float gs, int zero) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gg = g[i] * gs;
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm; v[i] = vv;
+    th[i] -= lr_t * mm / (sqrtf(vv) + eps);
+    if (zero) g[i] = 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ th, float* __restrict__ g, float* __restrict__ vel,
+                                                  long long n, float lr, float mu, float gs, int zero) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float vv = mu * vel[i] - lr * g[i] * gs;
+    vel[i] = vv; th[i] += vv;
+    if (zero) g[i] = 0.f;
+  }
+}
+extern "C" int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                             float eps, float grad_scale, int zero_grad, void* stream) {
+  RUA_CHECK_ARG(theta && g && m && v && n > 0, "rua_adam_step: bad arguments");
+  int64_t gr = (n + 255) / 256; if (gr > 4096) gr = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, (long long)n, lr_t, beta1, beta2, eps, grad_scale, zero_grad);
+  RUA_LAUNCH_CHECK("rua_adam_step");
+  return RUA_OK;
+}
+extern "C" int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, float momentum, float grad_scale,
+                            int zero_grad, void* stream) {
+  RUA_CHECK_ARG(theta && g && vel && n > 0, "rua_sgd_step: bad arguments");
+  int64_t gr = (n + 255) / 256; if (gr > 4096) gr = 4096;
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, vel, (long long)n, lr, momentum, grad_scale, zero_grad);
+  RUA_LAUNCH_CHECK("rua_sgd_step");
+  return RUA_OK;
+}

@@ -1,0 +1,240 @@
+// Few-channel 1x1 convolutions that do not fill an MFMA tile: the stem (3/6/7 bands -> 32,
+// model2.py:101) and the heads (32 -> num_classes / 3 with softmax / sigmoid, model2.py:145-188).
+// Both are HBM-bound; weights live in LDS / registers, one thread per pixel (or pixel x piece).
+#include "common.h"
+
+template <typename T> __device__ __forceinline__ void st8(unsigned char* base, size_t elem_off, const float* f) {
+  if constexpr (sizeof(T) == 2) stg16(base + elem_off * 2, ET<T>::pack(f));
+  else { stg16(base + elem_off * 4, ET<T>::pack(f)); stg16(base + elem_off * 4 + 16, ET<T>::pack(f + 4)); }
+}
+template <typename T> __device__ __forceinline__ void ld8(const unsigned char* base, size_t elem_off, float* f) {
+  if constexpr (sizeof(T) == 2) ET<T>::unpack(ldg16(base + elem_off * 2), f);
+  else { ET<T>::unpack(ldg16(base + elem_off * 4), f); ET<T>::unpack(ldg16(base + elem_off * 4 + 16), f + 4); }
+}
+
+// ---- stem ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                        unsigned char* y, long long M, int Cin, int Cout) {
+  extern __shared__ float sw[];                       // [Cout][Cin] then [Cout]
+  for (int i = threadIdx.x; i < Cout * Cin; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < Cout; i += 256) sw[Cout * Cin + i] = b ? b[i] : 0.f;
+  __syncthreads();
+  const int CG8 = Cout / 8;
+  const long long total = M * CG8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / CG8; const int cg = (int)(i - m * CG8);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = sw[Cout * Cin + cg * 8 + j];
+    for (int c = 0; c < Cin; ++c) {
+      const float xv = x[m * Cin + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaf(xv, sw[(cg * 8 + j) * Cin + c], o[j]);
+    }
+    st8<T>(y, (size_t)m * Cout + cg * 8, o);
+  }
+}
+
+template <typename T, int CINP>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ x, const unsigned char* dy, float* dw, float* db,
+                                                        long long M, int Cin, int Cout, int rows_per_block) {
+  extern __shared__ float red[];                      // [Cout][CINP+1]
+  for (int i = threadIdx.x; i < Cout * (CINP + 1); i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int CG8 = Cout / 8;
+  const int cg = threadIdx.x % CG8, pl = threadIdx.x / CG8, PL = 256 / CG8;
+  float acc[8][CINP], bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bs[j] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CINP; ++c) acc[j][c] = 0.f; }
+  long long r = (long long)blockIdx.x * rows_per_block + pl;
+  long long rend = (long long)(blockIdx.x + 1) * rows_per_block; if (rend > M) rend = M;
+  if (pl < PL) {
+    for (; r < rend; r += PL) {
+      float g[8], xv[CINP];
+      ld8<T>(dy, (size_t)r * Cout + cg * 8, g);
+#pragma unroll
+      for (int c = 0; c < CINP; ++c) xv[c] = c < Cin ? x[r * Cin + c] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { bs[j] += g[j];
+#pragma unroll
+        for (int c = 0; c < CINP; ++c) acc[j][c] = fmaf(g[j], xv[c], acc[j][c]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int c = 0; c < CINP; ++c) if (c < Cin) atomicAdd(&red[(cg * 8 + j) * (CINP + 1) + c], acc[j][c]);
+      atomicAdd(&red[(cg * 8 + j) * (CINP + 1) + CINP], bs[j]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cout * (CINP + 1); i += 256) {
+    const int co = i / (CINP + 1), c = i - co * (CINP + 1);
+    if (c < Cin) unsafeAtomicAdd(&dw[co * Cin + c], red[i]);
+    else if (c == CINP && db) unsafeAtomicAdd(&db[co], red[i]);
+  }
+}
+
+extern "C" int rua_stem_fwd(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, void* stream) {
+  RUA_CHECK_ARG(x && w && y && M > 0, "rua_stem_fwd: bad arguments");
+  RUA_CHECK_ARG(Cin >= 1 && Cin <= 16, "rua_stem_fwd: Cin=%d must be in 1..16", Cin);
+  RUA_CHECK_ARG(Cout % 8 == 0 && Cout <= 256, "rua_stem_fwd: Cout=%d must be a multiple of 8 (<=256)", Cout);
+  const size_t smem = (size_t)(Cout * Cin + Cout) * 4;
+  int64_t g = (M * (Cout / 8) + 255) / 256; if (g > 4096) g = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout);
+  else hipLaunchKernelGGL((stem_fwd_kernel<float>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout);
+  RUA_LAUNCH_CHECK("rua_stem_fwd");
+  return RUA_OK;
+}
+
+extern "C" int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db, int64_t M, int Cin, int Cout, int dtype, void* stream) {
+  RUA_CHECK_ARG(x && dy && dw && M > 0, "rua_stem_bwd: bad arguments");
+  RUA_CHECK_ARG(Cin >= 1 && Cin <= 16, "rua_stem_bwd: Cin=%d must be in 1..16", Cin);
+  RUA_CHECK_ARG(Cout % 8 == 0 && Cout <= 256 && 256 % (Cout / 8) == 0, "rua_stem_bwd: unsupported Cout=%d", Cout);
+  int64_t blocks = 1024; int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
+  const int g = (int)((M + rpb - 1) / rpb);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned char* d = (const unsigned char*)dy;
+  if (Cin <= 8) {
+    const size_t smem = (size_t)Cout * 9 * 4;
+    if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, 8>), dim3(g), dim3(256), smem, st, x, d, dw, db, (long long)M, Cin, Cout, (int)rpb);
+    else hipLaunchKernelGGL((stem_bwd_kernel<float, 8>), dim3(g), dim3(256), smem, st, x, d, dw, db, (long long)M, Cin, Cout, (int)rpb);
+  } else {
+    const size_t smem = (size_t)Cout * 17 * 4;
+    if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, 16>), dim3(g), dim3(256), smem, st, x, d, dw, db, (long long)M, Cin, Cout, (int)rpb);
+    else hipLaunchKernelGGL((stem_bwd_kernel<float, 16>), dim3(g), dim3(256), smem, st, x, d, dw, db, (long long)M, Cin, Cout, (int)rpb);
+  }
+  RUA_LAUNCH_CHECK("rua_stem_bwd");
+  return RUA_OK;
+}
+
+// ---- heads -------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned char* x, const float* __restrict__ w, const float* __restrict__ b,
+                                                        float* z, float* p, long long M, int Cin, int Cout, int act) {
+  constexpr int VEC = ET<T>::VEC;
+  extern __shared__ float sw[];                       // [Cout][Cin] + [Cout]
+  for (int i = threadIdx.x; i < Cout * Cin; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < Cout; i += 256) sw[Cout * Cin + i] = b ? b[i] : 0.f;
+  __syncthreads();
+  const int CGI = Cin / VEC;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+    float acc[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) acc[co] = co < Cout ? sw[Cout * Cin + co] : 0.f;
+    for (int cp = 0; cp < CGI; ++cp) {
+      float xv[VEC];
+      ET<T>::unpack(ldg16(x + ((size_t)m * CGI + cp) * 16), xv);
+#pragma unroll
+      for (int co = 0; co < 8; ++co) {
+        if (co < Cout) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[co] = fmaf(xv[j], sw[co * Cin + cp * VEC + j], acc[co]);
+        }
+      }
+    }
+    float pr[8];
+    if (act == RUA_ACT_SOFTMAX) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int co = 0; co < 8; ++co) if (co < Cout) mx = fmaxf(mx, acc[co]);
+      float s = 0.f;
+#pragma unroll
+      for (int co = 0; co < 8; ++co) { pr[co] = co < Cout ? expf(acc[co] - mx) : 0.f; s += pr[co]; }
+      const float inv = 1.f / s;
+#pragma unroll
+      for (int co = 0; co < 8; ++co) pr[co] *= inv;
+    } else if (act == RUA_ACT_SIGMOID) {
+#pragma unroll
+      for (int co = 0; co < 8; ++co) pr[co] = 1.f / (1.f + expf(-acc[co]));
+    } else {
+#pragma unroll
+      for (int co = 0; co < 8; ++co) pr[co] = acc[co];
+    }
+#pragma unroll
+    for (int co = 0; co < 8; ++co) if (co < Cout) { if (z) z[m * Cout + co] = acc[co]; p[m * Cout + co] = pr[co]; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, const float* __restrict__ dz, const float* __restrict__ w,
+                                                        unsigned char* dx, int accumulate_dx, float* dw, float* db,
+                                                        long long M, int Cin, int Cout, int rows_per_block) {
+  constexpr int VEC = ET<T>::VEC;
+  extern __shared__ float red[];                      // [Cout][Cin] + [Cout]
+  for (int i = threadIdx.x; i < Cout * Cin + Cout; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int CGI = Cin / VEC;
+  const int cp = threadIdx.x % CGI, pl = threadIdx.x / CGI, PL = 256 / CGI;
+  float wr[8][VEC], acc[8][VEC], bs[8];
+#pragma unroll
+  for (int co = 0; co < 8; ++co) { bs[co] = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { wr[co][j] = co < Cout ? w[co * Cin + cp * VEC + j] : 0.f; acc[co][j] = 0.f; } }
+  long long r = (long long)blockIdx.x * rows_per_block + pl;
+  long long rend = (long long)(blockIdx.x + 1) * rows_per_block; if (rend > M) rend = M;
+  if (pl < PL) {
+    for (; r < rend; r += PL) {
+      float xv[VEC], g[8], o[VEC];
+      ET<T>::unpack(ldg16(x + ((size_t)r * CGI + cp) * 16), xv);
+#pragma unroll
+      for (int co = 0; co < 8; ++co) g[co] = co < Cout ? dz[r * Cout + co] : 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+      if (dx && accumulate_dx) ET<T>::unpack(ldg16(dx + ((size_t)r * CGI + cp) * 16), o);
+#pragma unroll
+      for (int co = 0; co < 8; ++co) {
+        bs[co] += g[co];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { o[j] = fmaf(g[co], wr[co][j], o[j]); acc[co][j] = fmaf(g[co], xv[j], acc[co][j]); }
+      }
+      if (dx) stg16(dx + ((size_t)r * CGI + cp) * 16, ET<T>::pack(o));
+    }
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+      if (co < Cout) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) atomicAdd(&red[co * Cin + cp * VEC + j], acc[co][j]);
+        if (cp == 0) atomicAdd(&red[Cout * Cin + co], bs[co]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cout * Cin + Cout; i += 256) {
+    if (i < Cout * Cin) unsafeAtomicAdd(&dw[i], red[i]);
+    else if (db) unsafeAtomicAdd(&db[i - Cout * Cin], red[i]);
+  }
+}
+
+extern "C" int rua_head_fwd(const void* x, const float* w, const float* b, float* z, float* p, int64_t M, int Cin, int Cout, int act, int dtype, void* stream) {
+  RUA_CHECK_ARG(x && w && p && M > 0, "rua_head_fwd: bad arguments");
+  const int vec = dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(Cin % vec == 0 && Cin <= 256, "rua_head_fwd: Cin=%d must be a multiple of %d (<=256)", Cin, vec);
+  RUA_CHECK_ARG(Cout >= 1 && Cout <= 8, "rua_head_fwd: Cout=%d must be in 1..8", Cout);
+  const size_t smem = (size_t)(Cout * Cin + Cout) * 4;
+  int64_t g = (M + 255) / 256; if (g > 4096) g = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((head_fwd_kernel<bf16_t>), dim3((int)g), dim3(256), smem, st, (const unsigned char*)x, w, b, z, p, (long long)M, Cin, Cout, act);
+  else hipLaunchKernelGGL((head_fwd_kernel<float>), dim3((int)g), dim3(256), smem, st, (const unsigned char*)x, w, b, z, p, (long long)M, Cin, Cout, act);
+  RUA_LAUNCH_CHECK("rua_head_fwd");
+  return RUA_OK;
+}
+
+extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db,
+                            int64_t M, int Cin, int Cout, int dtype, void* stream) {
+  RUA_CHECK_ARG(x && dz && w && dw && M > 0, "rua_head_bwd: bad arguments");
+  const int vec = dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(Cin % vec == 0 && Cin <= 256 && 256 % (Cin / vec) == 0, "rua_head_bwd: unsupported Cin=%d", Cin);
+  RUA_CHECK_ARG(Cout >= 1 && Cout <= 8, "rua_head_bwd: Cout=%d must be in 1..8", Cout);
+  int64_t blocks = 2048; int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
+  const int g = (int)((M + rpb - 1) / rpb);
+  const size_t smem = (size_t)(Cout * Cin + Cout) * 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((head_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, (unsigned char*)dx, accumulate_dx, dw, db, (long long)M, Cin, Cout, (int)rpb);
+  else hipLaunchKernelGGL((head_bwd_kernel<float>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, (unsigned char*)dx, accumulate_dx, dw, db, (long long)M, Cin, Cout, (int)rpb);
+  RUA_LAUNCH_CHECK("rua_head_bwd");
+  return RUA_OK;
+}

@@ -1,0 +1,941 @@
+"""Static-plan execution engine for the ResUnet-a training path on MI355X.
+
+The network is a fixed graph on fixed shapes, so instead of tracing or autograd the engine
+RECORDS, once per (batch, mode), the exact list of librua_hip.so launches for forward,
+backward and the optimizer, with every buffer pre-allocated; a step replays that list on one
+HIP stream (optionally as a captured HIP graph).  PyTorch is used for device memory, streams
+and torch.distributed only.  Reference call sites replaced: ResUnet_a/model2.py:14-193
+(graph), train_ISPRS.py:131,148,167,186 (train_on_batch / test_on_batch), :404-407 (optimizers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+BN_EPS, BN_MOMENTUM, KERAS_EPS = 1e-3, 0.99, 1e-7
+HEADS = ["seg", "bound", "dist", "color"]
+
+
+@dataclass
+class ModelConfig:
+    input_shape: Tuple[int, int, int] = (256, 256, 3)
+    num_classes: int = 5
+    multitasking: bool = False
+    variant: str = "model2"
+    width: int = 32
+    depth: int = 6
+
+    def levels(self):
+        dil = [[1, 3, 15, 31], [1, 3, 15, 31], [1, 3, 15], [1, 3, 15], [1], [1], [1]]
+        return [(self.width * (2 ** i), dil[i]) for i in range(self.depth)]
+
+
+@dataclass
+class LossSpec:
+    """What model.compile(...) received (train_ISPRS.py:411-461)."""
+    kind: Dict[str, int] = field(default_factory=dict)       # head -> L.LOSS_*
+    weight: Dict[str, float] = field(default_factory=dict)   # head -> loss weight
+    class_weights: Optional[List[float]] = None
+    optimizer: str = "adam"
+    lr: float = 1e-3
+    beta_1: float = 0.9
+    beta_2: float = 0.999
+    momentum: float = 0.8
+
+
+# ---------------------------------------------------------------------------------------
+class ParamStore:
+    """All trainable parameters in ONE flat fp32 buffer (Keras creation order), so the optimizer
+    is one launch and gradient all-reduce buckets are contiguous slices.  BN moving statistics
+    live in a second flat buffer.  Conv kernels are stored [tap][Cout][Cin_segment]."""
+
+    def __init__(self):
+        self.entries: List[dict] = []      # trainable entries in order
+        self.state: List[dict] = []        # moving_mean / moving_variance
+        self.n = 0
+        self.ns = 0
+        self.nw = 0                        # elements in the activation-dtype weight copies
+        self.convs: Dict[str, dict] = {}
+        self.bns: Dict[str, dict] = {}
+        self.n_conv = 0
+        self.n_bn = 0
+
+    def _add(self, name, size, **kw):
+        off = self.n
+        self.entries.append(dict(name=name, off=off, size=size, **kw))
+        self.n += (size + 15) // 16 * 16          # 64-byte aligned slices
+        return off
+
+    def conv(self, cins: List[int], cout: int, taps: int, name: Optional[str] = None, mfma: bool = True):
+        if name is None:
+            name = "conv2d" if self.n_conv == 0 else f"conv2d_{self.n_conv}"
+            self.n_conv += 1
+        segs = []
+        c0 = 0
+        for ci in cins:
+            off = self._add(name + "/kernel", taps * cout * ci, kind="kernel", layer=name, taps=taps, cout=cout, cin=ci, cin_off=c0,
+                            cin_total=sum(cins))
+            dst = -1
+            if mfma:
+                dst = self.nw
+                self.nw += (taps * cout * ci + 15) // 16 * 16
+            segs.append(dict(off=off, dst=dst, C=ci))
+            c0 += ci
+        boff = self._add(name + "/bias", cout, kind="bias", layer=name)
+        rec = dict(name=name, segs=segs, bias=boff, taps=taps, cout=cout, mfma=mfma)
+        self.convs[name] = rec
+        return rec
+
+    def bn(self, c: int):
+        name = "batch_normalization" if self.n_bn == 0 else f"batch_normalization_{self.n_bn}"
+        self.n_bn += 1
+        g = self._add(name + "/gamma", c, kind="gamma", layer=name)
+        b = self._add(name + "/beta", c, kind="beta", layer=name)
+        mm = self.ns
+        self.state.append(dict(name=name + "/moving_mean", off=mm, size=c, init=0.0))
+        self.ns += (c + 15) // 16 * 16
+        mv = self.ns
+        self.state.append(dict(name=name + "/moving_variance", off=mv, size=c, init=1.0))
+        self.ns += (c + 15) // 16 * 16
+        rec = dict(name=name, gamma=g, beta=b, mm=mm, mv=mv, C=c)
+        self.bns[name] = rec
+        return rec
+
+    # -- host <-> device ------------------------------------------------------------------
+    def init_host(self, seed: int) -> Tuple[np.ndarray, np.ndarray]:
+        rng = np.random.default_rng(seed)
+        P = np.zeros(self.n, np.float32)
+        S = np.zeros(self.ns, np.float32)
+        limits = {}
+        for e in self.entries:
+            if e["kind"] == "kernel":
+                fan = e["taps"] * e["cin_total"] + e["taps"] * e["cout"]
+                lim = math.sqrt(6.0 / fan)
+                P[e["off"]:e["off"] + e["size"]] = rng.uniform(-lim, lim, e["size"]).astype(np.float32)
+            elif e["kind"] == "gamma":
+                P[e["off"]:e["off"] + e["size"]] = 1.0
+        for s in self.state:
+            S[s["off"]:s["off"] + s["size"]] = s["init"]
+        return P, S
+
+    def from_keras(self, weights: Dict[str, np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+        """Keras-layout dict (kernel HWIO, bias, gamma, beta, moving_*) -> flat host buffers."""
+        P = np.zeros(self.n, np.float32)
+        S = np.zeros(self.ns, np.float32)
+        for e in self.entries:
+            w = np.asarray(weights[e["name"]], np.float32)
+            if e["kind"] == "kernel":
+                kh, kw, cin, cout = w.shape
+                assert kh * kw == e["taps"] and cout == e["cout"] and cin == e["cin_total"], (e["name"], w.shape)
+                seg = w[:, :, e["cin_off"]:e["cin_off"] + e["cin"], :]                      # (kh,kw,ci,co)
+                P[e["off"]:e["off"] + e["size"]] = seg.reshape(kh * kw, e["cin"], cout).transpose(0, 2, 1).reshape(-1)
+            else:
+                assert w.size == e["size"], (e["name"], w.shape)
+                P[e["off"]:e["off"] + e["size"]] = w.reshape(-1)
+        for s in self.state:
+            S[s["off"]:s["off"] + s["size"]] = np.asarray(weights[s["name"]], np.float32).reshape(-1)
+        return P, S
+
+    def to_keras(self, P: np.ndarray, S: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
+        out: Dict[str, np.ndarray] = {}
+        for e in self.entries:
+            v = P[e["off"]:e["off"] + e["size"]]
+            if e["kind"] == "kernel":
+                k = int(round(math.sqrt(e["taps"])))
+                seg = v.reshape(e["taps"], e["cout"], e["cin"]).transpose(0, 2, 1).reshape(k, k, e["cin"], e["cout"])
+                if e["name"] not in out:
+                    out[e["name"]] = np.zeros((k, k, e["cin_total"], e["cout"]), np.float32)
+                out[e["name"]][:, :, e["cin_off"]:e["cin_off"] + e["cin"], :] = seg
+            else:
+                out[e["name"]] = v.copy()
+        if S is not None:
+            for s in self.state:
+                out[s["name"]] = S[s["off"]:s["off"] + s["size"]].copy()
+        return out
+
+    def count(self) -> int:
+        return sum(e["size"] for e in self.entries) + sum(s["size"] for s in self.state)
+
+
+# ---------------------------------------------------------------------------------------
+class Ten:
+    """A device activation tensor [N][H][W][C] (storage owned by a torch tensor)."""
+    __slots__ = ("N", "H", "W", "C", "t", "ptr", "grad", "gw", "stats", "f32")
+
+    def __init__(self, t: torch.Tensor, N, H, W, C, f32=False):
+        self.t, self.N, self.H, self.W, self.C, self.f32 = t, N, H, W, C, f32
+        self.ptr = t.data_ptr()
+        self.grad: Optional["Ten"] = None
+        self.gw = False
+        self.stats: Optional[int] = None
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+
+class _Dummy:
+    """Stand-in for a device allocation during the dry (parameter-enumeration) pass."""
+
+    def __init__(self, n=0):
+        self._n = n
+
+    def data_ptr(self):
+        return 0
+
+    def numel(self):
+        return self._n
+
+    def element_size(self):
+        return 4
+
+    def stride(self, i):
+        return 0
+
+
+class Plan:
+    def __init__(self, dry=False):
+        self.calls: List[tuple] = []
+        self.keep: List[object] = []
+        self.dry = dry
+
+    def add(self, name: str, *args):
+        if not self.dry:
+            self.calls.append((L.lib().raw(name), name, args))
+
+    def run(self, stream_ptr: int):
+        lib = L.lib()
+        s = C.c_void_p(stream_ptr)
+        for fn, name, args in self.calls:
+            rc = fn(*args, s)
+            if rc != 0:
+                lib.check(rc, name)
+
+
+class Coef:
+    """Per-channel fp32 vectors of one BN application (scale, shift, mean, rstd, A, B, C)."""
+
+    def __init__(self, g: "Graph", C: int):
+        t = g.alloc((7, (C + 15) // 16 * 16), torch.float32, zero=True)
+        self.t = t
+        p, st = t.data_ptr(), t.stride(0) * 4
+        self.scale, self.shift, self.mean, self.rstd, self.A, self.B, self.Cc = [p + i * st for i in range(7)]
+
+
+class Graph:
+    """One recorded instance of the network for a fixed batch size and mode."""
+
+    def __init__(self, eng: "Engine", batch: int, training: bool, dry: bool = False):
+        self.e = eng
+        self.dry = dry
+        self.cfg = eng.cfg
+        self.B = batch
+        self.training = training
+        self.dev = eng.dev
+        self.dt = eng.dt
+        self.tdt = torch.bfloat16 if eng.dt == L.RUA_BF16 else torch.float32
+        self.vec = 8 if eng.dt == L.RUA_BF16 else 4
+        self.fwd = Plan(dry)
+        self.bwd = Plan(dry)
+        self.loss_plan = Plan(dry)
+        self.back_steps: List = []
+        self.stats_used = 16                 # the first 16 doubles of the arena are the loss / metric scalars
+        self.act_bytes = 0
+        self._build()
+
+    # -- allocation -------------------------------------------------------------------------
+    def alloc(self, shape, dtype, zero=False):
+        if self.dry:
+            return _Dummy(int(np.prod(shape)))
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+        self.act_bytes += t.numel() * t.element_size()
+        return t
+
+    def new(self, N, H, W, C, f32=False) -> Ten:
+        return Ten(self.alloc((N, H, W, C), torch.float32 if f32 else self.tdt), N, H, W, C, f32)
+
+    def like(self, x: Ten) -> Ten:
+        return self.new(x.N, x.H, x.W, x.C, x.f32)
+
+    def salloc(self, n: int) -> int:
+        """n doubles from the per-step statistics arena (zeroed at the start of every step)."""
+        off = self.stats_used
+        self.stats_used += (n + 7) // 8 * 8
+        if self.dry:
+            return 0
+        assert self.stats_used <= self.e.stats_arena.numel(), "statistics arena exhausted"
+        return self.e.stats_arena.data_ptr() + off * 8
+
+    def gacc(self, x: Ten) -> Tuple[Ten, int]:
+        """Gradient buffer of x and whether the next writer must accumulate."""
+        if x.grad is None:
+            x.grad = self.like(x)
+        acc = 1 if x.gw else 0
+        x.gw = True
+        return x.grad, acc
+
+    # -- primitive recorders ------------------------------------------------------------------
+    def P(self, off):   # pointer into the flat fp32 parameter buffer
+        return 0 if self.dry else self.e.P.data_ptr() + off * 4
+
+    def G(self, off):
+        return 0 if self.dry else self.e.G.data_ptr() + off * 4
+
+    def S(self, off):
+        return 0 if self.dry else self.e.S.data_ptr() + off * 4
+
+    def Wf(self, dst):
+        return 0 if self.dry else self.e.Wf.data_ptr() + dst * self.e.esize
+
+    def Wd(self, dst):
+        return 0 if self.dry else self.e.Wd.data_ptr() + dst * self.e.esize
+
+    def col_stats(self, plan: Plan, x: Ten) -> int:
+        s = self.salloc(2 * x.C)
+        plan.add("rua_col_stats", x.ptr, x.M, x.C, s, self.dt)
+        return s
+
+    def bn_finalize(self, plan: Plan, stats, count, bn, bessel=None) -> Coef:
+        c = Coef(self, bn["C"])
+        plan.keep.append(c)
+        plan.add("rua_bn_finalize", stats if self.training else None, float(count), float(bessel or count),
+                 self.P(bn["gamma"]), self.P(bn["beta"]), self.S(bn["mm"]), self.S(bn["mv"]), BN_MOMENTUM, BN_EPS,
+                 1 if self.training else 0, c.scale, c.shift, c.mean, c.rstd, bn["C"])
+        return c
+
+    def bn_apply(self, plan: Plan, x: Ten, coefs: List[Coef], relu: bool) -> List[Ten]:
+        outs = [self.like(x) for _ in coefs]
+        sc = L.ptr_array([c.scale for c in coefs]); sh = L.ptr_array([c.shift for c in coefs]); ou = L.ptr_array([o.ptr for o in outs])
+        plan.keep += [sc, sh, ou]
+        plan.add("rua_bn_apply", x.ptr, len(coefs), sc, sh, 1 if relu else 0, ou, x.M, x.C, self.dt)
+        return outs
+
+    def conv(self, plan: Plan, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual: Optional[Ten] = None,
+             out_relu=False, stats=None):
+        """segs: [(Ten, up_shift, dil, taps)], layer_segs: [param seg dict] (same order)."""
+        d = L.ConvDesc()
+        d.nseg = len(segs)
+        for i, ((t, up, dil, taps), ps) in enumerate(zip(segs, layer_segs)):
+            assert t.C == ps["C"], (t.C, ps)
+            s = d.seg[i]
+            s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = t.ptr, self.Wf(ps["dst"]), t.C, t.H, t.W, up, dil, taps
+        d.N, d.H, d.W, d.Cout, d.stride, d.dtype = out.N, out.H, out.W, cout, stride, self.dt
+        d.bias = bias_ptr
+        if residual is not None:
+            d.aux, d.aux_mode = residual.ptr, 1
+        d.out_relu = 1 if out_relu else 0
+        d.y, d.out_stride, d.OH, d.OW = out.ptr, 1, out.H, out.W
+        if stats is not None:
+            d.stats, d.stats_mode = stats, 1
+        plan.keep.append(d)
+        plan.add("rua_conv_fwd", C.byref(d))
+
+    def dgrad(self, plan: Plan, dy: Ten, wd_ptr, cin: int, dil: int, taps: int, out: Ten, accumulate: int,
+              mask: Optional[Tuple[Ten, Optional[int], Optional[int]]] = None, stats2: Optional[int] = None,
+              stat_aux: Optional[Ten] = None, out_stride: int = 1):
+        """out (=|+=) conv(dy, W^T flipped) [* relu-mask(aux)], optional sum g / sum g*aux statistics."""
+        d = L.ConvDesc()
+        d.nseg = 1
+        s = d.seg[0]
+        s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = dy.ptr, wd_ptr, dy.C, dy.H, dy.W, 0, dil, taps
+        d.N, d.H, d.W, d.Cout, d.stride, d.dtype = dy.N, dy.H, dy.W, cin, 1, self.dt
+        d.accumulate = accumulate
+        d.y, d.out_stride, d.OH, d.OW = out.ptr, out_stride, out.H, out.W
+        if mask is not None:
+            d.aux, d.aux_mode, d.mscale, d.mshift = mask[0].ptr, 2, mask[1], mask[2]
+        elif stat_aux is not None:
+            d.aux, d.aux_mode = stat_aux.ptr, 3
+        if stats2 is not None:
+            d.stats, d.stats_mode = stats2, 2
+        plan.keep.append(d)
+        plan.add("rua_conv_fwd", C.byref(d))
+
+    def wgrad(self, plan: Plan, a: Ten, dy: Ten, dw_off: int, stride: int, dil: int, taps: int):
+        d = L.WgradDesc()
+        d.a, d.C, d.Hs, d.Ws = a.ptr, a.C, a.H, a.W
+        d.dy, d.Cout, d.H, d.W = dy.ptr, dy.C, dy.H, dy.W
+        d.N, d.stride, d.dil, d.taps, d.dtype = dy.N, stride, dil, taps, self.dt
+        d.dw = self.G(dw_off)
+        plan.keep.append(d)
+        plan.add("rua_conv_wgrad", C.byref(d))
+
+    def bias_grad(self, plan: Plan, dy: Ten, bias_offs: List[int]):
+        s = self.col_stats(plan, dy)
+        dst = L.ptr_array([self.G(o) for o in bias_offs])
+        plan.keep.append(dst)
+        plan.add("rua_stats_to_f32", s, dy.C, dst, len(bias_offs))
+
+    def bn_bwd_finalize(self, plan: Plan, stats2, count, bn, coef: Coef):
+        plan.add("rua_bn_bwd_finalize", stats2, float(count), self.P(bn["gamma"]), coef.mean, coef.rstd,
+                 self.G(bn["gamma"]), self.G(bn["beta"]), coef.A, coef.B, coef.Cc, bn["C"])
+
+    def bn_bwd_apply(self, plan: Plan, gs: List[Ten], coefs: List[Coef], x: Ten, out: Ten, accumulate: int,
+                     dskip: Optional[Ten] = None, masked=False):
+        g = L.ptr_array([t.ptr for t in gs]); A = L.ptr_array([c.A for c in coefs]); Bc = L.ptr_array([c.B for c in coefs])
+        Cc = L.ptr_array([c.Cc for c in coefs]); ms = L.ptr_array([c.scale for c in coefs]); mt = L.ptr_array([c.shift for c in coefs])
+        plan.keep += [g, A, Bc, Cc, ms, mt]
+        plan.add("rua_bn_bwd_apply", len(gs), g, A, Bc, Cc, ms, mt, 1 if masked else 0, x.ptr,
+                 dskip.ptr if dskip is not None else None, out.ptr, accumulate, x.M, x.C, self.dt)
+
+    # -- layers: created on the first graph build, replayed (same order) on later builds ----------
+    def Lconv(self, cins, cout, taps, name=None, mfma=True):
+        return self.e.layer("conv", cins, cout, taps, name, mfma)
+
+    def Lbn(self, c):
+        return self.e.layer("bn", c)
+
+    # -- composites -------------------------------------------------------------------------------
+    def resblock(self, x: Ten, nf: int, dils: List[int]) -> Ten:
+        """model2.py:15-34.  BN1 statistics are shared by all branches (same input)."""
+        tr, F = self.training, self.fwd
+        v2 = self.cfg.variant == "model2"
+        lay = [(self.Lbn(nf), self.Lconv([nf], nf, 9), self.Lbn(nf), self.Lconv([nf], nf, 9)) for _ in dils]
+        cnt = x.M
+        if tr and x.stats is None:
+            x.stats = self.col_stats(F, x)
+        coef1 = [self.bn_finalize(F, x.stats, cnt, l[0]) for l in lay]
+        a1 = self.bn_apply(F, x, coef1, True)
+        y1, coef2, a2 = [], [], []
+        for d, l, a in zip(dils, lay, a1):
+            y = self.like(x)
+            st = self.salloc(2 * nf) if tr else None
+            self.conv(F, [(a, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st)
+            c2 = self.bn_finalize(F, st, cnt, l[2])
+            y1.append(y); coef2.append(c2)
+            a2.append(self.bn_apply(F, y, [c2], True)[0])
+        bsum = self.alloc(((nf + 15) // 16 * 16,), torch.float32, zero=True)
+        bl = L.ptr_array([self.P(l[3]["bias"]) for l in lay])
+        F.keep += [bsum, bl]
+        F.add("rua_add_n", len(lay), bl, bsum.data_ptr(), 0, nf, L.RUA_F32)
+        out = self.like(x)
+        self.conv(F, [(a, 0, d, 9) for a, d in zip(a2, dils)], [l[3]["segs"][0] for l in lay], nf, bsum.data_ptr(), out,
+                  residual=x if v2 else None)
+        if not tr:
+            return out
+
+        def back():
+            Bp = self.bwd
+            dO = out.grad
+            self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
+            g1s = []
+            for d, l, a_1, y, c2, a_2, c1 in zip(dils, lay, a1, y1, coef2, a2, coef1):
+                self.wgrad(Bp, a_2, dO, l[3]["segs"][0]["off"], 1, d, 9)
+                g2 = self.like(x)
+                s2 = self.salloc(2 * nf)
+                self.dgrad(Bp, dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
+                self.bn_bwd_finalize(Bp, s2, cnt, l[2], c2)
+                dy1 = self.like(x)
+                self.bn_bwd_apply(Bp, [g2], [c2], y, dy1, 0)
+                self.bias_grad(Bp, dy1, [l[1]["bias"]])
+                self.wgrad(Bp, a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9)
+                g1 = g2                                    # g2 is dead after bn_bwd_apply: reuse its storage
+                s1 = self.salloc(2 * nf)
+                self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
+                self.bn_bwd_finalize(Bp, s1, cnt, l[0], c1)
+                g1s.append(g1)
+            gx, acc = self.gacc(x)
+            self.bn_bwd_apply(Bp, g1s, coef1, x, gx, acc, dskip=dO if v2 else None)
+        self.back_steps.append(back)
+        return out
+
+    def down(self, x: Ten, nf: int) -> Ten:
+        """Conv2D(nf,(1,1),strides=(2,2)) model2.py:103-111: samples pixels 0,2,4,..; no BN, no activation."""
+        F, tr = self.fwd, self.training
+        lay = self.Lconv([x.C], nf, 1)
+        y = self.new(x.N, x.H // 2, x.W // 2, nf)
+        st = self.salloc(2 * nf) if tr else None
+        self.conv(F, [(x, 0, 1, 1)], lay["segs"], nf, self.P(lay["bias"]), y, stride=2, stats=st)
+        y.stats = st
+        if tr:
+            def back():
+                Bp = self.bwd
+                dy = y.grad
+                self.bias_grad(Bp, dy, [lay["bias"]])
+                self.wgrad(Bp, x, dy, lay["segs"][0]["off"], 2, 1, 1)
+                gx, acc = self.gacc(x)
+                if not acc:
+                    Bp.add("rua_fill_zero", gx.ptr, gx.t.numel() * gx.t.element_size())
+                self.dgrad(Bp, dy, self.Wd(lay["segs"][0]["dst"]), x.C, 1, 1, gx, 1, out_stride=2)
+            self.back_steps.append(back)
+        return y
+
+    def bn_node(self, x: Ten, bn, relu: bool, count=None, bessel=None, stats=None):
+        """y = [relu](BN(x)) materialised; returns (y, coef, backward(fused: bool)).
+        If the single consumer's dgrad wrote g (masked) and statistics itself, `fused` skips both."""
+        F, tr = self.fwd, self.training
+        cnt = count or x.M
+        if tr and stats is None:
+            stats = x.stats if x.stats is not None else self.col_stats(F, x)
+        coef = self.bn_finalize(F, stats, cnt, bn, bessel)
+        y = self.bn_apply(F, x, [coef], relu)[0]
+        node = dict(x=x, y=y, coef=coef, bn=bn, relu=relu, cnt=cnt, s2=None, fused=False)
+
+        def back():
+            Bp = self.bwd
+            g = y.grad
+            if not node["fused"]:
+                node["s2"] = self.salloc(2 * x.C)
+                Bp.add("rua_col_stats2", g.ptr, x.ptr, coef.scale, coef.shift, 1 if relu else 0, x.M, x.C, node["s2"], self.dt)
+            self.bn_bwd_finalize(Bp, node["s2"], cnt, bn, coef)
+            gx, acc = self.gacc(x)
+            self.bn_bwd_apply(Bp, [g], [coef], x, gx, acc, masked=(relu and not node["fused"]))
+        node["back"] = back
+        return y, node
+
+    def fuse_target(self, node):
+        """dgrad epilogue arguments that make `node`'s backward fused (single consumer only)."""
+        node["fused"] = True
+        node["s2"] = self.salloc(2 * node["x"].C)
+        g, _ = self.gacc(node["y"])
+        if node["relu"]:
+            return dict(out=g, mask=(node["x"], node["coef"].scale, node["coef"].shift), stats2=node["s2"])
+        return dict(out=g, stat_aux=node["x"], stats2=node["s2"])
+
+    def conv1x1_multi(self, segs, cout, out_hw, want_stats=True):
+        """1x1 conv over concatenated sources [(Ten, up_shift)] -> raw output (with statistics)."""
+        F, tr = self.fwd, self.training
+        lay = self.Lconv([t.C for t, _ in segs], cout, 1)
+        y = self.new(self.B, out_hw[0], out_hw[1], cout)
+        st = self.salloc(2 * cout) if (tr and want_stats) else None
+        self.conv(F, [(t, up, 1, 1) for t, up in segs], lay["segs"], cout, self.P(lay["bias"]), y, stats=st)
+        y.stats = st
+        return y, lay
+
+    def conv1x1_multi_back(self, Bp, segs, lay, y: Ten, targets):
+        """Backward of conv1x1_multi.  targets[i] = dict(out, mask/stat_aux/stats2) for a fused BN source,
+        or None for a plain accumulate into the source's gradient."""
+        dy = y.grad
+        self.bias_grad(Bp, dy, [lay["bias"]])
+        pooled = {0: dy}
+        for (t, up), seg, tg in zip(segs, lay["segs"], targets):
+            if up not in pooled:
+                k = 1 << up
+                pd = self.new(dy.N, dy.H // k, dy.W // k, dy.C)
+                Bp.add("rua_sumpool", dy.ptr, pd.ptr, dy.N, dy.H, dy.W, dy.C, k, self.dt)
+                pooled[up] = pd
+            d = pooled[up]
+            self.wgrad(Bp, t, d, seg["off"], 1, 1, 1)
+            if tg is None:
+                gx, acc = self.gacc(t)
+                self.dgrad(Bp, d, self.Wd(seg["dst"]), t.C, 1, 1, gx, acc)
+            else:
+                self.dgrad(Bp, d, self.Wd(seg["dst"]), t.C, 1, 1, tg["out"], 0, mask=tg.get("mask"), stats2=tg.get("stats2"),
+                           stat_aux=tg.get("stat_aux"))
+
+    def psp(self, x: Ten, nf: int) -> Ten:
+        """PSPPooling + the ReLU the caller applies (model2.py:41-79,116,142): max-pool k -> [nearest up] ->
+        1x1 conv + BN per branch, concat with the input, 1x1 conv + BN, ReLU.  The pooled branches are
+        convolved and normalised at pooled resolution (conv and BN statistics commute with replication)
+        and the upsample is folded into the fuse conv's read."""
+        F, tr = self.fwd, self.training
+        w_in = self.cfg.input_shape[1]
+        ks = [1, 2] + ([4] if w_in >= 128 else []) + ([8] if w_in >= 256 else [])
+        pooled, idxs = [], []
+        for k in ks:
+            if k == 1:
+                pooled.append(x); idxs.append(None)
+            else:
+                assert x.H % k == 0 and x.W % k == 0, f"PSP pool {k} does not divide {x.H}x{x.W}"
+                p = self.new(x.N, x.H // k, x.W // k, x.C)
+                idx = self.alloc((p.t.numel(),), torch.uint8)
+                F.keep.append(idx)
+                F.add("rua_maxpool_fwd", x.ptr, p.ptr, idx.data_ptr(), x.N, x.H, x.W, x.C, k, self.dt)
+                pooled.append(p); idxs.append(idx)
+        # Keras creates the branch Conv2DN layers (conv, bn) in order, then the fuse Conv2DN
+        br = []
+        for k, p in zip(ks, pooled):
+            z, lay = self.conv1x1_multi([(p, 0)], nf // 4, (p.H, p.W))
+            bn = self.Lbn(nf // 4)
+            zb, node = self.bn_node(z, bn, False, count=z.M, bessel=z.M * k * k, stats=z.stats)
+            br.append((k, p, z, lay, zb, node))
+        segs = [(b[4], int(math.log2(b[0]))) for b in br] + [(x, 0)]
+        zf, layf = self.conv1x1_multi(segs, nf, (x.H, x.W))
+        bnf = self.Lbn(nf)
+        out, nodef = self.bn_node(zf, bnf, True, stats=zf.stats)
+        if tr:
+            def back():
+                Bp = self.bwd
+                nodef["back"]()                                    # out.grad -> zf.grad (unfused: several consumers)
+                targets = [self.fuse_target(b[5]) for b in br] + [None]
+                self.conv1x1_multi_back(Bp, segs, layf, zf, targets)
+                for (k, p, z, lay, zb, node), idx in zip(br, idxs):
+                    node["back"]()                                 # zb.grad -> z.grad
+                    self.conv1x1_multi_back(Bp, [(p, 0)], lay, z, [None])   # -> p.grad (p is x for k == 1)
+                    if k > 1:
+                        gx, acc = self.gacc(x)
+                        Bp.add("rua_maxpool_bwd", p.grad.ptr, idx.data_ptr(), gx.ptr, acc, x.N, x.H, x.W, x.C, k, self.dt)
+            self.back_steps.append(back)
+        return out
+
+    def up_combine(self, x: Ten, skip: Ten, nf: int) -> Ten:
+        """UpSampling(x, nf/2) then combine(., skip, nf)  (model2.py:81-94): nearest x2 -> 1x1 conv -> BN, then
+        ReLU || skip -> 1x1 conv -> BN.  The 1x1 conv and its BN run at LOW resolution (exact: conv and BN
+        batch statistics commute with nearest replication) and the x2 is folded into the combine conv's read."""
+        F, tr = self.fwd, self.training
+        z, lay_u = self.conv1x1_multi([(x, 0)], nf // 2, (x.H, x.W))
+        bn_u = self.Lbn(nf // 2)
+        a, node_u = self.bn_node(z, bn_u, True, count=z.M, bessel=z.M * 4, stats=z.stats)
+        segs = [(a, 1), (skip, 0)]
+        zc, lay_c = self.conv1x1_multi(segs, nf, (skip.H, skip.W))
+        bn_c = self.Lbn(nf)
+        t, node_c = self.bn_node(zc, bn_c, False, stats=zc.stats)
+        if tr:
+            def back():
+                Bp = self.bwd
+                node_c["back"]()
+                self.conv1x1_multi_back(Bp, segs, lay_c, zc, [self.fuse_target(node_u), None])
+                node_u["back"]()
+                self.conv1x1_multi_back(Bp, [(x, 0)], lay_u, z, [None])
+            self.back_steps.append(back)
+        return t
+
+    def final_combine(self, x: Ten, c1: Ten, nf: int) -> Ten:
+        """x_comb = combine(x, c1, 32)  (model2.py:140): ReLU(x) || c1 -> 1x1 conv -> BN."""
+        F, tr = self.fwd, self.training
+        r = self.like(x)
+        F.add("rua_relu", x.ptr, r.ptr, x.t.numel(), self.dt)
+        segs = [(r, 0), (c1, 0)]
+        zc, lay = self.conv1x1_multi(segs, nf, (x.H, x.W))
+        bn = self.Lbn(nf)
+        t, node = self.bn_node(zc, bn, False, stats=zc.stats)
+        if tr:
+            def back():
+                Bp = self.bwd
+                node["back"]()
+                gx, acc = self.gacc(x)
+                assert acc == 0
+                self.conv1x1_multi_back(Bp, segs, lay, zc, [dict(out=gx, mask=(x, None, None)), None])
+            self.back_steps.append(back)
+        return t
+
+    def conv3x3_relu(self, x: Ten, nf: int, name=None):
+        """ZeroPadding2D(1)+Conv2D(32,(3,3),relu,valid) of the heads (model2.py:153-158) == same-pad 3x3 + ReLU."""
+        F, tr = self.fwd, self.training
+        lay = self.Lconv([x.C], nf, 9, name=name)
+        y = self.new(x.N, x.H, x.W, nf)
+        self.conv(F, [(x, 0, 1, 9)], lay["segs"], nf, self.P(lay["bias"]), y, out_relu=True)
+        if tr:
+            def back():
+                Bp = self.bwd
+                dy = y.grad
+                Bp.add("rua_relu_mask", dy.ptr, y.ptr, y.t.numel(), self.dt)
+                self.bias_grad(Bp, dy, [lay["bias"]])
+                self.wgrad(Bp, x, dy, lay["segs"][0]["off"], 1, 1, 9)
+                gx, acc = self.gacc(x)
+                self.dgrad(Bp, dy, self.Wd(lay["segs"][0]["dst"]), x.C, 1, 9, gx, acc)
+            self.back_steps.append(back)
+        return y
+
+    def head(self, x: Ten, cout: int, act: int, hname: str, name=None):
+        """Conv2D(C,(1,1)) + softmax/sigmoid, its loss and the gradient w.r.t. the logits."""
+        F, tr = self.fwd, self.training
+        lay = self.Lconv([x.C], cout, 1, name=name, mfma=False)
+        z = self.new(x.N, x.H, x.W, cout, f32=True)
+        p = self.new(x.N, x.H, x.W, cout, f32=True)
+        F.add("rua_head_fwd", x.ptr, self.P(lay["segs"][0]["off"]), self.P(lay["bias"]), z.ptr, p.ptr, x.M, x.C, cout, act, self.dt)
+        y = self.new(x.N, x.H, x.W, cout, f32=True)           # label buffer (host uploads into it)
+        h = dict(name=hname, x=x, z=z, p=p, y=y, lay=lay, act=act, C=cout, slot=len(self.heads))
+        self.heads.append(h)
+        return h
+
+    def head_loss(self, h):
+        """Loss value (fp64 scalar slot) and, in training, d(total)/d(logits) -> head weights and x.grad."""
+        sp, LP = self.e.loss, self.loss_plan
+        kind, wgt = sp.kind[h["name"]], sp.weight[h["name"]]
+        B, HW, Cc = self.B, h["x"].H * h["x"].W, h["C"]
+        M = B * HW
+        slot = self.e.scalars_ptr + h["slot"] * 8
+        coef = None
+        if kind == L.LOSS_TANIMOTO:
+            sums = self.salloc(B * Cc * 6)
+            coef = self.alloc((B * Cc * 3,), torch.float32, zero=True)
+            LP.keep.append(coef)
+            LP.add("rua_tanimoto_sums", h["p"].ptr, h["y"].ptr, B, HW, Cc, sums)
+            LP.add("rua_tanimoto_finalize", sums, B, HW, Cc, wgt / B, slot, coef.data_ptr())
+            h["norm"] = 1.0
+        else:
+            LP.add("rua_pixel_loss", kind, h["p"].ptr, h["z"].ptr, h["y"].ptr, self.e.class_w_ptr, M, Cc, slot)
+            h["norm"] = 1.0 / M
+        if not self.training:
+            return
+
+        def back():
+            Bp = self.bwd
+            dz = self.new(B, h["x"].H, h["x"].W, Cc, f32=True)
+            gs = wgt / B if kind == L.LOSS_TANIMOTO else wgt / M
+            Bp.add("rua_head_dz", kind, h["act"], h["p"].ptr, h["y"].ptr, coef.data_ptr() if coef is not None else None,
+                   self.e.class_w_ptr, gs, B, HW, Cc, dz.ptr)
+            gx, acc = self.gacc(h["x"])
+            lay = h["lay"]
+            Bp.add("rua_head_bwd", h["x"].ptr, dz.ptr, self.P(lay["segs"][0]["off"]), gx.ptr, acc, self.G(lay["segs"][0]["off"]),
+                   self.G(lay["bias"]), M, h["x"].C, Cc, self.dt)
+        self.back_steps.append(back)
+
+    # -- whole network ---------------------------------------------------------------------------------
+    def _build(self):
+        cfg, F, tr = self.cfg, self.fwd, self.training
+        if cfg.variant != "model2":
+            raise NotImplementedError("variant 'model' (ResUnet_a/model.py graph) is not built yet; use model2")
+        H, W, Cin = cfg.input_shape
+        lv = cfg.levels()
+        w0 = lv[0][0]
+        self.heads: List[dict] = []
+        self.x_in = self.new(self.B, H, W, Cin, f32=True)
+        stem = self.Lconv([Cin], w0, 1, mfma=False)
+        c1 = self.new(self.B, H, W, w0)
+        F.add("rua_stem_fwd", self.x_in.ptr, self.P(stem["segs"][0]["off"]), self.P(stem["bias"]), c1.ptr, c1.M, Cin, w0, self.dt)
+        if tr:
+            def stem_back():
+                self.bwd.add("rua_stem_bwd", self.x_in.ptr, c1.grad.ptr, self.G(stem["segs"][0]["off"]), self.G(stem["bias"]),
+                             c1.M, Cin, w0, self.dt)
+            self.back_steps.append(stem_back)
+        x = c1
+        skips = []
+        for i, (nf, dils) in enumerate(lv):
+            if i > 0:
+                x = self.down(x, nf)
+            x = self.resblock(x, nf, dils)
+            skips.append(x)
+        x = self.psp(x, lv[-1][0])
+        for i in range(len(lv) - 2, -1, -1):
+            nf, dils = lv[i]
+            x = self.up_combine(x, skips[i], nf)
+            x = self.resblock(x, nf, dils)
+        x_comb = self.final_combine(x, c1, w0)
+        x_psp = self.psp(x_comb, w0)
+        Cc = cfg.num_classes
+        if not cfg.multitasking:
+            self.head(x_psp, Cc, L.ACT_SOFTMAX, "seg")
+        else:
+            s = self.conv3x3_relu(x_psp, w0, "seg1")
+            s = self.conv3x3_relu(s, w0, "seg2")
+            self.head(s, Cc, L.ACT_SOFTMAX, "seg", "seg3")
+            b = self.conv3x3_relu(x_psp, w0)
+            self.head(b, Cc, L.ACT_SIGMOID, "bound")
+            d = self.conv3x3_relu(x_comb, w0)
+            d = self.conv3x3_relu(d, w0)
+            self.head(d, Cc, L.ACT_SOFTMAX, "dist")
+            self.head(x_comb, 3, L.ACT_SIGMOID, "color", "color")
+        self.outputs = {h["name"]: h for h in self.heads}
+        if self.e.loss is not None and not self.dry:
+            self._record_losses()
+
+    def _record_losses(self):
+        """Loss / metric launches and (training) the whole backward plan, in reverse creation order."""
+        for h in self.heads:
+            self.head_loss(h)
+        seg = self.outputs["seg"]
+        self.loss_plan.add("rua_seg_metrics", seg["p"].ptr, seg["y"].ptr, seg["x"].M, seg["C"], self.e.scalars_ptr + 8 * 8)
+        if self.training:
+            for step in reversed(self.back_steps):
+                step()
+            self.back_steps = []
+
+
+# ---------------------------------------------------------------------------------------
+class Engine:
+    """Owns parameters, optimizer state and the recorded graphs; one instance per process (= per GPU)."""
+
+    def __init__(self, cfg: ModelConfig, dtype: str = "bf16", device: Optional[torch.device] = None, seed: int = 0,
+                 _layout_only: bool = False):
+        assert dtype in ("bf16", "f32")
+        self.cfg = cfg
+        self.dt = L.RUA_BF16 if dtype == "bf16" else L.RUA_F32
+        self.dtype = dtype
+        self.esize = 2 if dtype == "bf16" else 4
+        if cfg.width % 32 != 0:
+            raise ValueError(f"width={cfg.width}: the first-stage width must be a multiple of 32 (PSP branches are width/4 "
+                             "channels and the MFMA epilogue stores 8-channel pieces)")
+        self.dev = None
+        self.params = ParamStore()
+        self.layers: List[dict] = []
+        self.cursor = 0
+        self.built = False
+        self.loss: Optional[LossSpec] = None
+        self.graphs: Dict[Tuple[int, bool], Graph] = {}
+        self.class_w_ptr = None
+        self.scalars_ptr = 0
+        Graph(self, 1, True, dry=True)                      # enumerate layers / parameters (no device needed)
+        self.built = True
+        ps = self.params
+        if _layout_only:
+            return
+        L.lib()                                             # raises if librua_hip.so is missing
+        if not torch.cuda.is_available():
+            raise L.RuaError("no HIP device visible: the ResUnet-a training path runs on MI355X only (there is no CPU fallback)")
+        self.dev = device or torch.device("cuda", torch.cuda.current_device())
+        z = lambda n, dt=torch.float32: torch.zeros(max(n, 16), dtype=dt, device=self.dev)
+        self.P, self.G, self.M1, self.V1, self.S = z(ps.n), z(ps.n), z(ps.n), z(ps.n), z(ps.ns)
+        tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.Wf, self.Wd = z(ps.nw, tdt), z(ps.nw, tdt)
+        items = np.zeros(0, dtype=[("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("cout", "<i4"), ("c", "<i4"), ("pad", "<i4")])
+        rows, mx = [], 1
+        for lay in self.layers:
+            if "segs" in lay and lay["mfma"]:
+                for sg in lay["segs"]:
+                    rows.append((sg["off"], sg["dst"], lay["taps"], lay["cout"], sg["C"], 0))
+                    mx = max(mx, lay["taps"] * lay["cout"] * sg["C"])
+        items = np.array(rows, dtype=items.dtype)
+        self.wprep_items = torch.from_numpy(np.frombuffer(items.tobytes(), dtype=np.uint8).copy()).to(self.dev)
+        self.wprep_n, self.wprep_max = len(rows), mx
+        self.stats_arena = torch.zeros(1 << 20, dtype=torch.float64, device=self.dev)
+        self.scalars_ptr = self.stats_arena.data_ptr()
+        self.t = 0
+        self.weights_dirty = True
+        self.world = 1
+        self.dist = None
+        P, S = ps.init_host(seed)
+        self.P.copy_(torch.from_numpy(P)); self.S.copy_(torch.from_numpy(S))
+
+    @classmethod
+    def param_layout(cls, cfg: ModelConfig, dtype: str = "f32") -> ParamStore:
+        """Parameter table (names, shapes, flat offsets) without touching a device."""
+        return cls(cfg, dtype, _layout_only=True).params
+
+    # -- layer registry ------------------------------------------------------------------------------
+    def layer(self, kind, *args):
+        if not self.built:
+            rec = self.params.conv(*args) if kind == "conv" else self.params.bn(*args)
+            self.layers.append(rec)
+            return rec
+        rec = self.layers[self.cursor]
+        self.cursor += 1
+        return rec
+
+    def graph(self, batch: int, training: bool) -> Graph:
+        key = (batch, training)
+        if key not in self.graphs:
+            assert self.loss is not None, "compile() first"
+            self.cursor = 0
+            self.graphs[key] = Graph(self, batch, training)
+            assert self.cursor == len(self.layers)
+        return self.graphs[key]
+
+    def compile(self, spec: LossSpec):
+        self.loss = spec
+        self.graphs = {}
+        if spec.class_weights is not None:
+            self.class_w = torch.tensor(list(spec.class_weights) + [0.0] * 8, dtype=torch.float32, device=self.dev)
+            self.class_w_ptr = self.class_w.data_ptr()
+        else:
+            self.class_w_ptr = None
+
+    # -- weights ---------------------------------------------------------------------------------------
+    def set_weights(self, keras_dict: Dict[str, np.ndarray]):
+        P, S = self.params.from_keras(keras_dict)
+        self.P.copy_(torch.from_numpy(P)); self.S.copy_(torch.from_numpy(S))
+        self.weights_dirty = True
+
+    def get_weights(self) -> Dict[str, np.ndarray]:
+        return self.params.to_keras(self.P.cpu().numpy(), self.S.cpu().numpy())
+
+    def grads_keras(self) -> Dict[str, np.ndarray]:
+        return self.params.to_keras(self.G.cpu().numpy())
+
+    def count_params(self) -> int:
+        return self.params.count()
+
+    # -- execution ---------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _prep_weights(self, s):
+        if self.weights_dirty:
+            L.lib().call("rua_weight_prep", self.P.data_ptr(), self.Wf.data_ptr(), self.Wd.data_ptr(), self.wprep_items.data_ptr(),
+                         self.wprep_n, self.wprep_max, self.dt, C.c_void_p(s))
+            self.weights_dirty = False
+
+    def _upload(self, g: Graph, x, y):
+        def put(dst: torch.Tensor, src):
+            if src is None:
+                return
+            if isinstance(src, np.ndarray):
+                src = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32))
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"expected shape {tuple(dst.shape)}, got {tuple(src.shape)}")
+            dst.copy_(src, non_blocking=True)
+        put(g.x_in.t, x)
+        if y is not None:
+            if isinstance(y, dict):
+                for h in g.heads:
+                    put(h["y"].t, y[h["name"]])
+            else:
+                put(g.heads[0]["y"].t, y)
+
+    def _zero_arena(self, g: Graph, s):
+        L.lib().call("rua_fill_zero", self.stats_arena.data_ptr(), g.stats_used * 8, C.c_void_p(s))
+
+    def _results(self, g: Graph):
+        sc = self.stats_arena[:16].cpu().numpy()
+        per = [float(sc[h["slot"]] * h["norm"]) for h in g.heads]
+        total = sum(self.loss.weight[h["name"]] * v for h, v in zip(g.heads, per))
+        M = g.outputs["seg"]["x"].M
+        mets = [float(sc[8] / M), float(sc[9]), float(sc[10]), float(sc[11]), float(sc[12])]
+        if self.cfg.multitasking:
+            return [total] + per + mets
+        return [total] + mets
+
+    def forward_backward(self, x=None, y=None):
+        """forward + losses + backward on the current stream; gradients are left in self.G."""
+        B = x.shape[0] if x is not None else self._last_B
+        self._last_B = B
+        g = self.graph(B, True)
+        s = self._stream()
+        self._upload(g, x, y)
+        self._zero_arena(g, s)
+        self._prep_weights(s)
+        g.fwd.run(s)
+        g.loss_plan.run(s)
+        g.bwd.run(s)
+        return g
+
+    def optimizer_step(self, grad_scale: float = 1.0):
+        sp, s = self.loss, self._stream()
+        self.t += 1
+        if sp.optimizer == "adam":
+            lr_t = sp.lr * math.sqrt(1.0 - sp.beta_2 ** self.t) / (1.0 - sp.beta_1 ** self.t)
+            L.lib().call("rua_adam_step", self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.V1.data_ptr(), self.params.n,
+                         lr_t, sp.beta_1, sp.beta_2, KERAS_EPS, grad_scale, 1, C.c_void_p(s))
+        else:
+            L.lib().call("rua_sgd_step", self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.params.n, sp.lr, sp.momentum,
+                         grad_scale, 1, C.c_void_p(s))
+        self.weights_dirty = True
+
+    def train_step(self, x=None, y=None, fetch: bool = True):
+        """One Keras train_on_batch (train_ISPRS.py:131,148): returns the metric list in the reference's order."""
+        g = self.forward_backward(x, y)
+        if self.dist is not None:
+            self.dist.reduce_gradients(self)
+        self.optimizer_step(1.0 / self.world)
+        return self._results(g) if fetch else None
+
+    def test_step(self, x, y):
+        """Keras test_on_batch (train_ISPRS.py:167,186): BN uses moving statistics, nothing is updated."""
+        g = self.graph(x.shape[0], False)
+        s = self._stream()
+        self._upload(g, x, y)
+        self._zero_arena(g, s)
+        self._prep_weights(s)
+        g.fwd.run(s)
+        g.loss_plan.run(s)
+        return self._results(g)
+
+    def predict(self, x):
+        g = self.graph(x.shape[0], False)
+        s = self._stream()
+        self._upload(g, x, None)
+        self._prep_weights(s)
+        g.fwd.run(s)
+        outs = {h["name"]: h["p"].t.cpu().numpy() for h in g.heads}
+        return outs if self.cfg.multitasking else outs["seg"]
+
+    def logits(self, training: bool, batch: int) -> Dict[str, np.ndarray]:
+        g = self.graph(batch, training)
+        return {h["name"]: h["z"].t.cpu().numpy() for h in g.heads}

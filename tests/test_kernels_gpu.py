@@ -1,0 +1,457 @@
+"""Kernel-level parity through the C ABI (librua_hip.so) against plain PyTorch-CPU fp32 references.
+fp32 storage must match to ~1e-5 relative (exact-fp32 MFMA, different summation order);
+bf16 storage is compared with the bf16-rounded inputs, tolerance 2e-2 of the output scale."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from resunet_a_mltsk_keras_amd import _lib as L  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def tdt(dt):
+    return torch.bfloat16 if dt == L.RUA_BF16 else torch.float32
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_dev(a, dt):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev()).to(tdt(dt)).contiguous()
+
+
+def rel_err(got, exp):
+    got = np.asarray(got, np.float64); exp = np.asarray(exp, np.float64)
+    return float(np.abs(got - exp).max() / (np.abs(exp).max() + 1e-12))
+
+
+def tol(dt):
+    return 2e-2 if dt == L.RUA_BF16 else 2e-5
+
+
+def rnd(dt, a):
+    """what the device sees after storage rounding"""
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return t.to(tdt(dt)).float()
+
+
+def ref_conv_nhwc(x, w_tco_ci, bias, dil, taps, stride=1, up=0):
+    """x NHWC float tensor, w [taps][Cout][Cin] -> NHWC"""
+    xt = x.permute(0, 3, 1, 2)
+    if up:
+        k = 1 << up
+        xt = xt.repeat_interleave(k, 2).repeat_interleave(k, 3)
+    k = 3 if taps == 9 else 1
+    Cout, Cin = w_tco_ci.shape[1], w_tco_ci.shape[2]
+    w = w_tco_ci.reshape(k, k, Cout, Cin).permute(2, 3, 0, 1)
+    y = F.conv2d(xt.double(), w.double(), None if bias is None else bias.double(), stride=stride, padding=dil * (k // 2), dilation=dil)
+    return y.permute(0, 2, 3, 1)
+
+
+CONV_CASES = [
+    # N, H, W, [(C, up, dil, taps)], Cout, stride
+    (2, 16, 16, [(32, 0, 1, 9)], 32, 1),
+    (1, 20, 12, [(32, 0, 3, 9)], 64, 1),
+    (2, 16, 16, [(16, 0, 15, 9)], 32, 1),
+    (1, 40, 40, [(64, 0, 31, 9)], 64, 1),
+    (2, 8, 8, [(128, 0, 1, 9)], 256, 1),
+    (2, 16, 16, [(32, 0, 1, 1)], 64, 2),
+    (2, 16, 16, [(16, 1, 1, 1), (32, 0, 1, 1)], 32, 1),
+    (1, 16, 16, [(8, 0, 1, 1), (8, 1, 1, 1), (8, 2, 1, 1), (8, 3, 1, 1), (32, 0, 1, 1)], 32, 1),
+    (1, 16, 16, [(32, 0, 1, 9), (32, 0, 3, 9), (32, 0, 15, 9)], 32, 1),
+    (3, 8, 8, [(40, 0, 1, 9)], 8, 1),
+]
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(case, dt):
+    N, H, W, segs, Cout, stride = case
+    rng = np.random.default_rng(1)
+    lib = L.lib()
+    d = L.ConvDesc()
+    d.nseg = len(segs)
+    keep = []
+    exp = 0
+    for i, (Cs, up, dil, taps) in enumerate(segs):
+        Hs, Ws = (H * stride) >> up, (W * stride) >> up
+        x = rng.standard_normal((N, Hs, Ws, Cs)).astype(np.float32)
+        w = (rng.standard_normal((taps, Cout, Cs)) / np.sqrt(taps * Cs)).astype(np.float32)
+        xd, wd = to_dev(x, dt), to_dev(w, dt)
+        keep += [xd, wd]
+        s = d.seg[i]
+        s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = xd.data_ptr(), wd.data_ptr(), Cs, Hs, Ws, up, dil, taps
+        exp = exp + ref_conv_nhwc(rnd(dt, x), rnd(dt, w), None, dil, taps, stride, up)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    bd, rd = torch.from_numpy(bias).to(dev()), to_dev(res, dt)
+    y = torch.empty((N, H, W, Cout), dtype=tdt(dt), device=dev())
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev())
+    d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cout, stride, dt
+    d.bias, d.aux, d.aux_mode = bd.data_ptr(), rd.data_ptr(), 1
+    d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+    d.stats, d.stats_mode = stats.data_ptr(), 1
+    lib.call("rua_conv_fwd", C.byref(d), stream())
+    torch.cuda.synchronize()
+    exp = (exp + torch.from_numpy(bias).double() + rnd(dt, res).double()).numpy()
+    got = y.float().cpu().numpy()
+    assert rel_err(got, exp) < tol(dt)
+    st = stats.cpu().numpy()
+    assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
+    assert rel_err(st[Cout:], (exp ** 2).sum(axis=(0, 1, 2))) < 5 * tol(dt)
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+def test_conv_mask_accumulate_strided_out(dt):
+    """dgrad-style epilogues: ReLU mask from aux with scale/shift, statistics sum g / sum g*aux,
+    accumulate into a strided (stride-2 scatter) output."""
+    rng = np.random.default_rng(2)
+    lib = L.lib()
+    N, H, W, Cs, Cout = 2, 8, 8, 32, 32
+    x = rng.standard_normal((N, H, W, Cs)).astype(np.float32)
+    w = (rng.standard_normal((9, Cout, Cs)) / 17).astype(np.float32)
+    aux = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    ms = rng.standard_normal(Cout).astype(np.float32)
+    mt = rng.standard_normal(Cout).astype(np.float32)
+    xd, wd, ad = to_dev(x, dt), to_dev(w, dt), to_dev(aux, dt)
+    msd, mtd = torch.from_numpy(ms).to(dev()), torch.from_numpy(mt).to(dev())
+    y = torch.empty((N, H, W, Cout), dtype=tdt(dt), device=dev())
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev())
+    d = L.ConvDesc()
+    d.nseg = 1
+    s = d.seg[0]
+    s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = xd.data_ptr(), wd.data_ptr(), Cs, H, W, 0, 3, 9
+    d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cout, 1, dt
+    d.aux, d.aux_mode, d.mscale, d.mshift = ad.data_ptr(), 2, msd.data_ptr(), mtd.data_ptr()
+    d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+    d.stats, d.stats_mode = stats.data_ptr(), 2
+    lib.call("rua_conv_fwd", C.byref(d), stream())
+    torch.cuda.synchronize()
+    conv = ref_conv_nhwc(rnd(dt, x), rnd(dt, w), None, 3, 9).numpy()
+    a = rnd(dt, aux).numpy().astype(np.float64)
+    mask = (np.float32(ms) * a.astype(np.float32) + np.float32(mt)) > 0
+    exp = conv * mask
+    assert rel_err(y.float().cpu().numpy(), exp) < tol(dt)
+    st = stats.cpu().numpy()
+    assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
+    assert rel_err(st[Cout:], (exp * a).sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
+    # strided accumulate: 1x1 conv of a half-resolution tensor scattered to even pixels of a full-res buffer
+    x2 = rng.standard_normal((N, H // 2, W // 2, Cs)).astype(np.float32)
+    w1 = (rng.standard_normal((1, Cout, Cs)) / 6).astype(np.float32)
+    base = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    x2d, w1d, yd = to_dev(x2, dt), to_dev(w1, dt), to_dev(base, dt)
+    d2 = L.ConvDesc()
+    d2.nseg = 1
+    s = d2.seg[0]
+    s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = x2d.data_ptr(), w1d.data_ptr(), Cs, H // 2, W // 2, 0, 1, 1
+    d2.N, d2.H, d2.W, d2.Cout, d2.stride, d2.dtype = N, H // 2, W // 2, Cout, 1, dt
+    d2.accumulate = 1
+    d2.y, d2.out_stride, d2.OH, d2.OW = yd.data_ptr(), 2, H, W
+    lib.call("rua_conv_fwd", C.byref(d2), stream())
+    torch.cuda.synchronize()
+    exp2 = rnd(dt, base).double().numpy()
+    exp2[:, ::2, ::2, :] += ref_conv_nhwc(rnd(dt, x2), rnd(dt, w1), None, 1, 1).numpy()
+    assert rel_err(yd.float().cpu().numpy(), exp2) < tol(dt)
+
+
+WGRAD_CASES = [
+    # N, Hs, Ws, C, Cout, stride, dil, taps
+    (2, 16, 16, 32, 32, 1, 1, 9),
+    (1, 24, 20, 64, 32, 1, 3, 9),
+    (2, 16, 16, 16, 48, 1, 15, 9),
+    (2, 16, 16, 32, 64, 2, 1, 1),
+    (3, 8, 8, 128, 72, 1, 1, 1),
+    (1, 12, 12, 8, 8, 1, 1, 9),
+]
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(case, dt):
+    N, Hs, Ws, Cs, Cout, stride, dil, taps = case
+    H, W = Hs // stride, Ws // stride
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((N, Hs, Ws, Cs)).astype(np.float32)
+    dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    ad, dyd = to_dev(a, dt), to_dev(dy, dt)
+    dw = torch.zeros((taps, Cout, Cs), dtype=torch.float32, device=dev())
+    d = L.WgradDesc()
+    d.a, d.C, d.Hs, d.Ws = ad.data_ptr(), Cs, Hs, Ws
+    d.dy, d.Cout, d.H, d.W = dyd.data_ptr(), Cout, H, W
+    d.N, d.stride, d.dil, d.taps, d.dtype = N, stride, dil, taps, dt
+    d.dw = dw.data_ptr()
+    L.lib().call("rua_conv_wgrad", C.byref(d), stream())
+    torch.cuda.synchronize()
+    w = torch.zeros((taps, Cout, Cs), dtype=torch.float64, requires_grad=True)
+    y = ref_conv_nhwc(rnd(dt, a).double(), w, None, dil, taps, stride)
+    y.backward(rnd(dt, dy).double())
+    assert rel_err(dw.cpu().numpy(), w.grad.numpy()) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+def test_weight_prep_layouts(dt):
+    rng = np.random.default_rng(4)
+    specs = [(9, 32, 16), (1, 8, 64), (9, 8, 8)]
+    offs, total = [], 0
+    for t, co, ci in specs:
+        offs.append(total); total += (t * co * ci + 15) // 16 * 16
+    master = rng.standard_normal(total).astype(np.float32)
+    items = np.array([(o, o, t, co, ci, 0) for o, (t, co, ci) in zip(offs, specs)],
+                     dtype=[("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("cout", "<i4"), ("c", "<i4"), ("pad", "<i4")])
+    it = torch.from_numpy(np.frombuffer(items.tobytes(), dtype=np.uint8).copy()).to(dev())
+    m = torch.from_numpy(master).to(dev())
+    wf = torch.zeros(total, dtype=tdt(dt), device=dev()); wd = torch.zeros(total, dtype=tdt(dt), device=dev())
+    L.lib().call("rua_weight_prep", m.data_ptr(), wf.data_ptr(), wd.data_ptr(), it.data_ptr(), len(specs), 9 * 32 * 16, dt, stream())
+    torch.cuda.synchronize()
+    for o, (t, co, ci) in zip(offs, specs):
+        src = rnd(dt, master[o:o + t * co * ci]).numpy().reshape(t, co, ci)
+        assert np.array_equal(wf[o:o + t * co * ci].float().cpu().numpy().reshape(t, co, ci), src)
+        exp = src[::-1].transpose(0, 2, 1)
+        assert np.array_equal(wd[o:o + t * co * ci].float().cpu().numpy().reshape(t, ci, co), exp)
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+def test_dgrad_equals_autograd(dt):
+    """conv with prepared dgrad weights == d/dx of the forward conv (3x3 dilated and 1x1)."""
+    rng = np.random.default_rng(5)
+    lib = L.lib()
+    for (taps, dil) in [(9, 1), (9, 3), (1, 1)]:
+        N, H, W, Cin, Cout = 2, 12, 12, 16, 32
+        w = (rng.standard_normal((taps, Cout, Cin)) / 8).astype(np.float32)
+        dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+        n = taps * Cout * Cin
+        items = np.array([(0, 0, taps, Cout, Cin, 0)], dtype=[("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("cout", "<i4"), ("c", "<i4"), ("pad", "<i4")])
+        it = torch.from_numpy(np.frombuffer(items.tobytes(), dtype=np.uint8).copy()).to(dev())
+        m = torch.from_numpy(w.reshape(-1)).to(dev())
+        wf = torch.zeros(n, dtype=tdt(dt), device=dev()); wd = torch.zeros(n, dtype=tdt(dt), device=dev())
+        lib.call("rua_weight_prep", m.data_ptr(), wf.data_ptr(), wd.data_ptr(), it.data_ptr(), 1, n, dt, stream())
+        dyd = to_dev(dy, dt)
+        dx = torch.empty((N, H, W, Cin), dtype=tdt(dt), device=dev())
+        d = L.ConvDesc()
+        d.nseg = 1
+        s = d.seg[0]
+        s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = dyd.data_ptr(), wd.data_ptr(), Cout, H, W, 0, dil, taps
+        d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cin, 1, dt
+        d.y, d.out_stride, d.OH, d.OW = dx.data_ptr(), 1, H, W
+        lib.call("rua_conv_fwd", C.byref(d), stream())
+        torch.cuda.synchronize()
+        x = torch.zeros((N, H, W, Cin), dtype=torch.float64, requires_grad=True)
+        y = ref_conv_nhwc(x, rnd(dt, w).double(), None, dil, taps)
+        y.backward(rnd(dt, dy).double())
+        assert rel_err(dx.float().cpu().numpy(), x.grad.numpy()) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+def test_bn_stats_apply_backward(dt):
+    rng = np.random.default_rng(6)
+    lib = L.lib()
+    N, H, W, Cc = 2, 10, 6, 32
+    M = N * H * W
+    x = (rng.standard_normal((M, Cc)) * 2 + 0.5).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, Cc).astype(np.float32); beta = rng.standard_normal(Cc).astype(np.float32)
+    xd = to_dev(x, dt)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+    gd, bd = f(gamma), f(beta)
+    mm, mv = f(np.zeros(Cc)), f(np.ones(Cc))
+    stats = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
+    coef = torch.zeros(7, Cc, dtype=torch.float32, device=dev())
+    cp = [coef[i].data_ptr() for i in range(7)]
+    lib.call("rua_col_stats", xd.data_ptr(), M, Cc, stats.data_ptr(), dt, stream())
+    lib.call("rua_bn_finalize", stats.data_ptr(), float(M), float(M), gd.data_ptr(), bd.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+             0.99, 1e-3, 1, cp[0], cp[1], cp[2], cp[3], Cc, stream())
+    out = torch.empty((M, Cc), dtype=tdt(dt), device=dev())
+    sc, sh, ou = L.ptr_array([cp[0]]), L.ptr_array([cp[1]]), L.ptr_array([out.data_ptr()])
+    lib.call("rua_bn_apply", xd.data_ptr(), 1, sc, sh, 1, ou, M, Cc, dt, stream())
+    torch.cuda.synchronize()
+    xr = rnd(dt, x).double().requires_grad_(True)
+    mean = xr.mean(0); var = xr.var(0, unbiased=False)
+    yr = torch.relu((xr - mean) / torch.sqrt(var + 1e-3) * torch.from_numpy(gamma).double() + torch.from_numpy(beta).double())
+    assert rel_err(out.float().cpu().numpy(), yr.detach().numpy()) < tol(dt)
+    assert np.allclose(mm.cpu().numpy(), 0.01 * mean.detach().numpy(), rtol=1e-4, atol=1e-6)
+    assert np.allclose(mv.cpu().numpy(), 0.99 + 0.01 * var.detach().numpy() * M / (M - 1), rtol=1e-4)
+    # backward
+    g = rng.standard_normal((M, Cc)).astype(np.float32)
+    gdv = to_dev(g, dt)
+    yr.backward(rnd(dt, g).double())
+    st2 = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
+    lib.call("rua_col_stats2", gdv.data_ptr(), xd.data_ptr(), cp[0], cp[1], 1, M, Cc, st2.data_ptr(), dt, stream())
+    dgam = torch.zeros(Cc, device=dev()); dbet = torch.zeros(Cc, device=dev())
+    lib.call("rua_bn_bwd_finalize", st2.data_ptr(), float(M), gd.data_ptr(), cp[2], cp[3], dgam.data_ptr(), dbet.data_ptr(),
+             cp[4], cp[5], cp[6], Cc, stream())
+    dx = torch.empty((M, Cc), dtype=tdt(dt), device=dev())
+    ga, A, B_, C_, ms, mt = (L.ptr_array([gdv.data_ptr()]), L.ptr_array([cp[4]]), L.ptr_array([cp[5]]), L.ptr_array([cp[6]]),
+                             L.ptr_array([cp[0]]), L.ptr_array([cp[1]]))
+    lib.call("rua_bn_bwd_apply", 1, ga, A, B_, C_, ms, mt, 1, xd.data_ptr(), None, dx.data_ptr(), 0, M, Cc, dt, stream())
+    torch.cuda.synchronize()
+    assert rel_err(dx.float().cpu().numpy(), xr.grad.numpy()) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+def test_pooling_family(dt):
+    rng = np.random.default_rng(7)
+    lib = L.lib()
+    N, H, W, Cc = 2, 16, 16, 16
+    x = rng.standard_normal((N, H, W, Cc)).astype(np.float32)
+    xd = to_dev(x, dt)
+    xr = rnd(dt, x)
+    for k in (2, 4, 8):
+        y = torch.empty((N, H // k, W // k, Cc), dtype=tdt(dt), device=dev())
+        idx = torch.empty(y.numel(), dtype=torch.uint8, device=dev())
+        lib.call("rua_maxpool_fwd", xd.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, Cc, k, dt, stream())
+        xt = xr.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        yt = F.max_pool2d(xt, k, k)
+        torch.cuda.synchronize()
+        assert np.array_equal(y.float().cpu().numpy(), yt.detach().permute(0, 2, 3, 1).numpy())
+        g = rng.standard_normal((N, H // k, W // k, Cc)).astype(np.float32)
+        gd = to_dev(g, dt)
+        dx = torch.empty((N, H, W, Cc), dtype=tdt(dt), device=dev())
+        lib.call("rua_maxpool_bwd", gd.data_ptr(), idx.data_ptr(), dx.data_ptr(), 0, N, H, W, Cc, k, dt, stream())
+        yt.backward(rnd(dt, g).permute(0, 3, 1, 2))
+        torch.cuda.synchronize()
+        assert np.array_equal(dx.float().cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
+        sp = torch.empty((N, H // k, W // k, Cc), dtype=tdt(dt), device=dev())
+        lib.call("rua_sumpool", xd.data_ptr(), sp.data_ptr(), N, H, W, Cc, k, dt, stream())
+        torch.cuda.synchronize()
+        exp = F.avg_pool2d(xr.permute(0, 3, 1, 2).double(), k, k).permute(0, 2, 3, 1).numpy() * k * k
+        assert rel_err(sp.float().cpu().numpy(), exp) < tol(dt)
+
+
+def test_stem_and_head_kernels():
+    rng = np.random.default_rng(8)
+    lib = L.lib()
+    for dt in (L.RUA_F32, L.RUA_BF16):
+        M, Cin, Cout = 500, 6, 32
+        x = rng.standard_normal((M, Cin)).astype(np.float32)
+        w = rng.standard_normal((Cout, Cin)).astype(np.float32); b = rng.standard_normal(Cout).astype(np.float32)
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+        xd, wd, bd = f(x), f(w), f(b)
+        y = torch.empty((M, Cout), dtype=tdt(dt), device=dev())
+        lib.call("rua_stem_fwd", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, Cin, Cout, dt, stream())
+        torch.cuda.synchronize()
+        assert rel_err(y.float().cpu().numpy(), x @ w.T + b) < tol(dt)
+        dy = rng.standard_normal((M, Cout)).astype(np.float32)
+        dyd = to_dev(dy, dt)
+        dw = torch.zeros((Cout, Cin), device=dev()); db = torch.zeros(Cout, device=dev())
+        lib.call("rua_stem_bwd", xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), M, Cin, Cout, dt, stream())
+        torch.cuda.synchronize()
+        dyr = rnd(dt, dy).numpy()
+        assert rel_err(dw.cpu().numpy(), dyr.T @ x) < 1e-4
+        assert rel_err(db.cpu().numpy(), dyr.sum(0)) < 1e-4
+        # head
+        Ci, Co = 32, 6
+        hx = rng.standard_normal((M, Ci)).astype(np.float32)
+        hw = (rng.standard_normal((Co, Ci)) / 4).astype(np.float32); hb = rng.standard_normal(Co).astype(np.float32)
+        hxd, hwd, hbd = to_dev(hx, dt), f(hw), f(hb)
+        z = torch.empty((M, Co), device=dev()); p = torch.empty((M, Co), device=dev())
+        for act in (L.ACT_SOFTMAX, L.ACT_SIGMOID):
+            lib.call("rua_head_fwd", hxd.data_ptr(), hwd.data_ptr(), hbd.data_ptr(), z.data_ptr(), p.data_ptr(), M, Ci, Co, act, dt, stream())
+            torch.cuda.synchronize()
+            zr = rnd(dt, hx).double().numpy() @ hw.T.astype(np.float64) + hb
+            assert rel_err(z.cpu().numpy(), zr) < 1e-5
+            pr = torch.softmax(torch.from_numpy(zr), 1).numpy() if act == L.ACT_SOFTMAX else 1 / (1 + np.exp(-zr))
+            assert rel_err(p.cpu().numpy(), pr) < 1e-5
+        dz = rng.standard_normal((M, Co)).astype(np.float32)
+        dzd = f(dz)
+        dx = torch.empty((M, Ci), dtype=tdt(dt), device=dev())
+        dwh = torch.zeros((Co, Ci), device=dev()); dbh = torch.zeros(Co, device=dev())
+        lib.call("rua_head_bwd", hxd.data_ptr(), dzd.data_ptr(), hwd.data_ptr(), dx.data_ptr(), 0, dwh.data_ptr(), dbh.data_ptr(), M, Ci, Co, dt, stream())
+        torch.cuda.synchronize()
+        assert rel_err(dx.float().cpu().numpy(), dz @ hw) < tol(dt)
+        assert rel_err(dwh.cpu().numpy(), dz.T @ rnd(dt, hx).numpy()) < 1e-4
+        assert rel_err(dbh.cpu().numpy(), dz.sum(0)) < 1e-4
+
+
+def test_losses_against_oracle():
+    """Tanimoto dual / weighted CE / CE / BCE / MSE values and logits-gradients vs torch autograd of the oracle."""
+    from oracle import resuneta_ref as ref
+    rng = np.random.default_rng(9)
+    lib = L.lib()
+    B, H, W, Cc = 3, 12, 10, 5
+    HW = H * W
+    M = B * HW
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+    ids = rng.integers(0, Cc - 1, size=(B, H, W))            # last class absent everywhere -> inf weight path
+    y1h = np.eye(Cc, dtype=np.float32)[ids]
+    ysoft = rng.uniform(0, 1, (B, H, W, Cc)).astype(np.float32)
+    cw = np.array([4.3, 2.9, 3.9, 5.6, 37.0], np.float32)
+    cases = [(L.LOSS_TANIMOTO, L.ACT_SOFTMAX, y1h), (L.LOSS_TANIMOTO, L.ACT_SIGMOID, ysoft), (L.LOSS_WCE, L.ACT_SOFTMAX, y1h),
+             (L.LOSS_CE_LOGITS, L.ACT_SOFTMAX, y1h), (L.LOSS_BCE_LOGITS, L.ACT_SIGMOID, y1h), (L.LOSS_MSE, L.ACT_SOFTMAX, ysoft),
+             (L.LOSS_MSE, L.ACT_SIGMOID, ysoft)]
+    for kind, act, y in cases:
+        z = (rng.standard_normal((B, H, W, Cc)) * 2).astype(np.float32)
+        zt = torch.from_numpy(z).permute(0, 3, 1, 2).double().requires_grad_(True)
+        yt = torch.from_numpy(y).permute(0, 3, 1, 2).double()
+        pt = torch.softmax(zt, 1) if act == L.ACT_SOFTMAX else torch.sigmoid(zt)
+        wgt = 0.7
+        if kind == L.LOSS_TANIMOTO:
+            lt = ref.tanimoto_dual_loss(yt, pt).mean()
+        elif kind == L.LOSS_WCE:
+            lt = (-(yt * torch.log(torch.clamp(pt / pt.sum(1, keepdim=True), 1e-7, 1 - 1e-7)) * torch.from_numpy(cw).double()[None, :, None, None]).sum(1)).mean()
+        elif kind == L.LOSS_CE_LOGITS:
+            lt = ref.categorical_ce_logits(yt, zt).mean()
+        elif kind == L.LOSS_BCE_LOGITS:
+            lt = ref.binary_ce_logits(yt, zt).mean()
+        else:
+            lt = ref.mse(yt, pt).mean()
+        (wgt * lt).backward()
+        gz = zt.grad.permute(0, 2, 3, 1).numpy()
+        pd, yd, zd = f(pt.detach().permute(0, 2, 3, 1).numpy()), f(y), f(z)
+        scal = torch.zeros(16, dtype=torch.float64, device=dev())
+        dz = torch.empty((B, H, W, Cc), device=dev())
+        cwd = f(cw)
+        coef = torch.zeros(B * Cc * 3, device=dev())
+        if kind == L.LOSS_TANIMOTO:
+            sums = torch.zeros(B * Cc * 6, dtype=torch.float64, device=dev())
+            lib.call("rua_tanimoto_sums", pd.data_ptr(), yd.data_ptr(), B, HW, Cc, sums.data_ptr(), stream())
+            lib.call("rua_tanimoto_finalize", sums.data_ptr(), B, HW, Cc, wgt / B, scal.data_ptr(), coef.data_ptr(), stream())
+            gs, norm = wgt / B, 1.0
+        else:
+            lib.call("rua_pixel_loss", kind, pd.data_ptr(), zd.data_ptr(), yd.data_ptr(), cwd.data_ptr(), M, Cc, scal.data_ptr(), stream())
+            gs, norm = wgt / M, 1.0 / M
+        lib.call("rua_head_dz", kind, act, pd.data_ptr(), yd.data_ptr(), coef.data_ptr(), cwd.data_ptr(), gs, B, HW, Cc, dz.data_ptr(), stream())
+        torch.cuda.synchronize()
+        assert abs(float(scal[0]) * norm - float(lt.detach())) < 1e-5 * max(1.0, abs(float(lt))), (kind, act)
+        assert rel_err(dz.cpu().numpy(), gz) < 2e-4, (kind, act)
+
+
+def test_metrics_and_optimizers():
+    from oracle import naive_ops as nv
+    rng = np.random.default_rng(10)
+    lib = L.lib()
+    M, Cc = 777, 6
+    p = rng.uniform(0, 1, (M, Cc)).astype(np.float32); p /= p.sum(1, keepdims=True)
+    y = np.eye(Cc, dtype=np.float32)[rng.integers(0, Cc, M)]
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+    out = torch.zeros(5, dtype=torch.float64, device=dev())
+    pd, yd = f(p), f(y)
+    lib.call("rua_seg_metrics", pd.data_ptr(), yd.data_ptr(), M, Cc, out.data_ptr(), stream())
+    torch.cuda.synchronize()
+    t, q = y > 0.5, p > 0.5
+    exp = [(p.argmax(1) == y.argmax(1)).sum(), (t & q).sum(), (~t & q).sum(), (~t & ~q).sum(), (t & ~q).sum()]
+    assert np.array_equal(out.cpu().numpy(), np.array(exp, np.float64))
+    n = 1000
+    th = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32)
+    thd, gd, md, vd = f(th), f(g), f(np.zeros(n)), f(np.zeros(n))
+    e_th, e_m, e_v = th.astype(np.float64), np.zeros(n), np.zeros(n)
+    for step in (1, 2):
+        lr_t = 1e-3 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        gd.copy_(f(g))
+        lib.call("rua_adam_step", thd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr_t, 0.9, 0.999, 1e-7, 0.5, 1, stream())
+        e_th, e_m, e_v = nv.adam_step(e_th, 0.5 * g.astype(np.float64), e_m, e_v, step, 1e-3)
+    torch.cuda.synchronize()
+    assert np.allclose(thd.cpu().numpy(), e_th, rtol=1e-5, atol=1e-6)
+    assert float(gd.abs().max()) == 0.0
+    thd, gd, vd = f(th), f(g), f(np.zeros(n))
+    lib.call("rua_sgd_step", thd.data_ptr(), gd.data_ptr(), vd.data_ptr(), n, 0.1, 0.8, 1.0, 0, stream())
+    torch.cuda.synchronize()
+    e_th, _ = nv.sgd_step(th.astype(np.float64), g.astype(np.float64), np.zeros(n), 0.1)
+    assert np.allclose(thd.cpu().numpy(), e_th, rtol=1e-5, atol=1e-6)

