@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Headline benchmark: training patches/sec of the ResUnet-a multitask path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A step = one full train_on_batch on one resident synthetic batch per GPU: forward (training-mode BN),
+Tanimoto-dual losses on the four heads, backward, gradient all-reduce (N>1), Adam update, bf16 weight
+refresh.  Default workload = BASELINE config 3 (256x256x6, 6 classes, multitask, bs 8/GPU, bf16).
+Prints ONE JSON line (rank 0) with the bench contract fields plus `roofline` (dominant kernel, timed
+live with events on the launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (patch, channels, classes, multitask, batch/GPU, train GFLOP/patch)
+    "cfg3": (256, 6, 6, True, 8, 252.4),
+    "cfg2": (256, 6, 6, False, 8, 234.1),
+    "cfg5": (128, 7, 2, False, 32, 58.4),
+}
+BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def conv_flops(desc):
+    k = sum(desc.seg[i].taps * desc.seg[i].C for i in range(desc.nseg))
+    return 2.0 * desc.N * desc.H * desc.W * desc.Cout * k
+
+
+def wgrad_flops(d):
+    return 2.0 * d.N * d.H * d.W * d.Cout * d.C * d.taps
+
+
+def profile_kernels(eng, g, dtype):
+    """One extra (untimed) step with an event pair around every conv / wgrad launch on the launch stream.
+    Returns per-kernel-instantiation totals: {name: [launches, seconds, flops]}."""
+    from resunet_a_mltsk_keras_amd import _lib as L
+    lib = L.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    sp = C.c_void_p(s)
+    tname = "bf16" if dtype == "bf16" else "f32"
+    rec = []
+    eng._zero_arena(g, s)
+    eng._prep_weights(s)
+    for plan in (g.fwd, g.loss_plan, g.bwd):
+        for fn, name, args in plan.calls:
+            if name in ("rua_conv_fwd", "rua_conv_wgrad"):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*args, sp)
+                e1.record()
+                d = args[0]._obj
+                if name == "rua_conv_fwd":
+                    kn = f"conv_igemm<{tname},{lib.raw('rua_conv_tile_bn')(C.byref(d))}>"
+                    rec.append((kn, e0, e1, conv_flops(d)))
+                else:
+                    rec.append((f"wgrad_kernel<{tname}>", e0, e1, wgrad_flops(d)))
+            else:
+                rc = fn(*args, sp)
+            if rc != 0:
+                lib.check(rc, name)
+    eng.optimizer_step(1.0 / eng.world)
+    torch.cuda.synchronize()
+    out = {}
+    for kn, e0, e1, fl in rec:
+        t = out.setdefault(kn, [0, 0.0, 0.0])
+        t[0] += 1; t[1] += e0.elapsed_time(e1) * 1e-3; t[2] += fl
+    return out
+
+
+def cpu_baseline(sample_steps=2):
+    """CPU oracle (PyTorch-CPU fp32 restatement of the Keras graph) on BASELINE config 1:
+    256x256x3, 6 classes, single task, bs 4, weighted CE, Adam — full train steps on all host cores."""
+    from oracle import resuneta_ref as ref
+    from resunet_a_mltsk_keras_amd.synthetic import make_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = ref.RefConfig(input_shape=(256, 256, 3), num_classes=6, multitasking=False)
+    params, order = ref.init_params(cfg, 0)
+    spec = ref.CompileSpec(loss="weighted_cross_entropy", class_weights=[1.0] * 6, lr=1e-3)
+    tr = ref.RefTrainer(cfg, params, order, spec)
+    x, y = make_batch(4, 256, 3, 6, False, seed=1234)
+    tr.train_on_batch(x, y)                                    # warm-up
+    t0 = time.time()
+    for _ in range(sample_steps):
+        tr.train_on_batch(x, y)
+    dt = time.time() - t0
+    return {"value": round(4 * sample_steps / dt, 3), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_steps} full train steps (fwd+loss+bwd+Adam) of config 1 (256x256x3, 6 classes, bs 4, fp32) "
+                      f"after 1 warm-up step, PyTorch-CPU oracle standing in for Keras-CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=25.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from resunet_a_mltsk_keras_amd import _lib as L
+    from resunet_a_mltsk_keras_amd.engine import Engine, LossSpec, ModelConfig
+    from resunet_a_mltsk_keras_amd.synthetic import make_batch
+
+    patch, ch, ncls, mt, bs, gflop_patch = WORKLOADS[args.workload]
+    B = args.batch or bs
+    eng = Engine(ModelConfig(input_shape=(patch, patch, ch), num_classes=ncls, multitasking=mt), dtype=args.dtype, seed=0)
+    heads = ["seg", "bound", "dist", "color"]
+    eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in heads}, weight={h: 1.0 for h in heads}, optimizer="adam", lr=1e-3))
+    if world > 1:
+        from resunet_a_mltsk_keras_amd.dist import DataParallel
+        DataParallel(eng, bucket_mb=args.bucket_mb, overlap=not args.no_overlap)
+    x, y = make_batch(B, patch, ch, ncls, mt, seed=1234 + rank)
+    eng.train_step(x, y, fetch=False)                           # builds the plan, uploads the resident batch
+    for _ in range(max(args.warmup - 1, 0)):
+        eng.train_step(None, None, fetch=False)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step(None, None, fetch=False)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res = eng._results(eng.graph(B, True))
+    value = B * world * args.steps / dt
+
+    out = {
+        "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] if args.workload != "cfg5" else "training patches/sec (128x128, 7-ch, bs=32/GPU)",
+        "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: ResUnet-a d6 {'multitask (seg+bound+dist+color) Tanimoto-dual' if mt else 'single-task seg Tanimoto-dual'}, "
+                               f"{patch}x{patch}x{ch}, {ncls} classes, Adam, full train step (fwd+loss+bwd+allreduce+update)",
+                   "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss_last_step": round(res[0], 5)},
+        "model_tflops_per_s": round(value * gflop_patch / 1e3, 2),
+    }
+    if rank == 0:
+        peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+        prof = profile_kernels(eng, eng.graph(B, True), args.dtype)
+        dom = max(prof.items(), key=lambda kv: kv[1][1])
+        kn, (n, sec, fl) = dom
+        out["roofline"] = {
+            "bound": "mfma", "kernel": kn, "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
+            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
+            "achieved": round(fl / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4),
+            "traffic": None,
+            "all_mfma_kernels": {k: {"launches": v[0], "ms_per_step": round(1e3 * v[1], 3), "tflops": round(v[2] / v[1] / 1e12, 2)}
+                                 for k, v in sorted(prof.items())},
+            "whole_step_frac_of_peak": round(value / world * gflop_patch / 1e3 / peak, 4),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

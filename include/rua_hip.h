@@ -67,6 +67,7 @@ typedef struct rua_conv_desc {
 } rua_conv_desc;
 int rua_conv_fwd(const rua_conv_desc* d, void* stream);
 int rua_conv_smem_bytes(const rua_conv_desc* d);
+int rua_conv_tile_bn(const rua_conv_desc* d);   /* 32 / 64 / 128: which conv_igemm<T,BN> instantiation a descriptor launches */
 
 /* ---- weight gradient (MFMA, split over pixels, fp32 atomic accumulation) ----------------
  * dW[t][co][c] += sum_pixels dy[n,h,w,co] * a[n, h*stride+dy_t*dil, w*stride+dx_t*dil, c]

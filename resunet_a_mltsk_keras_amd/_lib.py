@@ -43,6 +43,7 @@ _SIGS = {
     "rua_device_info": ([C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32], i32),
     "rua_conv_fwd": ([C.POINTER(ConvDesc), vp], i32),
     "rua_conv_smem_bytes": ([C.POINTER(ConvDesc)], i32),
+    "rua_conv_tile_bn": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_wgrad": ([C.POINTER(WgradDesc), vp], i32),
     "rua_weight_prep": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "rua_stem_fwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),

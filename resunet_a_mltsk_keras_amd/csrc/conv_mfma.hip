@@ -605,3 +605,9 @@ extern "C" int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, 
   RUA_LAUNCH_CHECK("wprep_kernel");
   return RUA_OK;
 }
+
+// tile width (output channels per block) the launcher picks for a descriptor: identifies the kernel instantiation
+extern "C" int rua_conv_tile_bn(const rua_conv_desc* d) {
+  if (!d) return RUA_ERR_ARG;
+  return pick_bn(d, (long long)d->N * d->H * d->W);
+}

@@ -1,0 +1,119 @@
+"""Data-parallel training over RCCL/xGMI: one process per GPU, patches sharded by sample.
+
+Semantics follow tf.distribute.MirroredStrategy as the reference uses it (train_ISPRS.py:347,432):
+every replica runs the step on its local shard with LOCAL BatchNorm batch statistics and LOCAL
+Tanimoto class volumes, gradients are summed and divided by the number of replicas, BN moving
+statistics are mean-aggregated.  The only data-path collective is the gradient all-reduce: the flat
+fp32 gradient buffer is cut into contiguous buckets; a bucket is reduced on a side HIP stream as soon
+as the backward plan has issued the last launch that writes into it, so the all-reduce of the deep
+(parameter-heavy) stages overlaps the backward of the shallow (FLOP-heavy) ones.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def make_buckets(entries: List[Tuple[int, int]], total: int, bucket_elems: int) -> List[Tuple[int, int]]:
+    """Contiguous [begin, end) slices of the flat buffer, walking parameters from the END of the buffer
+    (the order backward produces them), each at least bucket_elems long except the last."""
+    bounds = sorted(set([0, total] + [o for o, _ in entries]))
+    buckets, end = [], total
+    cur = total
+    for b in reversed(bounds[:-1]):
+        if end - b >= bucket_elems or b == 0:
+            buckets.append((b, end))
+            end = b
+    return buckets
+
+
+class GradReducer:
+    """Bucketed all-reduce (sum) of a flat tensor.  Device-agnostic so that the bucketing / readiness logic is
+    testable with gloo on CPU; on GPUs the collectives run on `side` and are fenced with events."""
+
+    def __init__(self, flat: torch.Tensor, buckets: List[Tuple[int, int]], group=None, use_side_stream: bool = True,
+                 host_staged: bool = False):
+        self.flat, self.buckets, self.group = flat, buckets, group
+        self.cuda = flat.is_cuda
+        self.host_staged = host_staged           # gloo backend with device tensors: stage through pinned host memory
+        self.side = torch.cuda.Stream(device=flat.device) if (self.cuda and use_side_stream and not host_staged) else None
+        self.works: List = []
+        self.fired = [False] * len(buckets)
+
+    def begin(self):
+        self.works = []
+        self.fired = [False] * len(self.buckets)
+
+    def ready(self, i: int):
+        """Bucket i is final on the current stream: launch its all-reduce (async)."""
+        if self.fired[i]:
+            return
+        self.fired[i] = True
+        a, b = self.buckets[i]
+        view = self.flat[a:b]
+        if self.host_staged:
+            h = view.cpu()
+            dist.all_reduce(h, group=self.group)
+            view.copy_(h)
+            return
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self.works.append(dist.all_reduce(view, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, group=self.group, async_op=True))
+
+    def finish(self):
+        """Every bucket reduced and visible to the current stream."""
+        for i in range(len(self.buckets)):
+            self.ready(i)
+        for w in self.works:
+            w.wait()
+        if self.side is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+        self.works = []
+
+
+class DataParallel:
+    """Attaches to an Engine: broadcasts rank-0 weights, reduces gradients during backward, averages BN state."""
+
+    def __init__(self, eng, bucket_mb: float = 25.0, group=None, overlap: bool = True):
+        assert dist.is_initialized()
+        self.eng, self.group = eng, group
+        self.world = dist.get_world_size(group)
+        self.overlap = overlap
+        eng.world = self.world
+        eng.dist = self
+        backend = dist.get_backend(group)
+        self.host_staged = backend == "gloo" and eng.P.is_cuda
+        entries = [(e["off"], e["size"]) for e in eng.params.entries]
+        self.buckets = make_buckets(entries, eng.params.n, int(bucket_mb * (1 << 20) / 4))
+        self.reducer = GradReducer(eng.G[:eng.params.n], self.buckets, group, use_side_stream=overlap, host_staged=self.host_staged)
+        self._bcast(eng.P); self._bcast(eng.S)
+        eng.weights_dirty = True
+
+    def _bcast(self, t):
+        if self.host_staged:
+            h = t.cpu(); dist.broadcast(h, 0, group=self.group); t.copy_(h)
+        else:
+            dist.broadcast(t, 0, group=self.group)
+
+    def bucket_of(self, off: int) -> int:
+        for i, (a, b) in enumerate(self.buckets):
+            if a <= off < b:
+                return i
+        raise ValueError(off)
+
+    def reduce_gradients(self, eng):
+        """Called after the backward plan (buckets already fired by the plan's markers when overlap is on)."""
+        self.reducer.finish()
+        S = eng.S
+        if self.host_staged:
+            h = S.cpu(); dist.all_reduce(h, group=self.group); S.copy_(h / self.world)
+        else:
+            dist.all_reduce(S, group=self.group)
+            S.div_(self.world)

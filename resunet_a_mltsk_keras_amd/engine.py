@@ -210,13 +210,23 @@ class Plan:
         if not self.dry:
             self.calls.append((L.lib().raw(name), name, args))
 
-    def run(self, stream_ptr: int):
+    def run(self, stream_ptr: int, hooks=None):
+        """Replay.  hooks: {call index -> python callable run right after that launch} (gradient buckets)."""
         lib = L.lib()
         s = C.c_void_p(stream_ptr)
-        for fn, name, args in self.calls:
+        if not hooks:
+            for fn, name, args in self.calls:
+                rc = fn(*args, s)
+                if rc != 0:
+                    lib.check(rc, name)
+            return
+        for i, (fn, name, args) in enumerate(self.calls):
             rc = fn(*args, s)
             if rc != 0:
                 lib.check(rc, name)
+            h = hooks.get(i)
+            if h is not None:
+                h()
 
 
 class Coef:
@@ -246,6 +256,7 @@ class Graph:
         self.bwd = Plan(dry)
         self.loss_plan = Plan(dry)
         self.back_steps: List = []
+        self.grad_touch: Dict[int, int] = {}
         self.stats_used = 16                 # the first 16 doubles of the arena are the loss / metric scalars
         self.act_bytes = 0
         self._build()
@@ -286,7 +297,10 @@ class Graph:
         return 0 if self.dry else self.e.P.data_ptr() + off * 4
 
     def G(self, off):
-        return 0 if self.dry else self.e.G.data_ptr() + off * 4
+        if self.dry:
+            return 0
+        self.grad_touch[off] = len(self.bwd.calls)          # index of the launch about to be recorded
+        return self.e.G.data_ptr() + off * 4
 
     def S(self, off):
         return 0 if self.dry else self.e.S.data_ptr() + off * 4
@@ -893,8 +907,31 @@ class Engine:
         self._prep_weights(s)
         g.fwd.run(s)
         g.loss_plan.run(s)
-        g.bwd.run(s)
+        hooks = None
+        if self.dist is not None:
+            self.dist.reducer.begin()
+            if self.dist.overlap:
+                hooks = self._bucket_hooks(g)
+        g.bwd.run(s, hooks)
         return g
+
+    def _bucket_hooks(self, g: Graph):
+        """{backward launch index -> fire the all-reduce of every gradient bucket that is complete after it}."""
+        if getattr(g, "_hooks", None) is None:
+            last = [-1] * len(self.dist.buckets)
+            for off, idx in g.grad_touch.items():
+                b = self.dist.bucket_of(off)
+                last[b] = max(last[b], idx)
+            hooks: Dict[int, object] = {}
+            by_idx: Dict[int, List[int]] = {}
+            for b, idx in enumerate(last):
+                if idx >= 0:
+                    by_idx.setdefault(idx, []).append(b)
+            red = self.dist.reducer
+            for idx, bs in by_idx.items():
+                hooks[idx] = (lambda bs=bs: [red.ready(b) for b in bs])
+            g._hooks = hooks
+        return g._hooks
 
     def optimizer_step(self, grad_scale: float = 1.0):
         sp, s = self.loss, self._stream()
