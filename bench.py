@@ -78,22 +78,49 @@ def profile_kernels(eng, g, dtype):
     return out
 
 
+def host_cores():
+    """CPU share actually available: affinity mask capped by the cgroup quota (os.cpu_count() reports the host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(sample_steps=2):
     """CPU oracle (PyTorch-CPU fp32 restatement of the Keras graph) on BASELINE config 1:
     256x256x3, 6 classes, single task, bs 4, weighted CE, Adam — full train steps on all host cores."""
     from oracle import resuneta_ref as ref
     from resunet_a_mltsk_keras_amd.synthetic import make_batch
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} host cores ...")
     cfg = ref.RefConfig(input_shape=(256, 256, 3), num_classes=6, multitasking=False)
     params, order = ref.init_params(cfg, 0)
     spec = ref.CompileSpec(loss="weighted_cross_entropy", class_weights=[1.0] * 6, lr=1e-3)
     tr = ref.RefTrainer(cfg, params, order, spec)
     x, y = make_batch(4, 256, 3, 6, False, seed=1234)
+    t0 = time.time()
     tr.train_on_batch(x, y)                                    # warm-up
+    log(f"cpu warm-up step {time.time() - t0:.1f} s")
     t0 = time.time()
     for _ in range(sample_steps):
         tr.train_on_batch(x, y)
+        log(f"cpu step done at {time.time() - t0:.1f} s")
     dt = time.time() - t0
     return {"value": round(4 * sample_steps / dt, 3), "unit": "patches/s", "cores": cores, "kind": "port",
             "sample": f"{sample_steps} full train steps (fwd+loss+bwd+Adam) of config 1 (256x256x3, 6 classes, bs 4, fp32) "
@@ -137,9 +164,18 @@ def main():
         from resunet_a_mltsk_keras_amd.dist import DataParallel
         DataParallel(eng, bucket_mb=args.bucket_mb, overlap=not args.no_overlap)
     x, y = make_batch(B, patch, ch, ncls, mt, seed=1234 + rank)
+    t_build = time.time()
     eng.train_step(x, y, fetch=False)                           # builds the plan, uploads the resident batch
+    torch.cuda.synchronize()
+    g0 = eng.graph(B, True)
+    if rank == 0:
+        log(f"plan recorded in {time.time() - t_build:.1f} s: {len(g0.fwd.calls)} fwd + {len(g0.loss_plan.calls)} loss + "
+            f"{len(g0.bwd.calls)} bwd launches, activations {g0.act_bytes / 2**30:.2f} GiB")
     for _ in range(max(args.warmup - 1, 0)):
         eng.train_step(None, None, fetch=False)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log("warm-up done")
 
     def fence():
         if world > 1:
@@ -158,6 +194,8 @@ def main():
         dt = float(t.item())
     res = eng._results(eng.graph(B, True))
     value = B * world * args.steps / dt
+    if rank == 0:
+        log(f"{args.steps} steps in {dt:.3f} s -> {value:.1f} patches/s")
 
     out = {
         "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] if args.workload != "cfg5" else "training patches/sec (128x128, 7-ch, bs=32/GPU)",

@@ -343,7 +343,7 @@ class RefTrainer:
     def test_on_batch(self, x, y):
         with torch.no_grad():
             _, vals, mets, _ = self._losses(x, y, training=False)
-        return [float(v) for v in vals] + mets
+        return [float(v.detach()) for v in vals] + mets
 
     def train_on_batch(self, x, y):
         for k in self.order:
@@ -370,7 +370,7 @@ class RefTrainer:
                 p.grad = None
             for k, v in net.new_stats.items():
                 self.params[k] = v.detach().clone()
-        return [float(v) for v in vals] + mets
+        return [float(v.detach()) for v in vals] + mets
 
 
 # ---- analytic work model (conv MACs only) -------------------------------

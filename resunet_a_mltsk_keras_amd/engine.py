@@ -257,6 +257,7 @@ class Graph:
         self.loss_plan = Plan(dry)
         self.back_steps: List = []
         self.grad_touch: Dict[int, int] = {}
+        self.allocs: List[torch.Tensor] = []
         self.stats_used = 16                 # the first 16 doubles of the arena are the loss / metric scalars
         self.act_bytes = 0
         self._build()
@@ -267,6 +268,7 @@ class Graph:
             return _Dummy(int(np.prod(shape)))
         t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
         self.act_bytes += t.numel() * t.element_size()
+        self.allocs.append(t)          # the plan holds raw pointers: the graph owns every buffer for its lifetime
         return t
 
     def new(self, N, H, W, C, f32=False) -> Ten:
@@ -874,7 +876,7 @@ class Engine:
                 src = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32))
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError(f"expected shape {tuple(dst.shape)}, got {tuple(src.shape)}")
-            dst.copy_(src, non_blocking=True)
+            dst.copy_(src)            # blocking: the source may be a temporary pageable host tensor
         put(g.x_in.t, x)
         if y is not None:
             if isinstance(y, dict):
