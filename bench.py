@@ -62,9 +62,11 @@ def profile_kernels(eng, g, dtype):
                 d = args[0]._obj
                 if name == "rua_conv_fwd":
                     kn = f"conv_igemm<{tname},{lib.raw('rua_conv_tile_bn')(C.byref(d))}>"
-                    rec.append((kn, e0, e1, conv_flops(d)))
+                    kk = sum(d.seg[i].taps * d.seg[i].C for i in range(d.nseg))
+                    flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "")
+                    rec.append((kn, e0, e1, conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags)))
                 else:
-                    rec.append((f"wgrad_kernel<{tname}>", e0, e1, wgrad_flops(d)))
+                    rec.append((f"wgrad_kernel<{tname}>", e0, e1, wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, "")))
             else:
                 rc = fn(*args, sp)
             if rc != 0:
@@ -72,9 +74,18 @@ def profile_kernels(eng, g, dtype):
     eng.optimizer_step(1.0 / eng.world)
     torch.cuda.synchronize()
     out = {}
-    for kn, e0, e1, fl in rec:
+    for kn, e0, e1, fl, _ in rec:
         t = out.setdefault(kn, [0, 0.0, 0.0])
         t[0] += 1; t[1] += e0.elapsed_time(e1) * 1e-3; t[2] += fl
+    if os.environ.get("RUA_BENCH_DETAIL"):
+        groups = {}
+        for kn, e0, e1, fl, tag in rec:
+            gkey = (kn,) + tag
+            t = groups.setdefault(gkey, [0, 0.0, 0.0])
+            t[0] += 1; t[1] += e0.elapsed_time(e1) * 1e-3; t[2] += fl
+        log("per-shape MFMA kernel table (kernel, M, Cout, K, dil, flags): launches, total ms, avg us, TFLOP/s")
+        for gkey, (n, sec, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+            log(f"  {str(gkey):90s} n={n:3d} {1e3 * sec:8.3f} ms {1e6 * sec / n:8.1f} us {fl / sec / 1e12:7.1f} TF/s")
     return out
 
 

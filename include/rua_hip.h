@@ -62,11 +62,16 @@ typedef struct rua_conv_desc {
   int32_t accumulate;          /* y += result instead of y = result */
   void* y;                     /* [N][OH][OW][Cout], written at (h*out_stride, w*out_stride) */
   int32_t out_stride, OH, OW;
-  double* stats;               /* [2][Cout] atomically accumulated, or NULL */
+  double* stats;               /* [stats_replicas][2][Cout] atomically accumulated, or NULL */
   int32_t stats_mode;          /* 1: sum v, sum v^2   2: sum v, sum v*aux */
+  void* workspace;             /* optional fp32 scratch of rua_conv_workspace_bytes(): enables split-K for small output grids */
+  int64_t workspace_bytes;
+  int32_t stats_replicas;      /* power of two >= 1: block b adds into replica b % R (spreads atomic contention);
+                                  the finalize kernels sum the replicas */
 } rua_conv_desc;
 int rua_conv_fwd(const rua_conv_desc* d, void* stream);
 int rua_conv_smem_bytes(const rua_conv_desc* d);
+int64_t rua_conv_workspace_bytes(const rua_conv_desc* d);   /* N*H*W*Cout fp32: needed only if split-K is wanted */
 int rua_conv_tile_bn(const rua_conv_desc* d);   /* 32 / 64 / 128: which conv_igemm<T,BN> instantiation a descriptor launches */
 
 /* ---- weight gradient (MFMA, split over pixels, fp32 atomic accumulation) ----------------
@@ -98,24 +103,26 @@ int rua_head_bwd(const void* x, const float* dz, const float* w, void* dx, int a
                  int64_t M, int Cin, int Cout, int dtype, void* stream);
 
 /* ---- BatchNormalization (model2.py:17,21,38,86,93; Keras eps 1e-3, momentum .99) -------- */
-/* per-channel sum / sum of squares over all rows of x [M][C] -> stats[2][C] (fp64, accumulated) */
-int rua_col_stats(const void* x, int64_t M, int C, double* stats, int dtype, void* stream);
+/* per-channel sum / sum of squares over all rows of x [M][C] -> stats[R][2][C] (fp64, accumulated over R replicas) */
+int rua_col_stats(const void* x, int64_t M, int C, double* stats, int replicas, int dtype, void* stream);
+/* replicas to use for a statistics buffer fed by a kernel of `blocks` workgroups */
+int rua_stats_replicas(int64_t blocks);
 /* sum g*m and sum g*m*x with m = (mscale*x+mshift > 0) when masked, else 1 */
 int rua_col_stats2(const void* g, const void* x, const float* mscale, const float* mshift, int masked,
-                   int64_t M, int C, double* stats, int dtype, void* stream);
+                   int64_t M, int C, double* stats, int replicas, int dtype, void* stream);
 /* training: stats -> scale/shift (+ mean, rstd, moving-stat update with the Bessel factor
  * bessel_n/(bessel_n-1), bessel_n = element count Keras sees, i.e. after nearest upsampling);
  * inference: moving stats -> scale/shift */
-int rua_bn_finalize(const double* stats, double count, double bessel_n, const float* gamma, const float* beta,
+int rua_bn_finalize(const double* stats, int replicas, double count, double bessel_n, const float* gamma, const float* beta,
                     float* moving_mean, float* moving_var, float momentum, float eps, int training,
                     float* scale, float* shift, float* mean, float* rstd, int C, void* stream);
 /* (float)stats[c] -> n (<=4) fp32 vectors: bias gradients from per-channel sums of dy */
-int rua_stats_to_f32(const double* stats, int C, float* const* dst, int n, void* stream);
+int rua_stats_to_f32(const double* stats, int replicas, int C, float* const* dst, int n, void* stream);
 /* out_b = [relu](scale_b * x + shift_b) for b < nb (all branches of a ResBlock read x once) */
 int rua_bn_apply(const void* x, int nb, const float* const* scale, const float* const* shift, int relu,
                  void* const* out, int64_t M, int C, int dtype, void* stream);
 /* backward statistics -> dgamma, dbeta and the coefficients A,B,Cc of dx = A*g + B*x + Cc */
-int rua_bn_bwd_finalize(const double* stats2, double count, const float* gamma, const float* mean, const float* rstd,
+int rua_bn_bwd_finalize(const double* stats2, int replicas, double count, const float* gamma, const float* mean, const float* rstd,
                         float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC, int C, void* stream);
 /* dx (=|+=) [dskip] + sum_b (A_b * g_b * m_b + B_b * x + C_b),  m_b = ReLU mask of branch b (or 1) */
 int rua_bn_bwd_apply(int nb, const void* const* g, const float* const* coefA, const float* const* coefB,
@@ -161,10 +168,11 @@ int rua_head_dz(int kind, int act, const float* p, const float* y, const float* 
 int rua_seg_metrics(const float* p, const float* y, int64_t M, int C, double* out, void* stream);
 
 /* ---- optimizers on the flat parameter buffer (train_ISPRS.py:404-407) --------------------- */
-/* Keras Adam: theta -= lr_t * m / (sqrt(v) + eps); g is read as g*grad_scale and zeroed if zero_grad */
-int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+/* Keras Adam: theta -= lr_t * m / (sqrt(v) + eps); g is read as g*grad_scale and zeroed if zero_grad.
+ * lr_t_dev (optional): device scalar overriding lr_t, so a captured HIP graph can be replayed every step */
+int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1, float beta2,
                   float eps, float grad_scale, int zero_grad, void* stream);
-int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, float momentum, float grad_scale,
+int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, const float* lr_dev, float momentum, float grad_scale,
                  int zero_grad, void* stream);
 
 #ifdef __cplusplus

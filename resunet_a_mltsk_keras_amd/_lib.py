@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
     _fields_ = [("seg", ConvSeg * RUA_MAX_SEG), ("nseg", i32), ("N", i32), ("H", i32), ("W", i32), ("Cout", i32),
                 ("stride", i32), ("dtype", i32), ("bias", vp), ("aux", vp), ("aux_mode", i32), ("mscale", vp),
                 ("mshift", vp), ("out_relu", i32), ("accumulate", i32), ("y", vp), ("out_stride", i32), ("OH", i32),
-                ("OW", i32), ("stats", vp), ("stats_mode", i32)]
+                ("OW", i32), ("stats", vp), ("stats_mode", i32), ("workspace", vp), ("workspace_bytes", i64), ("stats_replicas", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -44,19 +44,21 @@ _SIGS = {
     "rua_conv_fwd": ([C.POINTER(ConvDesc), vp], i32),
     "rua_conv_smem_bytes": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_tile_bn": ([C.POINTER(ConvDesc)], i32),
+    "rua_conv_workspace_bytes": ([C.POINTER(ConvDesc)], i64),
     "rua_conv_wgrad": ([C.POINTER(WgradDesc), vp], i32),
     "rua_weight_prep": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "rua_stem_fwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "rua_stem_bwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "rua_head_fwd": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp], i32),
     "rua_head_bwd": ([vp, vp, vp, vp, i32, vp, vp, i64, i32, i32, i32, vp], i32),
-    "rua_col_stats": ([vp, i64, i32, vp, i32, vp], i32),
-    "rua_col_stats2": ([vp, vp, vp, vp, i32, i64, i32, vp, i32, vp], i32),
-    "rua_bn_finalize": ([vp, f64, f64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, vp], i32),
+    "rua_col_stats": ([vp, i64, i32, vp, i32, i32, vp], i32),
+    "rua_col_stats2": ([vp, vp, vp, vp, i32, i64, i32, vp, i32, i32, vp], i32),
+    "rua_stats_replicas": ([i64], i32),
+    "rua_bn_finalize": ([vp, i32, f64, f64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, vp], i32),
     "rua_bn_apply": ([vp, i32, PP, PP, i32, PP, i64, i32, i32, vp], i32),
-    "rua_bn_bwd_finalize": ([vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp], i32),
+    "rua_bn_bwd_finalize": ([vp, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp], i32),
     "rua_bn_bwd_apply": ([i32, PP, PP, PP, PP, PP, PP, i32, vp, vp, vp, i32, i64, i32, i32, vp], i32),
-    "rua_stats_to_f32": ([vp, i32, PP, i32, vp], i32),
+    "rua_stats_to_f32": ([vp, i32, i32, PP, i32, vp], i32),
     "rua_maxpool_fwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "rua_maxpool_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "rua_sumpool": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
@@ -72,8 +74,8 @@ _SIGS = {
     "rua_pixel_loss": ([i32, vp, vp, vp, vp, i64, i32, vp, vp], i32),
     "rua_head_dz": ([i32, i32, vp, vp, vp, vp, f32, i32, i64, i32, vp, vp], i32),
     "rua_seg_metrics": ([vp, vp, i64, i32, vp, vp], i32),
-    "rua_adam_step": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp], i32),
-    "rua_sgd_step": ([vp, vp, vp, i64, f32, f32, f32, i32, vp], i32),
+    "rua_adam_step": ([vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, i32, vp], i32),
+    "rua_sgd_step": ([vp, vp, vp, i64, f32, vp, f32, f32, i32, vp], i32),
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["rua_last_error"])

@@ -17,8 +17,8 @@ struct ConvK {
   int N, H, W, Cout, stride;
   long long M;
   const float* bias; const unsigned char* aux; int aux_mode; const float* mscale; const float* mshift;
-  int out_relu, accumulate; unsigned char* y; int out_stride, OH, OW; double* stats; int stats_mode;
-  int nbn;
+  int out_relu, accumulate; unsigned char* y; int out_stride, OH, OW; double* stats; int stats_mode; int stats_R;
+  int nbn, nbm, ksplit, stages_per_split; float* ws;
 };
 
 template <typename T> __device__ __forceinline__ void load8(const unsigned char* base, size_t elem_off, float* f) {
@@ -35,6 +35,110 @@ template <typename T> __device__ __forceinline__ void store8(unsigned char* base
   } else {
     stg16(base + elem_off * 4, ET<T>::pack(f));
     stg16(base + elem_off * 4 + 16, ET<T>::pack(f + 4));
+  }
+}
+
+// Shared epilogue of one 128 x BN output tile whose fp32 sums sit in `src` (LDS tile or split-K workspace):
+// 8-channel pieces per thread: bias, accumulate, residual / ReLU mask from aux, output ReLU, per-channel
+// statistics (fp32 partials -> wave shuffles -> LDS -> one fp64 atomic per channel and block), 16-byte stores.
+template <typename T, int BN>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int n0, int bm_i, const float* src, int sstride, float* sred) {
+  constexpr int BM = 128;
+  constexpr int CG = BN / 8;
+  constexpr int ROWS_PP = 256 / CG;
+  constexpr int EP = BM / ROWS_PP;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int HW = p.H * p.W;
+  const int cg = tid % CG, r0 = tid / CG;
+  const int co = n0 + cg * 8;
+  const bool cok = co < p.Cout;
+  float s1[8], s2[8], bias8[8], ms8[8], mt8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; bias8[j] = 0.f; ms8[j] = 1.f; mt8[j] = 0.f; }
+  if (cok) {
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bias8[j] = p.bias[co + j];
+    }
+    if (p.aux_mode == 2) {
+      if (p.mscale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ms8[j] = p.mscale[co + j];
+      }
+      if (p.mshift) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mt8[j] = p.mshift[co + j];
+      }
+    }
+  }
+  const bool plain_out = (p.out_stride == 1 && p.OH == p.H && p.OW == p.W);
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    const int row = r0 + e * ROWS_PP;
+    const long long m = m0 + row;
+    if (m < p.M && cok) {
+      float v[8];
+      const float4 t0 = *reinterpret_cast<const float4*>(&src[(size_t)row * sstride + cg * 8]);
+      const float4 t1 = *reinterpret_cast<const float4*>(&src[(size_t)row * sstride + cg * 8 + 4]);
+      v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+      size_t ooff;
+      if (plain_out) {
+        ooff = (size_t)m * p.Cout + co;
+      } else {
+        const int mm = (int)m;
+        const int n = mm / HW, rem = mm - n * HW, h = rem / p.W, w = rem - h * p.W;
+        ooff = ((size_t)(n * p.OH + h * p.out_stride) * p.OW + w * p.out_stride) * p.Cout + co;
+      }
+      if (p.accumulate) {
+        float o[8];
+        load8<T>(p.y, ooff, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += o[j];
+      }
+      float a8[8];
+      if (p.aux_mode != 0) {
+        load8<T>(p.aux, (size_t)m * p.Cout + co, a8);
+        if (p.aux_mode == 1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += a8[j];
+        } else if (p.aux_mode == 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (fmaf(ms8[j], a8[j], mt8[j]) > 0.f) ? v[j] : 0.f;
+        }
+      }
+      if (p.out_relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (p.stats_mode == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+      } else if (p.stats_mode == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], a8[j], s2[j]); }
+      }
+      store8<T>(p.y, ooff, v);
+    }
+  }
+  if (p.stats_mode != 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int o = CG; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    if (lane < CG) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sred[(wid * CG + lane) * 16 + j] = s1[j]; sred[(wid * CG + lane) * 16 + 8 + j] = s2[j]; }
+    }
+    __syncthreads();
+    if (tid < CG * 16) {
+      const int g = tid / 16, k = tid % 16;
+      const float t = sred[(0 * CG + g) * 16 + k] + sred[(1 * CG + g) * 16 + k] + sred[(2 * CG + g) * 16 + k] + sred[(3 * CG + g) * 16 + k];
+      const int c = n0 + g * 8 + (k & 7);
+      if (c < p.Cout) atomicAdd(&p.stats[(size_t)(bm_i & (p.stats_R - 1)) * 2 * p.Cout + (k >> 3) * p.Cout + c], (double)t);
+    }
   }
 }
 
@@ -62,7 +166,9 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int bn_i = vid % p.nbn, bm_i = vid / p.nbn;
+  const int bn_i = vid % p.nbn;
+  const int bm_i = (vid / p.nbn) % p.nbm;
+  const int ks_i = vid / (p.nbn * p.nbm);
   const long long m0 = (long long)bm_i * BM;
   const int n0 = bn_i * BN;
 
@@ -173,9 +279,12 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-  const int nstages = (p.nunits + KU - 1) / KU;
-  load_stage(0);
-  for (int st = 0; st < nstages; ++st) {
+  const int nstages_all = (p.nunits + KU - 1) / KU;
+  const int st_begin = ks_i * p.stages_per_split;
+  int nstages = st_begin + p.stages_per_split;
+  if (nstages > nstages_all) nstages = nstages_all;
+  load_stage(st_begin);
+  for (int st = st_begin; st < nstages; ++st) {
     __syncthreads();
     write_stage();
     __syncthreads();
@@ -219,6 +328,21 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------
+  if (p.ksplit > 1) {
+    // split-K: add the partial tile into the fp32 workspace (128-byte row segments per wave instruction);
+    // bias / mask / statistics / store happen in conv_splitk_finish once every slice has landed.
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long long m = m0 + wm * (BM / WM) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+          const int c = n0 + wn * (BN / WN) + b * 32 + lr;
+          if (m < p.M && c < p.Cout) unsafeAtomicAdd(&p.ws[(size_t)m * p.Cout + c], acc[a][b][i]);
+        }
+    return;
+  }
   __syncthreads();
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -231,102 +355,18 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
         sC[row * CSTR + col] = acc[a][b][i];
       }
   __syncthreads();
+  conv_epilogue<T, BN>(p, m0, n0, bm_i, sC, CSTR, sC + BM * CSTR);
+}
 
-  constexpr int CG = BN / 8;
-  constexpr int ROWS_PP = 256 / CG;
-  constexpr int EP = BM / ROWS_PP;
-  const int cg = tid % CG, r0 = tid / CG;
-  const int co = n0 + cg * 8;
-  const bool cok = co < p.Cout;
-  float s1[8], s2[8], bias8[8], ms8[8], mt8[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; bias8[j] = 0.f; ms8[j] = 1.f; mt8[j] = 0.f; }
-  if (cok) {
-    if (p.bias) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bias8[j] = p.bias[co + j];
-    }
-    if (p.aux_mode == 2) {
-      if (p.mscale) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ms8[j] = p.mscale[co + j];
-      }
-      if (p.mshift) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) mt8[j] = p.mshift[co + j];
-      }
-    }
-  }
-  const bool plain_out = (p.out_stride == 1 && p.OH == p.H && p.OW == p.W);
-#pragma unroll
-  for (int e = 0; e < EP; ++e) {
-    const int row = r0 + e * ROWS_PP;
-    const long long m = m0 + row;
-    if (m < p.M && cok) {
-      float v[8];
-      const float4 t0 = *reinterpret_cast<const float4*>(&sC[row * CSTR + cg * 8]);
-      const float4 t1 = *reinterpret_cast<const float4*>(&sC[row * CSTR + cg * 8 + 4]);
-      v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += bias8[j];
-      size_t ooff;
-      if (plain_out) {
-        ooff = (size_t)m * p.Cout + co;
-      } else {
-        const int mm = (int)m;
-        const int n = mm / HW, rem = mm - n * HW, h = rem / p.W, w = rem - h * p.W;
-        ooff = ((size_t)(n * p.OH + h * p.out_stride) * p.OW + w * p.out_stride) * p.Cout + co;
-      }
-      if (p.accumulate) {
-        float o[8];
-        load8<T>(p.y, ooff, o);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += o[j];
-      }
-      float a8[8];
-      if (p.aux_mode != 0) {
-        load8<T>(p.aux, (size_t)m * p.Cout + co, a8);
-        if (p.aux_mode == 1) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += a8[j];
-        } else if (p.aux_mode == 2) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (fmaf(ms8[j], a8[j], mt8[j]) > 0.f) ? v[j] : 0.f;
-        }
-      }
-      if (p.out_relu) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-      }
-      if (p.stats_mode == 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
-      } else if (p.stats_mode == 2) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], a8[j], s2[j]); }
-      }
-      store8<T>(p.y, ooff, v);
-    }
-  }
-  if (p.stats_mode != 0) {
-    float* sred = sC + BM * CSTR;                 // [4 waves][CG][16]
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-      for (int o = CG; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
-    }
-    if (lane < CG) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { sred[(wid * CG + lane) * 16 + j] = s1[j]; sred[(wid * CG + lane) * 16 + 8 + j] = s2[j]; }
-    }
-    __syncthreads();
-    if (tid < CG * 16) {
-      const int g = tid / 16, k = tid % 16;
-      const float t = sred[(0 * CG + g) * 16 + k] + sred[(1 * CG + g) * 16 + k] + sred[(2 * CG + g) * 16 + k] + sred[(3 * CG + g) * 16 + k];
-      const int c = n0 + g * 8 + (k & 7);
-      if (c < p.Cout) atomicAdd(&p.stats[(k >> 3) * p.Cout + c], (double)t);
-    }
-  }
+// split-K finisher: the shared epilogue over the fp32 workspace (one block per 128 x 64 output tile)
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK p) {
+  __shared__ float sred[4 * 8 * 16];
+  const int nbn = (p.Cout + 63) / 64;
+  const int bn_i = blockIdx.x % nbn, bm_i = blockIdx.x / nbn;
+  const long long m0 = (long long)bm_i * 128;
+  const int n0 = bn_i * 64;
+  conv_epilogue<T, 64>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sred);
 }
 
 template <typename T, int BN> static constexpr int conv_smem() {
@@ -343,9 +383,28 @@ template <typename T, int BN> static int launch_conv(const ConvK& k, int nbm, hi
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm<T, BN>), dim3(nbm * k.nbn), dim3(256), smem, st, k);
+  if (k.ksplit > 1) {
+    hipError_t e = hipMemsetAsync(k.ws, 0, (size_t)k.M * k.Cout * sizeof(float), st);
+    if (e != hipSuccess) { rua_set_error("conv split-K memset: %s", hipGetErrorString(e)); return RUA_ERR_LAUNCH; }
+  }
+  hipLaunchKernelGGL((conv_igemm<T, BN>), dim3(nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
   RUA_LAUNCH_CHECK("conv_igemm");
+  if (k.ksplit > 1) {
+    hipLaunchKernelGGL((conv_splitk_finish<T>), dim3(nbm * ((k.Cout + 63) / 64)), dim3(256), 0, st, k);
+    RUA_LAUNCH_CHECK("conv_splitk_finish");
+  }
   return RUA_OK;
+}
+
+// split-K factor: only when the output grid cannot fill the chip and the K loop is long
+static int pick_ksplit(long long tiles, int nstages, long long M, int Cout, size_t ws_bytes) {
+  if (ws_bytes < (size_t)M * Cout * sizeof(float)) return 1;
+  if (tiles >= 256 || nstages < 8) return 1;
+  long long want = (512 + tiles - 1) / tiles;
+  long long cap = nstages / 4;
+  if (want > cap) want = cap;
+  if (want > 32) want = 32;
+  return want < 2 ? 1 : (int)want;
 }
 
 static int pick_bn(const rua_conv_desc* d, long long M) {
@@ -403,9 +462,17 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.mscale = d->mscale; k.mshift = d->mshift; k.out_relu = d->out_relu; k.accumulate = d->accumulate;
   k.y = (unsigned char*)d->y; k.out_stride = d->out_stride; k.OH = d->OH; k.OW = d->OW;
   k.stats = d->stats; k.stats_mode = d->stats_mode;
+  k.stats_R = d->stats_replicas < 1 ? 1 : d->stats_replicas;
+  RUA_CHECK_ARG((k.stats_R & (k.stats_R - 1)) == 0, "rua_conv_fwd: stats_replicas must be a power of two");
   const int bn = pick_bn(d, k.M);
   k.nbn = (d->Cout + bn - 1) / bn;
   const int nbm = (int)((k.M + 127) / 128);
+  k.nbm = nbm;
+  const int nstages = (units + 1) / 2;
+  k.ws = (float*)d->workspace;
+  k.ksplit = d->workspace ? pick_ksplit((long long)nbm * k.nbn, nstages, k.M, d->Cout, (size_t)d->workspace_bytes) : 1;
+  k.stages_per_split = (nstages + k.ksplit - 1) / k.ksplit;
+  k.ksplit = (nstages + k.stages_per_split - 1) / k.stages_per_split;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == RUA_BF16) {
     if (bn == 32) return launch_conv<bf16_t, 32>(k, nbm, st);
@@ -607,6 +674,11 @@ extern "C" int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, 
 }
 
 // tile width (output channels per block) the launcher picks for a descriptor: identifies the kernel instantiation
+extern "C" int64_t rua_conv_workspace_bytes(const rua_conv_desc* d) {
+  if (!d) return 0;
+  return (int64_t)d->N * d->H * d->W * d->Cout * (int64_t)sizeof(float);
+}
+
 extern "C" int rua_conv_tile_bn(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
   return pick_bn(d, (long long)d->N * d->H * d->W);

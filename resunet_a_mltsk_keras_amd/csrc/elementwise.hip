@@ -13,7 +13,7 @@ static inline int grid_for(int64_t pieces) {
 // ---------------------------------------------------------------------------------------
 // per-channel statistics
 struct StatsK { const unsigned char* x; const unsigned char* g; const float* ms; const float* mt; int masked;
-                long long M; int C, CG, TX, TY, rows_per_block; double* stats; };
+                long long M; int C, CG, TX, TY, rows_per_block; double* stats; int R; };
 
 template <typename T, int MODE>   // MODE 1: sum x, sum x^2 ; MODE 2: sum g*m, sum g*m*x
 __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
@@ -59,17 +59,25 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { s1[j] += sred[((k * p.TX + tx) * 2) * VEC + j]; s2[j] += sred[((k * p.TX + tx) * 2 + 1) * VEC + j]; }
     }
+    double* st = p.stats + (size_t)(blockIdx.x & (p.R - 1)) * 2 * p.C;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      atomicAdd(&p.stats[cp * VEC + j], (double)s1[j]);
-      atomicAdd(&p.stats[p.C + cp * VEC + j], (double)s2[j]);
+      atomicAdd(&st[cp * VEC + j], (double)s1[j]);
+      atomicAdd(&st[p.C + cp * VEC + j], (double)s2[j]);
     }
   }
 }
 
+extern "C" int rua_stats_replicas(int64_t blocks) {
+  int r = 1;
+  while (r < 32 && (int64_t)r * 64 < blocks) r *= 2;     // keep <= ~64 blocks per replica address
+  return r;
+}
+
 template <int MODE>
 static int launch_stats(const void* g, const void* x, const float* ms, const float* mt, int masked,
-                        int64_t M, int C, double* stats, int dtype, void* stream, const char* name) {
+                        int64_t M, int C, double* stats, int replicas, int dtype, void* stream, const char* name) {
+  RUA_CHECK_ARG(replicas >= 1 && (replicas & (replicas - 1)) == 0, "%s: replicas must be a power of two", name);
   RUA_CHECK_ARG(x && stats && M > 0, "%s: bad arguments", name);
   RUA_CHECK_ARG(dtype == RUA_F32 || dtype == RUA_BF16, "%s: bad dtype", name);
   const int vec = dtype == RUA_BF16 ? 8 : 4;
@@ -80,11 +88,11 @@ static int launch_stats(const void* g, const void* x, const float* ms, const flo
   int tx = 1; while (tx * 2 <= k.CG && tx < 256) tx *= 2;
   k.TX = tx; k.TY = 256 / tx;
   const int gy = (k.CG + tx - 1) / tx;
-  int64_t target_blocks = 2048 / gy; if (target_blocks < 1) target_blocks = 1;
+  int64_t target_blocks = 1024 / gy; if (target_blocks < 1) target_blocks = 1;
   int64_t rpb = (M + target_blocks - 1) / target_blocks;
   if (rpb < k.TY * 4) rpb = k.TY * 4;
   k.rows_per_block = (int)rpb;
-  k.stats = stats;
+  k.stats = stats; k.R = replicas;
   const int gx = (int)((M + rpb - 1) / rpb);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RUA_BF16) hipLaunchKernelGGL((col_stats_kernel<bf16_t, MODE>), dim3(gx, gy), dim3(256), 0, st, k);
@@ -93,25 +101,27 @@ static int launch_stats(const void* g, const void* x, const float* ms, const flo
   return RUA_OK;
 }
 
-extern "C" int rua_col_stats(const void* x, int64_t M, int C, double* stats, int dtype, void* stream) {
-  return launch_stats<1>(nullptr, x, nullptr, nullptr, 0, M, C, stats, dtype, stream, "rua_col_stats");
+extern "C" int rua_col_stats(const void* x, int64_t M, int C, double* stats, int replicas, int dtype, void* stream) {
+  return launch_stats<1>(nullptr, x, nullptr, nullptr, 0, M, C, stats, replicas, dtype, stream, "rua_col_stats");
 }
 extern "C" int rua_col_stats2(const void* g, const void* x, const float* mscale, const float* mshift, int masked,
-                              int64_t M, int C, double* stats, int dtype, void* stream) {
+                              int64_t M, int C, double* stats, int replicas, int dtype, void* stream) {
   RUA_CHECK_ARG(g != nullptr, "rua_col_stats2: null g");
-  return launch_stats<2>(g, x, mscale, mshift, masked, M, C, stats, dtype, stream, "rua_col_stats2");
+  return launch_stats<2>(g, x, mscale, mshift, masked, M, C, stats, replicas, dtype, stream, "rua_col_stats2");
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const double* stats, double count, double bessel_n, const float* gamma, const float* beta,
+__global__ void bn_finalize_kernel(const double* stats, int R, double count, double bessel_n, const float* gamma, const float* beta,
                                    float* mmean, float* mvar, float momentum, float eps, int training,
                                    float* scale, float* shift, float* mean_o, float* rstd_o, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double mean, var;
   if (training) {
-    mean = stats[c] / count;
-    var = stats[C + c] / count - mean * mean;
+    double s1 = 0, s2 = 0;
+    for (int r = 0; r < R; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
+    mean = s1 / count;
+    var = s2 / count - mean * mean;
     if (var < 0) var = 0;
     if (mmean) {
       const double unb = bessel_n > 1 ? var * (bessel_n / (bessel_n - 1)) : var;
@@ -129,22 +139,23 @@ __global__ void bn_finalize_kernel(const double* stats, double count, double bes
   if (rstd_o) rstd_o[c] = (float)r;
 }
 
-extern "C" int rua_bn_finalize(const double* stats, double count, double bessel_n, const float* gamma, const float* beta,
+extern "C" int rua_bn_finalize(const double* stats, int replicas, double count, double bessel_n, const float* gamma, const float* beta,
                                float* moving_mean, float* moving_var, float momentum, float eps, int training,
                                float* scale, float* shift, float* mean, float* rstd, int C, void* stream) {
   RUA_CHECK_ARG(gamma && beta && scale && shift && C > 0, "rua_bn_finalize: bad arguments");
   RUA_CHECK_ARG(training ? (stats != nullptr && count > 0) : (moving_mean && moving_var), "rua_bn_finalize: missing statistics");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(rua_div_up(C, 128)), dim3(128), 0, (hipStream_t)stream,
-                     stats, count, bessel_n, gamma, beta, moving_mean, moving_var, momentum, eps, training, scale, shift, mean, rstd, C);
+                     stats, replicas < 1 ? 1 : replicas, count, bessel_n, gamma, beta, moving_mean, moving_var, momentum, eps, training, scale, shift, mean, rstd, C);
   RUA_LAUNCH_CHECK("rua_bn_finalize");
   return RUA_OK;
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* st2, double count, const float* gamma, const float* mean, const float* rstd,
+__global__ void bn_bwd_finalize_kernel(const double* st2, int R, double count, const float* gamma, const float* mean, const float* rstd,
                                        float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double sg = st2[c], sgx = st2[C + c];
+  double sg = 0, sgx = 0;
+  for (int r = 0; r < R; ++r) { sg += st2[(size_t)r * 2 * C + c]; sgx += st2[(size_t)r * 2 * C + C + c]; }
   const double mu = mean[c], r = rstd[c], gm = gamma[c];
   const double dbe = sg;
   const double dga = r * (sgx - mu * sg);
@@ -156,26 +167,28 @@ __global__ void bn_bwd_finalize_kernel(const double* st2, double count, const fl
   cC[c] = (float)(-s * dbe / count + s * r * mu * dga / count);
 }
 
-extern "C" int rua_bn_bwd_finalize(const double* stats2, double count, const float* gamma, const float* mean, const float* rstd,
+extern "C" int rua_bn_bwd_finalize(const double* stats2, int replicas, double count, const float* gamma, const float* mean, const float* rstd,
                                    float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC, int C, void* stream) {
   RUA_CHECK_ARG(stats2 && gamma && mean && rstd && coefA && coefB && coefC && C > 0 && count > 0, "rua_bn_bwd_finalize: bad arguments");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rua_div_up(C, 128)), dim3(128), 0, (hipStream_t)stream,
-                     stats2, count, gamma, mean, rstd, dgamma, dbeta, coefA, coefB, coefC, C);
+                     stats2, replicas < 1 ? 1 : replicas, count, gamma, mean, rstd, dgamma, dbeta, coefA, coefB, coefC, C);
   RUA_LAUNCH_CHECK("rua_bn_bwd_finalize");
   return RUA_OK;
 }
 
 // per-channel sums (fp64) -> n fp32 destinations (bias gradients: d b = sum over pixels of dy)
-__global__ void stats_to_f32_kernel(const double* stats, int C, float* d0, float* d1, float* d2, float* d3, int n) {
+__global__ void stats_to_f32_kernel(const double* stats, int R, int C, float* d0, float* d1, float* d2, float* d3, int n) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float v = (float)stats[c];
+  double a = 0;
+  for (int r = 0; r < R; ++r) a += stats[(size_t)r * 2 * C + c];
+  const float v = (float)a;
   d0[c] = v; if (n > 1) d1[c] = v; if (n > 2) d2[c] = v; if (n > 3) d3[c] = v;
 }
-extern "C" int rua_stats_to_f32(const double* stats, int C, float* const* dst, int n, void* stream) {
+extern "C" int rua_stats_to_f32(const double* stats, int replicas, int C, float* const* dst, int n, void* stream) {
   RUA_CHECK_ARG(stats && dst && n >= 1 && n <= 4 && C > 0, "rua_stats_to_f32: bad arguments");
   for (int i = 0; i < n; ++i) RUA_CHECK_ARG(dst[i], "rua_stats_to_f32: null destination");
-  hipLaunchKernelGGL(stats_to_f32_kernel, dim3(rua_div_up(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, C,
+  hipLaunchKernelGGL(stats_to_f32_kernel, dim3(rua_div_up(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, replicas < 1 ? 1 : replicas, C,
                      dst[0], n > 1 ? dst[1] : nullptr, n > 2 ? dst[2] : nullptr, n > 3 ? dst[3] : nullptr, n);
   RUA_LAUNCH_CHECK("rua_stats_to_f32");
   return RUA_OK;

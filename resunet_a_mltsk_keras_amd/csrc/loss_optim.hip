@@ -297,7 +297,8 @@ extern "C" int rua_seg_metrics(const float* p, const float* y, int64_t M, int C,
 
 // ---- optimizers on the flat parameter buffer ---------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ th, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                   long long n, float lr_t, float b1, float b2, float eps, float gs, int zero) {
+                                                   long long n, float lr_t, const float* __restrict__ lr_dev, float b1, float b2, float eps, float gs, int zero) {
+  if (lr_dev) lr_t = lr_dev[0];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float gg = g[i] * gs;
     const float mm = b1 * m[i] + (1.f - b1) * gg;
@@ -308,26 +309,27 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ th, float
   }
 }
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ th, float* __restrict__ g, float* __restrict__ vel,
-                                                  long long n, float lr, float mu, float gs, int zero) {
+                                                  long long n, float lr, const float* __restrict__ lr_dev, float mu, float gs, int zero) {
+  if (lr_dev) lr = lr_dev[0];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float vv = mu * vel[i] - lr * g[i] * gs;
     vel[i] = vv; th[i] += vv;
     if (zero) g[i] = 0.f;
   }
 }
-extern "C" int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+extern "C" int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1, float beta2,
                              float eps, float grad_scale, int zero_grad, void* stream) {
   RUA_CHECK_ARG(theta && g && m && v && n > 0, "rua_adam_step: bad arguments");
   int64_t gr = (n + 255) / 256; if (gr > 4096) gr = 4096;
-  hipLaunchKernelGGL(adam_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, (long long)n, lr_t, beta1, beta2, eps, grad_scale, zero_grad);
+  hipLaunchKernelGGL(adam_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, (long long)n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, zero_grad);
   RUA_LAUNCH_CHECK("rua_adam_step");
   return RUA_OK;
 }
-extern "C" int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, float momentum, float grad_scale,
+extern "C" int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, const float* lr_dev, float momentum, float grad_scale,
                             int zero_grad, void* stream) {
   RUA_CHECK_ARG(theta && g && vel && n > 0, "rua_sgd_step: bad arguments");
   int64_t gr = (n + 255) / 256; if (gr > 4096) gr = 4096;
-  hipLaunchKernelGGL(sgd_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, vel, (long long)n, lr, momentum, grad_scale, zero_grad);
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, vel, (long long)n, lr, lr_dev, momentum, grad_scale, zero_grad);
   RUA_LAUNCH_CHECK("rua_sgd_step");
   return RUA_OK;
 }

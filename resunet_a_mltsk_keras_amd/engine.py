@@ -181,6 +181,22 @@ class Ten:
         return self.N * self.H * self.W
 
 
+def stats_replicas(blocks: int) -> int:
+    """Mirror of rua_stats_replicas(): replicas of a statistics buffer fed by `blocks` workgroups."""
+    r = 1
+    while r < 32 and r * 64 < blocks:
+        r *= 2
+    return r
+
+
+class Stat:
+    """fp64 statistics buffer [R][2][C] in the per-step arena."""
+    __slots__ = ("ptr", "R")
+
+    def __init__(self, ptr, R):
+        self.ptr, self.R = ptr, R
+
+
 class _Dummy:
     """Stand-in for a device allocation during the dry (parameter-enumeration) pass."""
 
@@ -286,6 +302,10 @@ class Graph:
         assert self.stats_used <= self.e.stats_arena.numel(), "statistics arena exhausted"
         return self.e.stats_arena.data_ptr() + off * 8
 
+    def stat(self, C: int, blocks: int) -> Stat:
+        R = stats_replicas(blocks)
+        return Stat(self.salloc(R * 2 * C), R)
+
     def gacc(self, x: Ten) -> Tuple[Ten, int]:
         """Gradient buffer of x and whether the next writer must accumulate."""
         if x.grad is None:
@@ -313,15 +333,15 @@ class Graph:
     def Wd(self, dst):
         return 0 if self.dry else self.e.Wd.data_ptr() + dst * self.e.esize
 
-    def col_stats(self, plan: Plan, x: Ten) -> int:
-        s = self.salloc(2 * x.C)
-        plan.add("rua_col_stats", x.ptr, x.M, x.C, s, self.dt)
+    def col_stats(self, plan: Plan, x: Ten) -> Stat:
+        s = self.stat(x.C, min(1024, (x.M + 63) // 64))
+        plan.add("rua_col_stats", x.ptr, x.M, x.C, s.ptr, s.R, self.dt)
         return s
 
-    def bn_finalize(self, plan: Plan, stats, count, bn, bessel=None) -> Coef:
+    def bn_finalize(self, plan: Plan, stats: Optional[Stat], count, bn, bessel=None) -> Coef:
         c = Coef(self, bn["C"])
         plan.keep.append(c)
-        plan.add("rua_bn_finalize", stats if self.training else None, float(count), float(bessel or count),
+        plan.add("rua_bn_finalize", stats.ptr if self.training else None, stats.R if self.training else 1, float(count), float(bessel or count),
                  self.P(bn["gamma"]), self.P(bn["beta"]), self.S(bn["mm"]), self.S(bn["mv"]), BN_MOMENTUM, BN_EPS,
                  1 if self.training else 0, c.scale, c.shift, c.mean, c.rstd, bn["C"])
         return c
@@ -349,9 +369,15 @@ class Graph:
         d.out_relu = 1 if out_relu else 0
         d.y, d.out_stride, d.OH, d.OW = out.ptr, 1, out.H, out.W
         if stats is not None:
-            d.stats, d.stats_mode = stats, 1
+            d.stats, d.stats_mode, d.stats_replicas = stats.ptr, 1, stats.R
+        self._ws(d)
         plan.keep.append(d)
         plan.add("rua_conv_fwd", C.byref(d))
+
+    def _ws(self, d):
+        """Shared split-K scratch (launches are serialised on one stream, so one buffer serves every conv)."""
+        if not self.dry and d.N * d.H * d.W * d.Cout * 4 <= self.e.workspace.numel() * 4:
+            d.workspace, d.workspace_bytes = self.e.workspace.data_ptr(), self.e.workspace.numel() * 4
 
     def dgrad(self, plan: Plan, dy: Ten, wd_ptr, cin: int, dil: int, taps: int, out: Ten, accumulate: int,
               mask: Optional[Tuple[Ten, Optional[int], Optional[int]]] = None, stats2: Optional[int] = None,
@@ -369,7 +395,8 @@ class Graph:
         elif stat_aux is not None:
             d.aux, d.aux_mode = stat_aux.ptr, 3
         if stats2 is not None:
-            d.stats, d.stats_mode = stats2, 2
+            d.stats, d.stats_mode, d.stats_replicas = stats2.ptr, 2, stats2.R
+        self._ws(d)
         plan.keep.append(d)
         plan.add("rua_conv_fwd", C.byref(d))
 
@@ -386,10 +413,10 @@ class Graph:
         s = self.col_stats(plan, dy)
         dst = L.ptr_array([self.G(o) for o in bias_offs])
         plan.keep.append(dst)
-        plan.add("rua_stats_to_f32", s, dy.C, dst, len(bias_offs))
+        plan.add("rua_stats_to_f32", s.ptr, s.R, dy.C, dst, len(bias_offs))
 
     def bn_bwd_finalize(self, plan: Plan, stats2, count, bn, coef: Coef):
-        plan.add("rua_bn_bwd_finalize", stats2, float(count), self.P(bn["gamma"]), coef.mean, coef.rstd,
+        plan.add("rua_bn_bwd_finalize", stats2.ptr, stats2.R, float(count), self.P(bn["gamma"]), coef.mean, coef.rstd,
                  self.G(bn["gamma"]), self.G(bn["beta"]), coef.A, coef.B, coef.Cc, bn["C"])
 
     def bn_bwd_apply(self, plan: Plan, gs: List[Ten], coefs: List[Coef], x: Ten, out: Ten, accumulate: int,
@@ -421,7 +448,7 @@ class Graph:
         y1, coef2, a2 = [], [], []
         for d, l, a in zip(dils, lay, a1):
             y = self.like(x)
-            st = self.salloc(2 * nf) if tr else None
+            st = self.stat(nf, (cnt + 127) // 128) if tr else None
             self.conv(F, [(a, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st)
             c2 = self.bn_finalize(F, st, cnt, l[2])
             y1.append(y); coef2.append(c2)
@@ -444,7 +471,7 @@ class Graph:
             for d, l, a_1, y, c2, a_2, c1 in zip(dils, lay, a1, y1, coef2, a2, coef1):
                 self.wgrad(Bp, a_2, dO, l[3]["segs"][0]["off"], 1, d, 9)
                 g2 = self.like(x)
-                s2 = self.salloc(2 * nf)
+                s2 = self.stat(nf, (cnt + 127) // 128)
                 self.dgrad(Bp, dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
                 self.bn_bwd_finalize(Bp, s2, cnt, l[2], c2)
                 dy1 = self.like(x)
@@ -452,7 +479,7 @@ class Graph:
                 self.bias_grad(Bp, dy1, [l[1]["bias"]])
                 self.wgrad(Bp, a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9)
                 g1 = g2                                    # g2 is dead after bn_bwd_apply: reuse its storage
-                s1 = self.salloc(2 * nf)
+                s1 = self.stat(nf, (cnt + 127) // 128)
                 self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
                 self.bn_bwd_finalize(Bp, s1, cnt, l[0], c1)
                 g1s.append(g1)
@@ -466,7 +493,7 @@ class Graph:
         F, tr = self.fwd, self.training
         lay = self.Lconv([x.C], nf, 1)
         y = self.new(x.N, x.H // 2, x.W // 2, nf)
-        st = self.salloc(2 * nf) if tr else None
+        st = self.stat(nf, (y.M + 127) // 128) if tr else None
         self.conv(F, [(x, 0, 1, 1)], lay["segs"], nf, self.P(lay["bias"]), y, stride=2, stats=st)
         y.stats = st
         if tr:
@@ -497,8 +524,8 @@ class Graph:
             Bp = self.bwd
             g = y.grad
             if not node["fused"]:
-                node["s2"] = self.salloc(2 * x.C)
-                Bp.add("rua_col_stats2", g.ptr, x.ptr, coef.scale, coef.shift, 1 if relu else 0, x.M, x.C, node["s2"], self.dt)
+                node["s2"] = self.stat(x.C, min(1024, (x.M + 63) // 64))
+                Bp.add("rua_col_stats2", g.ptr, x.ptr, coef.scale, coef.shift, 1 if relu else 0, x.M, x.C, node["s2"].ptr, node["s2"].R, self.dt)
             self.bn_bwd_finalize(Bp, node["s2"], cnt, bn, coef)
             gx, acc = self.gacc(x)
             self.bn_bwd_apply(Bp, [g], [coef], x, gx, acc, masked=(relu and not node["fused"]))
@@ -508,7 +535,7 @@ class Graph:
     def fuse_target(self, node):
         """dgrad epilogue arguments that make `node`'s backward fused (single consumer only)."""
         node["fused"] = True
-        node["s2"] = self.salloc(2 * node["x"].C)
+        node["s2"] = self.stat(node["x"].C, (node["x"].M + 127) // 128)
         g, _ = self.gacc(node["y"])
         if node["relu"]:
             return dict(out=g, mask=(node["x"], node["coef"].scale, node["coef"].shift), stats2=node["s2"])
@@ -519,7 +546,7 @@ class Graph:
         F, tr = self.fwd, self.training
         lay = self.Lconv([t.C for t, _ in segs], cout, 1)
         y = self.new(self.B, out_hw[0], out_hw[1], cout)
-        st = self.salloc(2 * cout) if (tr and want_stats) else None
+        st = self.stat(cout, (y.M + 127) // 128) if (tr and want_stats) else None
         self.conv(F, [(t, up, 1, 1) for t, up in segs], lay["segs"], cout, self.P(lay["bias"]), y, stats=st)
         y.stats = st
         return y, lay
@@ -802,6 +829,10 @@ class Engine:
         self.wprep_items = torch.from_numpy(np.frombuffer(items.tobytes(), dtype=np.uint8).copy()).to(self.dev)
         self.wprep_n, self.wprep_max = len(rows), mx
         self.stats_arena = torch.zeros(1 << 20, dtype=torch.float64, device=self.dev)
+        self.workspace = torch.zeros(8 << 20, dtype=torch.float32, device=self.dev)       # 32 MiB split-K scratch
+        self.lr_dev = torch.zeros(16, dtype=torch.float32, device=self.dev)               # step-dependent optimizer scalars
+        self.use_graph = True
+        self._captured: Dict[int, object] = {}
         self.scalars_ptr = self.stats_arena.data_ptr()
         self.t = 0
         self.weights_dirty = True
@@ -935,20 +966,64 @@ class Engine:
             g._hooks = hooks
         return g._hooks
 
-    def optimizer_step(self, grad_scale: float = 1.0):
-        sp, s = self.loss, self._stream()
+    def _set_lr(self):
+        """Advance the step counter and put the step-dependent learning rate into device memory."""
+        sp = self.loss
         self.t += 1
+        lr = sp.lr
         if sp.optimizer == "adam":
-            lr_t = sp.lr * math.sqrt(1.0 - sp.beta_2 ** self.t) / (1.0 - sp.beta_1 ** self.t)
+            lr = sp.lr * math.sqrt(1.0 - sp.beta_2 ** self.t) / (1.0 - sp.beta_1 ** self.t)
+        self.lr_dev[:1].fill_(lr)
+
+    def _launch_optimizer(self, grad_scale, s):
+        sp = self.loss
+        if sp.optimizer == "adam":
             L.lib().call("rua_adam_step", self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.V1.data_ptr(), self.params.n,
-                         lr_t, sp.beta_1, sp.beta_2, KERAS_EPS, grad_scale, 1, C.c_void_p(s))
+                         0.0, self.lr_dev.data_ptr(), sp.beta_1, sp.beta_2, KERAS_EPS, grad_scale, 1, C.c_void_p(s))
         else:
-            L.lib().call("rua_sgd_step", self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.params.n, sp.lr, sp.momentum,
-                         grad_scale, 1, C.c_void_p(s))
+            L.lib().call("rua_sgd_step", self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.params.n, 0.0,
+                         self.lr_dev.data_ptr(), sp.momentum, grad_scale, 1, C.c_void_p(s))
+
+    def optimizer_step(self, grad_scale: float = 1.0):
+        self._set_lr()
+        self._launch_optimizer(grad_scale, self._stream())
         self.weights_dirty = True
+
+    def _graph_step(self, x, y):
+        """Single-GPU fast path: the whole step (arena zeroing, weight refresh, forward, losses, backward, optimizer)
+        captured once into a HIP graph and replayed; only the input upload and the lr scalar stay outside."""
+        B = x.shape[0] if x is not None else self._last_B
+        self._last_B = B
+        g = self.graph(B, True)
+        self._upload(g, x, y)
+        self._set_lr()
+        cap = self._captured.get(B)
+        if cap is None:
+            # warm-up run outside capture (sets kernel attributes, pays first-launch costs), then capture
+            s = self._stream()
+            self._zero_arena(g, s); self.weights_dirty = True; self._prep_weights(s)
+            g.fwd.run(s); g.loss_plan.run(s); g.bwd.run(s)
+            self._launch_optimizer(1.0, s)
+            torch.cuda.synchronize()
+            cap = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cap):
+                s = self._stream()
+                self._zero_arena(g, s); self.weights_dirty = True; self._prep_weights(s)
+                g.fwd.run(s); g.loss_plan.run(s); g.bwd.run(s)
+                self._launch_optimizer(1.0, s)
+            self._captured[B] = cap
+            self.weights_dirty = True
+            # the warm-up consumed this step's update; the capture itself launched nothing
+            return g
+        cap.replay()
+        self.weights_dirty = True
+        return g
 
     def train_step(self, x=None, y=None, fetch: bool = True):
         """One Keras train_on_batch (train_ISPRS.py:131,148): returns the metric list in the reference's order."""
+        if self.use_graph and self.dist is None:
+            g = self._graph_step(x, y)
+            return self._results(g) if fetch else None
         g = self.forward_backward(x, y)
         if self.dist is not None:
             self.dist.reduce_gradients(self)

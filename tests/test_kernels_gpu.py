@@ -95,19 +95,54 @@ def test_conv_fwd(case, dt):
     res = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
     bd, rd = torch.from_numpy(bias).to(dev()), to_dev(res, dt)
     y = torch.empty((N, H, W, Cout), dtype=tdt(dt), device=dev())
-    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev())
+    stats = torch.zeros(2 * 2 * Cout, dtype=torch.float64, device=dev())
     d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cout, stride, dt
     d.bias, d.aux, d.aux_mode = bd.data_ptr(), rd.data_ptr(), 1
     d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
-    d.stats, d.stats_mode = stats.data_ptr(), 1
+    d.stats, d.stats_mode, d.stats_replicas = stats.data_ptr(), 1, 2
     lib.call("rua_conv_fwd", C.byref(d), stream())
     torch.cuda.synchronize()
     exp = (exp + torch.from_numpy(bias).double() + rnd(dt, res).double()).numpy()
     got = y.float().cpu().numpy()
     assert rel_err(got, exp) < tol(dt)
-    st = stats.cpu().numpy()
+    st = stats.cpu().numpy().reshape(2, 2 * Cout).sum(0)
     assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
     assert rel_err(st[Cout:], (exp ** 2).sum(axis=(0, 1, 2))) < 5 * tol(dt)
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+def test_conv_split_k_matches_single_pass(dt):
+    """Small output grid + long K (the 8x8x1024 level): with a workspace the launcher splits K over blocks
+    (fp32 atomics + finisher); result, statistics and mask must match the torch reference."""
+    rng = np.random.default_rng(12)
+    lib = L.lib()
+    N, H, W, Cs, Cout = 2, 8, 8, 256, 128
+    x = rng.standard_normal((N, H, W, Cs)).astype(np.float32)
+    w = (rng.standard_normal((9, Cout, Cs)) / np.sqrt(9 * Cs)).astype(np.float32)
+    aux = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    xd, wd, ad, bd = to_dev(x, dt), to_dev(w, dt), to_dev(aux, dt), torch.from_numpy(bias).to(dev())
+    y = torch.empty((N, H, W, Cout), dtype=tdt(dt), device=dev())
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev())
+    ws = torch.empty(N * H * W * Cout, dtype=torch.float32, device=dev())
+    d = L.ConvDesc()
+    d.nseg = 1
+    s = d.seg[0]
+    s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = xd.data_ptr(), wd.data_ptr(), Cs, H, W, 0, 1, 9
+    d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cout, 1, dt
+    d.bias, d.aux, d.aux_mode = bd.data_ptr(), ad.data_ptr(), 2
+    d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+    d.stats, d.stats_mode, d.stats_replicas = stats.data_ptr(), 2, 1
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    assert lib.raw("rua_conv_workspace_bytes")(C.byref(d)) == ws.numel() * 4
+    lib.call("rua_conv_fwd", C.byref(d), stream())
+    torch.cuda.synchronize()
+    a = rnd(dt, aux).double().numpy()
+    exp = (ref_conv_nhwc(rnd(dt, x), rnd(dt, w), torch.from_numpy(bias), 1, 9).numpy()) * (a > 0)
+    assert rel_err(y.float().cpu().numpy(), exp) < tol(dt)
+    st = stats.cpu().numpy()
+    assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
+    assert rel_err(st[Cout:], (exp * a).sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
 
 
 @pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
@@ -265,8 +300,10 @@ def test_bn_stats_apply_backward(dt):
     stats = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
     coef = torch.zeros(7, Cc, dtype=torch.float32, device=dev())
     cp = [coef[i].data_ptr() for i in range(7)]
-    lib.call("rua_col_stats", xd.data_ptr(), M, Cc, stats.data_ptr(), dt, stream())
-    lib.call("rua_bn_finalize", stats.data_ptr(), float(M), float(M), gd.data_ptr(), bd.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+    R = 4
+    stats = torch.zeros(R * 2 * Cc, dtype=torch.float64, device=dev())
+    lib.call("rua_col_stats", xd.data_ptr(), M, Cc, stats.data_ptr(), R, dt, stream())
+    lib.call("rua_bn_finalize", stats.data_ptr(), R, float(M), float(M), gd.data_ptr(), bd.data_ptr(), mm.data_ptr(), mv.data_ptr(),
              0.99, 1e-3, 1, cp[0], cp[1], cp[2], cp[3], Cc, stream())
     out = torch.empty((M, Cc), dtype=tdt(dt), device=dev())
     sc, sh, ou = L.ptr_array([cp[0]]), L.ptr_array([cp[1]]), L.ptr_array([out.data_ptr()])
@@ -282,10 +319,10 @@ def test_bn_stats_apply_backward(dt):
     g = rng.standard_normal((M, Cc)).astype(np.float32)
     gdv = to_dev(g, dt)
     yr.backward(rnd(dt, g).double())
-    st2 = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
-    lib.call("rua_col_stats2", gdv.data_ptr(), xd.data_ptr(), cp[0], cp[1], 1, M, Cc, st2.data_ptr(), dt, stream())
+    st2 = torch.zeros(2 * 2 * Cc, dtype=torch.float64, device=dev())
+    lib.call("rua_col_stats2", gdv.data_ptr(), xd.data_ptr(), cp[0], cp[1], 1, M, Cc, st2.data_ptr(), 2, dt, stream())
     dgam = torch.zeros(Cc, device=dev()); dbet = torch.zeros(Cc, device=dev())
-    lib.call("rua_bn_bwd_finalize", st2.data_ptr(), float(M), gd.data_ptr(), cp[2], cp[3], dgam.data_ptr(), dbet.data_ptr(),
+    lib.call("rua_bn_bwd_finalize", st2.data_ptr(), 2, float(M), gd.data_ptr(), cp[2], cp[3], dgam.data_ptr(), dbet.data_ptr(),
              cp[4], cp[5], cp[6], Cc, stream())
     dx = torch.empty((M, Cc), dtype=tdt(dt), device=dev())
     ga, A, B_, C_, ms, mt = (L.ptr_array([gdv.data_ptr()]), L.ptr_array([cp[4]]), L.ptr_array([cp[5]]), L.ptr_array([cp[6]]),
@@ -445,13 +482,13 @@ def test_metrics_and_optimizers():
     for step in (1, 2):
         lr_t = 1e-3 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
         gd.copy_(f(g))
-        lib.call("rua_adam_step", thd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr_t, 0.9, 0.999, 1e-7, 0.5, 1, stream())
+        lib.call("rua_adam_step", thd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr_t, None, 0.9, 0.999, 1e-7, 0.5, 1, stream())
         e_th, e_m, e_v = nv.adam_step(e_th, 0.5 * g.astype(np.float64), e_m, e_v, step, 1e-3)
     torch.cuda.synchronize()
     assert np.allclose(thd.cpu().numpy(), e_th, rtol=1e-5, atol=1e-6)
     assert float(gd.abs().max()) == 0.0
     thd, gd, vd = f(th), f(g), f(np.zeros(n))
-    lib.call("rua_sgd_step", thd.data_ptr(), gd.data_ptr(), vd.data_ptr(), n, 0.1, 0.8, 1.0, 0, stream())
+    lib.call("rua_sgd_step", thd.data_ptr(), gd.data_ptr(), vd.data_ptr(), n, 0.1, None, 0.8, 1.0, 0, stream())
     torch.cuda.synchronize()
     e_th, _ = nv.sgd_step(th.astype(np.float64), g.astype(np.float64), np.zeros(n), 0.1)
     assert np.allclose(thd.cpu().numpy(), e_th, rtol=1e-5, atol=1e-6)

@@ -87,7 +87,7 @@ def check_step(trainer, eng, x, y, mt, tol_loss, tol_logit, tol_grad, tol_w, che
     for k in trainer.params:
         e = trainer.params[k].detach().numpy()
         d = np.abs(w[k] - e)
-        assert d.mean() <= tol_w * np.abs(e).mean() + 2e-5, (k, float(d.mean()))
+        assert d.mean() <= tol_w * np.abs(e).mean() + 5e-5, (k, float(d.mean()))
         assert d.max() <= tol_w * np.abs(e).max() + 2.5 * lr, (k, float(d.max()))
     return got, exp
 
@@ -109,7 +109,7 @@ def test_tiny_multitask_fp32_two_steps(loss, opt):
     pred = eng.predict(x)
     rp = ref.forward(trainer.cfg, trainer.params, x, training=False)
     for h in pred:
-        assert np.abs(pred[h] - rp[h]).max() < 2e-3
+        assert np.abs(pred[h] - rp[h]).max() < 5e-3        # after two noisy Adam steps (see check_step)
 
 
 def test_tiny_singletask_fp32_128():
@@ -151,3 +151,25 @@ def test_cfg3_full_size_fp32_loss_and_logits():
     for h, z in eng.logits(True, 2).items():
         assert rel(z, trainer.last_taps[h + "_logits"]) < 1e-3, h
     assert eng.count_params() == 42736869
+
+
+def test_graph_replay_equals_eager_launches():
+    """The captured-HIP-graph step (single GPU fast path) must reproduce the eager launch sequence up to
+    atomic-order noise: same losses and same weights after three SGD steps (SGD is linear in the gradient, so
+    rounding noise is not sign-amplified the way Adam's first steps do)."""
+    shape, C = (64, 64, 6), 6
+    outs = []
+    for use_graph in (False, True):
+        _, eng = make_pair(shape, C, True, 32, "tanimoto", "sgd", dtype="bf16", seed=5)
+        eng.use_graph = use_graph
+        losses = []
+        for step in range(3):
+            x, y = make_batch(2, 64, 6, C, True, seed=40 + step, block=16)
+            losses.append(eng.train_step(x, y)[:5])
+        torch.cuda.synchronize()
+        outs.append((np.array(losses), eng.P.cpu().numpy().copy(), eng.t))
+    assert outs[0][2] == outs[1][2] == 3
+    assert np.allclose(outs[0][0], outs[1][0], rtol=2e-3, atol=2e-4), (outs[0][0], outs[1][0])
+    d = np.abs(outs[0][1] - outs[1][1])
+    moved = np.abs(outs[0][1]).mean()
+    assert d.mean() < 1e-4 * moved and d.max() < 1e-3, (float(d.mean()), float(d.max()), float(moved))
