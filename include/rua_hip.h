@@ -116,12 +116,12 @@ int rua_col_stats2(const void* g, const void* x, const float* mscale, const floa
 int rua_bn_finalize(const double* stats, int replicas, double count, double bessel_n, const float* gamma, const float* beta,
                     float* moving_mean, float* moving_var, float momentum, float eps, int training,
                     float* scale, float* shift, float* mean, float* rstd, int C, void* stream);
-/* (float)stats[c] -> n (<=4) fp32 vectors: bias gradients from per-channel sums of dy */
+/* dst_i[c] += (float)stats[c] for n (<=4) fp32 vectors: bias gradients from per-channel sums of dy */
 int rua_stats_to_f32(const double* stats, int replicas, int C, float* const* dst, int n, void* stream);
 /* out_b = [relu](scale_b * x + shift_b) for b < nb (all branches of a ResBlock read x once) */
 int rua_bn_apply(const void* x, int nb, const float* const* scale, const float* const* shift, int relu,
                  void* const* out, int64_t M, int C, int dtype, void* stream);
-/* backward statistics -> dgamma, dbeta and the coefficients A,B,Cc of dx = A*g + B*x + Cc */
+/* backward statistics -> dgamma += , dbeta += , and the coefficients A,B,Cc of dx = A*g + B*x + Cc */
 int rua_bn_bwd_finalize(const double* stats2, int replicas, double count, const float* gamma, const float* mean, const float* rstd,
                         float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC, int C, void* stream);
 /* dx (=|+=) [dskip] + sum_b (A_b * g_b * m_b + B_b * x + C_b),  m_b = ReLU mask of branch b (or 1) */
@@ -156,11 +156,14 @@ int rua_fill_zero(void* p, int64_t bytes, void* stream);
 #define RUA_ACT_SIGMOID 2
 /* six moments per (sample, class): sum p, sum (1-l), sum p*l, sum p^2+l^2, sum (1-p)(1-l), sum (1-p)^2+(1-l)^2 */
 int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t HW, int C, double* sums, void* stream);
-/* loss_out[0] = mean_n Tanimoto_dual ; coef[B][C][3] : dLoss/dp = c0 + c1*p + c2*l (already * grad_scale) */
-int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef, void* stream);
-/* loss_out[0] += sum over pixels of the per-pixel loss of kind 1..4 (caller divides) */
+/* loss_out[0] = mean_n Tanimoto_dual ; coef[B][C][3] (optional): dLoss/dp = c0 + c1*p + c2*l (already * grad_scale);
+ * per_sample[B] (optional): the (B,) vector the reference's loss function returns (multitasking_utils.py:84) */
+int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,
+                          float* per_sample, void* stream);
+/* loss_out[0] += sum over pixels of the per-pixel loss of kind 1..4 (caller divides);
+ * per_pixel[M] (optional): the (B,H,W) map the reference's loss function returns (utils.py:486) */
 int rua_pixel_loss(int kind, const float* p, const float* z, const float* y, const float* class_w,
-                   int64_t M, int C, double* loss_out, void* stream);
+                   int64_t M, int C, double* loss_out, float* per_pixel, void* stream);
 /* dz = d(total)/d(logits) for every loss kind; coef only for Tanimoto; grad_scale = loss_weight/denominator */
 int rua_head_dz(int kind, int act, const float* p, const float* y, const float* coef, const float* class_w,
                 float grad_scale, int B, int64_t HW, int C, float* dz, void* stream);

@@ -1,0 +1,6 @@
+"""Loss factory of the reference's multitask path (reference multitasking_utils.py:38-85), evaluated by HIP kernels."""
+from resunet_a_mltsk_keras_amd.keras_api import Tanimoto_dual_loss, TanimotoDualLoss  # noqa: F401
+
+
+def Tanimoto_loss(label, pred):
+    raise NotImplementedError("only the dual form is on the training path: use Tanimoto_dual_loss()")

@@ -70,8 +70,8 @@ _SIGS = {
     "rua_cast_to_f32": ([vp, vp, i64, i32, vp], i32),
     "rua_fill_zero": ([vp, i64, vp], i32),
     "rua_tanimoto_sums": ([vp, vp, i32, i64, i32, vp, vp], i32),
-    "rua_tanimoto_finalize": ([vp, i32, i64, i32, f32, vp, vp, vp], i32),
-    "rua_pixel_loss": ([i32, vp, vp, vp, vp, i64, i32, vp, vp], i32),
+    "rua_tanimoto_finalize": ([vp, i32, i64, i32, f32, vp, vp, vp, vp], i32),
+    "rua_pixel_loss": ([i32, vp, vp, vp, vp, i64, i32, vp, vp, vp], i32),
     "rua_head_dz": ([i32, i32, vp, vp, vp, vp, f32, i32, i64, i32, vp, vp], i32),
     "rua_seg_metrics": ([vp, vp, i64, i32, vp, vp], i32),
     "rua_adam_step": ([vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, i32, vp], i32),

@@ -160,8 +160,8 @@ __global__ void bn_bwd_finalize_kernel(const double* st2, int R, double count, c
   const double dbe = sg;
   const double dga = r * (sgx - mu * sg);
   const double s = gm * r;
-  if (dgamma) dgamma[c] = (float)dga;
-  if (dbeta) dbeta[c] = (float)dbe;
+  if (dgamma) dgamma[c] += (float)dga;      // gradients accumulate (the optimizer zeroes the flat buffer)
+  if (dbeta) dbeta[c] += (float)dbe;
   cA[c] = (float)s;
   cB[c] = (float)(-s * r * dga / count);
   cC[c] = (float)(-s * dbe / count + s * r * mu * dga / count);
@@ -183,7 +183,7 @@ __global__ void stats_to_f32_kernel(const double* stats, int R, int C, float* d0
   double a = 0;
   for (int r = 0; r < R; ++r) a += stats[(size_t)r * 2 * C + c];
   const float v = (float)a;
-  d0[c] = v; if (n > 1) d1[c] = v; if (n > 2) d2[c] = v; if (n > 3) d3[c] = v;
+  d0[c] += v; if (n > 1) d1[c] += v; if (n > 2) d2[c] += v; if (n > 3) d3[c] += v;
 }
 extern "C" int rua_stats_to_f32(const double* stats, int replicas, int C, float* const* dst, int n, void* stream) {
   RUA_CHECK_ARG(stats && dst && n >= 1 && n <= 4 && C > 0, "rua_stats_to_f32: bad arguments");

@@ -69,7 +69,7 @@ extern "C" int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t 
 
 // One block.  Follows Tanimoto_dual_loss: loss1 = T(label:=pred, pred:=label) so the class weights of
 // the first term come from the PREDICTION volumes (and carry gradient); loss2 = T(1-label, 1-pred).
-__global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B, int C, float grad_scale, double* loss_out, float* coef) {
+__global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B, int C, float grad_scale, double* loss_out, float* coef, float* per_sample) {
   __shared__ double w1[8], w2[8], v1[8], kap[8];
   __shared__ double E1[256], F1[256], E2[256], F2[256];
   __shared__ int inf1[8];
@@ -105,7 +105,9 @@ __global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B,
       N2 += w2[c] * s[4]; D2 += w2[c] * (s[5] - s[4]);
     }
     E1[n] = D1 + smooth; F1[n] = N1 + smooth; E2[n] = D2 + smooth; F2[n] = N2 + smooth;
-    lsum += 1.0 - 0.5 * (F1[n] / E1[n] + F2[n] / E2[n]);
+    const double ln = 1.0 - 0.5 * (F1[n] / E1[n] + F2[n] / E2[n]);
+    if (per_sample) per_sample[n] = (float)ln;
+    lsum += ln;
   }
   // block sum of lsum (B <= 256, blockDim 64: one wave)
   for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
@@ -122,6 +124,7 @@ __global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B,
   }
   __syncthreads();
   const double sc = -0.5 * (double)grad_scale;      // d(1 - .5(l1+l2)); grad_scale = loss_weight / B
+  if (coef)
   for (int i = t; i < B * C; i += blockDim.x) {
     const int n = i / C, c = i - n * C;
     const double a1 = w1[c] / (E1[n] * E1[n]), a2 = w2[c] / (E2[n] * E2[n]);
@@ -132,11 +135,12 @@ __global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B,
   }
 }
 
-extern "C" int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef, void* stream) {
-  RUA_CHECK_ARG(sums && loss_out && coef && B > 0 && B <= 256, "rua_tanimoto_finalize: B must be in 1..256");
+extern "C" int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,
+                                     float* per_sample, void* stream) {
+  RUA_CHECK_ARG(sums && loss_out && B > 0 && B <= 256, "rua_tanimoto_finalize: B must be in 1..256");
   RUA_CHECK_ARG(C >= 1 && C <= 8, "rua_tanimoto_finalize: C=%d must be in 1..8", C);
   (void)HW;
-  hipLaunchKernelGGL(tanimoto_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, B, C, grad_scale, loss_out, coef);
+  hipLaunchKernelGGL(tanimoto_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, B, C, grad_scale, loss_out, coef, per_sample);
   RUA_LAUNCH_CHECK("rua_tanimoto_finalize");
   return RUA_OK;
 }
@@ -146,7 +150,7 @@ extern "C" int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int 
 #define KERAS_EPS 1e-7f
 __global__ __launch_bounds__(256) void pixel_loss_kernel(int kind, const float* __restrict__ p, const float* __restrict__ z,
                                                          const float* __restrict__ y, const float* __restrict__ cw,
-                                                         long long M, int C, double* out) {
+                                                         long long M, int C, double* out, float* per_pixel) {
   __shared__ float sh[4];
   float acc = 0.f;
   for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
@@ -175,19 +179,20 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(int kind, const float* 
       for (int c = 0; c < C; ++c) { const float d = y[m * C + c] - p[m * C + c]; l = fmaf(d, d, l); }
       l /= C;
     }
+    if (per_pixel) per_pixel[m] = l;
     acc += l;
   }
   block_atomic_add(out, acc, sh, 0);
 }
 
 extern "C" int rua_pixel_loss(int kind, const float* p, const float* z, const float* y, const float* class_w,
-                              int64_t M, int C, double* loss_out, void* stream) {
+                              int64_t M, int C, double* loss_out, float* per_pixel, void* stream) {
   RUA_CHECK_ARG(p && y && loss_out && M > 0 && C >= 1 && C <= 64, "rua_pixel_loss: bad arguments");
   RUA_CHECK_ARG(kind >= RUA_LOSS_WCE && kind <= RUA_LOSS_MSE, "rua_pixel_loss: kind %d is not a per-pixel loss", kind);
   RUA_CHECK_ARG(kind != RUA_LOSS_WCE || class_w, "rua_pixel_loss: weighted CE needs class weights");
   RUA_CHECK_ARG((kind != RUA_LOSS_CE_LOGITS && kind != RUA_LOSS_BCE_LOGITS) || z, "rua_pixel_loss: logits needed");
   int64_t g = (M + 255) / 256; if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(pixel_loss_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, kind, p, z, y, class_w, (long long)M, C, loss_out);
+  hipLaunchKernelGGL(pixel_loss_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, kind, p, z, y, class_w, (long long)M, C, loss_out, per_pixel);
   RUA_LAUNCH_CHECK("rua_pixel_loss");
   return RUA_OK;
 }

@@ -701,10 +701,10 @@ class Graph:
             coef = self.alloc((B * Cc * 3,), torch.float32, zero=True)
             LP.keep.append(coef)
             LP.add("rua_tanimoto_sums", h["p"].ptr, h["y"].ptr, B, HW, Cc, sums)
-            LP.add("rua_tanimoto_finalize", sums, B, HW, Cc, wgt / B, slot, coef.data_ptr())
+            LP.add("rua_tanimoto_finalize", sums, B, HW, Cc, wgt / B, slot, coef.data_ptr(), None)
             h["norm"] = 1.0
         else:
-            LP.add("rua_pixel_loss", kind, h["p"].ptr, h["z"].ptr, h["y"].ptr, self.e.class_w_ptr, M, Cc, slot)
+            LP.add("rua_pixel_loss", kind, h["p"].ptr, h["z"].ptr, h["y"].ptr, self.e.class_w_ptr, M, Cc, slot, None)
             h["norm"] = 1.0 / M
         if not self.training:
             return

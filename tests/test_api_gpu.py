@@ -1,0 +1,174 @@
+"""GPU tests of the drop-in surface: committed goldens (no oracle at run time), the Keras-style API, checkpoints,
+the CLI end to end on a synthetic dataset in the reference's on-disk format, and data-parallel semantics
+(one GPU emulating two MirroredStrategy replicas) against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADS = ["seg", "bound", "dist", "color"]
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def test_golden_tiny_multitask_fp32():
+    """HIP path vs tests/golden/tiny_multitask.npz.  The golden holds the oracle's weights seed, not the weights;
+    the weights are regenerated with the same glorot/numpy recipe (oracle/make_golden.py)."""
+    from oracle import resuneta_ref as ref            # only for the seeded initial weights
+    from resunet_a_mltsk_keras_amd import _lib as L
+    from resunet_a_mltsk_keras_amd.engine import Engine, LossSpec, ModelConfig
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tiny_multitask.npz"))
+    params, _ = ref.init_params(ref.RefConfig(input_shape=(64, 64, 6), num_classes=6, multitasking=True), int(g["seed"]))
+    eng = Engine(ModelConfig(input_shape=(64, 64, 6), num_classes=6, multitasking=True), dtype="f32")
+    eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in HEADS}, weight=dict(zip(HEADS, g["loss_weights"].tolist()))))
+    eng.set_weights({k: v.numpy() for k, v in params.items()})
+    pred = eng.predict(g["x"])
+    for h in HEADS:
+        assert np.abs(pred[h] - g["pred_eval_" + h]).max() < 1e-4, h
+    gr = eng.forward_backward(g["x"], {h: g["y_" + h] for h in HEADS})
+    torch.cuda.synchronize()
+    res = eng._results(gr)
+    assert np.allclose(res[:5], g["losses"], rtol=1e-3, atol=1e-5)
+    for h, z in eng.logits(True, 2).items():
+        assert rel(z, g["logits_" + h]) < 1e-3, h
+    grads = eng.grads_keras()
+    for name, s in zip(g["grad_names"], g["grad_abs_sums"]):
+        assert abs(float(np.abs(grads[str(name)]).sum()) - s) < 5e-3 * s, name
+
+
+def test_loss_factories_evaluate_on_gpu():
+    from multitasking_utils import Tanimoto_dual_loss
+    from utils import weighted_categorical_crossentropy
+    k = np.load(os.path.join(ROOT, "tests", "golden", "tanimoto_kat.npz"))
+    f = Tanimoto_dual_loss()
+    assert np.allclose(f(k["y_swap"], k["p_swap"]), k["l_swap"], rtol=1e-5)
+    assert np.allclose(f(k["y_rand"], k["p_rand"]), k["l_rand"], rtol=1e-5)
+    y = np.eye(3, dtype=np.float32)[np.array([[[0, 1], [2, 0]]])]
+    p = np.full_like(y, 1 / 3)
+    w = [0.5, 2.0, 10.0]
+    out = weighted_categorical_crossentropy(w)(y, p)
+    assert out.shape == (1, 2, 2) and np.allclose(out, (y * w).sum(-1) * np.log(3), rtol=1e-6)
+
+
+class Args:
+    multitasking = True
+    gpu_parallel = False
+    dtype = "f32"
+
+
+def test_keras_style_model_roundtrip(tmp_path):
+    from ResUnet_a.model2 import Resunet_a
+    from multitasking_utils import Tanimoto_dual_loss
+    from utils import Adam, K, load_model
+    from resunet_a_mltsk_keras_amd.synthetic import make_batch
+    net = Resunet_a((64, 64, 3), 4, Args())
+    assert (net.num_classes, net.img_height, net.img_width, net.img_channel) == (4, 64, 64, 3)
+    model = net.model
+    lines = []
+    model.summary(print_fn=lines.append)
+    assert any("conv2d_1/kernel" in l for l in lines) and "Total params" in lines[-1]
+    loss = Tanimoto_dual_loss()
+    model.compile(optimizer=Adam(lr=1e-3, beta_1=0.9), loss={h: loss for h in HEADS},
+                  loss_weights={"seg": 1.0, "bound": 1.0, "dist": 1.0, "color": 1.0}, metrics={"seg": ["accuracy"]})
+    assert model.metrics_names[:5] == ["loss", "seg_loss", "bound_loss", "dist_loss", "color_loss"] and len(model.metrics_names) == 10
+    assert model.output_names == HEADS
+    x, y = make_batch(2, 64, 3, 4, True, seed=2, block=16)
+    first = model.train_on_batch(x=x, y=y, return_dict=False)
+    assert len(first) == 10 and all(np.isfinite(first))
+    for _ in range(5):
+        last = model.train_on_batch(x, y)
+    assert last[0] < first[0]                                  # the same batch gets easier
+    ev = model.test_on_batch(x=x, y=y)
+    assert len(ev) == 10
+    pred = model.predict(x, batch_size=1)
+    assert set(pred) == set(HEADS) and pred["seg"].shape == (2, 64, 64, 4) and pred["color"].shape == (2, 64, 64, 3)
+    assert np.allclose(pred["seg"].sum(-1), 1.0, atol=1e-5)
+    path = str(tmp_path / "best_model.h5")
+    model.save(path)
+    m2 = load_model(path)
+    assert K.get_value(m2.optimizer.lr) == pytest.approx(1e-3)
+    K.set_value(m2.optimizer.lr, 5e-4)
+    p2 = m2.predict(x, batch_size=2)
+    assert np.abs(p2["seg"] - pred["seg"]).max() < 1e-6
+    a = m2.train_on_batch(x, y)
+    b = model.train_on_batch(x, y)
+    assert abs(a[0] - b[0]) < 1e-4                             # same state (weights, Adam moments, step count) continues
+    m3 = load_model(path, compile=False)
+    assert np.abs(m3.predict(x)["dist"] - pred["dist"]).max() < 1e-6
+
+
+def test_cli_end_to_end_on_synthetic_dataset(tmp_path):
+    sys.path.insert(0, ROOT)
+    import train_ISPRS as cli
+    from resunet_a_mltsk_keras_amd.synthetic import make_batch
+    x, y = make_batch(10, 64, 3, 4, True, seed=3, block=16)
+    ds = tmp_path / "ds"
+    os.makedirs(ds / "train")
+    for h in HEADS:
+        os.makedirs(ds / "labels" / h)
+    for i in range(10):
+        np.save(ds / "train" / f"patch_{i}.npy", x[i])
+        for h in HEADS:
+            np.save(ds / "labels" / h / f"patch_{i}.npy", y[h][i])
+    rp = tmp_path / "run"
+    cli.main(["--resunet_a", "True", "--multitasking", "True", "--loss", "tanimoto", "-dp", str(ds), "-rp", str(rp), "-bs", "2",
+              "--epochs", "2", "-ps", "64", "--num_classes", "4", "--dtype", "f32"])
+    assert os.path.exists(rp / "best_model.h5")
+    lines = open(rp / "logs" / "val" / "scalars.jsonl").read().strip().splitlines()
+    tags = {__import__("json").loads(l)["tag"] for l in lines}
+    assert {"Segmentation/Loss", "Boundary/Loss", "Distance/Loss", "Color/Loss", "Total/Loss", "Segmentation/MCC"} <= tags
+    from utils import load_model
+    m = load_model(str(rp / "best_model.h5"), compile=False)
+    assert m.predict(x[:1])["seg"].shape == (1, 64, 64, 4)
+
+
+def test_two_replica_semantics_on_one_gpu():
+    """MirroredStrategy semantics (train_ISPRS.py:347,432): every replica normalises with its OWN batch statistics
+    and its OWN Tanimoto class volumes; gradients are summed and divided by the replica count.  One GPU plays both
+    replicas (gradients accumulate in the flat buffer) and is compared with the oracle doing the same on the CPU."""
+    from oracle import resuneta_ref as ref
+    from resunet_a_mltsk_keras_amd import _lib as L
+    from resunet_a_mltsk_keras_amd.engine import Engine, LossSpec, ModelConfig
+    from resunet_a_mltsk_keras_amd.synthetic import make_batch
+    shape, C = (64, 64, 3), 4
+    rcfg = ref.RefConfig(input_shape=shape, num_classes=C, multitasking=True)
+    params, order = ref.init_params(rcfg, 11)
+    lw = {h: 1.0 for h in HEADS}
+    eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=True), dtype="f32")
+    eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in HEADS}, weight=lw, optimizer="sgd", lr=0.05, momentum=0.8))
+    eng.set_weights({k: v.numpy() for k, v in params.items()})
+    x, y = make_batch(4, 64, 3, C, True, seed=21, block=16)
+    shards = [(x[:2], {h: v[:2] for h, v in y.items()}), (x[2:], {h: v[2:] for h, v in y.items()})]
+    losses = []
+    for xs, ys in shards:                                   # replica r: local forward/backward, G accumulates
+        g = eng.forward_backward(xs, ys)
+        torch.cuda.synchronize()
+        losses.append(eng._results(g)[0])
+    eng.optimizer_step(grad_scale=0.5)
+    torch.cuda.synchronize()
+    # oracle: mean of the two replica losses, each from its own training-mode forward
+    p = {k: v.clone() for k, v in params.items()}
+    for k in order:
+        p[k].requires_grad_(True)
+    tot, exp_losses = 0, []
+    for xs, ys in shards:
+        tr = ref.RefTrainer(rcfg, p, order, ref.CompileSpec(loss="tanimoto", loss_weights=lw))
+        total, vals, _, _ = tr._losses(xs, ys, training=True)
+        tot = tot + 0.5 * total
+        exp_losses.append(float(total.detach()))
+    tot.backward()
+    assert np.allclose(losses, exp_losses, rtol=1e-3)
+    w = eng.get_weights()
+    worst = 0.0
+    for k in order:
+        e = (p[k].detach() - 0.05 * p[k].grad).numpy()        # first SGD-momentum step: v = -lr*g
+        worst = max(worst, float((np.abs(w[k] - e).max() - 1e-6) / (np.abs(e).max() + 1e-6)))
+    assert worst < 2e-3, worst

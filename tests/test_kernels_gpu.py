@@ -449,10 +449,13 @@ def test_losses_against_oracle():
         if kind == L.LOSS_TANIMOTO:
             sums = torch.zeros(B * Cc * 6, dtype=torch.float64, device=dev())
             lib.call("rua_tanimoto_sums", pd.data_ptr(), yd.data_ptr(), B, HW, Cc, sums.data_ptr(), stream())
-            lib.call("rua_tanimoto_finalize", sums.data_ptr(), B, HW, Cc, wgt / B, scal.data_ptr(), coef.data_ptr(), stream())
+            per = torch.zeros(B, device=dev())
+            lib.call("rua_tanimoto_finalize", sums.data_ptr(), B, HW, Cc, wgt / B, scal.data_ptr(), coef.data_ptr(), per.data_ptr(), stream())
             gs, norm = wgt / B, 1.0
+            torch.cuda.synchronize()
+            assert np.allclose(per.cpu().numpy(), ref.tanimoto_dual_loss(yt, pt).detach().numpy(), rtol=1e-5, atol=1e-6)
         else:
-            lib.call("rua_pixel_loss", kind, pd.data_ptr(), zd.data_ptr(), yd.data_ptr(), cwd.data_ptr(), M, Cc, scal.data_ptr(), stream())
+            lib.call("rua_pixel_loss", kind, pd.data_ptr(), zd.data_ptr(), yd.data_ptr(), cwd.data_ptr(), M, Cc, scal.data_ptr(), None, stream())
             gs, norm = wgt / M, 1.0 / M
         lib.call("rua_head_dz", kind, act, pd.data_ptr(), yd.data_ptr(), coef.data_ptr(), cwd.data_ptr(), gs, B, HW, Cc, dz.data_ptr(), stream())
         torch.cuda.synchronize()
