@@ -46,6 +46,18 @@ template <> struct ET<bf16_t> {
 };
 
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// Buffer loads with hardware range checking: an offset >= num_records returns zeros, so zero padding and
+// ragged edges need no branch (a predicated global load costs a branch + a drained vmcnt per load in hipcc).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#define RUA_OOB 0xFFFFFFF0u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ void stg16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
 
 __device__ __forceinline__ float wave_sum(float v) {

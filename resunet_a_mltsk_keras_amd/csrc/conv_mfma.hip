@@ -10,7 +10,7 @@
 // ReLU-mask from `aux`, per-channel statistics (fp32 partials, fp64 atomics), 16-byte stores.
 #include "common.h"
 
-struct SegK { const unsigned char* x; const unsigned char* w; int C, Hs, Ws, up, dil, taps, nchunk, ubegin; };
+struct SegK { const unsigned char* x; const unsigned char* w; int C, Hs, Ws, up, dil, taps, nchunk, ubegin; unsigned xbytes, wbytes; };
 struct ConvK {
   SegK seg[RUA_MAX_SEG];
   int nseg, nunits;
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
   const int tid = threadIdx.x;
   const int aq = tid % PPR, ar = tid / PPR;
   const int HW = p.H * p.W;
+  // per-thread pixel rows of the A tile: logical source coordinates (output coordinate * stride), decoded once
   int an[APASS], ah[APASS], aw[APASS];
   bool av[APASS];
 #pragma unroll
@@ -185,50 +186,68 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
     int n = mm / HW, rem = mm - n * HW, h = rem / p.W;
     an[i] = n; ah[i] = h * p.stride; aw[i] = (rem - h * p.W) * p.stride;
   }
+  constexpr int BROWS = (BPIECES < 256) ? BPIECES : 256;
+  const int bq = tid % PPR, br = tid / PPR;          // B piece column / row (pass j adds j*RPP rows)
+  const bool bthread = tid < BROWS;
 
   uint4 ra[KU][APASS], rb[KU][BPASS];
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  // ---- K iteration state: (segment, tap, 32-channel chunk), advanced without divisions ----------------
+  int cs = -1;                        // segment the per-thread bases below belong to
+  int u_seg = 0, u_tap = 0, u_chunk = 0;
+  // per-segment, per-thread precomputed element offsets (32-bit: every tensor here is < 2^31 elements)
+  int abase[APASS];                   // ((n*Hs + (hS>>up))*Ws + (wS>>up))*C + aq*VEC   (tap offset added per unit)
+  int bbase[BPASS];                   // row*C + bq*VEC
+  __amdgpu_buffer_rsrc_t rx = make_rsrc(p.seg[0].x, p.seg[0].xbytes), rw = make_rsrc(p.seg[0].w, p.seg[0].wbytes);
+  int sC_ = 0, sWs = 0, sdil = 1, staps = 1, snchunk = 1; unsigned sHL = 0, sWL = 0;
+
+  auto enter_segment = [&](int s) {
+    const SegK sg = p.seg[s];
+    cs = s; rx = make_rsrc(sg.x, sg.xbytes); rw = make_rsrc(sg.w, sg.wbytes); sC_ = sg.C; sWs = sg.Ws; sdil = sg.dil; staps = sg.taps; snchunk = sg.nchunk;
+    sHL = (unsigned)(sg.Hs << sg.up); sWL = (unsigned)(sg.Ws << sg.up);
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      abase[i] = ((an[i] * sg.Hs + (ah[i] >> sg.up)) * sg.Ws + (aw[i] >> sg.up)) * sg.C + aq * VEC;
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) bbase[j] = (n0 + br + j * RPP) * sg.C + bq * VEC;
+  };
+  auto seek_unit = [&](int unit) {    // used once (split-K start): the only place that divides
+    int s = 0;
+    while (s + 1 < p.nseg && unit >= p.seg[s + 1].ubegin) ++s;
+    const int loc = unit - p.seg[s].ubegin;
+    u_seg = s; u_tap = loc / p.seg[s].nchunk; u_chunk = loc - u_tap * p.seg[s].nchunk;
+  };
+  auto next_unit = [&]() {
+    if (++u_chunk == snchunk) { u_chunk = 0; if (++u_tap == staps) { u_tap = 0; ++u_seg; } }
+  };
 
   auto load_stage = [&](int st) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const int unit = st * KU + u;
       if (unit < p.nunits) {
-        int s = 0;
-        while (s + 1 < p.nseg && unit >= p.seg[s + 1].ubegin) ++s;
-        const SegK sg = p.seg[s];
-        const int loc = unit - sg.ubegin;
-        const int tap = loc / sg.nchunk, chunk = loc - tap * sg.nchunk;
+        if (u_seg != cs) enter_segment(u_seg);
         int dh = 0, dw = 0;
-        if (sg.taps == 9) { dh = (tap / 3 - 1) * sg.dil; dw = (tap % 3 - 1) * sg.dil; }
-        const unsigned HL = (unsigned)(sg.Hs << sg.up), WL = (unsigned)(sg.Ws << sg.up);
-        const int c = chunk * 32 + aq * VEC;
-        const bool cok = c < sg.C;
+        if (staps == 9) {
+          const int t3 = (u_tap >= 6) ? 2 : (u_tap >= 3) ? 1 : 0;
+          dh = (t3 - 1) * sdil; dw = (u_tap - 3 * t3 - 1) * sdil;
+        }
+        const int toff = (dh * sWs + dw) * sC_ + u_chunk * 32;       // uniform element offset of this tap / chunk
+        const bool cok = u_chunk * 32 + aq * VEC < sC_;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
-          const int hs = ah[i] + dh, ws = aw[i] + dw;
-          const bool ok = av[i] && cok && (unsigned)hs < HL && (unsigned)ws < WL;
-          uint4 v = zero4;
-          if (ok) {
-            const size_t off = ((size_t)(an[i] * sg.Hs + (hs >> sg.up)) * sg.Ws + (ws >> sg.up)) * sg.C + c;
-            v = ldg16(sg.x + off * ES);
-          }
-          ra[u][i] = v;
+          const bool ok = av[i] && cok && (unsigned)(ah[i] + dh) < sHL && (unsigned)(aw[i] + dw) < sWL;
+          ra[u][i] = bufload16(rx, ok ? (unsigned)((abase[i] + toff) * ES) : RUA_OOB);
         }
+        const int woff = u_tap * p.Cout * sC_ + u_chunk * 32;
+        const bool bcok = u_chunk * 32 + bq * VEC < sC_;
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
-          const int piece = tid + j * 256;
-          uint4 v = zero4;
-          if (piece < BPIECES) {
-            const int row = piece / PPR, qq = piece % PPR;
-            const int co = n0 + row, cc = chunk * 32 + qq * VEC;
-            if (co < p.Cout && cc < sg.C) {
-              const size_t off = ((size_t)tap * p.Cout + co) * sg.C + cc;
-              v = ldg16(sg.w + off * ES);
-            }
-          }
-          rb[u][j] = v;
+          const bool ok = bthread && bcok && (n0 + br + j * RPP) < p.Cout;
+          rb[u][j] = bufload16(rw, ok ? (unsigned)((bbase[j] + woff) * ES) : RUA_OOB);
         }
+        next_unit();
       } else {
 #pragma unroll
         for (int i = 0; i < APASS; ++i) ra[u][i] = zero4;
@@ -253,9 +272,8 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
       }
 #pragma unroll
       for (int j = 0; j < BPASS; ++j) {
-        const int piece = tid + j * 256;
-        if (piece < BPIECES) {
-          unsigned char* dst = sB + (u * BN + piece / PPR) * ROWB + (piece % PPR) * 16;
+        if (bthread) {
+          unsigned char* dst = sB + (u * BN + br + j * RPP) * ROWB + bq * 16;
           if constexpr (ES == 2) {
             *reinterpret_cast<uint4*>(dst) = rb[u][j];
           } else {
@@ -283,6 +301,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
   const int st_begin = ks_i * p.stages_per_split;
   int nstages = st_begin + p.stages_per_split;
   if (nstages > nstages_all) nstages = nstages_all;
+  seek_unit(st_begin * KU);
   load_stage(st_begin);
   for (int st = st_begin; st < nstages; ++st) {
     __syncthreads();
@@ -448,11 +467,15 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     RUA_CHECK_ARG((long long)(d->H - 1) * d->stride < ((long long)g.Hs << g.up_shift) &&
                   (long long)(d->W - 1) * d->stride < ((long long)g.Ws << g.up_shift),
                   "rua_conv_fwd: segment %d source %dx%d (up %d) too small for output %dx%d stride %d", s, g.Hs, g.Ws, g.up_shift, d->H, d->W, d->stride);
-    RUA_CHECK_ARG((long long)d->N * g.Hs * g.Ws < (1ll << 31), "rua_conv_fwd: source too large");
+    RUA_CHECK_ARG((long long)d->N * g.Hs * g.Ws * g.C * 4 < (1ll << 31), "rua_conv_fwd: source tensor must stay below 2 GiB (32-bit offsets)");
+    RUA_CHECK_ARG(g.up_shift == 0 || g.taps == 1, "rua_conv_fwd: nearest-upsampled sources are 1x1 only");
+    RUA_CHECK_ARG((long long)g.taps * d->Cout * g.C * 4 < (1ll << 31), "rua_conv_fwd: weight block too large");
     SegK& o = k.seg[s];
     o.x = (const unsigned char*)g.x; o.w = (const unsigned char*)g.w;
     o.C = g.C; o.Hs = g.Hs; o.Ws = g.Ws; o.up = g.up_shift; o.dil = g.dil; o.taps = g.taps;
     o.nchunk = (g.C + 31) / 32; o.ubegin = units;
+    o.xbytes = (unsigned)((size_t)d->N * g.Hs * g.Ws * g.C * (d->dtype == RUA_BF16 ? 2 : 4));
+    o.wbytes = (unsigned)((size_t)g.taps * d->Cout * g.C * (d->dtype == RUA_BF16 ? 2 : 4));
     units += g.taps * o.nchunk;
   }
   k.nunits = units;
@@ -493,6 +516,7 @@ struct WgK {
   const unsigned char* a; const unsigned char* dy; float* dw;
   int C, Hs, Ws, Cout, H, W, N, stride, dil, taps;
   long long M; int pix_per_block, ntc, nti, ksplit;
+  int wshift, hshift;      // log2(W), log2(H) when both are powers of two, else -1 (generic division path)
 };
 
 template <typename T>
@@ -531,22 +555,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
   const int lr = lane & 31, lh = lane >> 5;
 
   uint4 rd[PASS], rx[PASS];
+  const int co_t = co0 + pq * VEC, ci_t = ci0 + pq * VEC;
+  const bool cok = co_t < p.Cout, xok = ci_t < p.C;
+  const int kend32 = (int)k_end;
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, (unsigned)((size_t)p.M * p.Cout * ES));
+  const __amdgpu_buffer_rsrc_t rxa = make_rsrc(p.a, (unsigned)((size_t)p.N * p.Hs * p.Ws * p.C * ES));
   auto load_stage = [&](long long k0) {
 #pragma unroll
     for (int i = 0; i < PASS; ++i) {
-      const long long m = k0 + pr + i * RPP;
-      uint4 vd = zero4, vx = zero4;
-      if (m < k_end) {
-        const int co = co0 + pq * VEC;
-        if (co < p.Cout) vd = ldg16(p.dy + ((size_t)m * p.Cout + co) * ES);
-        const int ci = ci0 + pq * VEC;
-        const int mm = (int)m;
-        const int n = mm / HW, rem = mm - n * HW, h = rem / p.W, w = rem - h * p.W;
-        const int hs = h * p.stride + dh, ws = w * p.stride + dw;
-        if (ci < p.C && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws)
-          vx = ldg16(p.a + (((size_t)(n * p.Hs + hs)) * p.Ws + ws) * p.C * ES + (size_t)ci * ES);
-      }
-      rd[i] = vd; rx[i] = vx;
+      const int mm = (int)k0 + pr + i * RPP;
+      const bool in = mm < kend32;
+      int n, h, w;
+      if (p.wshift >= 0) { w = mm & (p.W - 1); h = (mm >> p.wshift) & (p.H - 1); n = mm >> (p.wshift + p.hshift); }
+      else { n = mm / HW; const int rem = mm - n * HW; h = rem / p.W; w = rem - h * p.W; }
+      const int hs = h * p.stride + dh, ws = w * p.stride + dw;
+      const bool inx = in && xok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+      rd[i] = bufload16(rdy, (in && cok) ? (unsigned)((mm * p.Cout + co_t) * ES) : RUA_OOB);
+      rx[i] = bufload16(rxa, inx ? (unsigned)((((n * p.Hs + hs) * p.Ws + ws) * p.C + ci_t) * ES) : RUA_OOB);
     }
   };
   auto write_stage = [&]() {
@@ -628,7 +653,11 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   k.C = d->C; k.Hs = d->Hs; k.Ws = d->Ws; k.Cout = d->Cout; k.H = d->H; k.W = d->W; k.N = d->N;
   k.stride = d->stride; k.dil = d->dil; k.taps = d->taps;
   k.M = (long long)d->N * d->H * d->W;
-  RUA_CHECK_ARG(k.M < (1ll << 31) && (long long)d->N * d->Hs * d->Ws < (1ll << 31), "rua_conv_wgrad: too many pixels");
+  RUA_CHECK_ARG(k.M * d->Cout * 4 < (1ll << 31) && (long long)d->N * d->Hs * d->Ws * d->C * 4 < (1ll << 31),
+                "rua_conv_wgrad: tensors must stay below 2 GiB (32-bit offsets)");
+  auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+  k.wshift = lg2(d->W); k.hshift = lg2(d->H);
+  if (k.wshift < 0 || k.hshift < 0) k.wshift = k.hshift = -1;
   k.ntc = (d->Cout + 63) / 64; k.nti = (d->C + 63) / 64;
   const long long tiles = (long long)k.ntc * k.nti * d->taps;
   long long want = 2048 / tiles; if (want < 1) want = 1;

@@ -376,7 +376,7 @@ class Graph:
 
     def _ws(self, d):
         """Shared split-K scratch (launches are serialised on one stream, so one buffer serves every conv)."""
-        if not self.dry and d.N * d.H * d.W * d.Cout * 4 <= self.e.workspace.numel() * 4:
+        if not self.dry and self.e.split_k and d.N * d.H * d.W * d.Cout * 4 <= self.e.workspace.numel() * 4:
             d.workspace, d.workspace_bytes = self.e.workspace.data_ptr(), self.e.workspace.numel() * 4
 
     def dgrad(self, plan: Plan, dy: Ten, wd_ptr, cin: int, dil: int, taps: int, out: Ten, accumulate: int,
@@ -787,7 +787,7 @@ class Engine:
     """Owns parameters, optimizer state and the recorded graphs; one instance per process (= per GPU)."""
 
     def __init__(self, cfg: ModelConfig, dtype: str = "bf16", device: Optional[torch.device] = None, seed: int = 0,
-                 _layout_only: bool = False):
+                 split_k: bool = True, _layout_only: bool = False):
         assert dtype in ("bf16", "f32")
         self.cfg = cfg
         self.dt = L.RUA_BF16 if dtype == "bf16" else L.RUA_F32
@@ -797,6 +797,8 @@ class Engine:
             raise ValueError(f"width={cfg.width}: the first-stage width must be a multiple of 32 (PSP branches are width/4 "
                              "channels and the MFMA epilogue stores 8-channel pieces)")
         self.dev = None
+        self.split_k = split_k       # False: bit-reproducible convolutions (no fp32-atomic K slices); parity tests on tiny
+                                     # inputs use it because a BatchNorm over 2 samples amplifies atomic-order noise ~1e4x
         self.params = ParamStore()
         self.layers: List[dict] = []
         self.cursor = 0

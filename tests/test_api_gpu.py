@@ -27,7 +27,7 @@ def test_golden_tiny_multitask_fp32():
     from resunet_a_mltsk_keras_amd.engine import Engine, LossSpec, ModelConfig
     g = np.load(os.path.join(ROOT, "tests", "golden", "tiny_multitask.npz"))
     params, _ = ref.init_params(ref.RefConfig(input_shape=(64, 64, 6), num_classes=6, multitasking=True), int(g["seed"]))
-    eng = Engine(ModelConfig(input_shape=(64, 64, 6), num_classes=6, multitasking=True), dtype="f32")
+    eng = Engine(ModelConfig(input_shape=(64, 64, 6), num_classes=6, multitasking=True), dtype="f32", split_k=False)
     eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in HEADS}, weight=dict(zip(HEADS, g["loss_weights"].tolist()))))
     eng.set_weights({k: v.numpy() for k, v in params.items()})
     pred = eng.predict(g["x"])
@@ -142,7 +142,7 @@ def test_two_replica_semantics_on_one_gpu():
     rcfg = ref.RefConfig(input_shape=shape, num_classes=C, multitasking=True)
     params, order = ref.init_params(rcfg, 11)
     lw = {h: 1.0 for h in HEADS}
-    eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=True), dtype="f32")
+    eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=True), dtype="f32", split_k=False)
     eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in HEADS}, weight=lw, optimizer="sgd", lr=0.05, momentum=0.8))
     eng.set_weights({k: v.numpy() for k, v in params.items()})
     x, y = make_batch(4, 64, 3, C, True, seed=21, block=16)

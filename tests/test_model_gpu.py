@@ -15,13 +15,16 @@ from resunet_a_mltsk_keras_amd.synthetic import make_batch  # noqa: E402
 KIND = {"tanimoto": L.LOSS_TANIMOTO}
 
 
-def make_pair(shape, C, mt, width, loss, optimizer="adam", dtype="f32", seed=3, cw=None, lw=None):
+def make_pair(shape, C, mt, width, loss, optimizer="adam", dtype="f32", seed=3, cw=None, lw=None, split_k=False):
+    """split_k=False by default: on 64x64 inputs the bottleneck BatchNorms see 2-8 samples per channel and amplify the
+    atomic-order noise of split-K convolutions ~1e4x, which would drown the 1e-3 comparisons (kernels themselves are
+    checked with split-K in test_kernels_gpu.py; the full-size and bf16 tests below run with it)."""
     rcfg = ref.RefConfig(input_shape=shape, num_classes=C, multitasking=mt, width=width)
     params, order = ref.init_params(rcfg, seed)
     lw = lw or {"seg": 1.0, "bound": 0.7, "dist": 1.3, "color": 0.5}
     rspec = ref.CompileSpec(loss=loss, class_weights=cw, loss_weights=lw, optimizer=optimizer, lr=1e-3)
     trainer = ref.RefTrainer(rcfg, {k: v.clone() for k, v in params.items()}, order, rspec)
-    eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=mt, width=width), dtype=dtype, seed=0)
+    eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=mt, width=width), dtype=dtype, seed=0, split_k=split_k)
     if loss == "tanimoto":
         kind = {h: L.LOSS_TANIMOTO for h in ref.HEADS}
     elif loss == "weighted_cross_entropy":
@@ -123,7 +126,7 @@ def test_tiny_singletask_fp32_128():
 def test_full_width_block_bf16_close_to_oracle():
     """bf16 storage on the reference width (32): loss within 3e-2, logits within 6e-2 of their scale."""
     shape, C = (64, 64, 6), 6
-    trainer, eng = make_pair(shape, C, True, 32, "tanimoto", dtype="bf16")
+    trainer, eng = make_pair(shape, C, True, 32, "tanimoto", dtype="bf16", split_k=True)
     x, y = make_batch(2, 64, 6, C, True, seed=7, block=16)
     exp = trainer.train_on_batch(x, y)
     g = eng.forward_backward(x, y)
@@ -140,7 +143,7 @@ def test_cfg3_full_size_fp32_loss_and_logits():
     loss and per-head logits within the north-star 1e-3 relative tolerance of the CPU oracle."""
     shape, C = (256, 256, 6), 6
     lw = {"seg": 1.0, "bound": 1.0, "dist": 1.0, "color": 1.0}
-    trainer, eng = make_pair(shape, C, True, 32, "tanimoto", lw=lw)
+    trainer, eng = make_pair(shape, C, True, 32, "tanimoto", lw=lw, split_k=True)
     x, y = make_batch(2, 256, 6, C, True, seed=1234)
     exp = trainer.train_on_batch(x, y)
     g = eng.forward_backward(x, y)
@@ -160,7 +163,7 @@ def test_graph_replay_equals_eager_launches():
     shape, C = (64, 64, 6), 6
     outs = []
     for use_graph in (False, True):
-        _, eng = make_pair(shape, C, True, 32, "tanimoto", "sgd", dtype="bf16", seed=5)
+        _, eng = make_pair(shape, C, True, 32, "tanimoto", "sgd", dtype="bf16", seed=5, split_k=False)
         eng.use_graph = use_graph
         losses = []
         for step in range(3):
