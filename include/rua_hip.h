@@ -82,9 +82,13 @@ typedef struct rua_wgrad_desc {
   const void* a;  int32_t C, Hs, Ws;        /* conv input  [N][Hs][Ws][C]  */
   const void* dy; int32_t Cout, H, W;       /* out-gradient [N][H][W][Cout] */
   int32_t N, stride, dil, taps, dtype;
-  float* dw;                                /* [taps][Cout][C] fp32 */
+  float* dw;                                /* [taps][Cout][C] fp32, accumulated */
+  void* workspace;                          /* optional fp32 scratch of rua_wgrad_workspace_bytes(): enables the all-taps */
+  int64_t workspace_bytes;                  /* kernel of the two top levels (C = Cout in {32,64}, 3x3, W % 64 == 0, bf16) */
 } rua_wgrad_desc;
 int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream);
+int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d);
+int rua_wgrad_kind(const rua_wgrad_desc* d);   /* 1: all-taps kernel + deterministic partial reduce, 0: generic tiled kernel */
 
 /* Master fp32 weights [taps][Cout][C] -> activation-dtype copies: forward layout (same) and
  * data-gradient layout [taps reversed][C][Cout].  One launch for the whole parameter table. */

@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
 
 class WgradDesc(C.Structure):
     _fields_ = [("a", vp), ("C", i32), ("Hs", i32), ("Ws", i32), ("dy", vp), ("Cout", i32), ("H", i32), ("W", i32),
-                ("N", i32), ("stride", i32), ("dil", i32), ("taps", i32), ("dtype", i32), ("dw", vp)]
+                ("N", i32), ("stride", i32), ("dil", i32), ("taps", i32), ("dtype", i32), ("dw", vp), ("workspace", vp), ("workspace_bytes", i64)]
 
 
 class WprepItem(C.Structure):
@@ -46,6 +46,8 @@ _SIGS = {
     "rua_conv_tile_bn": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_workspace_bytes": ([C.POINTER(ConvDesc)], i64),
     "rua_conv_wgrad": ([C.POINTER(WgradDesc), vp], i32),
+    "rua_wgrad_workspace_bytes": ([C.POINTER(WgradDesc)], i64),
+    "rua_wgrad_kind": ([C.POINTER(WgradDesc)], i32),
     "rua_weight_prep": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "rua_stem_fwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "rua_stem_bwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),

@@ -640,12 +640,248 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
   }
 }
 
+// =========================================================================================
+// All-taps weight gradient for the two top levels (Cin = Cout = CC in {32, 64}, 3x3, stride 1, W % 64 == 0; bf16).
+// A stage is a run of 64 consecutive pixels of one image row.  Per stage a pixel group (3 waves) stages dy[64][32]
+// once and a 3-row halo a[3][64+2d][CC] of the conv input; wave `tr` computes the three taps of kernel row tr
+// (dh = (tr-1)*d) for every 16-pixel k-step from shifted views of its halo row, so the nine taps cost ~3x the pixel
+// traffic instead of 9x and dy is read once.  NPG pixel groups per block run interleaved stages and are summed in
+// LDS; the block writes ONE fp32 partial (plain coalesced stores); wgrad_taps_reduce adds the partials into dW in a
+// fixed order (deterministic, no atomics).  blockIdx.y selects the 32-wide output-channel half (CC = 64).
+struct WgtK {
+  const unsigned char* a; const unsigned char* dy; float* scratch; float* dw;
+  int H, W, N, dil, S, NPG, workers, iters, halo, group_bytes, wshift, hshift, gx;
+  unsigned abytes, dybytes;
+};
+
+template <int CC>
+__global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
+  constexpr int NH = CC / 32;             // 32-wide input-channel halves = waves per kernel row
+  constexpr int GW = 3 * NH;              // waves per pixel group
+  constexpr int GT = GW * 64;             // threads per pixel group
+  constexpr int PP = CC / 8;              // 16-byte pieces per pixel of the a image
+  constexpr int AROWB = CC * 2;           // a image row bytes (CC = 64: 16-byte chunks XOR-swizzled, see swz())
+  constexpr int DROWB = 64;               // dy image: this block's 32 output channels
+  constexpr int MAXP = (3 * 126 * PP + GT - 1) / GT;
+  constexpr int DP = (256 + GT - 1) / GT; // dy piece passes
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int pg = wv / GW, rr = wv - pg * GW;
+  const int tr = rr / NH, cih = rr - tr * NH;
+  const int gt = tid - pg * GT;
+  unsigned char* sD = smem + pg * p.group_bytes;
+  unsigned char* sA = sD + 64 * DROWB;
+  const int halo = p.halo, d = p.dil, W = p.W, H = p.H;
+  const int co0 = blockIdx.y * 32;
+  const int worker = blockIdx.x * p.NPG + pg;
+  const __amdgpu_buffer_rsrc_t ra_ = make_rsrc(p.a, p.abytes), rd_ = make_rsrc(p.dy, p.dybytes);
+
+  auto swz = [](int row, int chunk) { return (CC == 64) ? (chunk ^ (((row >> 1) & 1) << 2)) : chunk; };
+
+  // ---- everything that does not depend on the stage is computed once ---------------------------------
+  // halo piece k of this thread: byte offset relative to the stage's first pixel, LDS write offset, and which
+  // border conditions would invalidate it (bit0: needs row h-d, bit1: needs row h+d, bit2: left of the run,
+  // bit3: right of the run)
+  int prel[MAXP], plds[MAXP], pneed[MAXP];
+  const int total = 3 * halo * PP;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int i = gt + k * GT;
+    const int r3 = i / (halo * PP), rem = i - r3 * halo * PP;
+    const int j = rem / PP, q = rem - j * PP;
+    const int row = r3 * halo + j;
+    prel[k] = (((r3 - 1) * d * W + (j - d)) * CC + q * 8) * 2;
+    plds[k] = (i < total) ? row * AROWB + swz(row, q) * 16 : -1;
+    pneed[k] = (r3 == 0 ? 1 : 0) | (r3 == 2 ? 2 : 0) | (j < d ? 4 : 0) | (j >= 64 + d ? 8 : 0) | (i < total ? 0 : 16);
+  }
+  int drel[DP], dlds[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) {
+    const int i = gt + k * GT;
+    drel[k] = ((i >> 2) * CC + co0 + (i & 3) * 8) * 2;
+    dlds[k] = (i < 256) ? (i >> 2) * DROWB + (i & 3) * 16 : -1;
+  }
+  // transposing-read lane geometry (see wgrad_kernel) and the stage-invariant fragment addresses
+  const int li = lane & 15, g = lane >> 4;
+  const int q4 = li >> 2, pp = li & 3;
+  const int chan = 16 * (g & 1) + 4 * pp;
+  const int hrow = 8 * (g >> 1) + q4;
+  typedef s16x4 __attribute__((address_space(3))) * lds4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const unsigned char* dybase = sD + hrow * DROWB + chan * 2;
+  const unsigned char* abase[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int row = tr * halo + j * d + hrow;
+    const int ch = cih * 32 + chan;
+    abase[j] = sA + row * AROWB + swz(row, ch >> 3) * 16 + (ch & 7) * 2;     // +16 rows / +4 rows never flip the swizzle bit
+  }
+
+  uint4 va[MAXP], vd[DP];
+  auto load_stage = [&](int it) {
+    const int s = worker + it * p.workers;
+    const int m0 = s * 64;
+    int h, w0;
+    if (p.wshift >= 0) { w0 = m0 & (W - 1); h = (m0 >> p.wshift) & (H - 1); }
+    else { const int rem = m0 % (H * W); h = rem / W; w0 = rem - h * W; }
+    // border conditions of this run of 64 pixels as one scalar mask (bit4: stage beyond the end)
+    const int bad = (h - d < 0 ? 1 : 0) | (h + d >= H ? 2 : 0) | (w0 == 0 ? 4 : 0) | (w0 + 64 == W ? 8 : 0) | (s < p.S ? 0 : 31) | 16;
+    const int segb = m0 * CC * 2;
+#pragma unroll
+    for (int k = 0; k < DP; ++k)
+      vd[k] = bufload16(rd_, (s < p.S && dlds[k] >= 0) ? (unsigned)(m0 * CC * 2 + drel[k]) : RUA_OOB);
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k)
+      va[k] = bufload16(ra_, (pneed[k] & bad) == 0 ? (unsigned)(segb + prel[k]) : RUA_OOB);
+  };
+  auto write_stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < DP; ++k)
+      if (dlds[k] >= 0) *reinterpret_cast<uint4*>(sD + dlds[k]) = vd[k];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k)
+      if (plds[k] >= 0) *reinterpret_cast<uint4*>(sA + plds[k]) = va[k];
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  load_stage(0);
+  for (int it = 0; it < p.iters; ++it) {
+    __syncthreads();
+    write_stage();
+    __syncthreads();
+    if (it + 1 < p.iters) load_stage(it + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(dybase + ks * 16 * DROWB));
+      const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(dybase + ks * 16 * DROWB + 4 * DROWB));
+      const s16x8 fd = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(abase[j] + ks * 16 * AROWB));
+        const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(abase[j] + ks * 16 * AROWB + 4 * AROWB));
+        const s16x8 fx = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // ---- reduce the pixel groups through LDS, then one partial per block -------------------------
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+  if (pg > 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[((((pg - 1) * GW + rr) * 3 + j) * 16 + i) * 64 + lane] = acc[j][i];
+  }
+  __syncthreads();
+  if (pg == 0) {
+    float* part = p.scratch + (size_t)(blockIdx.y * p.gx + blockIdx.x) * 9 * 32 * CC;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = acc[j][i];
+        for (int gg = 1; gg < p.NPG; ++gg) v += red[((((gg - 1) * GW + rr) * 3 + j) * 16 + i) * 64 + lane];
+        const int co = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        part[((tr * 3 + j) * 32 + co) * CC + cih * 32 + (lane & 31)] = v;
+      }
+  }
+}
+
+// dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 16 elements x 16 slices:
+// every thread has all its loads in flight at once, slices are folded through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_taps_reduce(const float* __restrict__ scratch, float* __restrict__ dw, int CC, int gx) {
+  __shared__ float sh[256];
+  const int total = 9 * CC * CC;
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  float s = 0.f;
+  if (e < total) {
+    const int tap = e / (CC * CC), r = e - tap * CC * CC, co = r / CC, ci = r - co * CC;
+    const float* src = scratch + ((size_t)(co >> 5) * gx * 9 + tap) * 32 * CC + (co & 31) * CC + ci;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int b = sl;
+    for (; b + 48 < gx; b += 64) {
+      t0 += src[(size_t)b * 9 * 32 * CC]; t1 += src[(size_t)(b + 16) * 9 * 32 * CC];
+      t2 += src[(size_t)(b + 32) * 9 * 32 * CC]; t3 += src[(size_t)(b + 48) * 9 * 32 * CC];
+    }
+    for (; b < gx; b += 16) t0 += src[(size_t)b * 9 * 32 * CC];
+    s = (t0 + t1) + (t2 + t3);
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && e < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k * 16 + el];
+    dw[e] += t;
+  }
+}
+
+static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
+  const int CC = d->C;
+  WgtK k;
+  k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.scratch = (float*)d->workspace; k.dw = d->dw;
+  k.H = d->H; k.W = d->W; k.N = d->N; k.dil = d->dil;
+  const long long M = (long long)d->N * d->H * d->W;
+  k.S = (int)(M / 64);
+  k.halo = 64 + 2 * d->dil;
+  k.group_bytes = 64 * 64 + 3 * k.halo * CC * 2;
+  k.NPG = (CC == 32) ? 4 : 2;                          // 12 waves per block either way (3 kernel rows x CC/32 halves per group)
+  const int gy = CC / 32;
+  int gx = 256 / gy;
+  if (gx * k.NPG > k.S) gx = (k.S + k.NPG - 1) / k.NPG;
+  if (gx < 1) gx = 1;
+  k.gx = gx;
+  k.workers = gx * k.NPG;
+  k.iters = (k.S + k.workers - 1) / k.workers;
+  auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+  k.wshift = lg2(d->W); k.hshift = lg2(d->H);
+  if (k.wshift < 0 || k.hshift < 0) k.wshift = k.hshift = -1;
+  k.abytes = (unsigned)((size_t)M * CC * 2); k.dybytes = k.abytes;
+  size_t smem = (size_t)k.group_bytes * k.NPG;
+  const size_t red = (size_t)(k.NPG - 1) * 3 * (CC / 32) * 3 * 16 * 64 * 4;
+  if (red > smem) smem = red;
+  static bool attr32 = false, attr64 = false;
+  if (CC == 32) {
+    if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr32 = true; }
+    hipLaunchKernelGGL((wgrad_taps_kernel<32>), dim3(gx, gy), dim3(768), smem, st, k);
+  } else {
+    if (!attr64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr64 = true; }
+    hipLaunchKernelGGL((wgrad_taps_kernel<64>), dim3(gx, gy), dim3(768), smem, st, k);
+  }
+  RUA_LAUNCH_CHECK("wgrad_taps_kernel");
+  hipLaunchKernelGGL(wgrad_taps_reduce, dim3(rua_div_up(9 * CC * CC, 16)), dim3(256), 0, st, (const float*)k.scratch, d->dw, CC, gx);
+  RUA_LAUNCH_CHECK("wgrad_taps_reduce");
+  return RUA_OK;
+}
+
+extern "C" int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d) {
+  if (!d) return 0;
+  return (int64_t)256 * 9 * 32 * (int64_t)d->C * 4;
+}
+
+// which kernel a descriptor launches: 1 = all-taps (top levels), 0 = generic tiled
+extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
+  if (!d) return RUA_ERR_ARG;
+  const bool ok = d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->C == d->Cout && (d->C == 32 || d->C == 64) &&
+                  d->W % 64 == 0 && d->Hs == d->H && d->Ws == d->W && d->dil >= 1 && d->dil <= 31 && d->workspace &&
+                  d->workspace_bytes >= rua_wgrad_workspace_bytes(d) && (long long)d->N * d->H * d->W * d->C * 2 < (1ll << 31);
+  return ok ? 1 : 0;
+}
+
 extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   RUA_CHECK_ARG(d && d->a && d->dy && d->dw, "rua_conv_wgrad: null pointer");
   RUA_CHECK_ARG(d->dtype == RUA_F32 || d->dtype == RUA_BF16, "rua_conv_wgrad: bad dtype");
   const int vec = d->dtype == RUA_BF16 ? 8 : 4;
   RUA_CHECK_ARG(d->C % vec == 0 && d->Cout % vec == 0, "rua_conv_wgrad: C=%d Cout=%d must be multiples of %d", d->C, d->Cout, vec);
   RUA_CHECK_ARG(d->taps == 1 || d->taps == 9, "rua_conv_wgrad: taps must be 1 or 9");
+  if (rua_wgrad_kind(d) == 1) return launch_wgrad_taps(d, (hipStream_t)stream);
   RUA_CHECK_ARG((long long)(d->H - 1) * d->stride < d->Hs && (long long)(d->W - 1) * d->stride < d->Ws,
                 "rua_conv_wgrad: input %dx%d too small for gradient %dx%d stride %d", d->Hs, d->Ws, d->H, d->W, d->stride);
   WgK k;

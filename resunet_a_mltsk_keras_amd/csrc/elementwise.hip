@@ -111,6 +111,22 @@ extern "C" int rua_col_stats2(const void* g, const void* x, const float* mscale,
 }
 
 // ---------------------------------------------------------------------------------------
+// Sum of the R replicas of stats[.][2][C] for channel c: the R loads are issued together (independent
+// addresses, unrolled) instead of a dependent chain, so a finalize launch costs one memory round trip.
+__device__ __forceinline__ void replica_sum(const double* __restrict__ stats, int R, int C, int c, double& s1, double& s2) {
+  double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+  int r = 0;
+  for (; r + 4 <= R; r += 4) {
+    const double x0 = stats[(size_t)(r + 0) * 2 * C + c], y0 = stats[(size_t)(r + 0) * 2 * C + C + c];
+    const double x1 = stats[(size_t)(r + 1) * 2 * C + c], y1 = stats[(size_t)(r + 1) * 2 * C + C + c];
+    const double x2 = stats[(size_t)(r + 2) * 2 * C + c], y2 = stats[(size_t)(r + 2) * 2 * C + C + c];
+    const double x3 = stats[(size_t)(r + 3) * 2 * C + c], y3 = stats[(size_t)(r + 3) * 2 * C + C + c];
+    a1 += x0 + x1; b1 += x2 + x3; a2 += y0 + y1; b2 += y2 + y3;
+  }
+  for (; r < R; ++r) { a1 += stats[(size_t)r * 2 * C + c]; a2 += stats[(size_t)r * 2 * C + C + c]; }
+  s1 = a1 + b1; s2 = a2 + b2;
+}
+
 __global__ void bn_finalize_kernel(const double* stats, int R, double count, double bessel_n, const float* gamma, const float* beta,
                                    float* mmean, float* mvar, float momentum, float eps, int training,
                                    float* scale, float* shift, float* mean_o, float* rstd_o, int C) {
@@ -118,8 +134,8 @@ __global__ void bn_finalize_kernel(const double* stats, int R, double count, dou
   if (c >= C) return;
   double mean, var;
   if (training) {
-    double s1 = 0, s2 = 0;
-    for (int r = 0; r < R; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
+    double s1, s2;
+    replica_sum(stats, R, C, c, s1, s2);
     mean = s1 / count;
     var = s2 / count - mean * mean;
     if (var < 0) var = 0;
@@ -144,7 +160,7 @@ extern "C" int rua_bn_finalize(const double* stats, int replicas, double count, 
                                float* scale, float* shift, float* mean, float* rstd, int C, void* stream) {
   RUA_CHECK_ARG(gamma && beta && scale && shift && C > 0, "rua_bn_finalize: bad arguments");
   RUA_CHECK_ARG(training ? (stats != nullptr && count > 0) : (moving_mean && moving_var), "rua_bn_finalize: missing statistics");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(rua_div_up(C, 128)), dim3(128), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(rua_div_up(C, 64)), dim3(64), 0, (hipStream_t)stream,
                      stats, replicas < 1 ? 1 : replicas, count, bessel_n, gamma, beta, moving_mean, moving_var, momentum, eps, training, scale, shift, mean, rstd, C);
   RUA_LAUNCH_CHECK("rua_bn_finalize");
   return RUA_OK;
@@ -154,8 +170,8 @@ __global__ void bn_bwd_finalize_kernel(const double* st2, int R, double count, c
                                        float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double sg = 0, sgx = 0;
-  for (int r = 0; r < R; ++r) { sg += st2[(size_t)r * 2 * C + c]; sgx += st2[(size_t)r * 2 * C + C + c]; }
+  double sg, sgx;
+  replica_sum(st2, R, C, c, sg, sgx);
   const double mu = mean[c], r = rstd[c], gm = gamma[c];
   const double dbe = sg;
   const double dga = r * (sgx - mu * sg);
@@ -170,7 +186,7 @@ __global__ void bn_bwd_finalize_kernel(const double* st2, int R, double count, c
 extern "C" int rua_bn_bwd_finalize(const double* stats2, int replicas, double count, const float* gamma, const float* mean, const float* rstd,
                                    float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC, int C, void* stream) {
   RUA_CHECK_ARG(stats2 && gamma && mean && rstd && coefA && coefB && coefC && C > 0 && count > 0, "rua_bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rua_div_up(C, 128)), dim3(128), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rua_div_up(C, 64)), dim3(64), 0, (hipStream_t)stream,
                      stats2, replicas < 1 ? 1 : replicas, count, gamma, mean, rstd, dgamma, dbeta, coefA, coefB, coefC, C);
   RUA_LAUNCH_CHECK("rua_bn_bwd_finalize");
   return RUA_OK;
@@ -180,15 +196,15 @@ extern "C" int rua_bn_bwd_finalize(const double* stats2, int replicas, double co
 __global__ void stats_to_f32_kernel(const double* stats, int R, int C, float* d0, float* d1, float* d2, float* d3, int n) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double a = 0;
-  for (int r = 0; r < R; ++r) a += stats[(size_t)r * 2 * C + c];
+  double a, unused;
+  replica_sum(stats, R, C, c, a, unused);
   const float v = (float)a;
   d0[c] += v; if (n > 1) d1[c] += v; if (n > 2) d2[c] += v; if (n > 3) d3[c] += v;
 }
 extern "C" int rua_stats_to_f32(const double* stats, int replicas, int C, float* const* dst, int n, void* stream) {
   RUA_CHECK_ARG(stats && dst && n >= 1 && n <= 4 && C > 0, "rua_stats_to_f32: bad arguments");
   for (int i = 0; i < n; ++i) RUA_CHECK_ARG(dst[i], "rua_stats_to_f32: null destination");
-  hipLaunchKernelGGL(stats_to_f32_kernel, dim3(rua_div_up(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, replicas < 1 ? 1 : replicas, C,
+  hipLaunchKernelGGL(stats_to_f32_kernel, dim3(rua_div_up(C, 64)), dim3(64), 0, (hipStream_t)stream, stats, replicas < 1 ? 1 : replicas, C,
                      dst[0], n > 1 ? dst[1] : nullptr, n > 2 ? dst[2] : nullptr, n > 3 ? dst[3] : nullptr, n);
   RUA_LAUNCH_CHECK("rua_stats_to_f32");
   return RUA_OK;

@@ -406,6 +406,8 @@ class Graph:
         d.dy, d.Cout, d.H, d.W = dy.ptr, dy.C, dy.H, dy.W
         d.N, d.stride, d.dil, d.taps, d.dtype = dy.N, stride, dil, taps, self.dt
         d.dw = self.G(dw_off)
+        if not self.dry:
+            d.workspace, d.workspace_bytes = self.e.workspace.data_ptr(), self.e.workspace.numel() * 4
         plan.keep.append(d)
         plan.add("rua_conv_wgrad", C.byref(d))
 
@@ -476,7 +478,7 @@ class Graph:
                 self.bn_bwd_finalize(Bp, s2, cnt, l[2], c2)
                 dy1 = self.like(x)
                 self.bn_bwd_apply(Bp, [g2], [c2], y, dy1, 0)
-                self.bias_grad(Bp, dy1, [l[1]["bias"]])
+                # no bias gradient launch: the output of a BN backward sums to zero per channel, so d b1 == 0 exactly
                 self.wgrad(Bp, a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9)
                 g1 = g2                                    # g2 is dead after bn_bwd_apply: reuse its storage
                 s1 = self.stat(nf, (cnt + 127) // 128)
@@ -553,9 +555,10 @@ class Graph:
 
     def conv1x1_multi_back(self, Bp, segs, lay, y: Ten, targets):
         """Backward of conv1x1_multi.  targets[i] = dict(out, mask/stat_aux/stats2) for a fused BN source,
-        or None for a plain accumulate into the source's gradient."""
+        or None for a plain accumulate into the source's gradient.  Every conv1x1_multi is followed by a
+        training-mode BatchNorm, so its bias gradient (the per-channel sum of a BN backward output) is exactly
+        zero and no launch is spent on it."""
         dy = y.grad
-        self.bias_grad(Bp, dy, [lay["bias"]])
         pooled = {0: dy}
         for (t, up), seg, tg in zip(segs, lay["segs"], targets):
             if up not in pooled:

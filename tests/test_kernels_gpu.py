@@ -232,6 +232,39 @@ def test_conv_wgrad(case, dt):
     assert rel_err(dw.cpu().numpy(), w.grad.numpy()) < tol(dt)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 32, 1), (1, 128, 64, 32, 3), (2, 64, 128, 32, 15), (1, 64, 64, 32, 31),
+                                  (2, 64, 64, 64, 1), (1, 64, 128, 64, 15), (1, 128, 64, 64, 31), (3, 64, 64, 64, 3)])
+def test_wgrad_all_taps_kernel(case):
+    """Top-level weight gradient (C = Cout in {32, 64}, W % 64 == 0, bf16): all nine taps from one LDS halo,
+    deterministic partial reduction; must add into dW and match autograd."""
+    N, H, W, Cc, dil = case
+    dt = L.RUA_BF16
+    rng = np.random.default_rng(13)
+    a = rng.standard_normal((N, H, W, Cc)).astype(np.float32)
+    dy = rng.standard_normal((N, H, W, Cc)).astype(np.float32)
+    ad, dyd = to_dev(a, dt), to_dev(dy, dt)
+    base = rng.standard_normal((9, Cc, Cc)).astype(np.float32)
+    dw = torch.from_numpy(base).to(dev())
+    ws = torch.empty(256 * 9 * 32 * Cc, dtype=torch.float32, device=dev())
+    d = L.WgradDesc()
+    d.a, d.C, d.Hs, d.Ws = ad.data_ptr(), Cc, H, W
+    d.dy, d.Cout, d.H, d.W = dyd.data_ptr(), Cc, H, W
+    d.N, d.stride, d.dil, d.taps, d.dtype = N, 1, dil, 9, dt
+    d.dw, d.workspace, d.workspace_bytes = dw.data_ptr(), ws.data_ptr(), ws.numel() * 4
+    assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 1
+    outs = []
+    for rep in range(2):
+        dw.copy_(torch.from_numpy(base))
+        L.lib().call("rua_conv_wgrad", C.byref(d), stream())
+        torch.cuda.synchronize()
+        outs.append(dw.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])                    # deterministic (no atomics)
+    w = torch.zeros((9, Cc, Cc), dtype=torch.float64, requires_grad=True)
+    y = ref_conv_nhwc(rnd(dt, a).double(), w, None, dil, 9, 1)
+    y.backward(rnd(dt, dy).double())
+    assert rel_err(outs[0] - base, w.grad.numpy()) < 2e-3
+
+
 @pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
 def test_weight_prep_layouts(dt):
     rng = np.random.default_rng(4)
