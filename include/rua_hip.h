@@ -64,7 +64,8 @@ typedef struct rua_conv_desc {
   int32_t out_stride, OH, OW;
   double* stats;               /* [stats_replicas][2][Cout] atomically accumulated, or NULL */
   int32_t stats_mode;          /* 1: sum v, sum v^2   2: sum v, sum v*aux */
-  void* workspace;             /* optional fp32 scratch of rua_conv_workspace_bytes(): enables split-K for small output grids */
+  void* workspace;             /* optional fp32 scratch of rua_conv_workspace_bytes(): enables split-K for small output grids.
+                                  MUST be all zeros on entry (zero-fill it once); the call leaves it all zeros again */
   int64_t workspace_bytes;
   int32_t stats_replicas;      /* power of two >= 1: block b adds into replica b % R (spreads atomic contention);
                                   the finalize kernels sum the replicas */
@@ -103,8 +104,9 @@ int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db, int64_t M
 /* heads: Conv2D(num_classes,(1,1)) + softmax / sigmoid (model2.py:145-146,160-162,169-171,181-183,186-188).
  * act: 0 none, 1 softmax over channels, 2 sigmoid.  z (logits) and p are fp32 [M][Cout<=8]. */
 int rua_head_fwd(const void* x, const float* w, const float* b, float* z, float* p, int64_t M, int Cin, int Cout, int act, int dtype, void* stream);
+/* scratch (optional, >= 1024*(Cout*Cin+Cout)*4 bytes): per-block partials + fixed-order reduce instead of fp32 atomics */
 int rua_head_bwd(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db,
-                 int64_t M, int Cin, int Cout, int dtype, void* stream);
+                 float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, void* stream);
 
 /* ---- BatchNormalization (model2.py:17,21,38,86,93; Keras eps 1e-3, momentum .99) -------- */
 /* per-channel sum / sum of squares over all rows of x [M][C] -> stats[R][2][C] (fp64, accumulated over R replicas) */

@@ -41,7 +41,7 @@ template <typename T> __device__ __forceinline__ void store8(unsigned char* base
 // Shared epilogue of one 128 x BN output tile whose fp32 sums sit in `src` (LDS tile or split-K workspace):
 // 8-channel pieces per thread: bias, accumulate, residual / ReLU mask from aux, output ReLU, per-channel
 // statistics (fp32 partials -> wave shuffles -> LDS -> one fp64 atomic per channel and block), 16-byte stores.
-template <typename T, int BN>
+template <typename T, int BN, bool ZERO_SRC = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int n0, int bm_i, const float* src, int sstride, float* sred) {
   constexpr int BM = 128;
   constexpr int CG = BN / 8;
@@ -80,6 +80,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
       float v[8];
       const float4 t0 = *reinterpret_cast<const float4*>(&src[(size_t)row * sstride + cg * 8]);
       const float4 t1 = *reinterpret_cast<const float4*>(&src[(size_t)row * sstride + cg * 8 + 4]);
+      if (ZERO_SRC) {
+        *reinterpret_cast<float4*>(const_cast<float*>(&src[(size_t)row * sstride + cg * 8])) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(const_cast<float*>(&src[(size_t)row * sstride + cg * 8 + 4])) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += bias8[j];
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK p) {
   const int bn_i = blockIdx.x % nbn, bm_i = blockIdx.x / nbn;
   const long long m0 = (long long)bm_i * 128;
   const int n0 = bn_i * 64;
-  conv_epilogue<T, 64>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sred);
+  conv_epilogue<T, 64, true>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sred);
 }
 
 template <typename T, int BN> static constexpr int conv_smem() {
@@ -402,10 +406,8 @@ template <typename T, int BN> static int launch_conv(const ConvK& k, int nbm, hi
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  if (k.ksplit > 1) {
-    hipError_t e = hipMemsetAsync(k.ws, 0, (size_t)k.M * k.Cout * sizeof(float), st);
-    if (e != hipSuccess) { rua_set_error("conv split-K memset: %s", hipGetErrorString(e)); return RUA_ERR_LAUNCH; }
-  }
+  // split-K invariant: the workspace is all zeros on entry (caller zero-fills it once) and the finisher writes the
+  // zeros back after consuming the sums, so no memset is launched per convolution.
   hipLaunchKernelGGL((conv_igemm<T, BN>), dim3(nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
   RUA_LAUNCH_CHECK("conv_igemm");
   if (k.ksplit > 1) {
@@ -914,23 +916,44 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
 // =========================================================================================
 // Weight preparation: fp32 master [taps][Cout][C] -> dtype copies (forward layout, dgrad layout).
 template <typename T>
-__global__ void wprep_kernel(const float* __restrict__ master, T* __restrict__ wf, T* __restrict__ wd,
-                             const rua_wprep_item* __restrict__ items) {
+__global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ master, T* __restrict__ wf, T* __restrict__ wd,
+                                                    const rua_wprep_item* __restrict__ items) {
+  // one 32(co) x 32(ci) tile of one tap per block iteration: coalesced fp32 reads along ci, coalesced writes of the
+  // forward copy (same layout) and, through an LDS transpose, of the data-gradient copy [taps reversed][ci][co]
+  __shared__ float tile[32][33];
   const rua_wprep_item it = items[blockIdx.y];
-  const int per = it.Cout * it.C;
-  const int total = it.taps * per;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const float v = master[it.src_off + i];
-    wf[it.dst_off + i] = (T)v;
-    const int tap = i / per, r = i - tap * per, co = r / it.C, ci = r - co * it.C;
-    wd[it.dst_off + (size_t)(it.taps - 1 - tap) * per + (size_t)ci * it.Cout + co] = (T)v;
+  const int tco = (it.Cout + 31) / 32, tci = (it.C + 31) / 32;
+  const int ntiles = it.taps * tco * tci;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tap = t / (tco * tci), r = t - tap * tco * tci;
+    const int co0 = (r / tci) * 32, ci0 = (r % tci) * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int co = co0 + ty + k * 8, ci = ci0 + tx;
+      float v = 0.f;
+      if (co < it.Cout && ci < it.C) {
+        const size_t o = (size_t)tap * it.Cout * it.C + (size_t)co * it.C + ci;
+        v = master[it.src_off + o];
+        wf[it.dst_off + o] = (T)v;
+      }
+      tile[ty + k * 8][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ci = ci0 + ty + k * 8, co = co0 + tx;
+      if (co < it.Cout && ci < it.C)
+        wd[it.dst_off + (size_t)(it.taps - 1 - tap) * it.Cout * it.C + (size_t)ci * it.Cout + co] = (T)tile[tx][ty + k * 8];
+    }
+    __syncthreads();
   }
 }
 
 extern "C" int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev,
                                int n_items, int max_elems, int dtype, void* stream) {
   RUA_CHECK_ARG(master && w_fwd && w_dgrad && items_dev && n_items > 0, "rua_weight_prep: bad arguments");
-  int gx = rua_div_up(max_elems, 256 * 8); if (gx < 1) gx = 1; if (gx > 512) gx = 512;
+  int gx = rua_div_up(max_elems, 1024 * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RUA_BF16) hipLaunchKernelGGL((wprep_kernel<bf16_t>), dim3(gx, n_items), dim3(256), 0, st, master, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, items_dev);
   else hipLaunchKernelGGL((wprep_kernel<float>), dim3(gx, n_items), dim3(256), 0, st, master, (float*)w_fwd, (float*)w_dgrad, items_dev);

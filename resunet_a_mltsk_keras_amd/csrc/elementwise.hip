@@ -33,6 +33,21 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
     long long r = (long long)blockIdx.x * p.rows_per_block + ty;
     long long rend = (long long)(blockIdx.x + 1) * p.rows_per_block;
     if (rend > p.M) rend = p.M;
+    if (MODE == 1) {
+      // four independent 16-byte loads in flight per thread
+      for (; r + 3 * p.TY < rend; r += 4 * p.TY) {
+        uint4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = ldg16(p.x + ((size_t)(r + u * p.TY) * p.CG + cp) * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float xv[VEC];
+          ET<T>::unpack(q[u], xv);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { s1[j] += xv[j]; s2[j] = fmaf(xv[j], xv[j], s2[j]); }
+        }
+      }
+    }
     for (; r < rend; r += p.TY) {
       float xv[VEC];
       ET<T>::unpack(ldg16(p.x + ((size_t)r * p.CG + cp) * 16), xv);

@@ -161,14 +161,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned char* x, c
 
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, const float* __restrict__ dz, const float* __restrict__ w,
-                                                        unsigned char* dx, int accumulate_dx, float* dw, float* db,
+                                                        unsigned char* dx, int accumulate_dx, float* dw, float* db, float* partial,
                                                         long long M, int Cin, int Cout, int rows_per_block) {
   constexpr int VEC = ET<T>::VEC;
-  extern __shared__ float red[];                      // [Cout][Cin] + [Cout]
-  for (int i = threadIdx.x; i < Cout * Cin + Cout; i += 256) red[i] = 0.f;
-  __syncthreads();
+  extern __shared__ float red[];                      // [4 waves][Cout*Cin + Cout]
+  const int NE = Cout * Cin + Cout;
   const int CGI = Cin / VEC;
   const int cp = threadIdx.x % CGI, pl = threadIdx.x / CGI, PL = 256 / CGI;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float wr[8][VEC], acc[8][VEC], bs[8];
 #pragma unroll
   for (int co = 0; co < 8; ++co) { bs[co] = 0.f;
@@ -176,36 +176,63 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
     for (int j = 0; j < VEC; ++j) { wr[co][j] = co < Cout ? w[co * Cin + cp * VEC + j] : 0.f; acc[co][j] = 0.f; } }
   long long r = (long long)blockIdx.x * rows_per_block + pl;
   long long rend = (long long)(blockIdx.x + 1) * rows_per_block; if (rend > M) rend = M;
-  if (pl < PL) {
-    for (; r < rend; r += PL) {
-      float xv[VEC], g[8], o[VEC];
-      ET<T>::unpack(ldg16(x + ((size_t)r * CGI + cp) * 16), xv);
+  for (; r < rend; r += PL) {
+    float xv[VEC], g[8], o[VEC];
+    ET<T>::unpack(ldg16(x + ((size_t)r * CGI + cp) * 16), xv);
 #pragma unroll
-      for (int co = 0; co < 8; ++co) g[co] = co < Cout ? dz[r * Cout + co] : 0.f;
+    for (int co = 0; co < 8; ++co) g[co] = co < Cout ? dz[r * Cout + co] : 0.f;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) o[j] = 0.f;
-      if (dx && accumulate_dx) ET<T>::unpack(ldg16(dx + ((size_t)r * CGI + cp) * 16), o);
+    for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+    if (dx && accumulate_dx) ET<T>::unpack(ldg16(dx + ((size_t)r * CGI + cp) * 16), o);
 #pragma unroll
-      for (int co = 0; co < 8; ++co) {
-        bs[co] += g[co];
+    for (int co = 0; co < 8; ++co) {
+      bs[co] += g[co];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { o[j] = fmaf(g[co], wr[co][j], o[j]); acc[co][j] = fmaf(g[co], xv[j], acc[co][j]); }
-      }
-      if (dx) stg16(dx + ((size_t)r * CGI + cp) * 16, ET<T>::pack(o));
+      for (int j = 0; j < VEC; ++j) { o[j] = fmaf(g[co], wr[co][j], o[j]); acc[co][j] = fmaf(g[co], xv[j], acc[co][j]); }
     }
+    if (dx) stg16(dx + ((size_t)r * CGI + cp) * 16, ET<T>::pack(o));
+  }
+  // lanes that share a channel piece (same lane % CGI) are folded with shuffles, then one LDS slot per wave
+#pragma unroll
+  for (int co = 0; co < 8; ++co) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      for (int o = CGI; o < 64; o <<= 1) acc[co][j] += __shfl_xor(acc[co][j], o, 64);
+    for (int o = CGI; o < 64; o <<= 1) bs[co] += __shfl_xor(bs[co], o, 64);
+  }
+  if (lane < CGI) {
 #pragma unroll
     for (int co = 0; co < 8; ++co) {
       if (co < Cout) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) atomicAdd(&red[co * Cin + cp * VEC + j], acc[co][j]);
-        if (cp == 0) atomicAdd(&red[Cout * Cin + co], bs[co]);
+        for (int j = 0; j < VEC; ++j) red[wid * NE + co * Cin + lane * VEC + j] = acc[co][j];
+        if (lane == 0) red[wid * NE + Cout * Cin + co] = bs[co];
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < Cout * Cin + Cout; i += 256) {
-    if (i < Cout * Cin) unsafeAtomicAdd(&dw[i], red[i]);
-    else if (db) unsafeAtomicAdd(&db[i - Cout * Cin], red[i]);
+  for (int i = threadIdx.x; i < NE; i += 256) {
+    const float v = red[i] + red[NE + i] + red[2 * NE + i] + red[3 * NE + i];
+    if (partial) partial[(size_t)blockIdx.x * NE + i] = v;                       // deterministic two-stage path
+    else if (i < Cout * Cin) unsafeAtomicAdd(&dw[i], v);
+    else if (db) unsafeAtomicAdd(&db[i - Cout * Cin], v);
+  }
+}
+
+// dst[e] += sum_b partial[b][e]; 16 elements x 16 slices per block, slices folded in a fixed order
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int ne, int nparts, float* dw, int ndw, float* db) {
+  __shared__ float sh[256];
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  float s = 0.f;
+  if (e < ne) for (int b = sl; b < nparts; b += 16) s += partial[(size_t)b * ne + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && e < ne) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k * 16 + el];
+    if (e < ndw) dw[e] += t; else if (db) db[e - ndw] += t;
   }
 }
 
@@ -224,17 +251,23 @@ extern "C" int rua_head_fwd(const void* x, const float* w, const float* b, float
 }
 
 extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db,
-                            int64_t M, int Cin, int Cout, int dtype, void* stream) {
+                            float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, void* stream) {
   RUA_CHECK_ARG(x && dz && w && dw && M > 0, "rua_head_bwd: bad arguments");
   const int vec = dtype == RUA_BF16 ? 8 : 4;
   RUA_CHECK_ARG(Cin % vec == 0 && Cin <= 256 && 256 % (Cin / vec) == 0, "rua_head_bwd: unsupported Cin=%d", Cin);
   RUA_CHECK_ARG(Cout >= 1 && Cout <= 8, "rua_head_bwd: Cout=%d must be in 1..8", Cout);
-  int64_t blocks = 2048; int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
+  int64_t blocks = 1024; int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
   const int g = (int)((M + rpb - 1) / rpb);
-  const size_t smem = (size_t)(Cout * Cin + Cout) * 4;
+  const int ne = Cout * Cin + Cout;
+  const size_t smem = (size_t)4 * ne * 4;
+  float* partial = (scratch && scratch_bytes >= (int64_t)g * ne * 4) ? scratch : nullptr;   // else: fp32 atomics
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RUA_BF16) hipLaunchKernelGGL((head_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, (unsigned char*)dx, accumulate_dx, dw, db, (long long)M, Cin, Cout, (int)rpb);
-  else hipLaunchKernelGGL((head_bwd_kernel<float>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, (unsigned char*)dx, accumulate_dx, dw, db, (long long)M, Cin, Cout, (int)rpb);
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((head_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb);
+  else hipLaunchKernelGGL((head_bwd_kernel<float>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb);
   RUA_LAUNCH_CHECK("rua_head_bwd");
+  if (partial) {
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((ne + 15) / 16), dim3(256), 0, st, (const float*)partial, ne, g, dw, Cout * Cin, db);
+    RUA_LAUNCH_CHECK("partial_reduce_kernel");
+  }
   return RUA_OK;
 }

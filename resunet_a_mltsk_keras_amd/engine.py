@@ -407,7 +407,7 @@ class Graph:
         d.N, d.stride, d.dil, d.taps, d.dtype = dy.N, stride, dil, taps, self.dt
         d.dw = self.G(dw_off)
         if not self.dry:
-            d.workspace, d.workspace_bytes = self.e.workspace.data_ptr(), self.e.workspace.numel() * 4
+            d.workspace, d.workspace_bytes = self.e.scratch.data_ptr(), self.e.scratch.numel() * 4
         plan.keep.append(d)
         plan.add("rua_conv_wgrad", C.byref(d))
 
@@ -721,7 +721,7 @@ class Graph:
             gx, acc = self.gacc(h["x"])
             lay = h["lay"]
             Bp.add("rua_head_bwd", h["x"].ptr, dz.ptr, self.P(lay["segs"][0]["off"]), gx.ptr, acc, self.G(lay["segs"][0]["off"]),
-                   self.G(lay["bias"]), M, h["x"].C, Cc, self.dt)
+                   self.G(lay["bias"]), self.e.scratch.data_ptr(), self.e.scratch.numel() * 4, M, h["x"].C, Cc, self.dt)
         self.back_steps.append(back)
 
     # -- whole network ---------------------------------------------------------------------------------
@@ -834,7 +834,8 @@ class Engine:
         self.wprep_items = torch.from_numpy(np.frombuffer(items.tobytes(), dtype=np.uint8).copy()).to(self.dev)
         self.wprep_n, self.wprep_max = len(rows), mx
         self.stats_arena = torch.zeros(1 << 20, dtype=torch.float64, device=self.dev)
-        self.workspace = torch.zeros(8 << 20, dtype=torch.float32, device=self.dev)       # 32 MiB split-K scratch
+        self.workspace = torch.zeros(8 << 20, dtype=torch.float32, device=self.dev)       # 32 MiB split-K scratch (kept zero)
+        self.scratch = torch.zeros(8 << 20, dtype=torch.float32, device=self.dev)         # 32 MiB weight-gradient partials
         self.lr_dev = torch.zeros(16, dtype=torch.float32, device=self.dev)               # step-dependent optimizer scalars
         self.use_graph = True
         self._captured: Dict[int, object] = {}

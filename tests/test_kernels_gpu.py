@@ -124,7 +124,7 @@ def test_conv_split_k_matches_single_pass(dt):
     xd, wd, ad, bd = to_dev(x, dt), to_dev(w, dt), to_dev(aux, dt), torch.from_numpy(bias).to(dev())
     y = torch.empty((N, H, W, Cout), dtype=tdt(dt), device=dev())
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev())
-    ws = torch.empty(N * H * W * Cout, dtype=torch.float32, device=dev())
+    ws = torch.zeros(N * H * W * Cout, dtype=torch.float32, device=dev())
     d = L.ConvDesc()
     d.nseg = 1
     s = d.seg[0]
@@ -143,6 +143,7 @@ def test_conv_split_k_matches_single_pass(dt):
     st = stats.cpu().numpy()
     assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
     assert rel_err(st[Cout:], (exp * a).sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
+    assert float(ws.abs().max()) == 0.0                      # the finisher leaves the split-K workspace zeroed
 
 
 @pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
@@ -433,11 +434,15 @@ def test_stem_and_head_kernels():
         dzd = f(dz)
         dx = torch.empty((M, Ci), dtype=tdt(dt), device=dev())
         dwh = torch.zeros((Co, Ci), device=dev()); dbh = torch.zeros(Co, device=dev())
-        lib.call("rua_head_bwd", hxd.data_ptr(), dzd.data_ptr(), hwd.data_ptr(), dx.data_ptr(), 0, dwh.data_ptr(), dbh.data_ptr(), M, Ci, Co, dt, stream())
-        torch.cuda.synchronize()
-        assert rel_err(dx.float().cpu().numpy(), dz @ hw) < tol(dt)
-        assert rel_err(dwh.cpu().numpy(), dz.T @ rnd(dt, hx).numpy()) < 1e-4
-        assert rel_err(dbh.cpu().numpy(), dz.sum(0)) < 1e-4
+        scr = torch.empty(1024 * (Co * Ci + Co), device=dev())
+        for scratch in (None, scr):                        # fp32-atomic path and deterministic partial path
+            dwh.zero_(); dbh.zero_()
+            lib.call("rua_head_bwd", hxd.data_ptr(), dzd.data_ptr(), hwd.data_ptr(), dx.data_ptr(), 0, dwh.data_ptr(), dbh.data_ptr(),
+                     None if scratch is None else scratch.data_ptr(), 0 if scratch is None else scratch.numel() * 4, M, Ci, Co, dt, stream())
+            torch.cuda.synchronize()
+            assert rel_err(dx.float().cpu().numpy(), dz @ hw) < tol(dt)
+            assert rel_err(dwh.cpu().numpy(), dz.T @ rnd(dt, hx).numpy()) < 1e-4
+            assert rel_err(dbh.cpu().numpy(), dz.sum(0)) < 1e-4
 
 
 def test_losses_against_oracle():
