@@ -53,7 +53,9 @@ def profile_kernels(eng, g, dtype):
     eng._zero_arena(g, s)
     eng._prep_weights(s)
     for plan in (g.fwd, g.loss_plan, g.bwd):
-        for fn, name, args in plan.calls:
+        for fn, name, args, _lane in plan.calls:
+            if fn is None:
+                continue                                    # fork / join markers: this pass runs everything on one stream
             if name in ("rua_conv_fwd", "rua_conv_wgrad"):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -61,7 +63,7 @@ def profile_kernels(eng, g, dtype):
                 e1.record()
                 d = args[0]._obj
                 if name == "rua_conv_fwd":
-                    kn = f"conv_igemm<{tname},{lib.raw('rua_conv_tile_bn')(C.byref(d))}>"
+                    kn = f"conv_igemm<{tname},{lib.raw('rua_conv_tile_bm')(C.byref(d))},{lib.raw('rua_conv_tile_bn')(C.byref(d))}>"
                     kk = sum(d.seg[i].taps * d.seg[i].C for i in range(d.nseg))
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "")
                     rec.append((kn, e0, e1, conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags)))

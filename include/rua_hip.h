@@ -73,7 +73,8 @@ typedef struct rua_conv_desc {
 int rua_conv_fwd(const rua_conv_desc* d, void* stream);
 int rua_conv_smem_bytes(const rua_conv_desc* d);
 int64_t rua_conv_workspace_bytes(const rua_conv_desc* d);   /* N*H*W*Cout fp32: needed only if split-K is wanted */
-int rua_conv_tile_bn(const rua_conv_desc* d);   /* 32 / 64 / 128: which conv_igemm<T,BN> instantiation a descriptor launches */
+int rua_conv_tile_bn(const rua_conv_desc* d);   /* 32 / 64 / 128 and */
+int rua_conv_tile_bm(const rua_conv_desc* d);   /* 128 / 256: which conv_igemm<T,BM,BN> instantiation a descriptor launches */
 
 /* ---- weight gradient (MFMA, split over pixels, fp32 atomic accumulation) ----------------
  * dW[t][co][c] += sum_pixels dy[n,h,w,co] * a[n, h*stride+dy_t*dil, w*stride+dx_t*dil, c]

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librua_hip.so")
+LIB_PATH = os.environ.get("RUA_LIB_PATH") or os.path.join(HERE, "librua_hip.so")   # RUA_LIB_PATH: experiment builds only
 
 RUA_F32, RUA_BF16 = 0, 1
 RUA_MAX_SEG, RUA_MAX_BRANCH = 6, 4
@@ -44,6 +44,7 @@ _SIGS = {
     "rua_conv_fwd": ([C.POINTER(ConvDesc), vp], i32),
     "rua_conv_smem_bytes": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_tile_bn": ([C.POINTER(ConvDesc)], i32),
+    "rua_conv_tile_bm": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_workspace_bytes": ([C.POINTER(ConvDesc)], i64),
     "rua_conv_wgrad": ([C.POINTER(WgradDesc), vp], i32),
     "rua_wgrad_workspace_bytes": ([C.POINTER(WgradDesc)], i64),

@@ -9,6 +9,7 @@
 // Epilogue: accumulators -> LDS fp32 tile -> 8-channel pieces per thread: bias, residual /
 // ReLU-mask from `aux`, per-channel statistics (fp32 partials, fp64 atomics), 16-byte stores.
 #include "common.h"
+#include <stdlib.h>
 
 struct SegK { const unsigned char* x; const unsigned char* w; int C, Hs, Ws, up, dil, taps, nchunk, ubegin; unsigned xbytes, wbytes; };
 struct ConvK {
@@ -38,12 +39,18 @@ template <typename T> __device__ __forceinline__ void store8(unsigned char* base
   }
 }
 
+template <typename T, int BM, int BN> __host__ __device__ constexpr int conv_smem_base() {
+  constexpr int ROWB = (sizeof(T) == 2) ? 80 : 132;
+  constexpr int a = 2 * (BM + BN) * ROWB;
+  constexpr int b = BM * (BN + 4) * 4 + 4 * (BN / 8) * 16 * 4;
+  return ((a > b ? a : b) + 15) / 16 * 16;
+}
+
 // Shared epilogue of one 128 x BN output tile whose fp32 sums sit in `src` (LDS tile or split-K workspace):
 // 8-channel pieces per thread: bias, accumulate, residual / ReLU mask from aux, output ReLU, per-channel
 // statistics (fp32 partials -> wave shuffles -> LDS -> one fp64 atomic per channel and block), 16-byte stores.
-template <typename T, int BN, bool ZERO_SRC = false>
+template <typename T, int BM, int BN, bool ZERO_SRC = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int n0, int bm_i, const float* src, int sstride, float* sred) {
-  constexpr int BM = 128;
   constexpr int CG = BN / 8;
   constexpr int ROWS_PP = 256 / CG;
   constexpr int EP = BM / ROWS_PP;
@@ -146,9 +153,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
   }
 }
 
-template <typename T, int BN>
+template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
-  constexpr int BM = 128, KU = 2;
+  constexpr int KU = 2;
   constexpr int VEC = ET<T>::VEC, ES = sizeof(T);
   constexpr int PPR = 32 / VEC;
   constexpr int ROWB = (ES == 2) ? 80 : 132;
@@ -156,9 +163,10 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
   constexpr int APASS = BM / RPP;
   constexpr int BPIECES = BN * PPR;
   constexpr int BPASS = (BPIECES + 255) / 256;
-  constexpr int WN = (BN >= 64) ? 2 : 1, WM = 4 / WN;
+  constexpr int WN = (BN >= 128 || (BN == 64 && BM == 128)) ? 2 : 1, WM = 4 / WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int CSTR = BN + 4;
+  constexpr int UTAB_OFF = conv_smem_base<T, BM, BN>();     // the unit table sits behind the staging / epilogue area
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
@@ -194,21 +202,41 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
   const int bq = tid % PPR, br = tid / PPR;          // B piece column / row (pass j adds j*RPP rows)
   const bool bthread = tid < BROWS;
 
-  uint4 ra[KU][APASS], rb[KU][BPASS];
+  uint4 ra0[KU][APASS], rb0[KU][BPASS];
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-  // ---- K iteration state: (segment, tap, 32-channel chunk), advanced without divisions ----------------
+  // ---- K iteration: a per-unit table built once per block in LDS ------------------------------------------
+  // entry u = { tap/chunk element offset into the source, element offset into the weights, (dh << 16) | (dw & 0xffff),
+  //             segment | channels left in this chunk << 8 }.  The loader reads ONE broadcast 16-byte entry per unit
+  // instead of re-deriving segment / tap / chunk with scalar code every stage (that bookkeeping was ~50 SALU + ~35
+  // VALU instructions per unit and dominated the issue slots of the K loop).
+  int4* utab = reinterpret_cast<int4*>(smem + UTAB_OFF);
+  for (int u = tid; u < p.nunits; u += 256) {
+    int sgi = 0;
+    while (sgi + 1 < p.nseg && u >= p.seg[sgi + 1].ubegin) ++sgi;
+    const SegK sg = p.seg[sgi];
+    const int loc = u - sg.ubegin;
+    const int tap = loc / sg.nchunk, chunk = loc - tap * sg.nchunk;
+    int dh = 0, dw = 0;
+    if (sg.taps == 9) { dh = (tap / 3 - 1) * sg.dil; dw = (tap % 3 - 1) * sg.dil; }
+    int4 e;
+    e.x = (dh * sg.Ws + dw) * sg.C + chunk * 32;
+    e.y = tap * p.Cout * sg.C + chunk * 32;
+    e.z = (dh << 16) | (dw & 0xffff);
+    int left = sg.C - chunk * 32; if (left > 32) left = 32;
+    e.w = sgi | (left << 8);
+    utab[u] = e;
+  }
   int cs = -1;                        // segment the per-thread bases below belong to
-  int u_seg = 0, u_tap = 0, u_chunk = 0;
-  // per-segment, per-thread precomputed element offsets (32-bit: every tensor here is < 2^31 elements)
+  // per-segment, per-thread precomputed element offsets (32-bit: every tensor here is < 2^31 bytes)
   int abase[APASS];                   // ((n*Hs + (hS>>up))*Ws + (wS>>up))*C + aq*VEC   (tap offset added per unit)
   int bbase[BPASS];                   // row*C + bq*VEC
   __amdgpu_buffer_rsrc_t rx = make_rsrc(p.seg[0].x, p.seg[0].xbytes), rw = make_rsrc(p.seg[0].w, p.seg[0].wbytes);
-  int sC_ = 0, sWs = 0, sdil = 1, staps = 1, snchunk = 1; unsigned sHL = 0, sWL = 0;
+  unsigned sHL = 0, sWL = 0;
 
   auto enter_segment = [&](int s) {
     const SegK sg = p.seg[s];
-    cs = s; rx = make_rsrc(sg.x, sg.xbytes); rw = make_rsrc(sg.w, sg.wbytes); sC_ = sg.C; sWs = sg.Ws; sdil = sg.dil; staps = sg.taps; snchunk = sg.nchunk;
+    cs = s; rx = make_rsrc(sg.x, sg.xbytes); rw = make_rsrc(sg.w, sg.wbytes);
     sHL = (unsigned)(sg.Hs << sg.up); sWL = (unsigned)(sg.Ws << sg.up);
 #pragma unroll
     for (int i = 0; i < APASS; ++i)
@@ -216,42 +244,29 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) bbase[j] = (n0 + br + j * RPP) * sg.C + bq * VEC;
   };
-  auto seek_unit = [&](int unit) {    // used once (split-K start): the only place that divides
-    int s = 0;
-    while (s + 1 < p.nseg && unit >= p.seg[s + 1].ubegin) ++s;
-    const int loc = unit - p.seg[s].ubegin;
-    u_seg = s; u_tap = loc / p.seg[s].nchunk; u_chunk = loc - u_tap * p.seg[s].nchunk;
-  };
-  auto next_unit = [&]() {
-    if (++u_chunk == snchunk) { u_chunk = 0; if (++u_tap == staps) { u_tap = 0; ++u_seg; } }
-  };
 
-  auto load_stage = [&](int st) {
+  auto load_stage = [&](int st, uint4 (&ra)[KU][APASS], uint4 (&rb)[KU][BPASS]) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const int unit = st * KU + u;
       if (unit < p.nunits) {
-        if (u_seg != cs) enter_segment(u_seg);
-        int dh = 0, dw = 0;
-        if (staps == 9) {
-          const int t3 = (u_tap >= 6) ? 2 : (u_tap >= 3) ? 1 : 0;
-          dh = (t3 - 1) * sdil; dw = (u_tap - 3 * t3 - 1) * sdil;
-        }
-        const int toff = (dh * sWs + dw) * sC_ + u_chunk * 32;       // uniform element offset of this tap / chunk
-        const bool cok = u_chunk * 32 + aq * VEC < sC_;
+        const int4 e = utab[unit];
+        const int sgi = __builtin_amdgcn_readfirstlane(e.w & 0xff);
+        if (sgi != cs) enter_segment(sgi);
+        const int dh = e.z >> 16, dw = (int)(short)(e.z & 0xffff);
+        const int left = e.w >> 8;
+        const bool cok = aq * VEC < left;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
           const bool ok = av[i] && cok && (unsigned)(ah[i] + dh) < sHL && (unsigned)(aw[i] + dw) < sWL;
-          ra[u][i] = bufload16(rx, ok ? (unsigned)((abase[i] + toff) * ES) : RUA_OOB);
+          ra[u][i] = bufload16(rx, ok ? (unsigned)((abase[i] + e.x) * ES) : RUA_OOB);
         }
-        const int woff = u_tap * p.Cout * sC_ + u_chunk * 32;
-        const bool bcok = u_chunk * 32 + bq * VEC < sC_;
+        const bool bcok = bq * VEC < left;
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
           const bool ok = bthread && bcok && (n0 + br + j * RPP) < p.Cout;
-          rb[u][j] = bufload16(rw, ok ? (unsigned)((bbase[j] + woff) * ES) : RUA_OOB);
+          rb[u][j] = bufload16(rw, ok ? (unsigned)((bbase[j] + e.y) * ES) : RUA_OOB);
         }
-        next_unit();
       } else {
 #pragma unroll
         for (int i = 0; i < APASS; ++i) ra[u][i] = zero4;
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
     }
   };
 
-  auto write_stage = [&]() {
+  auto write_stage = [&](uint4 (&ra)[KU][APASS], uint4 (&rb)[KU][BPASS]) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
 #pragma unroll
@@ -305,49 +320,54 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
   const int st_begin = ks_i * p.stages_per_split;
   int nstages = st_begin + p.stages_per_split;
   if (nstages > nstages_all) nstages = nstages_all;
-  seek_unit(st_begin * KU);
-  load_stage(st_begin);
-  for (int st = st_begin; st < nstages; ++st) {
-    __syncthreads();
-    write_stage();
-    __syncthreads();
-    if (st + 1 < nstages) load_stage(st + 1);
+  __syncthreads();                     // unit table visible
+  auto mfma_stage = [&]() {
+    // Branch-free MFMA section: units past the end of K were staged as zeros, so they are simply multiplied
+    // (a conditional here splits the loop into blocks and makes hipcc copy every accumulator AGPR<->VGPR per stage).
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      if (st * KU + u < p.nunits) {
-        const unsigned char* pa = sA + (u * BM + wm * (BM / WM) + lr) * ROWB;
-        const unsigned char* pb = sB + (u * BN + wn * (BN / WN) + lr) * ROWB;
-        if constexpr (ES == 2) {
+      const unsigned char* pa = sA + (u * BM + wm * (BM / WM) + lr) * ROWB;
+      const unsigned char* pb = sB + (u * BN + wn * (BN / WN) + lr) * ROWB;
+      if constexpr (ES == 2) {
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[TM], fb[TN];
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 fa[TM], fb[TN];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(pa + a * 32 * ROWB + ks * 32 + lh * 16);
+          for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(pa + a * 32 * ROWB + ks * 32 + lh * 16);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(pb + b * 32 * ROWB + ks * 32 + lh * 16);
+          for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(pb + b * 32 * ROWB + ks * 32 + lh * 16);
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+          for (int a = 0; a < TM; ++a)
 #pragma unroll
-              for (int b = 0; b < TN; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
-          }
-        } else {
+            for (int b = 0; b < TN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) {
-            float fa[TM], fb[TN];
+        for (int ks = 0; ks < 16; ++ks) {
+          float fa[TM], fb[TN];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const float*>(pa + a * 32 * ROWB + (ks * 2 + lh) * 4);
+          for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const float*>(pa + a * 32 * ROWB + (ks * 2 + lh) * 4);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const float*>(pb + b * 32 * ROWB + (ks * 2 + lh) * 4);
+          for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const float*>(pb + b * 32 * ROWB + (ks * 2 + lh) * 4);
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+          for (int a = 0; a < TM; ++a)
 #pragma unroll
-              for (int b = 0; b < TN; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
-          }
+            for (int b = 0; b < TN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
       }
     }
+  };
+  // Software pipeline, depth 1: the loads of stage s+1 are in flight while stage s is multiplied.  (Depth 2 was
+  // measured slower at every level: the second register set costs a wave of occupancy per SIMD.)
+  load_stage(st_begin, ra0, rb0);
+  for (int st = st_begin; st < nstages; ++st) {
+    __syncthreads();
+    write_stage(ra0, rb0);
+    __syncthreads();
+    if (st + 1 < nstages) load_stage(st + 1, ra0, rb0);
+    mfma_stage();
   }
 
   // ---- epilogue -------------------------------------------------------------------------
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
         sC[row * CSTR + col] = acc[a][b][i];
       }
   __syncthreads();
-  conv_epilogue<T, BN>(p, m0, n0, bm_i, sC, CSTR, sC + BM * CSTR);
+  conv_epilogue<T, BM, BN>(p, m0, n0, bm_i, sC, CSTR, sC + BM * CSTR);
 }
 
 // split-K finisher: the shared epilogue over the fp32 workspace (one block per 128 x 64 output tile)
@@ -389,26 +409,23 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK p) {
   const int bn_i = blockIdx.x % nbn, bm_i = blockIdx.x / nbn;
   const long long m0 = (long long)bm_i * 128;
   const int n0 = bn_i * 64;
-  conv_epilogue<T, 64, true>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sred);
+  conv_epilogue<T, 128, 64, true>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sred);
 }
 
-template <typename T, int BN> static constexpr int conv_smem() {
-  constexpr int ROWB = (sizeof(T) == 2) ? 80 : 132;
-  constexpr int a = 2 * (128 + BN) * ROWB;
-  constexpr int b = 128 * (BN + 4) * 4 + 4 * (BN / 8) * 16 * 4;
-  return a > b ? a : b;
-}
+#define RUA_MAX_UNITS 1024
+template <typename T, int BM, int BN> static constexpr int conv_smem() { return conv_smem_base<T, BM, BN>() + RUA_MAX_UNITS * 16; }
 
-template <typename T, int BN> static int launch_conv(const ConvK& k, int nbm, hipStream_t st) {
+template <typename T, int BM, int BN> static int launch_conv(const ConvK& k, int nbm, hipStream_t st) {
   static bool attr_set = false;
-  constexpr int smem = conv_smem<T, BN>();
+  constexpr int smem = conv_smem<T, BM, BN>();
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   // split-K invariant: the workspace is all zeros on entry (caller zero-fills it once) and the finisher writes the
   // zeros back after consuming the sums, so no memset is launched per convolution.
-  hipLaunchKernelGGL((conv_igemm<T, BN>), dim3(nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
+  const int smem_now = conv_smem_base<T, BM, BN>() + ((k.nunits * 16 + 255) / 256) * 256;     // unit table sized to this launch
+  hipLaunchKernelGGL((conv_igemm<T, BM, BN>), dim3(nbm * k.nbn * k.ksplit), dim3(256), smem_now, st, k);
   RUA_LAUNCH_CHECK("conv_igemm");
   if (k.ksplit > 1) {
     hipLaunchKernelGGL((conv_splitk_finish<T>), dim3(nbm * ((k.Cout + 63) / 64)), dim3(256), 0, st, k);
@@ -428,19 +445,38 @@ static int pick_ksplit(long long tiles, int nstages, long long M, int Cout, size
   return want < 2 ? 1 : (int)want;
 }
 
+static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
+
 static int pick_bn(const rua_conv_desc* d, long long M) {
+  static const int force = env_int("RUA_CONV_FORCE_BN");          // experiments only
+  if (force == 32 || force == 64 || force == 128) return (d->Cout <= 32) ? 32 : (force == 128 && d->Cout < 128) ? 64 : (force == 32 ? 64 : force);
   if (d->Cout <= 32) return 32;
   if (d->Cout <= 64) return 64;
   const long long nbm = (M + 127) / 128;
   if (nbm * ((d->Cout + 127) / 128) < 512) return 64;   // small maps: more, smaller tiles
   return 128;
 }
+// pixel-tile height: 256 only where the grid stays large (the two top levels) and the N tile is narrow
+static int pick_bm(const rua_conv_desc* d, long long M, int bn) {
+  static const int force = env_int("RUA_CONV_FORCE_BM");
+  if (bn == 128) return 128;
+  if (force == 128 || force == 256) return force;
+  return (M >= 65536) ? 256 : 128;
+}
 
 extern "C" int rua_conv_smem_bytes(const rua_conv_desc* d) {
   const long long M = (long long)d->N * d->H * d->W;
-  const int bn = pick_bn(d, M);
-  if (d->dtype == RUA_BF16) return bn == 32 ? conv_smem<bf16_t, 32>() : bn == 64 ? conv_smem<bf16_t, 64>() : conv_smem<bf16_t, 128>();
-  return bn == 32 ? conv_smem<float, 32>() : bn == 64 ? conv_smem<float, 64>() : conv_smem<float, 128>();
+  const int bn = pick_bn(d, M), bm = pick_bm(d, M, bn);
+  const bool h = d->dtype == RUA_BF16;
+  if (bn == 128) return h ? conv_smem<bf16_t, 128, 128>() : conv_smem<float, 128, 128>();
+  if (bm == 256) return bn == 32 ? (h ? conv_smem<bf16_t, 256, 32>() : conv_smem<float, 256, 32>()) : (h ? conv_smem<bf16_t, 256, 64>() : conv_smem<float, 256, 64>());
+  return bn == 32 ? (h ? conv_smem<bf16_t, 128, 32>() : conv_smem<float, 128, 32>()) : (h ? conv_smem<bf16_t, 128, 64>() : conv_smem<float, 128, 64>());
+}
+
+template <typename T> static int dispatch_conv(const ConvK& k, int bm, int bn, int nbm, hipStream_t st) {
+  if (bn == 128) return launch_conv<T, 128, 128>(k, nbm, st);
+  if (bm == 256) return bn == 32 ? launch_conv<T, 256, 32>(k, nbm, st) : launch_conv<T, 256, 64>(k, nbm, st);
+  return bn == 32 ? launch_conv<T, 128, 32>(k, nbm, st) : launch_conv<T, 128, 64>(k, nbm, st);
 }
 
 extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
@@ -481,6 +517,7 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     units += g.taps * o.nchunk;
   }
   k.nunits = units;
+  RUA_CHECK_ARG(units <= RUA_MAX_UNITS, "rua_conv_fwd: K = %d units of 32 channels exceeds the unit-table capacity %d", units, RUA_MAX_UNITS);
   k.N = d->N; k.H = d->H; k.W = d->W; k.Cout = d->Cout; k.stride = d->stride;
   k.M = (long long)d->N * d->H * d->W;
   k.bias = d->bias; k.aux = (const unsigned char*)d->aux; k.aux_mode = d->aux_mode;
@@ -490,23 +527,18 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.stats_R = d->stats_replicas < 1 ? 1 : d->stats_replicas;
   RUA_CHECK_ARG((k.stats_R & (k.stats_R - 1)) == 0, "rua_conv_fwd: stats_replicas must be a power of two");
   const int bn = pick_bn(d, k.M);
+  int bm = pick_bm(d, k.M, bn);
   k.nbn = (d->Cout + bn - 1) / bn;
-  const int nbm = (int)((k.M + 127) / 128);
+  int nbm = (int)((k.M + bm - 1) / bm);
   k.nbm = nbm;
   const int nstages = (units + 1) / 2;
   k.ws = (float*)d->workspace;
-  k.ksplit = d->workspace ? pick_ksplit((long long)nbm * k.nbn, nstages, k.M, d->Cout, (size_t)d->workspace_bytes) : 1;
+  k.ksplit = (d->workspace && bm == 128) ? pick_ksplit((long long)nbm * k.nbn, nstages, k.M, d->Cout, (size_t)d->workspace_bytes) : 1;
   k.stages_per_split = (nstages + k.ksplit - 1) / k.ksplit;
   k.ksplit = (nstages + k.stages_per_split - 1) / k.stages_per_split;
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == RUA_BF16) {
-    if (bn == 32) return launch_conv<bf16_t, 32>(k, nbm, st);
-    if (bn == 64) return launch_conv<bf16_t, 64>(k, nbm, st);
-    return launch_conv<bf16_t, 128>(k, nbm, st);
-  }
-  if (bn == 32) return launch_conv<float, 32>(k, nbm, st);
-  if (bn == 64) return launch_conv<float, 64>(k, nbm, st);
-  return launch_conv<float, 128>(k, nbm, st);
+  if (d->dtype == RUA_BF16) return dispatch_conv<bf16_t>(k, bm, bn, nbm, st);
+  return dispatch_conv<float>(k, bm, bn, nbm, st);
 }
 
 // =========================================================================================
@@ -970,4 +1002,9 @@ extern "C" int64_t rua_conv_workspace_bytes(const rua_conv_desc* d) {
 extern "C" int rua_conv_tile_bn(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
   return pick_bn(d, (long long)d->N * d->H * d->W);
+}
+extern "C" int rua_conv_tile_bm(const rua_conv_desc* d) {
+  if (!d) return RUA_ERR_ARG;
+  const long long M = (long long)d->N * d->H * d->W;
+  return pick_bm(d, M, pick_bn(d, M));
 }

@@ -217,32 +217,79 @@ class _Dummy:
 
 
 class Plan:
+    """Recorded launches.  Entries carry a lane: lane 0 is the caller's stream, lanes 1..3 are engine-owned side
+    streams used for the independent branches of a ResBlock (fork / join markers become event dependencies, which a
+    HIP-graph capture turns into parallel graph branches)."""
+    FORK, JOIN = "fork", "join"
+
     def __init__(self, dry=False):
         self.calls: List[tuple] = []
         self.keep: List[object] = []
         self.dry = dry
+        self.lane = 0
+        self.open_fork = 0
 
     def add(self, name: str, *args):
         if not self.dry:
-            self.calls.append((L.lib().raw(name), name, args))
+            self.calls.append((L.lib().raw(name), name, args, self.lane))
 
-    def run(self, stream_ptr: int, hooks=None):
-        """Replay.  hooks: {call index -> python callable run right after that launch} (gradient buckets)."""
+    def fork(self, n: int):
+        if not self.dry and n > 1:
+            self.calls.append((None, Plan.FORK, n, 0))
+        self.open_fork = n
+
+    def join(self, n: int):
+        self.lane = 0
+        if not self.dry and n > 1:
+            self.calls.append((None, Plan.JOIN, n, 0))
+        self.open_fork = 0
+
+    def set_lane(self, lane: int):
+        self.lane = lane
+
+    def safe_hook_index(self, idx: int) -> int:
+        """First call index >= idx after which no side lane is running (where a 'gradients so far are final' hook may fire)."""
+        depth, out = 0, None
+        for i, c in enumerate(self.calls):
+            if c[1] == Plan.FORK:
+                depth += 1
+            elif c[1] == Plan.JOIN:
+                depth -= 1
+            if i >= idx and depth == 0:
+                return i
+        return len(self.calls) - 1
+
+    def run(self, stream_ptr: int, hooks=None, side=None, first=0, last=None):
+        """Replay calls [first, last).  side: torch streams for lanes 1..; None => everything on the caller's stream.
+        hooks: {call index -> python callable run right after that launch} (gradient buckets)."""
         lib = L.lib()
-        s = C.c_void_p(stream_ptr)
-        if not hooks:
-            for fn, name, args in self.calls:
-                rc = fn(*args, s)
+        ptrs = [C.c_void_p(stream_ptr)]
+        main = None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            ptrs += [C.c_void_p(st.cuda_stream) for st in side]
+        calls = self.calls if (first == 0 and last is None) else self.calls[first:last]
+        for i, (fn, name, args, lane) in enumerate(calls, start=first):
+            if fn is None:
+                if side is not None:
+                    if name == Plan.FORK:
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        for l in range(1, args):
+                            side[l - 1].wait_event(ev)
+                    else:
+                        for l in range(1, args):
+                            ev = torch.cuda.Event()
+                            ev.record(side[l - 1])
+                            main.wait_event(ev)
+            else:
+                rc = fn(*args, ptrs[lane if side is not None else 0])
                 if rc != 0:
                     lib.check(rc, name)
-            return
-        for i, (fn, name, args) in enumerate(self.calls):
-            rc = fn(*args, s)
-            if rc != 0:
-                lib.check(rc, name)
-            h = hooks.get(i)
-            if h is not None:
-                h()
+            if hooks:
+                h = hooks.get(i)
+                if h is not None:
+                    h()
 
 
 class Coef:
@@ -273,6 +320,7 @@ class Graph:
         self.loss_plan = Plan(dry)
         self.back_steps: List = []
         self.grad_touch: Dict[int, int] = {}
+        self.cur_lane = 0
         self.allocs: List[torch.Tensor] = []
         self.stats_used = 16                 # the first 16 doubles of the arena are the loss / metric scalars
         self.act_bytes = 0
@@ -377,7 +425,8 @@ class Graph:
     def _ws(self, d):
         """Shared split-K scratch (launches are serialised on one stream, so one buffer serves every conv)."""
         if not self.dry and self.e.split_k and d.N * d.H * d.W * d.Cout * 4 <= self.e.workspace.numel() * 4:
-            d.workspace, d.workspace_bytes = self.e.workspace.data_ptr(), self.e.workspace.numel() * 4
+            w = self.e.workspaces[self.cur_lane]
+            d.workspace, d.workspace_bytes = w.data_ptr(), w.numel() * 4
 
     def dgrad(self, plan: Plan, dy: Ten, wd_ptr, cin: int, dil: int, taps: int, out: Ten, accumulate: int,
               mask: Optional[Tuple[Ten, Optional[int], Optional[int]]] = None, stats2: Optional[int] = None,
@@ -407,7 +456,8 @@ class Graph:
         d.N, d.stride, d.dil, d.taps, d.dtype = dy.N, stride, dil, taps, self.dt
         d.dw = self.G(dw_off)
         if not self.dry:
-            d.workspace, d.workspace_bytes = self.e.scratch.data_ptr(), self.e.scratch.numel() * 4
+            sc = self.e.scratches[self.cur_lane]
+            d.workspace, d.workspace_bytes = sc.data_ptr(), sc.numel() * 4
         plan.keep.append(d)
         plan.add("rua_conv_wgrad", C.byref(d))
 
@@ -448,13 +498,16 @@ class Graph:
         coef1 = [self.bn_finalize(F, x.stats, cnt, l[0]) for l in lay]
         a1 = self.bn_apply(F, x, coef1, True)
         y1, coef2, a2 = [], [], []
-        for d, l, a in zip(dils, lay, a1):
+        F.fork(len(dils))                                   # the branches are independent until the final sum
+        for bi, (d, l, a) in enumerate(zip(dils, lay, a1)):
+            F.set_lane(bi); self.cur_lane = bi
             y = self.like(x)
             st = self.stat(nf, (cnt + 127) // 128) if tr else None
             self.conv(F, [(a, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st)
             c2 = self.bn_finalize(F, st, cnt, l[2])
             y1.append(y); coef2.append(c2)
             a2.append(self.bn_apply(F, y, [c2], True)[0])
+        F.join(len(dils)); self.cur_lane = 0
         bsum = self.alloc(((nf + 15) // 16 * 16,), torch.float32, zero=True)
         bl = L.ptr_array([self.P(l[3]["bias"]) for l in lay])
         F.keep += [bsum, bl]
@@ -470,7 +523,9 @@ class Graph:
             dO = out.grad
             self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
             g1s = []
-            for d, l, a_1, y, c2, a_2, c1 in zip(dils, lay, a1, y1, coef2, a2, coef1):
+            Bp.fork(len(dils))
+            for bi, (d, l, a_1, y, c2, a_2, c1) in enumerate(zip(dils, lay, a1, y1, coef2, a2, coef1)):
+                Bp.set_lane(bi); self.cur_lane = bi
                 self.wgrad(Bp, a_2, dO, l[3]["segs"][0]["off"], 1, d, 9)
                 g2 = self.like(x)
                 s2 = self.stat(nf, (cnt + 127) // 128)
@@ -485,6 +540,7 @@ class Graph:
                 self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
                 self.bn_bwd_finalize(Bp, s1, cnt, l[0], c1)
                 g1s.append(g1)
+            Bp.join(len(dils)); self.cur_lane = 0
             gx, acc = self.gacc(x)
             self.bn_bwd_apply(Bp, g1s, coef1, x, gx, acc, dskip=dO if v2 else None)
         self.back_steps.append(back)
@@ -834,8 +890,12 @@ class Engine:
         self.wprep_items = torch.from_numpy(np.frombuffer(items.tobytes(), dtype=np.uint8).copy()).to(self.dev)
         self.wprep_n, self.wprep_max = len(rows), mx
         self.stats_arena = torch.zeros(1 << 20, dtype=torch.float64, device=self.dev)
-        self.workspace = torch.zeros(8 << 20, dtype=torch.float32, device=self.dev)       # 32 MiB split-K scratch (kept zero)
-        self.scratch = torch.zeros(8 << 20, dtype=torch.float32, device=self.dev)         # 32 MiB weight-gradient partials
+        # one split-K workspace (kept zero) and one weight-gradient partial scratch per lane: branches run concurrently
+        self.workspaces = [torch.zeros(8 << 20, dtype=torch.float32, device=self.dev) for _ in range(4)]
+        self.scratches = [torch.zeros(8 << 20, dtype=torch.float32, device=self.dev) for _ in range(4)]
+        self.workspace, self.scratch = self.workspaces[0], self.scratches[0]
+        self.side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(3)]
+        self.use_lanes = False      # measured: no gain (13.5 vs 14.0 ms/step), the step is bound by shared memory-side resources
         self.lr_dev = torch.zeros(16, dtype=torch.float32, device=self.dev)               # step-dependent optimizer scalars
         self.use_graph = True
         self._captured: Dict[int, object] = {}
@@ -944,14 +1004,15 @@ class Engine:
         self._upload(g, x, y)
         self._zero_arena(g, s)
         self._prep_weights(s)
-        g.fwd.run(s)
+        side = self.side_streams if self.use_lanes else None
+        g.fwd.run(s, side=side)
         g.loss_plan.run(s)
         hooks = None
         if self.dist is not None:
             self.dist.reducer.begin()
             if self.dist.overlap:
                 hooks = self._bucket_hooks(g)
-        g.bwd.run(s, hooks)
+        g.bwd.run(s, hooks, side=side)
         return g
 
     def _bucket_hooks(self, g: Graph):
@@ -965,7 +1026,7 @@ class Engine:
             by_idx: Dict[int, List[int]] = {}
             for b, idx in enumerate(last):
                 if idx >= 0:
-                    by_idx.setdefault(idx, []).append(b)
+                    by_idx.setdefault(g.bwd.safe_hook_index(idx), []).append(b)    # never while side lanes are running
             red = self.dist.reducer
             for idx, bs in by_idx.items():
                 hooks[idx] = (lambda bs=bs: [red.ready(b) for b in bs])
@@ -1007,15 +1068,16 @@ class Engine:
         if cap is None:
             # warm-up run outside capture (sets kernel attributes, pays first-launch costs), then capture
             s = self._stream()
+            side = self.side_streams if self.use_lanes else None
             self._zero_arena(g, s); self.weights_dirty = True; self._prep_weights(s)
-            g.fwd.run(s); g.loss_plan.run(s); g.bwd.run(s)
+            g.fwd.run(s, side=side); g.loss_plan.run(s); g.bwd.run(s, side=side)
             self._launch_optimizer(1.0, s)
             torch.cuda.synchronize()
             cap = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cap):
                 s = self._stream()
                 self._zero_arena(g, s); self.weights_dirty = True; self._prep_weights(s)
-                g.fwd.run(s); g.loss_plan.run(s); g.bwd.run(s)
+                g.fwd.run(s, side=side); g.loss_plan.run(s); g.bwd.run(s, side=side)
                 self._launch_optimizer(1.0, s)
             self._captured[B] = cap
             self.weights_dirty = True
