@@ -136,6 +136,31 @@ int rua_bn_bwd_apply(int nb, const void* const* g, const float* const* coefA, co
                      const float* const* coefC, const float* const* mscale, const float* const* mshift, int masked,
                      const void* x, const void* dskip, void* dx, int accumulate, int64_t M, int C, int dtype, void* stream);
 
+/* Fused forms (one launch each; the engine uses these): statistics -> coefficients in every block's prologue, block 0
+ * publishes scale/shift/mean/rstd, updates the moving statistics (forward) or adds dgamma/dbeta (backward). */
+typedef struct rua_bn_branch {
+  const float* gamma; const float* beta; float* moving_mean; float* moving_var;   /* [C] */
+  float* scale; float* shift; float* mean; float* rstd;                           /* [C] published coefficients */
+  void* out;                                                                      /* [M][C] */
+} rua_bn_branch;
+typedef struct rua_bn_fwd_desc {
+  const void* x; int64_t M; int32_t C, dtype, nb, relu, training, replicas;
+  const double* stats;                       /* [replicas][2][C], shared by all branches (they normalise the same x) */
+  double count, bessel_n; float momentum, eps;
+  rua_bn_branch br[RUA_MAX_BRANCH];
+} rua_bn_fwd_desc;
+int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream);
+typedef struct rua_bn_bwd_branch {
+  const void* g; const double* stats2; int32_t replicas, pad;
+  const float* gamma; const float* mean; const float* rstd; const float* scale; const float* shift;
+  float* dgamma; float* dbeta;
+} rua_bn_bwd_branch;
+typedef struct rua_bn_bwd_desc {
+  const void* x; const void* dskip; void* dx; int64_t M; int32_t C, dtype, nb, masked, accumulate, pad; double count;
+  rua_bn_bwd_branch br[RUA_MAX_BRANCH];
+} rua_bn_bwd_desc;
+int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream);
+
 /* ---- pooling / resampling (PSPPooling model2.py:47-60; decoder model2.py:91) ---------- */
 int rua_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int k, int dtype, void* stream);
 int rua_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int accumulate, int N, int H, int W, int C, int k, int dtype, void* stream);

@@ -32,6 +32,26 @@ class WgradDesc(C.Structure):
                 ("N", i32), ("stride", i32), ("dil", i32), ("taps", i32), ("dtype", i32), ("dw", vp), ("workspace", vp), ("workspace_bytes", i64)]
 
 
+class BnBranch(C.Structure):
+    _fields_ = [("gamma", vp), ("beta", vp), ("moving_mean", vp), ("moving_var", vp), ("scale", vp), ("shift", vp),
+                ("mean", vp), ("rstd", vp), ("out", vp)]
+
+
+class BnFwdDesc(C.Structure):
+    _fields_ = [("x", vp), ("M", i64), ("C", i32), ("dtype", i32), ("nb", i32), ("relu", i32), ("training", i32), ("replicas", i32),
+                ("stats", vp), ("count", f64), ("bessel_n", f64), ("momentum", f32), ("eps", f32), ("br", BnBranch * RUA_MAX_BRANCH)]
+
+
+class BnBwdBranch(C.Structure):
+    _fields_ = [("g", vp), ("stats2", vp), ("replicas", i32), ("pad", i32), ("gamma", vp), ("mean", vp), ("rstd", vp),
+                ("scale", vp), ("shift", vp), ("dgamma", vp), ("dbeta", vp)]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [("x", vp), ("dskip", vp), ("dx", vp), ("M", i64), ("C", i32), ("dtype", i32), ("nb", i32), ("masked", i32),
+                ("accumulate", i32), ("pad", i32), ("count", f64), ("br", BnBwdBranch * RUA_MAX_BRANCH)]
+
+
 class WprepItem(C.Structure):
     _fields_ = [("src_off", i64), ("dst_off", i64), ("taps", i32), ("Cout", i32), ("C", i32), ("pad", i32)]
 
@@ -62,6 +82,8 @@ _SIGS = {
     "rua_bn_bwd_finalize": ([vp, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp], i32),
     "rua_bn_bwd_apply": ([i32, PP, PP, PP, PP, PP, PP, i32, vp, vp, vp, i32, i64, i32, i32, vp], i32),
     "rua_stats_to_f32": ([vp, i32, i32, PP, i32, vp], i32),
+    "rua_bn_fwd": ([C.POINTER(BnFwdDesc), vp], i32),
+    "rua_bn_bwd": ([C.POINTER(BnBwdDesc), vp], i32),
     "rua_maxpool_fwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "rua_maxpool_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "rua_sumpool": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),

@@ -350,6 +350,176 @@ extern "C" int rua_bn_bwd_apply(int nb, const void* const* g, const float* const
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused BatchNorm: statistics -> coefficients in the prologue of every block (no separate finalize launch);
+// block 0 also publishes the coefficients for later kernels (ReLU masks of data-gradient epilogues, backward) and
+// updates the moving statistics / parameter gradients.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, long long pieces, int CG) {
+  constexpr int VEC = ET<T>::VEC;
+  extern __shared__ float tab[];                       // [nb][2][C] scale/shift, then [2][C] mean/rstd
+  const int C = p.C;
+  float* mr = tab + p.nb * 2 * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double mean, var;
+    if (p.training) {
+      double s1, s2;
+      replica_sum(p.stats, p.replicas, C, c, s1, s2);
+      mean = s1 / p.count;
+      var = s2 / p.count - mean * mean;
+      if (var < 0) var = 0;
+    } else { mean = 0; var = 1; }
+    for (int b = 0; b < p.nb; ++b) {
+      const rua_bn_branch& br = p.br[b];
+      double m = mean, v = var;
+      if (!p.training) { m = br.moving_mean[c]; v = br.moving_var[c]; }
+      const double r = 1.0 / sqrt(v + (double)p.eps);
+      const double sc = (double)br.gamma[c] * r;
+      tab[(b * 2) * C + c] = (float)sc;
+      tab[(b * 2 + 1) * C + c] = (float)((double)br.beta[c] - m * sc);
+      if (blockIdx.x == 0) {
+        br.scale[c] = (float)sc; br.shift[c] = (float)((double)br.beta[c] - m * sc);
+        if (br.mean) br.mean[c] = (float)m;
+        if (br.rstd) br.rstd[c] = (float)r;
+        if (p.training && br.moving_mean) {
+          const double unb = p.bessel_n > 1 ? v * (p.bessel_n / (p.bessel_n - 1)) : v;
+          br.moving_mean[c] = (float)((double)br.moving_mean[c] * p.momentum + m * (1.0 - p.momentum));
+          br.moving_var[c] = (float)((double)br.moving_var[c] * p.momentum + unb * (1.0 - p.momentum));
+        }
+      }
+    }
+    (void)mr;
+  }
+  __syncthreads();
+  const unsigned char* x = (const unsigned char*)p.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += stride) {
+    const int c = (int)(i % CG) * VEC;
+    float xv[VEC];
+    ET<T>::unpack(ldg16(x + i * 16), xv);
+    for (int b = 0; b < p.nb; ++b) {
+      float o[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        o[j] = fmaf(tab[(b * 2) * C + c + j], xv[j], tab[(b * 2 + 1) * C + c + j]);
+        if (p.relu) o[j] = fmaxf(o[j], 0.f);
+      }
+      stg16((unsigned char*)p.br[b].out + i * 16, ET<T>::pack(o));
+    }
+  }
+}
+
+extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream) {
+  RUA_CHECK_ARG(d && d->x && d->nb >= 1 && d->nb <= RUA_MAX_BRANCH && d->M > 0 && d->C > 0, "rua_bn_fwd: bad arguments");
+  RUA_CHECK_ARG(d->dtype == RUA_F32 || d->dtype == RUA_BF16, "rua_bn_fwd: bad dtype");
+  const int vec = d->dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(d->C % vec == 0, "rua_bn_fwd: C=%d not a multiple of %d", d->C, vec);
+  RUA_CHECK_ARG(!d->training || (d->stats && d->count > 0 && d->replicas >= 1), "rua_bn_fwd: training needs statistics");
+  for (int b = 0; b < d->nb; ++b) {
+    const rua_bn_branch& br = d->br[b];
+    RUA_CHECK_ARG(br.gamma && br.beta && br.scale && br.shift && br.out, "rua_bn_fwd: null branch pointer");
+    RUA_CHECK_ARG(d->training || (br.moving_mean && br.moving_var), "rua_bn_fwd: inference needs moving statistics");
+  }
+  const size_t smem = (size_t)(d->nb * 2 + 2) * d->C * 4;
+  RUA_CHECK_ARG(smem <= 64 * 1024, "rua_bn_fwd: coefficient table too large");
+  const int CG = d->C / vec;
+  const long long pieces = d->M * CG;
+  int g = grid_for(pieces);
+  if ((long long)d->replicas * d->C >= 512 && g > 512) g = 512;      // the prologue re-reads replicas*C*2 doubles per block
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == RUA_BF16) hipLaunchKernelGGL((bn_fwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, *d, pieces, CG);
+  else hipLaunchKernelGGL((bn_fwd_kernel<float>), dim3(g), dim3(256), smem, st, *d, pieces, CG);
+  RUA_LAUNCH_CHECK("rua_bn_fwd");
+  return RUA_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, long long pieces, int CG) {
+  constexpr int VEC = ET<T>::VEC;
+  extern __shared__ float tab[];                       // [nb][3][C] : A, ms, mt ; then [2][C] : sumB, sumC
+  const int C = p.C;
+  float* tB = tab + p.nb * 3 * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sb = 0.f, sc_ = 0.f;
+    for (int b = 0; b < p.nb; ++b) {
+      const rua_bn_bwd_branch& br = p.br[b];
+      double sg, sgx;
+      replica_sum(br.stats2, br.replicas, C, c, sg, sgx);
+      const double mu = br.mean[c], r = br.rstd[c], gm = br.gamma[c];
+      const double dga = r * (sgx - mu * sg);
+      const double s = gm * r;
+      tab[(b * 3) * C + c] = (float)s;
+      tab[(b * 3 + 1) * C + c] = (p.masked && br.scale) ? br.scale[c] : 1.f;
+      tab[(b * 3 + 2) * C + c] = (p.masked && br.shift) ? br.shift[c] : 0.f;
+      sb += (float)(-s * r * dga / p.count);
+      sc_ += (float)(-s * sg / p.count + s * r * mu * dga / p.count);
+      if (blockIdx.x == 0) {
+        if (br.dgamma) br.dgamma[c] += (float)dga;
+        if (br.dbeta) br.dbeta[c] += (float)sg;
+      }
+    }
+    tB[c] = sb; tB[C + c] = sc_;
+  }
+  __syncthreads();
+  const unsigned char* x = (const unsigned char*)p.x;
+  const unsigned char* dskip = (const unsigned char*)p.dskip;
+  unsigned char* dx = (unsigned char*)p.dx;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += stride) {
+    const int c = (int)(i % CG) * VEC;
+    float xv[VEC], acc[VEC];
+    ET<T>::unpack(ldg16(x + i * 16), xv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(tB[c + j], xv[j], tB[C + c + j]);
+    if (dskip) {
+      float dd[VEC];
+      ET<T>::unpack(ldg16(dskip + i * 16), dd);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += dd[j];
+    }
+    if (p.accumulate) {
+      float dd[VEC];
+      ET<T>::unpack(ldg16(dx + i * 16), dd);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += dd[j];
+    }
+    for (int b = 0; b < p.nb; ++b) {
+      float gv[VEC];
+      ET<T>::unpack(ldg16((const unsigned char*)p.br[b].g + i * 16), gv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const bool on = !p.masked || fmaf(tab[(b * 3 + 1) * C + c + j], xv[j], tab[(b * 3 + 2) * C + c + j]) > 0.f;
+        acc[j] = fmaf(tab[(b * 3) * C + c + j], on ? gv[j] : 0.f, acc[j]);
+      }
+    }
+    stg16(dx + i * 16, ET<T>::pack(acc));
+  }
+}
+
+extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
+  RUA_CHECK_ARG(d && d->x && d->dx && d->nb >= 1 && d->nb <= RUA_MAX_BRANCH && d->M > 0 && d->C > 0 && d->count > 0, "rua_bn_bwd: bad arguments");
+  RUA_CHECK_ARG(d->dtype == RUA_F32 || d->dtype == RUA_BF16, "rua_bn_bwd: bad dtype");
+  const int vec = d->dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(d->C % vec == 0, "rua_bn_bwd: C=%d not a multiple of %d", d->C, vec);
+  int rmax = 1;
+  for (int b = 0; b < d->nb; ++b) {
+    const rua_bn_bwd_branch& br = d->br[b];
+    RUA_CHECK_ARG(br.g && br.stats2 && br.replicas >= 1 && br.gamma && br.mean && br.rstd, "rua_bn_bwd: null branch pointer");
+    if (br.replicas > rmax) rmax = br.replicas;
+  }
+  const size_t smem = (size_t)(d->nb * 3 + 2) * d->C * 4;
+  RUA_CHECK_ARG(smem <= 64 * 1024, "rua_bn_bwd: coefficient table too large");
+  const int CG = d->C / vec;
+  const long long pieces = d->M * CG;
+  int g = grid_for(pieces);
+  if ((long long)rmax * d->C * d->nb >= 512 && g > 512) g = 512;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == RUA_BF16) hipLaunchKernelGGL((bn_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, *d, pieces, CG);
+  else hipLaunchKernelGGL((bn_bwd_kernel<float>), dim3(g), dim3(256), smem, st, *d, pieces, CG);
+  RUA_LAUNCH_CHECK("rua_bn_bwd");
+  return RUA_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // pooling / resampling: one thread per output (or input) piece
 template <typename T>
 __global__ void maxpool_fwd_kernel(const unsigned char* x, unsigned char* y, uint8_t* idx, int N, int H, int W, int CG, int k) {

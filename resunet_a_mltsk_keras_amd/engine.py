@@ -401,6 +401,40 @@ class Graph:
         plan.add("rua_bn_apply", x.ptr, len(coefs), sc, sh, 1 if relu else 0, ou, x.M, x.C, self.dt)
         return outs
 
+    def bn_fwd(self, plan: Plan, x: Ten, bns: List[dict], relu: bool, stats: Optional[Stat], count, bessel=None):
+        """[relu](BN_b(x)) for every branch b in ONE launch: coefficients from the statistics in the kernel prologue,
+        published to `Coef` buffers (block 0) for the ReLU masks / backward; moving statistics updated in training."""
+        outs = [self.like(x) for _ in bns]
+        coefs = [Coef(self, bn["C"]) for bn in bns]
+        d = L.BnFwdDesc()
+        d.x, d.M, d.C, d.dtype, d.nb, d.relu = x.ptr, x.M, x.C, self.dt, len(bns), 1 if relu else 0
+        d.training = 1 if self.training else 0
+        if self.training:
+            d.stats, d.replicas = stats.ptr, stats.R
+        d.count, d.bessel_n, d.momentum, d.eps = float(count), float(bessel or count), BN_MOMENTUM, BN_EPS
+        for i, (bn, c, o) in enumerate(zip(bns, coefs, outs)):
+            b = d.br[i]
+            b.gamma, b.beta, b.moving_mean, b.moving_var = self.P(bn["gamma"]), self.P(bn["beta"]), self.S(bn["mm"]), self.S(bn["mv"])
+            b.scale, b.shift, b.mean, b.rstd, b.out = c.scale, c.shift, c.mean, c.rstd, o.ptr
+        plan.keep += [d] + coefs
+        plan.add("rua_bn_fwd", C.byref(d))
+        return outs, coefs
+
+    def bn_bwd(self, plan: Plan, gs: List[Ten], coefs: List[Coef], bns: List[dict], stats2: List[Stat], x: Ten, out: Ten,
+               accumulate: int, count, dskip: Optional[Ten] = None, masked=False):
+        """dx (=|+=) [dskip] + sum_b BN-backward_b(g_b) in ONE launch; dgamma/dbeta added by block 0."""
+        d = L.BnBwdDesc()
+        d.x, d.dx, d.M, d.C, d.dtype, d.nb = x.ptr, out.ptr, x.M, x.C, self.dt, len(gs)
+        d.dskip = dskip.ptr if dskip is not None else None
+        d.masked, d.accumulate, d.count = 1 if masked else 0, accumulate, float(count)
+        for i, (g, c, bn, s2) in enumerate(zip(gs, coefs, bns, stats2)):
+            b = d.br[i]
+            b.g, b.stats2, b.replicas = g.ptr, s2.ptr, s2.R
+            b.gamma, b.mean, b.rstd, b.scale, b.shift = self.P(bn["gamma"]), c.mean, c.rstd, c.scale, c.shift
+            b.dgamma, b.dbeta = self.G(bn["gamma"]), self.G(bn["beta"])
+        plan.keep.append(d)
+        plan.add("rua_bn_bwd", C.byref(d))
+
     def conv(self, plan: Plan, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual: Optional[Ten] = None,
              out_relu=False, stats=None):
         """segs: [(Ten, up_shift, dil, taps)], layer_segs: [param seg dict] (same order)."""
@@ -495,8 +529,7 @@ class Graph:
         cnt = x.M
         if tr and x.stats is None:
             x.stats = self.col_stats(F, x)
-        coef1 = [self.bn_finalize(F, x.stats, cnt, l[0]) for l in lay]
-        a1 = self.bn_apply(F, x, coef1, True)
+        a1, coef1 = self.bn_fwd(F, x, [l[0] for l in lay], True, x.stats, cnt)
         y1, coef2, a2 = [], [], []
         F.fork(len(dils))                                   # the branches are independent until the final sum
         for bi, (d, l, a) in enumerate(zip(dils, lay, a1)):
@@ -504,9 +537,10 @@ class Graph:
             y = self.like(x)
             st = self.stat(nf, (cnt + 127) // 128) if tr else None
             self.conv(F, [(a, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st)
-            c2 = self.bn_finalize(F, st, cnt, l[2])
+            o2, c2l = self.bn_fwd(F, y, [l[2]], True, st, cnt)
+            c2 = c2l[0]
             y1.append(y); coef2.append(c2)
-            a2.append(self.bn_apply(F, y, [c2], True)[0])
+            a2.append(o2[0])
         F.join(len(dils)); self.cur_lane = 0
         bsum = self.alloc(((nf + 15) // 16 * 16,), torch.float32, zero=True)
         bl = L.ptr_array([self.P(l[3]["bias"]) for l in lay])
@@ -522,7 +556,7 @@ class Graph:
             Bp = self.bwd
             dO = out.grad
             self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
-            g1s = []
+            g1s, s1s = [], []
             Bp.fork(len(dils))
             for bi, (d, l, a_1, y, c2, a_2, c1) in enumerate(zip(dils, lay, a1, y1, coef2, a2, coef1)):
                 Bp.set_lane(bi); self.cur_lane = bi
@@ -530,19 +564,17 @@ class Graph:
                 g2 = self.like(x)
                 s2 = self.stat(nf, (cnt + 127) // 128)
                 self.dgrad(Bp, dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
-                self.bn_bwd_finalize(Bp, s2, cnt, l[2], c2)
                 dy1 = self.like(x)
-                self.bn_bwd_apply(Bp, [g2], [c2], y, dy1, 0)
+                self.bn_bwd(Bp, [g2], [c2], [l[2]], [s2], y, dy1, 0, cnt)
                 # no bias gradient launch: the output of a BN backward sums to zero per channel, so d b1 == 0 exactly
                 self.wgrad(Bp, a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9)
                 g1 = g2                                    # g2 is dead after bn_bwd_apply: reuse its storage
                 s1 = self.stat(nf, (cnt + 127) // 128)
                 self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
-                self.bn_bwd_finalize(Bp, s1, cnt, l[0], c1)
-                g1s.append(g1)
+                g1s.append(g1); s1s.append(s1)
             Bp.join(len(dils)); self.cur_lane = 0
             gx, acc = self.gacc(x)
-            self.bn_bwd_apply(Bp, g1s, coef1, x, gx, acc, dskip=dO if v2 else None)
+            self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None)
         self.back_steps.append(back)
         return out
 
@@ -574,8 +606,8 @@ class Graph:
         cnt = count or x.M
         if tr and stats is None:
             stats = x.stats if x.stats is not None else self.col_stats(F, x)
-        coef = self.bn_finalize(F, stats, cnt, bn, bessel)
-        y = self.bn_apply(F, x, [coef], relu)[0]
+        ys, coefs = self.bn_fwd(F, x, [bn], relu, stats, cnt, bessel)
+        y, coef = ys[0], coefs[0]
         node = dict(x=x, y=y, coef=coef, bn=bn, relu=relu, cnt=cnt, s2=None, fused=False)
 
         def back():
@@ -584,9 +616,8 @@ class Graph:
             if not node["fused"]:
                 node["s2"] = self.stat(x.C, min(1024, (x.M + 63) // 64))
                 Bp.add("rua_col_stats2", g.ptr, x.ptr, coef.scale, coef.shift, 1 if relu else 0, x.M, x.C, node["s2"].ptr, node["s2"].R, self.dt)
-            self.bn_bwd_finalize(Bp, node["s2"], cnt, bn, coef)
             gx, acc = self.gacc(x)
-            self.bn_bwd_apply(Bp, [g], [coef], x, gx, acc, masked=(relu and not node["fused"]))
+            self.bn_bwd(Bp, [g], [coef], [bn], [node["s2"]], x, gx, acc, cnt, masked=(relu and not node["fused"]))
         node["back"] = back
         return y, node
 

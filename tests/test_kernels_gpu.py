@@ -367,6 +367,67 @@ def test_bn_stats_apply_backward(dt):
 
 
 @pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+def test_bn_fused_forward_backward_two_branches(dt):
+    """rua_bn_fwd / rua_bn_bwd: finalize folded into the launch, two branches sharing one input (the ResBlock case),
+    skip gradient added, moving statistics and parameter gradients updated by block 0."""
+    rng = np.random.default_rng(16)
+    lib = L.lib()
+    M, Cc, R = 640, 32, 4
+    x = (rng.standard_normal((M, Cc)) * 1.5 + 0.3).astype(np.float32)
+    xd = to_dev(x, dt)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+    gam = [rng.uniform(0.5, 1.5, Cc).astype(np.float32) for _ in range(2)]
+    bet = [rng.standard_normal(Cc).astype(np.float32) for _ in range(2)]
+    gd, bd = [f(g) for g in gam], [f(b) for b in bet]
+    mm, mv = [f(np.zeros(Cc)) for _ in range(2)], [f(np.ones(Cc)) for _ in range(2)]
+    coef = [torch.zeros(4, Cc, device=dev()) for _ in range(2)]
+    outs = [torch.empty((M, Cc), dtype=tdt(dt), device=dev()) for _ in range(2)]
+    stats = torch.zeros(R * 2 * Cc, dtype=torch.float64, device=dev())
+    lib.call("rua_col_stats", xd.data_ptr(), M, Cc, stats.data_ptr(), R, dt, stream())
+    d = L.BnFwdDesc()
+    d.x, d.M, d.C, d.dtype, d.nb, d.relu, d.training, d.replicas = xd.data_ptr(), M, Cc, dt, 2, 1, 1, R
+    d.stats, d.count, d.bessel_n, d.momentum, d.eps = stats.data_ptr(), float(M), float(M), 0.99, 1e-3
+    for b in range(2):
+        br = d.br[b]
+        br.gamma, br.beta, br.moving_mean, br.moving_var = gd[b].data_ptr(), bd[b].data_ptr(), mm[b].data_ptr(), mv[b].data_ptr()
+        br.scale, br.shift, br.mean, br.rstd = [coef[b][i].data_ptr() for i in range(4)]
+        br.out = outs[b].data_ptr()
+    lib.call("rua_bn_fwd", C.byref(d), stream())
+    torch.cuda.synchronize()
+    xr = rnd(dt, x).double().requires_grad_(True)
+    mean, var = xr.mean(0), xr.var(0, unbiased=False)
+    ys = [torch.relu((xr - mean) / torch.sqrt(var + 1e-3) * torch.from_numpy(gam[b]).double() + torch.from_numpy(bet[b]).double()) for b in range(2)]
+    for b in range(2):
+        assert rel_err(outs[b].float().cpu().numpy(), ys[b].detach().numpy()) < tol(dt)
+        assert np.allclose(mm[b].cpu().numpy(), 0.01 * mean.detach().numpy(), rtol=1e-4, atol=1e-6)
+        assert np.allclose(mv[b].cpu().numpy(), 0.99 + 0.01 * var.detach().numpy() * M / (M - 1), rtol=1e-4)
+    g = [rng.standard_normal((M, Cc)).astype(np.float32) for _ in range(2)]
+    skip = rng.standard_normal((M, Cc)).astype(np.float32)
+    gdv, skd = [to_dev(a, dt) for a in g], to_dev(skip, dt)
+    (ys[0] * rnd(dt, g[0]).double() + ys[1] * rnd(dt, g[1]).double()).sum().backward()
+    st2 = [torch.zeros(2 * 2 * Cc, dtype=torch.float64, device=dev()) for _ in range(2)]
+    for b in range(2):
+        lib.call("rua_col_stats2", gdv[b].data_ptr(), xd.data_ptr(), coef[b][0].data_ptr(), coef[b][1].data_ptr(), 1, M, Cc, st2[b].data_ptr(), 2, dt, stream())
+    dgam, dbet = [torch.zeros(Cc, device=dev()) for _ in range(2)], [torch.zeros(Cc, device=dev()) for _ in range(2)]
+    dx = torch.empty((M, Cc), dtype=tdt(dt), device=dev())
+    e = L.BnBwdDesc()
+    e.x, e.dskip, e.dx, e.M, e.C, e.dtype, e.nb, e.masked, e.accumulate, e.count = xd.data_ptr(), skd.data_ptr(), dx.data_ptr(), M, Cc, dt, 2, 1, 0, float(M)
+    for b in range(2):
+        br = e.br[b]
+        br.g, br.stats2, br.replicas, br.gamma = gdv[b].data_ptr(), st2[b].data_ptr(), 2, gd[b].data_ptr()
+        br.scale, br.shift, br.mean, br.rstd = [coef[b][i].data_ptr() for i in range(4)]
+        br.dgamma, br.dbeta = dgam[b].data_ptr(), dbet[b].data_ptr()
+    lib.call("rua_bn_bwd", C.byref(e), stream())
+    torch.cuda.synchronize()
+    assert rel_err(dx.float().cpu().numpy(), xr.grad.numpy() + rnd(dt, skip).numpy()) < tol(dt)
+    for b in range(2):
+        xhat = ((xr - mean) / torch.sqrt(var + 1e-3)).detach().numpy()
+        gm = rnd(dt, g[b]).numpy() * (ys[b].detach().numpy() > 0)
+        assert rel_err(dgam[b].cpu().numpy(), (gm * xhat).sum(0)) < 5 * tol(dt) + 1e-4
+        assert rel_err(dbet[b].cpu().numpy(), gm.sum(0)) < 5 * tol(dt) + 1e-4
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
 def test_pooling_family(dt):
     rng = np.random.default_rng(7)
     lib = L.lib()
