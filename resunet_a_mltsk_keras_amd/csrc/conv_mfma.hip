@@ -11,6 +11,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
+
 struct SegK { const unsigned char* x; const unsigned char* w; int C, Hs, Ws, up, dil, taps, nchunk, ubegin; unsigned xbytes, wbytes; };
 struct ConvK {
   SegK seg[RUA_MAX_SEG];
@@ -412,6 +414,220 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK p) {
   conv_epilogue<T, 128, 64, true>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sred);
 }
 
+// =========================================================================================
+// conv_dma<BM,BN>: the bf16 production kernel.  Same GEMM view, tiles, unit table and epilogue as conv_igemm, but the
+// A / B stage tiles are written by LDS-DMA (buffer_load ... lds: no VGPR staging, no ds_write; out-of-range lanes
+// write zeros, which IS the zero padding) into THREE stage buffers, with the loads of two stages in flight behind a
+// counted vmcnt and ONE raw barrier per stage.  LDS rows are 64 B (32 bf16 channels) unpadded, as the DMA requires
+// (destination = wave-uniform base + lane*16); bank conflicts of the ds_read_b128 fragment reads are removed by an
+// XOR swizzle of the 16-byte piece index, slot = piece ^ ((row >> 2) & 3), applied to the per-lane SOURCE address
+// and to the fragment read address (never to the DMA destination).
+typedef __attribute__((address_space(3))) void* lds_void_p;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_dma(const ConvK p) {
+  typedef bf16_t T;
+  constexpr int KU = 2, NBUF = 3, ROWB = 64;
+  constexpr int A_BYTES = KU * BM * ROWB, B_BYTES = KU * BN * ROWB;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int AI = BM / 64;                       // A DMA instructions per wave per unit (16 rows each)
+  constexpr int BI = (BN + 63) / 64;                // B DMA instructions per wave per unit (BN = 32: waves 2,3 load zeros)
+  constexpr int PER_STAGE = KU * (AI + BI);         // DMA instructions per wave per stage (uniform across waves)
+  constexpr int WN = (BN >= 128 || (BN == 64 && BM == 128)) ? 2 : 1, WM = 4 / WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int CSTR = BN + 4;
+  constexpr int DUMMY_OFF = NBUF * STAGE;           // 1 KiB sink for the padding instructions of BN = 32
+  constexpr int EPI = BM * CSTR * 4 + 4 * (BN / 8) * 16 * 4;
+  constexpr int BASE = ((NBUF * STAGE + 1024 > EPI ? NBUF * STAGE + 1024 : EPI) + 15) / 16 * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sC = reinterpret_cast<float*>(smem);
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bn_i = vid % p.nbn;
+  const int bm_i = (vid / p.nbn) % p.nbm;
+  const int ks_i = vid / (p.nbn * p.nbm);
+  const long long m0 = (long long)bm_i * BM;
+  const int n0 = bn_i * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int HW = p.H * p.W;
+
+  // this lane's rows: DMA instruction i of this wave covers tile rows (wid*AI + i)*16 .. +15, lane -> row lane/4,
+  // LDS slot lane%4, i.e. source piece (lane%4) ^ ((row >> 2) & 3)
+  const int lrow = lane >> 2, lslot = lane & 3;
+  int an[AI], ah[AI], aw[AI], aqv[AI];
+  bool av[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = (wid * AI + i) * 16 + lrow;
+    const long long m = m0 + row;
+    av[i] = m < p.M;
+    const int mm = av[i] ? (int)m : 0;
+    const int n = mm / HW, rem = mm - n * HW, h = rem / p.W;
+    an[i] = n; ah[i] = h * p.stride; aw[i] = (rem - h * p.W) * p.stride;
+    aqv[i] = (lslot ^ ((row >> 2) & 3)) * 8;             // first channel of the piece this lane fetches
+  }
+  int brow[BI], bqv[BI];
+  bool bv[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int row = (wid * BI + j) * 16 + lrow;          // B tile row (output channel); rows >= BN are padding
+    brow[j] = row; bv[j] = row < BN && (n0 + row) < p.Cout;
+    bqv[j] = (lslot ^ ((row >> 2) & 3)) * 8;
+  }
+
+  int cs = -1;
+  int abase[AI], bbase[BI];
+  __amdgpu_buffer_rsrc_t rx = make_rsrc(p.seg[0].x, p.seg[0].xbytes), rw = make_rsrc(p.seg[0].w, p.seg[0].wbytes);
+  unsigned sHL = 0, sWL = 0;
+  auto enter_segment = [&](int s_) {
+    const SegK sg = p.seg[s_];
+    cs = s_; rx = make_rsrc(sg.x, sg.xbytes); rw = make_rsrc(sg.w, sg.wbytes);
+    sHL = (unsigned)(sg.Hs << sg.up); sWL = (unsigned)(sg.Ws << sg.up);
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      abase[i] = ((an[i] * sg.Hs + (ah[i] >> sg.up)) * sg.Ws + (aw[i] >> sg.up)) * sg.C + aqv[i];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) bbase[j] = (n0 + brow[j]) * sg.C + bqv[j];
+  };
+
+  // K iteration state (segment, tap, chunk): scalar, division-free.  (No LDS table here: hipcc puts a vmcnt(0) in
+  // front of any ds_read issued while LDS-DMA writes are in flight, which would drain the pipeline every stage.)
+  int u_seg = 0, u_tap = 0, u_chunk = 0, s_taps = 1, s_nchunk = 1, s_C = 0, s_Ws = 0, s_dil = 1;
+  auto seek_unit = [&](int unit) {
+    int sgi = 0;
+    while (sgi + 1 < p.nseg && unit >= p.seg[sgi + 1].ubegin) ++sgi;
+    const int loc = unit - p.seg[sgi].ubegin;
+    u_seg = sgi; u_tap = loc / p.seg[sgi].nchunk; u_chunk = loc - u_tap * p.seg[sgi].nchunk;
+  };
+  auto issue_stage = [&](int st, int buf) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int unit = st * KU + u;
+      const bool live = unit < p.nunits;
+      int dh = 0, dw = 0, left = 0, ex = 0, ey = 0;
+      if (live) {
+        if (u_seg != cs) {
+          enter_segment(u_seg);
+          const SegK sg = p.seg[u_seg];
+          s_taps = sg.taps; s_nchunk = sg.nchunk; s_C = sg.C; s_Ws = sg.Ws; s_dil = sg.dil;
+        }
+        if (s_taps == 9) {
+          const int t3 = (u_tap >= 6) ? 2 : (u_tap >= 3) ? 1 : 0;
+          dh = (t3 - 1) * s_dil; dw = (u_tap - 3 * t3 - 1) * s_dil;
+        }
+        ex = (dh * s_Ws + dw) * s_C + u_chunk * 32;
+        ey = u_tap * p.Cout * s_C + u_chunk * 32;
+        left = s_C - u_chunk * 32; if (left > 32) left = 32;
+        if (++u_chunk == s_nchunk) { u_chunk = 0; if (++u_tap == s_taps) { u_tap = 0; ++u_seg; } }
+      }
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const bool ok = live && av[i] && aqv[i] < left && (unsigned)(ah[i] + dh) < sHL && (unsigned)(aw[i] + dw) < sWL;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sA + (u * BM + (wid * AI + i) * 16) * ROWB), 16,
+                                                 ok ? (unsigned)((abase[i] + ex) * 2) : RUA_OOB, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < BI; ++j) {
+        const bool ok = live && bv[j] && bqv[j] < left;
+        unsigned char* dst = (brow[j] - lrow < BN) ? sB + (u * BN + (wid * BI + j) * 16) * ROWB : smem + DUMMY_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_p)dst, 16, ok ? (unsigned)((bbase[j] + ey) * 2) : RUA_OOB, 0, 0, 0);
+      }
+    }
+  };
+
+  const int wm = wid / WN, wn = wid % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int xs = (lr >> 2) & 3;                          // swizzle term of this lane's fragment rows (tile offsets are multiples of 32)
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  auto mfma_stage = [&](int buf) {
+    const unsigned char* sA = smem + buf * STAGE;
+    const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const unsigned char* pa = sA + (u * BM + wm * (BM / WM) + lr) * ROWB;
+      const unsigned char* pb = sB + (u * BN + wn * (BN / WN) + lr) * ROWB;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int slot = ((ks * 2 + lh) ^ xs) * 16;
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(pa + a * 32 * ROWB + slot);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(pb + b * 32 * ROWB + slot);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nstages_all = (p.nunits + KU - 1) / KU;
+  const int st_begin = ks_i * p.stages_per_split;
+  int nstages = st_begin + p.stages_per_split;
+  if (nstages > nstages_all) nstages = nstages_all;
+  seek_unit(st_begin * KU);
+  issue_stage(st_begin, 0);
+  issue_stage(st_begin + 1, 1);                          // past-the-end stages load zeros: the instruction count per stage stays uniform
+  int buf = 0;
+  for (int st = st_begin; st < nstages; ++st) {
+    // all but the newest stage's DMAs of this wave have landed -> stage st is in LDS (this wave's part) ...
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STAGE) : "memory");
+    // ... and after the barrier every wave's part; every wave has also finished reading the buffer refilled next
+    __builtin_amdgcn_s_barrier();
+    int nb = buf + 2; if (nb >= NBUF) nb -= NBUF;
+    issue_stage(st + 2, nb);
+    mfma_stage(buf);
+    if (++buf == NBUF) buf = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain before the epilogue reuses the stage buffers
+  __builtin_amdgcn_s_barrier();
+
+  if (p.ksplit > 1) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long long m = m0 + wm * (BM / WM) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+          const int c = n0 + wn * (BN / WN) + b * 32 + lr;
+          if (m < p.M && c < p.Cout) unsafeAtomicAdd(&p.ws[(size_t)m * p.Cout + c], acc[a][b][i]);
+        }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = wm * (BM / WM) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        const int col = wn * (BN / WN) + b * 32 + lr;
+        sC[row * CSTR + col] = acc[a][b][i];
+      }
+  __syncthreads();
+  conv_epilogue<T, BM, BN>(p, m0, n0, bm_i, sC, CSTR, sC + BM * CSTR);
+}
+
+template <int BM, int BN> static constexpr int conv_dma_base() {
+  constexpr int STAGE = 2 * (BM + BN) * 64;
+  constexpr int EPI = BM * (BN + 4) * 4 + 4 * (BN / 8) * 16 * 4;
+  return ((3 * STAGE + 1024 > EPI ? 3 * STAGE + 1024 : EPI) + 15) / 16 * 16;
+}
+
 #define RUA_MAX_UNITS 1024
 template <typename T, int BM, int BN> static constexpr int conv_smem() { return conv_smem_base<T, BM, BN>() + RUA_MAX_UNITS * 16; }
 
@@ -445,13 +661,15 @@ static int pick_ksplit(long long tiles, int nstages, long long M, int Cout, size
   return want < 2 ? 1 : (int)want;
 }
 
-static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
 
 static int pick_bn(const rua_conv_desc* d, long long M) {
   static const int force = env_int("RUA_CONV_FORCE_BN");          // experiments only
   if (force == 32 || force == 64 || force == 128) return (d->Cout <= 32) ? 32 : (force == 128 && d->Cout < 128) ? 64 : (force == 32 ? 64 : force);
   if (d->Cout <= 32) return 32;
   if (d->Cout <= 64) return 64;
+  int units = 0;
+  for (int s_ = 0; s_ < d->nseg; ++s_) units += d->seg[s_].taps * ((d->seg[s_].C + 31) / 32);
+  if (d->Cout >= 256 && units >= 200) return 128;       // multi-branch 3x3 at the deep levels: A re-read dominates
   const long long nbm = (M + 127) / 128;
   if (nbm * ((d->Cout + 127) / 128) < 512) return 64;   // small maps: more, smaller tiles
   return 128;
@@ -471,6 +689,29 @@ extern "C" int rua_conv_smem_bytes(const rua_conv_desc* d) {
   if (bn == 128) return h ? conv_smem<bf16_t, 128, 128>() : conv_smem<float, 128, 128>();
   if (bm == 256) return bn == 32 ? (h ? conv_smem<bf16_t, 256, 32>() : conv_smem<float, 256, 32>()) : (h ? conv_smem<bf16_t, 256, 64>() : conv_smem<float, 256, 64>());
   return bn == 32 ? (h ? conv_smem<bf16_t, 128, 32>() : conv_smem<float, 128, 32>()) : (h ? conv_smem<bf16_t, 128, 64>() : conv_smem<float, 128, 64>());
+}
+
+template <int BM, int BN> static int launch_conv_dma(const ConvK& k, int nbm, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              conv_dma_base<BM, BN>());
+    attr_set = true;
+  }
+  const int smem_now = conv_dma_base<BM, BN>();
+  hipLaunchKernelGGL((conv_dma<BM, BN>), dim3(nbm * k.nbn * k.ksplit), dim3(256), smem_now, st, k);
+  RUA_LAUNCH_CHECK("conv_dma");
+  if (k.ksplit > 1) {
+    hipLaunchKernelGGL((conv_splitk_finish<bf16_t>), dim3(nbm * ((k.Cout + 63) / 64)), dim3(256), 0, st, k);
+    RUA_LAUNCH_CHECK("conv_splitk_finish");
+  }
+  return RUA_OK;
+}
+
+static int dispatch_conv_dma(const ConvK& k, int bm, int bn, int nbm, hipStream_t st) {
+  if (bn == 128) return launch_conv_dma<128, 128>(k, nbm, st);
+  if (bm == 256) return bn == 32 ? launch_conv_dma<256, 32>(k, nbm, st) : launch_conv_dma<256, 64>(k, nbm, st);
+  return bn == 32 ? launch_conv_dma<128, 32>(k, nbm, st) : launch_conv_dma<128, 64>(k, nbm, st);
 }
 
 template <typename T> static int dispatch_conv(const ConvK& k, int bm, int bn, int nbm, hipStream_t st) {
@@ -537,6 +778,14 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.stages_per_split = (nstages + k.ksplit - 1) / k.ksplit;
   k.ksplit = (nstages + k.stages_per_split - 1) / k.stages_per_split;
   hipStream_t st = (hipStream_t)stream;
+  // Kernel choice (measured per level, scratch/bench_conv.py): the LDS-DMA kernel wins where K is long and the grid is
+  // small (Cout >= 128: 5-12 %); the register-staged kernel wins on the two top levels (short K, occupancy-bound) and,
+  // with 128-wide tiles, on the very long K of the multi-branch convs at Cout >= 256.
+  static const int use_dma = getenv("RUA_CONV_DMA") ? atoi(getenv("RUA_CONV_DMA")) : -1;    // 0 / 1: force (experiments)
+  bool dma = d->dtype == RUA_BF16 && d->Cout >= 128 && !(bn == 128);
+  if (use_dma == 0) dma = false;
+  if (use_dma == 1 && d->dtype == RUA_BF16) dma = true;
+  if (dma) return dispatch_conv_dma(k, bm, bn, nbm, st);
   if (d->dtype == RUA_BF16) return dispatch_conv<bf16_t>(k, bm, bn, nbm, st);
   return dispatch_conv<float>(k, bm, bn, nbm, st);
 }
@@ -930,7 +1179,10 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   if (k.wshift < 0 || k.hshift < 0) k.wshift = k.hshift = -1;
   k.ntc = (d->Cout + 63) / 64; k.nti = (d->C + 63) / 64;
   const long long tiles = (long long)k.ntc * k.nti * d->taps;
-  long long want = 2048 / tiles; if (want < 1) want = 1;
+  // K split: every slice adds the whole dW tile with fp32 atomics (~1.3 TB/s chip-wide), so slices x |dW| must stay
+  // small: ~512 blocks fill the chip; 2048 blocks meant 33 MB of atomics (~25 us) per launch.
+  static const int target = env_int("RUA_WGRAD_BLOCKS") > 0 ? env_int("RUA_WGRAD_BLOCKS") : 512;
+  long long want = target / tiles; if (want < 1) want = 1;
   long long stages = (k.M + 63) / 64;
   if (want > stages) want = stages;
   long long spb = (stages + want - 1) / want;          // stages per block

@@ -120,7 +120,7 @@ def test_tiny_singletask_fp32_128():
     shape, C = (128, 128, 7), 2
     trainer, eng = make_pair(shape, C, False, 32, "tanimoto")
     x, y = make_batch(2, 128, 7, C, False, seed=5)
-    check_step(trainer, eng, x, y, False, 1e-3, 1e-3, 5e-3, 2e-3)
+    check_step(trainer, eng, x, y, False, 1e-3, 1e-3, 8e-3, 2e-3)
 
 
 def test_full_width_block_bf16_close_to_oracle():
