@@ -50,10 +50,19 @@ def profile_kernels(eng, g, dtype):
     sp = C.c_void_p(s)
     tname = "bf16" if dtype == "bf16" else "f32"
     rec = []
+    # Keep the GPU busy while the instrumented step is enqueued, so every launch is already queued when its turn comes and
+    # the event pair brackets GPU execution only (bracketing a launch into an idle queue adds ~10 us of dispatch latency
+    # per kernel and would disagree with rocprofv3's per-kernel durations).
+    for _ in range(4):
+        eng.train_step(None, None, fetch=False)
     eng._zero_arena(g, s)
     eng._prep_weights(s)
+    empty = []
     for plan in (g.fwd, g.loss_plan, g.bwd):
-        for fn, name, args, _lane in plan.calls:
+        for ci, (fn, name, args, _lane) in enumerate(plan.calls):
+            if ci % 16 == 0:                                # empty event pairs: the marker-to-marker cost to subtract
+                z0, z1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                z0.record(); z1.record(); empty.append((z0, z1))
             if fn is None:
                 continue                                    # fork / join markers: this pass runs everything on one stream
             if name in ("rua_conv_fwd", "rua_conv_wgrad"):
@@ -63,22 +72,27 @@ def profile_kernels(eng, g, dtype):
                 e1.record()
                 d = args[0]._obj
                 if name == "rua_conv_fwd":
-                    kn = f"conv_igemm<{tname},{lib.raw('rua_conv_tile_bm')(C.byref(d))},{lib.raw('rua_conv_tile_bn')(C.byref(d))}>"
+                    bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d)), lib.raw('rua_conv_tile_bn')(C.byref(d))
+                    kn = f"conv_dma<{bm_},{bn_}>" if lib.raw('rua_conv_kernel_id')(C.byref(d)) == 1 else f"conv_igemm<{tname},{bm_},{bn_}>"
                     kk = sum(d.seg[i].taps * d.seg[i].C for i in range(d.nseg))
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "")
                     rec.append((kn, e0, e1, conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags)))
                 else:
-                    rec.append((f"wgrad_kernel<{tname}>", e0, e1, wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, "")))
+                    wn = f"wgrad_taps_kernel<{d.C}>+reduce" if lib.raw('rua_wgrad_kind')(C.byref(d)) == 1 else f"wgrad_kernel<{tname}>"
+                    rec.append((wn, e0, e1, wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, "")))
             else:
                 rc = fn(*args, sp)
             if rc != 0:
                 lib.check(rc, name)
     eng.optimizer_step(1.0 / eng.world)
     torch.cuda.synchronize()
+    ov = sorted(z0.elapsed_time(z1) for z0, z1 in empty)
+    ov = ov[len(ov) // 2] * 1e-3 if ov else 0.0          # median seconds per empty bracket
     out = {}
     for kn, e0, e1, fl, _ in rec:
         t = out.setdefault(kn, [0, 0.0, 0.0])
-        t[0] += 1; t[1] += e0.elapsed_time(e1) * 1e-3; t[2] += fl
+        t[0] += 1; t[1] += max(e0.elapsed_time(e1) * 1e-3 - ov, 1e-7); t[2] += fl
+    out["_event_overhead_us"] = ov * 1e6
     if os.environ.get("RUA_BENCH_DETAIL"):
         groups = {}
         for kn, e0, e1, fl, tag in rec:
@@ -223,13 +237,14 @@ def main():
     if rank == 0:
         peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
         prof = profile_kernels(eng, eng.graph(B, True), args.dtype)
+        ev_ov = prof.pop("_event_overhead_us")
         dom = max(prof.items(), key=lambda kv: kv[1][1])
         kn, (n, sec, fl) = dom
         out["roofline"] = {
             "bound": "mfma", "kernel": kn, "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
             "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
             "achieved": round(fl / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4),
-            "traffic": None,
+            "traffic": None, "event_pair_overhead_us_subtracted": round(ev_ov, 2),
             "all_mfma_kernels": {k: {"launches": v[0], "ms_per_step": round(1e3 * v[1], 3), "tflops": round(v[2] / v[1] / 1e12, 2)}
                                  for k, v in sorted(prof.items())},
             "whole_step_frac_of_peak": round(value / world * gflop_patch / 1e3 / peak, 4),

@@ -682,6 +682,14 @@ static int pick_bm(const rua_conv_desc* d, long long M, int bn) {
   return (M >= 65536) ? 256 : 128;
 }
 
+static bool pick_dma(const rua_conv_desc* d, int bn) {
+  static const int use_dma = getenv("RUA_CONV_DMA") ? atoi(getenv("RUA_CONV_DMA")) : -1;    // 0 / 1: force (experiments)
+  bool dma = d->dtype == RUA_BF16 && d->Cout >= 128 && !(bn == 128);
+  if (use_dma == 0) dma = false;
+  if (use_dma == 1 && d->dtype == RUA_BF16) dma = true;
+  return dma;
+}
+
 extern "C" int rua_conv_smem_bytes(const rua_conv_desc* d) {
   const long long M = (long long)d->N * d->H * d->W;
   const int bn = pick_bn(d, M), bm = pick_bm(d, M, bn);
@@ -781,11 +789,7 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   // Kernel choice (measured per level, scratch/bench_conv.py): the LDS-DMA kernel wins where K is long and the grid is
   // small (Cout >= 128: 5-12 %); the register-staged kernel wins on the two top levels (short K, occupancy-bound) and,
   // with 128-wide tiles, on the very long K of the multi-branch convs at Cout >= 256.
-  static const int use_dma = getenv("RUA_CONV_DMA") ? atoi(getenv("RUA_CONV_DMA")) : -1;    // 0 / 1: force (experiments)
-  bool dma = d->dtype == RUA_BF16 && d->Cout >= 128 && !(bn == 128);
-  if (use_dma == 0) dma = false;
-  if (use_dma == 1 && d->dtype == RUA_BF16) dma = true;
-  if (dma) return dispatch_conv_dma(k, bm, bn, nbm, st);
+  if (pick_dma(d, bn)) return dispatch_conv_dma(k, bm, bn, nbm, st);
   if (d->dtype == RUA_BF16) return dispatch_conv<bf16_t>(k, bm, bn, nbm, st);
   return dispatch_conv<float>(k, bm, bn, nbm, st);
 }
@@ -1254,6 +1258,10 @@ extern "C" int64_t rua_conv_workspace_bytes(const rua_conv_desc* d) {
 extern "C" int rua_conv_tile_bn(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
   return pick_bn(d, (long long)d->N * d->H * d->W);
+}
+extern "C" int rua_conv_kernel_id(const rua_conv_desc* d) {   // 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA)
+  if (!d) return RUA_ERR_ARG;
+  return pick_dma(d, pick_bn(d, (long long)d->N * d->H * d->W)) ? 1 : 0;
 }
 extern "C" int rua_conv_tile_bm(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
