@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=25.0)
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (RCCL group of one rank) on one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,6 +178,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    elif args.force_dp:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local))
 
     from resunet_a_mltsk_keras_amd import _lib as L
     from resunet_a_mltsk_keras_amd.engine import Engine, LossSpec, ModelConfig
@@ -187,7 +191,7 @@ def main():
     eng = Engine(ModelConfig(input_shape=(patch, patch, ch), num_classes=ncls, multitasking=mt), dtype=args.dtype, seed=0)
     heads = ["seg", "bound", "dist", "color"]
     eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in heads}, weight={h: 1.0 for h in heads}, optimizer="adam", lr=1e-3))
-    if world > 1:
+    if world > 1 or args.force_dp:
         from resunet_a_mltsk_keras_amd.dist import DataParallel
         DataParallel(eng, bucket_mb=args.bucket_mb, overlap=not args.no_overlap)
     x, y = make_batch(B, patch, ch, ncls, mt, seed=1234 + rank)
@@ -234,9 +238,10 @@ def main():
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss_last_step": round(res[0], 5)},
         "model_tflops_per_s": round(value * gflop_patch / 1e3, 2),
     }
+    # every rank runs the instrumented pass (its keep-busy steps contain the gradient all-reduces); rank 0 reports
+    prof = profile_kernels(eng, eng.graph(B, True), args.dtype)
     if rank == 0:
         peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
-        prof = profile_kernels(eng, eng.graph(B, True), args.dtype)
         ev_ov = prof.pop("_event_overhead_us")
         dom = max(prof.items(), key=lambda kv: kv[1][1])
         kn, (n, sec, fl) = dom
@@ -252,7 +257,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

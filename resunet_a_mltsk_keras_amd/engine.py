@@ -930,6 +930,7 @@ class Engine:
         self.lr_dev = torch.zeros(16, dtype=torch.float32, device=self.dev)               # step-dependent optimizer scalars
         self.use_graph = True
         self._captured: Dict[int, object] = {}
+        self._captured_dp: Dict[int, list] = {}
         self.scalars_ptr = self.stats_arena.data_ptr()
         self.t = 0
         self.weights_dirty = True
@@ -1046,22 +1047,25 @@ class Engine:
         g.bwd.run(s, hooks, side=side)
         return g
 
-    def _bucket_hooks(self, g: Graph):
-        """{backward launch index -> fire the all-reduce of every gradient bucket that is complete after it}."""
-        if getattr(g, "_hooks", None) is None:
+    def _bucket_marks(self, g: Graph) -> Dict[int, List[int]]:
+        """{backward launch index -> gradient buckets that are complete after that launch}."""
+        if getattr(g, "_marks", None) is None:
             last = [-1] * len(self.dist.buckets)
             for off, idx in g.grad_touch.items():
                 b = self.dist.bucket_of(off)
                 last[b] = max(last[b], idx)
-            hooks: Dict[int, object] = {}
             by_idx: Dict[int, List[int]] = {}
             for b, idx in enumerate(last):
                 if idx >= 0:
                     by_idx.setdefault(g.bwd.safe_hook_index(idx), []).append(b)    # never while side lanes are running
+            g._marks = by_idx
+        return g._marks
+
+    def _bucket_hooks(self, g: Graph):
+        """{backward launch index -> fire the all-reduce of every gradient bucket that is complete after it}."""
+        if getattr(g, "_hooks", None) is None:
             red = self.dist.reducer
-            for idx, bs in by_idx.items():
-                hooks[idx] = (lambda bs=bs: [red.ready(b) for b in bs])
-            g._hooks = hooks
+            g._hooks = {idx: (lambda bs=bs: [red.ready(b) for b in bs]) for idx, bs in self._bucket_marks(g).items()}
         return g._hooks
 
     def _set_lr(self):
@@ -1118,10 +1122,64 @@ class Engine:
         self.weights_dirty = True
         return g
 
+    def _graph_step_dp(self, x, y):
+        """Data-parallel fast path: the step is cut at the launches after which a gradient bucket is complete; every
+        piece is its own HIP graph, the bucket all-reduces are issued eagerly between the replays on the reducer's side
+        stream (RCCL stays outside the captures), so they overlap the next pieces exactly like in the eager path."""
+        B = x.shape[0] if x is not None else self._last_B
+        self._last_B = B
+        g = self.graph(B, True)
+        self._upload(g, x, y)
+        red = self.dist.reducer
+        pieces = self._captured_dp.get(B)
+        if pieces is None:
+            # one eager step (first-launch costs, kernel attributes, RCCL channel set-up), then capture the pieces
+            self.forward_backward(None, None)
+            self.dist.reduce_gradients(self)
+            self.optimizer_step(1.0 / self.world)
+            torch.cuda.synchronize()
+            marks = self._bucket_marks(g) if self.dist.overlap else {}
+            cuts = sorted(marks)
+            nb = len(g.bwd.calls)
+            pieces, first = [], 0
+            for ci, idx in enumerate(cuts + [nb - 1]):
+                if ci == len(cuts) and first >= nb:
+                    break
+                cap = torch.cuda.CUDAGraph()
+                # thread_local: the process group's watchdog thread may query events while we capture
+                with torch.cuda.graph(cap, capture_error_mode="thread_local"):
+                    s = self._stream()
+                    if first == 0:
+                        self._zero_arena(g, s); self.weights_dirty = True; self._prep_weights(s)
+                        g.fwd.run(s); g.loss_plan.run(s)
+                    g.bwd.run(s, first=first, last=idx + 1)
+                pieces.append((cap, marks.get(idx, []) if ci < len(cuts) else []))
+                first = idx + 1
+            opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(opt, capture_error_mode="thread_local"):
+                self._launch_optimizer(1.0 / self.world, self._stream())
+            self._captured_dp[B] = pieces
+            self._opt_graph = opt
+            self.weights_dirty = True
+            return g
+        self._set_lr()
+        red.begin()
+        for cap, buckets in pieces:
+            cap.replay()
+            for b in buckets:
+                red.ready(b)
+        self.dist.reduce_gradients(self)
+        self._opt_graph.replay()
+        self.weights_dirty = True
+        return g
+
     def train_step(self, x=None, y=None, fetch: bool = True):
         """One Keras train_on_batch (train_ISPRS.py:131,148): returns the metric list in the reference's order."""
         if self.use_graph and self.dist is None:
             g = self._graph_step(x, y)
+            return self._results(g) if fetch else None
+        if self.use_graph and not self.dist.host_staged and not self.use_lanes:
+            g = self._graph_step_dp(x, y)
             return self._results(g) if fetch else None
         g = self.forward_backward(x, y)
         if self.dist is not None:
