@@ -27,7 +27,9 @@ WORKLOADS = {
     "cfg3": (256, 6, 6, True, 8, 252.4),
     "cfg2": (256, 6, 6, False, 8, 234.1),
     "cfg5": (128, 7, 2, False, 32, 58.4),
+    "cfg4": (512, 6, 6, True, 4, 1072.0),       # d7 extrapolation, 512x512 patches
 }
+DEPTH = {"cfg4": 7}
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MFMA_PEAK_TFLOPS = 157.3
 
@@ -188,7 +190,8 @@ def main():
 
     patch, ch, ncls, mt, bs, gflop_patch = WORKLOADS[args.workload]
     B = args.batch or bs
-    eng = Engine(ModelConfig(input_shape=(patch, patch, ch), num_classes=ncls, multitasking=mt), dtype=args.dtype, seed=0)
+    depth = DEPTH.get(args.workload, 6)
+    eng = Engine(ModelConfig(input_shape=(patch, patch, ch), num_classes=ncls, multitasking=mt, depth=depth), dtype=args.dtype, seed=0)
     heads = ["seg", "bound", "dist", "color"]
     eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in heads}, weight={h: 1.0 for h in heads}, optimizer="adam", lr=1e-3))
     if world > 1 or args.force_dp:
@@ -233,7 +236,7 @@ def main():
         "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{args.workload}: ResUnet-a d6 {'multitask (seg+bound+dist+color) Tanimoto-dual' if mt else 'single-task seg Tanimoto-dual'}, "
+        "config": {"workload": f"{args.workload}: ResUnet-a d{depth} {'multitask (seg+bound+dist+color) Tanimoto-dual' if mt else 'single-task seg Tanimoto-dual'}, "
                                f"{patch}x{patch}x{ch}, {ncls} classes, Adam, full train step (fwd+loss+bwd+allreduce+update)",
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss_last_step": round(res[0], 5)},
         "model_tflops_per_s": round(value * gflop_patch / 1e3, 2),

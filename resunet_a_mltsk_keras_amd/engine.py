@@ -640,12 +640,14 @@ class Graph:
         y.stats = st
         return y, lay
 
-    def conv1x1_multi_back(self, Bp, segs, lay, y: Ten, targets):
+    def conv1x1_multi_back(self, Bp, segs, lay, y: Ten, targets, bias: bool = False):
         """Backward of conv1x1_multi.  targets[i] = dict(out, mask/stat_aux/stats2) for a fused BN source,
-        or None for a plain accumulate into the source's gradient.  Every conv1x1_multi is followed by a
-        training-mode BatchNorm, so its bias gradient (the per-channel sum of a BN backward output) is exactly
-        zero and no launch is spent on it."""
+        or None for a plain accumulate into the source's gradient.  In the model2 graph every conv1x1_multi is
+        followed by a training-mode BatchNorm, so its bias gradient (the per-channel sum of a BN backward output) is
+        exactly zero and no launch is spent on it; the model.py graph has no BN there and asks for it (bias=True)."""
         dy = y.grad
+        if bias:
+            self.bias_grad(Bp, dy, [lay["bias"]])
         pooled = {0: dy}
         for (t, up), seg, tg in zip(segs, lay["segs"], targets):
             if up not in pooled:
@@ -748,6 +750,63 @@ class Graph:
             self.back_steps.append(back)
         return t
 
+    # -- ResUnet_a/model.py graph: no BN around the 1x1 convs, no ReLU after PSP, no skip term in ResBlock ---------
+    def psp_v1(self, x: Ten, nf: int) -> Ten:
+        """PSPPooling of model.py:35-64: max-pool k -> 1x1 conv (bias, no BN) -> nearest up k; concat with the input;
+        1x1 conv.  The convs already run at pooled resolution in the reference; the upsample is folded into the
+        fuse conv's read."""
+        F, tr = self.fwd, self.training
+        w_in = self.cfg.input_shape[1]
+        ks = [1, 2] + ([4] if w_in >= 128 else []) + ([8] if w_in >= 256 else [])
+        br = []
+        for k in ks:
+            p, idx = x, None
+            if k > 1:
+                assert x.H % k == 0 and x.W % k == 0, f"PSP pool {k} does not divide {x.H}x{x.W}"
+                p = self.new(x.N, x.H // k, x.W // k, x.C)
+                idx = self.alloc((p.t.numel(),), torch.uint8)
+                F.keep.append(idx)
+                F.add("rua_maxpool_fwd", x.ptr, p.ptr, idx.data_ptr(), x.N, x.H, x.W, x.C, k, self.dt)
+            br.append([k, p, idx])
+        for b in br:                                             # Keras creates the branch convs after all the pools
+            z, lay = self.conv1x1_multi([(b[1], 0)], nf // 4, (b[1].H, b[1].W), want_stats=False)
+            b += [z, lay]
+        segs = [(b[3], int(math.log2(b[0]))) for b in br] + [(x, 0)]
+        zf, layf = self.conv1x1_multi(segs, nf, (x.H, x.W), want_stats=False)
+        if tr:
+            def back():
+                Bp = self.bwd
+                self.conv1x1_multi_back(Bp, segs, layf, zf, [None] * len(segs), bias=True)
+                for k, p, idx, z, lay in br:
+                    self.conv1x1_multi_back(Bp, [(p, 0)], lay, z, [None], bias=True)     # -> p.grad (p is x for k == 1)
+                    if k > 1:
+                        gx, acc = self.gacc(x)
+                        Bp.add("rua_maxpool_bwd", p.grad.ptr, idx.data_ptr(), gx.ptr, acc, x.N, x.H, x.W, x.C, k, self.dt)
+            self.back_steps.append(back)
+        return zf
+
+    def relu_cat_conv_v1(self, z: Ten, up: int, skip: Ten, nf: int, want_stats: bool) -> Ten:
+        """combine() of model.py:66-70: ReLU(z) [nearest x2^up, folded into the read] || skip -> 1x1 conv (bias, no BN)."""
+        F, tr = self.fwd, self.training
+        r = self.like(z)
+        F.add("rua_relu", z.ptr, r.ptr, z.t.numel(), self.dt)
+        segs = [(r, up), (skip, 0)]
+        zc, lay = self.conv1x1_multi(segs, nf, (skip.H, skip.W), want_stats=want_stats)
+        if tr:
+            def back():
+                gz, acc = self.gacc(z)
+                assert acc == 0
+                self.conv1x1_multi_back(self.bwd, segs, lay, zc, [dict(out=gz, mask=(z, None, None)), None], bias=True)
+            self.back_steps.append(back)
+        return zc
+
+    def up_combine_v1(self, x: Ten, skip: Ten, nf: int) -> Ten:
+        """model.py:93-95: Conv2D(nf,(1,1)) at low resolution -> UpSampling2D -> combine(., skip, nf)."""
+        z, lay_u = self.conv1x1_multi([(x, 0)], nf, (x.H, x.W), want_stats=False)
+        if self.training:
+            self.back_steps.append(lambda: self.conv1x1_multi_back(self.bwd, [(x, 0)], lay_u, z, [None], bias=True))
+        return self.relu_cat_conv_v1(z, 1, skip, nf, want_stats=True)
+
     def conv3x3_relu(self, x: Ten, nf: int, name=None):
         """ZeroPadding2D(1)+Conv2D(32,(3,3),relu,valid) of the heads (model2.py:153-158) == same-pad 3x3 + ReLU."""
         F, tr = self.fwd, self.training
@@ -814,8 +873,9 @@ class Graph:
     # -- whole network ---------------------------------------------------------------------------------
     def _build(self):
         cfg, F, tr = self.cfg, self.fwd, self.training
-        if cfg.variant != "model2":
-            raise NotImplementedError("variant 'model' (ResUnet_a/model.py graph) is not built yet; use model2")
+        if cfg.variant not in ("model2", "model"):
+            raise ValueError(f"unknown graph variant {cfg.variant!r} (model2 = ResUnet_a/model2.py, model = ResUnet_a/model.py)")
+        v2 = cfg.variant == "model2"
         H, W, Cin = cfg.input_shape
         lv = cfg.levels()
         w0 = lv[0][0]
@@ -836,13 +896,13 @@ class Graph:
                 x = self.down(x, nf)
             x = self.resblock(x, nf, dils)
             skips.append(x)
-        x = self.psp(x, lv[-1][0])
+        x = self.psp(x, lv[-1][0]) if v2 else self.psp_v1(x, lv[-1][0])
         for i in range(len(lv) - 2, -1, -1):
             nf, dils = lv[i]
-            x = self.up_combine(x, skips[i], nf)
+            x = self.up_combine(x, skips[i], nf) if v2 else self.up_combine_v1(x, skips[i], nf)
             x = self.resblock(x, nf, dils)
-        x_comb = self.final_combine(x, c1, w0)
-        x_psp = self.psp(x_comb, w0)
+        x_comb = self.final_combine(x, c1, w0) if v2 else self.relu_cat_conv_v1(x, 0, c1, w0, want_stats=False)
+        x_psp = self.psp(x_comb, w0) if v2 else self.psp_v1(x_comb, w0)
         Cc = cfg.num_classes
         if not cfg.multitasking:
             self.head(x_psp, Cc, L.ACT_SOFTMAX, "seg")

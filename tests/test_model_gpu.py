@@ -15,16 +15,18 @@ from resunet_a_mltsk_keras_amd.synthetic import make_batch  # noqa: E402
 KIND = {"tanimoto": L.LOSS_TANIMOTO}
 
 
-def make_pair(shape, C, mt, width, loss, optimizer="adam", dtype="f32", seed=3, cw=None, lw=None, split_k=False):
+def make_pair(shape, C, mt, width, loss, optimizer="adam", dtype="f32", seed=3, cw=None, lw=None, split_k=False,
+              variant="model2", depth=6):
     """split_k=False by default: on 64x64 inputs the bottleneck BatchNorms see 2-8 samples per channel and amplify the
     atomic-order noise of split-K convolutions ~1e4x, which would drown the 1e-3 comparisons (kernels themselves are
     checked with split-K in test_kernels_gpu.py; the full-size and bf16 tests below run with it)."""
-    rcfg = ref.RefConfig(input_shape=shape, num_classes=C, multitasking=mt, width=width)
+    rcfg = ref.RefConfig(input_shape=shape, num_classes=C, multitasking=mt, width=width, variant=variant, depth=depth)
     params, order = ref.init_params(rcfg, seed)
     lw = lw or {"seg": 1.0, "bound": 0.7, "dist": 1.3, "color": 0.5}
     rspec = ref.CompileSpec(loss=loss, class_weights=cw, loss_weights=lw, optimizer=optimizer, lr=1e-3)
     trainer = ref.RefTrainer(rcfg, {k: v.clone() for k, v in params.items()}, order, rspec)
-    eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=mt, width=width), dtype=dtype, seed=0, split_k=split_k)
+    eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=mt, width=width, variant=variant, depth=depth),
+                 dtype=dtype, seed=0, split_k=split_k)
     if loss == "tanimoto":
         kind = {h: L.LOSS_TANIMOTO for h in ref.HEADS}
     elif loss == "weighted_cross_entropy":
@@ -41,7 +43,14 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-def check_step(trainer, eng, x, y, mt, tol_loss, tol_logit, tol_grad, tol_w, check_grads=True):
+def exact_grads(trainer, x, y):
+    """The same oracle step in float64 (call BEFORE the fp32 oracle step, it clones the current weights)."""
+    t64 = ref.RefTrainer(trainer.cfg, {k: v.detach().double() for k, v in trainer.params.items()}, trainer.order, trainer.spec)
+    t64.train_on_batch(x.astype(np.float64), {k: v.astype(np.float64) for k, v in y.items()} if isinstance(y, dict) else y.astype(np.float64))
+    return {k: t64.last_grads[k].numpy() for k in trainer.order}
+
+
+def check_step(trainer, eng, x, y, mt, tol_loss, tol_logit, tol_grad, tol_w, check_grads=True, exact=None):
     exp = trainer.train_on_batch(x, y)
     B = x.shape[0]
     g = eng.forward_backward(x, y)
@@ -63,7 +72,25 @@ def check_step(trainer, eng, x, y, mt, tol_loss, tol_logit, tol_grad, tol_w, che
         assert rel(z, trainer.last_taps[key]) < tol_logit, (h, rel(z, trainer.last_taps[key]))
     # gradients, tensor by tensor.  Biases (and BN betas) that feed a 1x1 conv + training-mode BN, or a BN
     # directly, have an exactly-zero true gradient: both sides then hold ~1e-10 rounding noise.
-    if check_grads:
+    if check_grads and exact is not None:
+        # Ill-conditioned case (the model.py graph has no identity path, so every gradient passes through chains of
+        # BatchNorm backward passes that cancel most of it): the fp32 ORACLE itself is then ~1e-2 away from the exact
+        # gradient.  Bar: the HIP gradient is as close to the float64 gradient as the fp32 oracle is.
+        grads = eng.grads_keras()
+        gmax = max(float(np.abs(exact[k]).max()) for k in trainer.order)
+        r_hip, r_ref = [], []
+        for k in trainer.order:
+            e = exact[k]
+            if np.abs(e).max() < 1e-5 * gmax:
+                assert np.abs(grads[k]).max() < 1e-4 * gmax, (k, float(np.abs(grads[k]).max()))
+                continue
+            r_hip.append(float(np.abs(grads[k] - e).max() / np.abs(e).max()))
+            r_ref.append(float(np.abs(trainer.last_grads[k].numpy() - e).max() / np.abs(e).max()))
+        r_hip, r_ref = np.array(r_hip), np.array(r_ref)
+        assert np.median(r_hip) <= 2.0 * np.median(r_ref) + 1e-3, (float(np.median(r_hip)), float(np.median(r_ref)))
+        assert r_hip.max() < 0.5
+        assert (r_hip > tol_grad + 3.0 * r_ref).sum() <= max(2, len(r_hip) // 25), (r_hip.max(), r_ref.max())
+    elif check_grads:
         grads = eng.grads_keras()
         gmax = max(float(np.abs(trainer.last_grads[k].numpy()).max()) for k in trainer.order)
         # A ReLU whose pre-activation is within ~1e-7 of zero can take different sides in two fp32 evaluation
@@ -176,3 +203,43 @@ def test_graph_replay_equals_eager_launches():
     d = np.abs(outs[0][1] - outs[1][1])
     moved = np.abs(outs[0][1]).mean()
     assert d.mean() < 1e-4 * moved and d.max() < 1e-3, (float(d.mean()), float(d.max()), float(moved))
+
+
+@pytest.mark.parametrize("mt,size,ch", [(True, 64, 3), (False, 128, 7)])
+def test_model_py_graph_variant_fp32(mt, size, ch):
+    """ResUnet_a/model.py graph (model.py:14-171): no skip term in ResBlock, PSP = pool -> conv -> upsample without BN,
+    1x1 conv before UpSampling2D, combine without BN, no ReLU after PSP.  Same bar as the model2 tests."""
+    shape, C = (size, size, ch), 4
+    trainer, eng = make_pair(shape, C, mt, 32, "tanimoto", "adam", variant="model")
+    assert eng.count_params() == ref.count_params(trainer.params)
+    for step in range(2):
+        x, y = make_batch(2, size, ch, C, mt, seed=17 + step, block=16)
+        ex = exact_grads(trainer, x, y) if step == 0 else None
+        check_step(trainer, eng, x, y, mt, 1e-3, 1e-3, 8e-3, 2e-3, check_grads=(step == 0), exact=ex)
+        # Adam moves noise-level gradient entries by +-lr either way, and this graph amplifies such weight differences
+        # ~10x into the logits: continue from the oracle's weights (check_step has just compared the updated ones)
+        eng.set_weights({k: v.detach().numpy() for k, v in trainer.params.items()})
+    x, y = make_batch(2, size, ch, C, mt, seed=33, block=16)
+    exp = trainer.test_on_batch(x, y)
+    got = eng.test_step(x, y)
+    for i in range(5 if mt else 1):
+        assert abs(got[i] - exp[i]) <= 2e-3 * max(1.0, abs(exp[i])), (i, got[i], exp[i])
+
+
+def test_d7_512_fp32_loss_and_logits():
+    """SURVEY A15 (not in the reference; restatement-vs-kernel only): the d7 extrapolation - encoder stage 7
+    (1x1 s2 -> 2048, ResBlock(2048,[1])), PSPPooling(2048) on the 8x8 bottleneck of a 512x512 patch, one more decoder
+    stage - runs through the same composites.  Loss and per-head logits within 1e-3 of the oracle."""
+    shape, C = (512, 512, 6), 6
+    lw = {"seg": 1.0, "bound": 1.0, "dist": 1.0, "color": 1.0}
+    trainer, eng = make_pair(shape, C, True, 32, "tanimoto", lw=lw, split_k=True, depth=7)
+    x, y = make_batch(1, 512, 6, C, True, seed=77)
+    exp = trainer.train_on_batch(x, y)
+    g = eng.forward_backward(x, y)
+    torch.cuda.synchronize()
+    got = eng._results(g)
+    for i in range(5):
+        assert abs(got[i] - exp[i]) <= 1e-3 * max(1.0, abs(exp[i])), (i, got[i], exp[i])
+    for h, z in eng.logits(True, 1).items():
+        assert rel(z, trainer.last_taps[h + "_logits"]) < 1e-3, h
+    assert eng.count_params() > 150e6
