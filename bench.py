@@ -43,6 +43,21 @@ def wgrad_flops(d):
     return 2.0 * d.N * d.H * d.W * d.Cout * d.C * d.taps
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/collect_traffic.sh ->
+    profiles/traffic_summary.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes).  The counters cannot be read from
+    inside this process, so this is the value measured on the same workload with rocprofv3; None if it was not collected
+    for this workload / dtype."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    if t.get("workload") != args.workload or t.get("dtype") != args.dtype:
+        return None
+    k = t["kernels"].get(kernel.split("+")[0])
+    return k["bytes_per_launch"] if k else None
+
+
 def profile_kernels(eng, g, dtype):
     """One extra (untimed) step with an event pair around every conv / wgrad launch on the launch stream.
     Returns per-kernel-instantiation totals: {name: [launches, seconds, flops]}."""
@@ -232,7 +247,8 @@ def main():
         log(f"{args.steps} steps in {dt:.3f} s -> {value:.1f} patches/s")
 
     out = {
-        "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] if args.workload != "cfg5" else "training patches/sec (128x128, 7-ch, bs=32/GPU)",
+        "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] if args.workload in ("cfg3", "cfg2")
+                  else f"training patches/sec ({patch}x{patch}, {ch}-ch, bs={B}/GPU)",
         "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
@@ -252,7 +268,8 @@ def main():
             "bound": "mfma", "kernel": kn, "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
             "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
             "achieved": round(fl / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4),
-            "traffic": None, "event_pair_overhead_us_subtracted": round(ev_ov, 2),
+            "traffic": measured_traffic(kn, args), "traffic_unit": "HBM bytes per launch (profiles/traffic.json: rocprofv3 PMC)",
+            "event_pair_overhead_us_subtracted": round(ev_ov, 2),
             "all_mfma_kernels": {k: {"launches": v[0], "ms_per_step": round(1e3 * v[1], 3), "tflops": round(v[2] / v[1] / 1e12, 2)}
                                  for k, v in sorted(prof.items())},
             "whole_step_frac_of_peak": round(value / world * gflop_patch / 1e3 / peak, 4),
