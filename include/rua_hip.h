@@ -64,17 +64,18 @@ typedef struct rua_conv_desc {
   int32_t out_stride, OH, OW;
   double* stats;               /* [stats_replicas][2][Cout] atomically accumulated, or NULL */
   int32_t stats_mode;          /* 1: sum v, sum v^2   2: sum v, sum v*aux */
-  void* workspace;             /* optional fp32 scratch of rua_conv_workspace_bytes(): enables split-K for small output grids.
-                                  MUST be all zeros on entry (zero-fill it once); the call leaves it all zeros again */
+  void* workspace;             /* optional fp32 scratch, >= 2 * rua_conv_workspace_bytes(): enables split-K for small output
+                                  grids (one N*H*W*Cout slab per K slice, plain stores, summed in a fixed order by the
+                                  finisher: deterministic).  Contents on entry are irrelevant and undefined on return */
   int64_t workspace_bytes;
   int32_t stats_replicas;      /* power of two >= 1: block b adds into replica b % R (spreads atomic contention);
                                   the finalize kernels sum the replicas */
 } rua_conv_desc;
 int rua_conv_fwd(const rua_conv_desc* d, void* stream);
 int rua_conv_smem_bytes(const rua_conv_desc* d);
-int64_t rua_conv_workspace_bytes(const rua_conv_desc* d);   /* N*H*W*Cout fp32: needed only if split-K is wanted */
+int64_t rua_conv_workspace_bytes(const rua_conv_desc* d);   /* bytes of ONE slab (N*H*W*Cout fp32); split-K uses up to 32 */
 int rua_conv_tile_bn(const rua_conv_desc* d);   /* 32 / 64 / 128 and */
-int rua_conv_kernel_id(const rua_conv_desc* d); /* 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA, bf16) */
+int rua_conv_kernel_id(const rua_conv_desc* d); /* 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA, bf16), 2: conv_dmap (LDS-DMA, pipelined across the stage barrier) */
 int rua_conv_tile_bm(const rua_conv_desc* d);   /* 128 / 256: which conv_igemm<T,BM,BN> instantiation a descriptor launches */
 
 /* ---- weight gradient (MFMA, split over pixels, fp32 atomic accumulation) ----------------

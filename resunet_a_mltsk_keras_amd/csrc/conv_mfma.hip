@@ -51,7 +51,8 @@ template <typename T, int BM, int BN> __host__ __device__ constexpr int conv_sme
 // Shared epilogue of one 128 x BN output tile whose fp32 sums sit in `src` (LDS tile or split-K workspace):
 // 8-channel pieces per thread: bias, accumulate, residual / ReLU mask from aux, output ReLU, per-channel
 // statistics (fp32 partials -> wave shuffles -> LDS -> one fp64 atomic per channel and block), 16-byte stores.
-template <typename T, int BM, int BN, bool ZERO_SRC = false>
+// SLABS: `src` is the first of p.ksplit fp32 slabs (stride M*Cout floats) whose sum is the tile (split-K finisher).
+template <typename T, int BM, int BN, bool SLABS = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int n0, int bm_i, const float* src, int sstride, float* sred) {
   constexpr int CG = BN / 8;
   constexpr int ROWS_PP = 256 / CG;
@@ -87,11 +88,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
     const long long m = m0 + row;
     if (m < p.M && cok) {
       float v[8];
-      const float4 t0 = *reinterpret_cast<const float4*>(&src[(size_t)row * sstride + cg * 8]);
-      const float4 t1 = *reinterpret_cast<const float4*>(&src[(size_t)row * sstride + cg * 8 + 4]);
-      if (ZERO_SRC) {
-        *reinterpret_cast<float4*>(const_cast<float*>(&src[(size_t)row * sstride + cg * 8])) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(const_cast<float*>(&src[(size_t)row * sstride + cg * 8 + 4])) = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 t0 = *reinterpret_cast<const float4*>(&src[(size_t)row * sstride + cg * 8]);
+      float4 t1 = *reinterpret_cast<const float4*>(&src[(size_t)row * sstride + cg * 8 + 4]);
+      if (SLABS) {
+        const size_t slab = (size_t)p.M * p.Cout;
+        for (int k = 1; k < p.ksplit; ++k) {                 // fixed order: split-K results are bit-reproducible
+          const float4 u0 = *reinterpret_cast<const float4*>(&src[k * slab + (size_t)row * sstride + cg * 8]);
+          const float4 u1 = *reinterpret_cast<const float4*>(&src[k * slab + (size_t)row * sstride + cg * 8 + 4]);
+          t0.x += u0.x; t0.y += u0.y; t0.z += u0.z; t0.w += u0.w; t1.x += u1.x; t1.y += u1.y; t1.z += u1.z; t1.w += u1.w;
+        }
       }
       v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
 #pragma unroll
@@ -374,8 +379,9 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
 
   // ---- epilogue -------------------------------------------------------------------------
   if (p.ksplit > 1) {
-    // split-K: add the partial tile into the fp32 workspace (128-byte row segments per wave instruction);
-    // bias / mask / statistics / store happen in conv_splitk_finish once every slice has landed.
+    // split-K: store the partial tile into this K slice's fp32 slab of the workspace (plain stores, 128-byte row
+    // segments per wave instruction: float atomics run at ~1.3 TB/s chip-wide, stores at ~6); the slabs are summed,
+    // and bias / mask / statistics / store applied, by conv_splitk_finish.
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
         for (int i = 0; i < 16; ++i) {
           const long long m = m0 + wm * (BM / WM) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
           const int c = n0 + wn * (BN / WN) + b * 32 + lr;
-          if (m < p.M && c < p.Cout) unsafeAtomicAdd(&p.ws[(size_t)m * p.Cout + c], acc[a][b][i]);
+          if (m < p.M && c < p.Cout) p.ws[((size_t)ks_i * p.M + m) * p.Cout + c] = acc[a][b][i];
         }
     return;
   }
@@ -403,15 +409,22 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
   conv_epilogue<T, BM, BN>(p, m0, n0, bm_i, sC, CSTR, sC + BM * CSTR);
 }
 
-// split-K finisher: the shared epilogue over the fp32 workspace (one block per 128 x 64 output tile)
-template <typename T>
+// split-K finisher: the shared epilogue over the sum of the K slices' fp32 slabs (one block per FM x 64 output tile;
+// FM = 32 where 128-row tiles would leave most of the chip idle: the 8x8 level has 4 x 16 of them)
+template <typename T, int FM>
 __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK p) {
   __shared__ float sred[4 * 8 * 16];
   const int nbn = (p.Cout + 63) / 64;
   const int bn_i = blockIdx.x % nbn, bm_i = blockIdx.x / nbn;
-  const long long m0 = (long long)bm_i * 128;
+  const long long m0 = (long long)bm_i * FM;
   const int n0 = bn_i * 64;
-  conv_epilogue<T, 128, 64, true>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sred);
+  conv_epilogue<T, FM, 64, true>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sred);
+}
+template <typename T> static void launch_splitk_finish(const ConvK& k, hipStream_t st) {
+  const int nbn = (k.Cout + 63) / 64;
+  const long long t128 = ((k.M + 127) / 128) * nbn;
+  if (t128 >= 512) hipLaunchKernelGGL((conv_splitk_finish<T, 128>), dim3((unsigned)t128), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((conv_splitk_finish<T, 32>), dim3((unsigned)(((k.M + 31) / 32) * nbn)), dim3(256), 0, st, k);
 }
 
 // =========================================================================================
@@ -604,7 +617,7 @@ __global__ __launch_bounds__(256) void conv_dma(const ConvK p) {
         for (int i = 0; i < 16; ++i) {
           const long long m = m0 + wm * (BM / WM) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
           const int c = n0 + wn * (BN / WN) + b * 32 + lr;
-          if (m < p.M && c < p.Cout) unsafeAtomicAdd(&p.ws[(size_t)m * p.Cout + c], acc[a][b][i]);
+          if (m < p.M && c < p.Cout) p.ws[((size_t)ks_i * p.M + m) * p.Cout + c] = acc[a][b][i];
         }
     return;
   }
@@ -620,6 +633,239 @@ __global__ __launch_bounds__(256) void conv_dma(const ConvK p) {
       }
   __syncthreads();
   conv_epilogue<T, BM, BN>(p, m0, n0, bm_i, sC, CSTR, sC + BM * CSTR);
+}
+
+// =========================================================================================
+// conv_dmap<BM,BN>: conv_dma with (a) a K iteration whose per-stage cost is one v_add per DMA instruction - everything
+// that depends on the tap (zero-padding validity, source offset) is recomputed only when the tap changes, which
+// requires every segment's C to be a multiple of 64 (a stage = 2 units of 32 channels never straddles a tap) -,
+// (b) 64x64 wave tiles (one LDS fragment read per MFMA instead of 1.5) and (c) a software pipeline across the stage
+// barrier: the fragments of k-step 0 of stage s+1 are read while the last MFMAs of stage s execute, so with one wave
+// per SIMD the LDS latency is not exposed after every barrier.  Three stage buffers:
+//   iteration s, k-steps 0..2 : read fragments of k-step kk+1, MFMA k-step kk
+//   k-step 3                  : vmcnt(PER_STAGE) [stage s+1 landed] ; lgkmcnt(0) [my reads of stage s done] ; s_barrier ;
+//                               DMA stage s+3 into the buffer of stage s ; read fragments (s+1, 0) ; MFMA k-step 3
+template <int BM, int BN, int ROWB>
+__global__ __launch_bounds__(256) void conv_dmap(const ConvK p) {
+  typedef bf16_t T;
+  // a stage = 64 channels, 4 k-steps of 16.  ROWB = 128: one LDS image [rows][128 B], every DMA row a full line;
+  // ROWB = 64: two sub-images [2][rows][64 B] (32 channels each)
+  constexpr int NBUF = 3, KS = 4;
+  constexpr int NSUB = 128 / ROWB, SPR = ROWB / 16, RPI = 1024 / ROWB;      // sub-images, 16-B slots per row, rows per DMA instruction
+  constexpr int SW = (ROWB == 64) ? 2 : 1;                                  // swizzle: slot = piece ^ ((row >> SW) & (SPR - 1))
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int AI = BM / (4 * RPI), BI = BN / (4 * RPI);                   // DMA instructions per wave per sub-image
+  constexpr int PER_STAGE = NSUB * (AI + BI);
+  constexpr int WN = 2, WM = 2;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int CSTR = BN + 4;
+  constexpr unsigned OOB = 0x80000000u;             // stays out of range after the per-stage chunk offset is added
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sC = reinterpret_cast<float*>(smem);
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bn_i = vid % p.nbn;
+  const int bm_i = (vid / p.nbn) % p.nbm;
+  const int ks_i = vid / (p.nbn * p.nbm);
+  const long long m0 = (long long)bm_i * BM;
+  const int n0 = bn_i * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int HW = p.H * p.W;
+
+  // LDS image: [row][8 slots of 16 B]; slot = piece ^ ((row >> 1) & 7) makes the ds_read_b128 fragment reads
+  // conflict-free (the 16-lane groups of a read see 8 even and 8 odd rows with 8 distinct slots each); the permutation
+  // is applied to the per-lane SOURCE piece within the row's own 128-byte line, so every DMA row is one full line
+  const int lrow = lane / SPR, lslot = lane % SPR;
+  int an[AI], ah[AI], aw[AI], aqv[AI];
+  bool av[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = (wid * AI + i) * RPI + lrow;
+    const long long m = m0 + row;
+    av[i] = m < p.M;
+    const int mm = av[i] ? (int)m : 0;
+    const int n = mm / HW, rem = mm - n * HW, h = rem / p.W;
+    an[i] = n; ah[i] = h * p.stride; aw[i] = (rem - h * p.W) * p.stride;
+    aqv[i] = (lslot ^ ((row >> SW) & (SPR - 1))) * 8;
+  }
+  int brow[BI], bqv[BI];
+  bool bv[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int row = (wid * BI + j) * RPI + lrow;
+    brow[j] = row; bv[j] = (n0 + row) < p.Cout;
+    bqv[j] = (lslot ^ ((row >> SW) & (SPR - 1))) * 8;
+  }
+
+  // iteration state: (segment, tap, chunk) scalars + per-tap byte offsets of this lane's DMA sources
+  int u_seg = 0, u_tap = 0, u_chunk = 0;
+  int s_taps = 1, s_nchunk = 1, s_C = 64, s_Ws = 1, s_dil = 1;      // s_nchunk: 64-channel stages per tap
+  unsigned sHL = 0, sWL = 0;
+  int abase[AI];
+  unsigned atap[AI], btap[BI];
+  __amdgpu_buffer_rsrc_t rx = make_rsrc(p.seg[0].x, p.seg[0].xbytes), rw = make_rsrc(p.seg[0].w, p.seg[0].wbytes);
+  auto enter_segment = [&]() {
+    const SegK sg = p.seg[u_seg];
+    rx = make_rsrc(sg.x, sg.xbytes); rw = make_rsrc(sg.w, sg.wbytes);
+    s_taps = sg.taps; s_nchunk = sg.nchunk >> 1; s_C = sg.C; s_Ws = sg.Ws; s_dil = sg.dil;
+    sHL = (unsigned)(sg.Hs << sg.up); sWL = (unsigned)(sg.Ws << sg.up);
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      abase[i] = ((an[i] * sg.Hs + (ah[i] >> sg.up)) * sg.Ws + (aw[i] >> sg.up)) * sg.C + aqv[i];
+  };
+  auto enter_tap = [&]() {
+    int dh = 0, dw = 0;
+    if (s_taps == 9) {
+      const int t3 = (u_tap >= 6) ? 2 : (u_tap >= 3) ? 1 : 0;
+      dh = (t3 - 1) * s_dil; dw = (u_tap - 3 * t3 - 1) * s_dil;
+    }
+    const int ex = (dh * s_Ws + dw) * s_C;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const bool ok = av[i] && (unsigned)(ah[i] + dh) < sHL && (unsigned)(aw[i] + dw) < sWL;
+      atap[i] = ok ? (unsigned)((abase[i] + ex) * 2) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j)
+      btap[j] = bv[j] ? (unsigned)(((u_tap * p.Cout + n0 + brow[j]) * s_C + bqv[j]) * 2) : OOB;
+  };
+  int st_left = 0;                                      // real stages of this block not yet issued
+  // DMA the next stage of the K range into `buf` and step the iteration state; past the end of the range the
+  // instructions still issue (out-of-range source => zeros) so that the vmcnt arithmetic stays uniform
+  // (the explicit (unsigned) casts on the offsets are load-bearing: without them hipcc 7.2 silently drops the HOST stub
+  //  of this kernel template - the implicit unsigned->int conversion of a template-dependent array element in a builtin
+  //  argument fails substitution on the host pass only)
+  auto issue_next = [&](int buf) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + A_BYTES;
+    const bool live = st_left > 0;
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+      const unsigned co = (unsigned)(u_chunk * 128 + u * ROWB);            // 64 channels * 2 bytes per stage
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sA + (u * BM + (wid * AI + i) * RPI) * ROWB), 16,
+                                                 (unsigned)(live ? atap[i] + co : OOB), 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < BI; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_p)(sB + (u * BN + (wid * BI + j) * RPI) * ROWB), 16,
+                                                 (unsigned)(live ? btap[j] + co : OOB), 0, 0, 0);
+    }
+    if (live && --st_left > 0) {
+      u_chunk += 1;
+      if (u_chunk >= s_nchunk) {
+        u_chunk = 0;
+        if (++u_tap == s_taps) { u_tap = 0; ++u_seg; enter_segment(); }
+        enter_tap();
+      }
+    }
+  };
+
+  const int wm = wid / WN, wn = wid % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int xs = (lr >> SW) & (SPR - 1);                          // swizzle term of this lane's fragment rows (tile offsets are multiples of 32)
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  const unsigned fa_off = (wm * (BM / WM) + lr) * ROWB, fb_off = A_BYTES + (wn * (BN / WN) + lr) * ROWB;
+  auto load_frags = [&](int buf, int kk, bf16x8* fa, bf16x8* fb) {
+    const unsigned char* sS = smem + buf * STAGE;
+    const int u = (ROWB == 64) ? (kk >> 1) : 0;
+    const int piece = (ROWB == 64) ? ((kk & 1) * 2 + lh) : (kk * 2 + lh);
+    const int slot = (piece ^ xs) * 16;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(sS + fa_off + (u * BM + a * 32) * ROWB + slot);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(sS + fb_off + (u * BN + b * 32) * ROWB + slot);
+  };
+
+  const int nstages_all = p.nunits / 2;
+  const int st_begin = ks_i * p.stages_per_split;
+  int nstages = st_begin + p.stages_per_split;
+  if (nstages > nstages_all) nstages = nstages_all;
+  const int nst = nstages - st_begin;
+  {
+    const int unit = st_begin * 2;
+    int sgi = 0;
+    while (sgi + 1 < p.nseg && unit >= p.seg[sgi + 1].ubegin) ++sgi;
+    const int loc = unit - p.seg[sgi].ubegin;
+    u_seg = sgi; u_tap = loc / p.seg[sgi].nchunk; u_chunk = (loc - u_tap * p.seg[sgi].nchunk) >> 1;
+  }
+  st_left = nst;
+  enter_segment(); enter_tap();
+  issue_next(0);
+  issue_next(1);
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STAGE) : "memory");
+  __builtin_amdgcn_s_barrier();
+  issue_next(2);
+  bf16x8 fa[2][TM], fb[2][TN];
+  load_frags(0, 0, fa[0], fb[0]);
+  int buf = 0;
+  for (int st = 0; st < nst; ++st) {
+    int nxt = buf + 1; if (nxt == NBUF) nxt = 0;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int cur = kk & 1;
+      if (kk < KS - 1) {
+        load_frags(buf, kk + 1, fa[cur ^ 1], fb[cur ^ 1]);
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" :: "n"(PER_STAGE) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_next(buf);
+        load_frags(nxt, 0, fa[cur ^ 1], fb[cur ^ 1]);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
+    }
+    buf = nxt;
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  if (p.ksplit > 1) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long long m = m0 + wm * (BM / WM) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+          const int c = n0 + wn * (BN / WN) + b * 32 + lr;
+          if (m < p.M && c < p.Cout) p.ws[((size_t)ks_i * p.M + m) * p.Cout + c] = acc[a][b][i];
+        }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = wm * (BM / WM) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        const int col = wn * (BN / WN) + b * 32 + lr;
+        sC[row * CSTR + col] = acc[a][b][i];
+      }
+  __syncthreads();
+  conv_epilogue<T, BM, BN>(p, m0, n0, bm_i, sC, CSTR, sC + BM * CSTR);
+}
+
+
+
+template <int BM, int BN> static constexpr int conv_dmap_smem() {
+  constexpr int STAGE = 2 * (BM + BN) * 64;
+  constexpr int EPI = BM * (BN + 4) * 4 + 4 * (BN / 8) * 16 * 4;
+  return ((3 * STAGE > EPI ? 3 * STAGE : EPI) + 15) / 16 * 16;
 }
 
 template <int BM, int BN> static constexpr int conv_dma_base() {
@@ -644,7 +890,7 @@ template <typename T, int BM, int BN> static int launch_conv(const ConvK& k, int
   hipLaunchKernelGGL((conv_igemm<T, BM, BN>), dim3(nbm * k.nbn * k.ksplit), dim3(256), smem_now, st, k);
   RUA_LAUNCH_CHECK("conv_igemm");
   if (k.ksplit > 1) {
-    hipLaunchKernelGGL((conv_splitk_finish<T>), dim3(nbm * ((k.Cout + 63) / 64)), dim3(256), 0, st, k);
+    launch_splitk_finish<T>(k, st);
     RUA_LAUNCH_CHECK("conv_splitk_finish");
   }
   return RUA_OK;
@@ -652,12 +898,14 @@ template <typename T, int BM, int BN> static int launch_conv(const ConvK& k, int
 
 // split-K factor: only when the output grid cannot fill the chip and the K loop is long
 static int pick_ksplit(long long tiles, int nstages, long long M, int Cout, size_t ws_bytes) {
-  if (ws_bytes < (size_t)M * Cout * sizeof(float)) return 1;
+  const long long slabs = (long long)(ws_bytes / ((size_t)M * Cout * sizeof(float)));     // one fp32 slab per K slice
+  if (slabs < 2) return 1;
   if (tiles >= 256 || nstages < 8) return 1;
   long long want = (512 + tiles - 1) / tiles;
   long long cap = nstages / 4;
   if (want > cap) want = cap;
   if (want > 32) want = 32;
+  if (want > slabs) want = slabs;
   return want < 2 ? 1 : (int)want;
 }
 
@@ -710,10 +958,36 @@ template <int BM, int BN> static int launch_conv_dma(const ConvK& k, int nbm, hi
   hipLaunchKernelGGL((conv_dma<BM, BN>), dim3(nbm * k.nbn * k.ksplit), dim3(256), smem_now, st, k);
   RUA_LAUNCH_CHECK("conv_dma");
   if (k.ksplit > 1) {
-    hipLaunchKernelGGL((conv_splitk_finish<bf16_t>), dim3(nbm * ((k.Cout + 63) / 64)), dim3(256), 0, st, k);
+    launch_splitk_finish<bf16_t>(k, st);
     RUA_LAUNCH_CHECK("conv_splitk_finish");
   }
   return RUA_OK;
+}
+
+template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dmap<BM, BN, ROWB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              conv_dmap_smem<BM, BN>());
+    attr_set = true;
+  }
+  constexpr int smem = conv_dmap_smem<BM, BN>();
+  hipLaunchKernelGGL((conv_dmap<BM, BN, ROWB>), dim3(k.nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
+  RUA_LAUNCH_CHECK("conv_dmap");
+  if (k.ksplit > 1) {
+    launch_splitk_finish<bf16_t>(k, st);
+    RUA_LAUNCH_CHECK("conv_splitk_finish");
+  }
+  return RUA_OK;
+}
+
+// conv_dmap eligibility: bf16, wide outputs, every segment a whole number of 64-channel stages
+static bool pick_dmap(const rua_conv_desc* d) {
+  static const int mode = getenv("RUA_CONV_DMAP") ? atoi(getenv("RUA_CONV_DMAP")) : 1;      // 0: off (experiments)
+  if (!mode || d->dtype != RUA_BF16 || d->Cout < 128) return false;
+  for (int s_ = 0; s_ < d->nseg; ++s_)
+    if (d->seg[s_].C % 64 != 0) return false;
+  return true;
 }
 
 static int dispatch_conv_dma(const ConvK& k, int bm, int bn, int nbm, hipStream_t st) {
@@ -775,6 +1049,30 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.stats = d->stats; k.stats_mode = d->stats_mode;
   k.stats_R = d->stats_replicas < 1 ? 1 : d->stats_replicas;
   RUA_CHECK_ARG((k.stats_R & (k.stats_R - 1)) == 0, "rua_conv_fwd: stats_replicas must be a power of two");
+  hipStream_t st = (hipStream_t)stream;
+  if (pick_dmap(d)) {
+    // 128 x 128 tiles; split K until the grid covers the chip once (every level of the reference network then runs
+    // 256 blocks of >= 18 stages: one block per CU, no tail)
+    static const int target = env_int("RUA_DMAP_TARGET") > 0 ? env_int("RUA_DMAP_TARGET") : 256;
+    k.nbn = (d->Cout + 127) / 128;
+    k.nbm = (int)((k.M + 127) / 128);
+    const int nstages = units / 2;
+    const long long tiles = (long long)k.nbm * k.nbn;
+    int want = 1;
+    const long long slabs = d->workspace ? (long long)((size_t)d->workspace_bytes / ((size_t)k.M * d->Cout * sizeof(float))) : 0;
+    if (slabs >= 2 && tiles < target) {
+      want = (int)((target + tiles - 1) / tiles);
+      if (want > nstages / 4) want = nstages / 4;
+      if (want > 32) want = 32;
+      if (want > slabs) want = (int)slabs;
+      if (want < 1) want = 1;
+    }
+    k.ws = (float*)d->workspace;
+    k.stages_per_split = (nstages + want - 1) / want;
+    k.ksplit = (nstages + k.stages_per_split - 1) / k.stages_per_split;
+    static const int rowb = env_int("RUA_DMAP_ROWB") == 128 ? 128 : 64;
+    return rowb == 128 ? launch_conv_dmap<128, 128, 128>(k, st) : launch_conv_dmap<128, 128, 64>(k, st);
+  }
   const int bn = pick_bn(d, k.M);
   int bm = pick_bm(d, k.M, bn);
   k.nbn = (d->Cout + bn - 1) / bn;
@@ -785,7 +1083,6 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.ksplit = (d->workspace && bm == 128) ? pick_ksplit((long long)nbm * k.nbn, nstages, k.M, d->Cout, (size_t)d->workspace_bytes) : 1;
   k.stages_per_split = (nstages + k.ksplit - 1) / k.ksplit;
   k.ksplit = (nstages + k.stages_per_split - 1) / k.stages_per_split;
-  hipStream_t st = (hipStream_t)stream;
   // Kernel choice (measured per level, scratch/bench_conv.py): the LDS-DMA kernel wins where K is long and the grid is
   // small (Cout >= 128: 5-12 %); the register-staged kernel wins on the two top levels (short K, occupancy-bound) and,
   // with 128-wide tiles, on the very long K of the multi-branch convs at Cout >= 256.
@@ -1257,14 +1554,18 @@ extern "C" int64_t rua_conv_workspace_bytes(const rua_conv_desc* d) {
 
 extern "C" int rua_conv_tile_bn(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
+  if (pick_dmap(d)) return 128;
   return pick_bn(d, (long long)d->N * d->H * d->W);
 }
-extern "C" int rua_conv_kernel_id(const rua_conv_desc* d) {   // 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA)
+// 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA), 2: conv_dmap (LDS-DMA, pipelined across the stage barrier)
+extern "C" int rua_conv_kernel_id(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
+  if (pick_dmap(d)) return 2;
   return pick_dma(d, pick_bn(d, (long long)d->N * d->H * d->W)) ? 1 : 0;
 }
 extern "C" int rua_conv_tile_bm(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
+  if (pick_dmap(d)) return 128;
   const long long M = (long long)d->N * d->H * d->W;
   return pick_bm(d, M, pick_bn(d, M));
 }

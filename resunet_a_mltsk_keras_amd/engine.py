@@ -981,7 +981,7 @@ class Engine:
         self.wprep_items = torch.from_numpy(np.frombuffer(items.tobytes(), dtype=np.uint8).copy()).to(self.dev)
         self.wprep_n, self.wprep_max = len(rows), mx
         self.stats_arena = torch.zeros(1 << 20, dtype=torch.float64, device=self.dev)
-        # one split-K workspace (kept zero) and one weight-gradient partial scratch per lane: branches run concurrently
+        # one split-K slab workspace and one weight-gradient partial scratch per lane: branches run concurrently
         self.workspaces = [torch.zeros(8 << 20, dtype=torch.float32, device=self.dev) for _ in range(4)]
         self.scratches = [torch.zeros(8 << 20, dtype=torch.float32, device=self.dev) for _ in range(4)]
         self.workspace, self.scratch = self.workspaces[0], self.scratches[0]
