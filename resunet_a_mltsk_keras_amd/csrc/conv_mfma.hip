@@ -53,7 +53,8 @@ template <typename T, int BM, int BN> __host__ __device__ constexpr int conv_sme
 // statistics (fp32 partials -> wave shuffles -> LDS -> one fp64 atomic per channel and block), 16-byte stores.
 // SLABS: `src` is the first of p.ksplit fp32 slabs (stride M*Cout floats) whose sum is the tile (split-K finisher).
 template <typename T, int BM, int BN, bool SLABS = false>
-__device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int n0, int bm_i, const float* src, int sstride, float* sred) {
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int n0, int bm_i, const float* src, int sstride, float* sred,
+                                              const int* rowtab = nullptr, int nrows = BM) {
   constexpr int CG = BN / 8;
   constexpr int ROWS_PP = 256 / CG;
   constexpr int EP = BM / ROWS_PP;
@@ -82,11 +83,44 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
     }
   }
   const bool plain_out = (p.out_stride == 1 && p.OH == p.H && p.OW == p.W);
+  // pass 1: addresses, and ALL global loads of this thread's pieces (aux, old output) issued back to back - one exposed
+  // memory latency per thread instead of one per piece (the pieces are independent; a load-use pair per loop iteration
+  // serialised them: 4-6 dependent HBM round trips per thread)
+  unsigned ooff[EP];                                 // element offsets (tensors are < 2 GiB: checked by the launcher)
+  int mrow[EP];
+  constexpr int NV = sizeof(T) == 2 ? 1 : 2;         // 16-byte vectors per 8-channel piece; kept RAW here so that no
+  uint4 araw[EP][NV], oraw[EP][NV];                 // unpack (= use) sits between the loads
 #pragma unroll
   for (int e = 0; e < EP; ++e) {
     const int row = r0 + e * ROWS_PP;
-    const long long m = m0 + row;
-    if (m < p.M && cok) {
+    long long m = m0 + row;
+    if (rowtab) m = (row < nrows) ? (long long)rowtab[row] : -1;      // tile row -> pixel table (lattice tiles of conv_halo)
+    if (!(m >= 0 && m < p.M && cok)) m = -1;
+    mrow[e] = (int)m;
+    ooff[e] = 0;
+    if (m >= 0) {
+      if (plain_out) {
+        ooff[e] = (unsigned)m * p.Cout + co;
+      } else {
+        const int mm = (int)m;
+        const int n = mm / HW, rem = mm - n * HW, h = rem / p.W, w = rem - h * p.W;
+        ooff[e] = (unsigned)(((n * p.OH + h * p.out_stride) * p.OW + w * p.out_stride) * p.Cout + co);
+      }
+      if (p.aux_mode != 0) {
+#pragma unroll
+        for (int v_ = 0; v_ < NV; ++v_) araw[e][v_] = ldg16(p.aux + ((size_t)m * p.Cout + co) * sizeof(T) + v_ * 16);
+      }
+      if (p.accumulate) {
+#pragma unroll
+        for (int v_ = 0; v_ < NV; ++v_) oraw[e][v_] = ldg16(p.y + (size_t)ooff[e] * sizeof(T) + v_ * 16);
+      }
+    }
+  }
+  // pass 2: arithmetic, statistics, stores
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    const int row = r0 + e * ROWS_PP;
+    if (mrow[e] >= 0) {
       float v[8];
       float4 t0 = *reinterpret_cast<const float4*>(&src[(size_t)row * sstride + cg * 8]);
       float4 t1 = *reinterpret_cast<const float4*>(&src[(size_t)row * sstride + cg * 8 + 4]);
@@ -101,30 +135,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
       v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += bias8[j];
-      size_t ooff;
-      if (plain_out) {
-        ooff = (size_t)m * p.Cout + co;
-      } else {
-        const int mm = (int)m;
-        const int n = mm / HW, rem = mm - n * HW, h = rem / p.W, w = rem - h * p.W;
-        ooff = ((size_t)(n * p.OH + h * p.out_stride) * p.OW + w * p.out_stride) * p.Cout + co;
-      }
-      if (p.accumulate) {
-        float o[8];
-        load8<T>(p.y, ooff, o);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += o[j];
-      }
       float a8[8];
+      if (p.accumulate) {
+        float o8[8];
+#pragma unroll
+        for (int v_ = 0; v_ < NV; ++v_) ET<T>::unpack(oraw[e][v_], o8 + v_ * 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += o8[j];
+      }
       if (p.aux_mode != 0) {
-        load8<T>(p.aux, (size_t)m * p.Cout + co, a8);
-        if (p.aux_mode == 1) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += a8[j];
-        } else if (p.aux_mode == 2) {
+        for (int v_ = 0; v_ < NV; ++v_) ET<T>::unpack(araw[e][v_], a8 + v_ * 4);
+      }
+      if (p.aux_mode == 1) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (fmaf(ms8[j], a8[j], mt8[j]) > 0.f) ? v[j] : 0.f;
-        }
+        for (int j = 0; j < 8; ++j) v[j] += a8[j];
+      } else if (p.aux_mode == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (fmaf(ms8[j], a8[j], mt8[j]) > 0.f) ? v[j] : 0.f;
       }
       if (p.out_relu) {
 #pragma unroll
@@ -137,7 +165,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], a8[j], s2[j]); }
       }
-      store8<T>(p.y, ooff, v);
+      store8<T>(p.y, ooff[e], v);
     }
   }
   if (p.stats_mode != 0) {
@@ -874,6 +902,151 @@ template <int BM, int BN> static constexpr int conv_dma_base() {
   return ((3 * STAGE + 1024 > EPI ? 3 * STAGE + 1024 : EPI) + 15) / 16 * 16;
 }
 
+// =========================================================================================
+// conv_halo<C>: 3x3 dilated convolution with C = Cout in {32} (the top level), bf16.  The implicit-GEMM kernels re-stage the
+// A tile from L2 for every tap (9 x the bytes; measured: they run at the L2 gather rate, not at MFMA or HBM rate).  Here a
+// block loads the input ONCE with its halo and serves all nine taps from LDS.  Dilation d is handled by lattice
+// decomposition: the pixels with y = ry (mod d), x = rx (mod d) form a dense grid on which the dilated conv IS a plain
+// 3x3 conv, so a tile is a TH x TW rectangle of ONE residue class, its halo the (TH+2) x (TW+2) lattice points around it
+// (64-byte pixel vectors gathered at stride d; a block takes NS such sub-tiles so that small lattices - d = 15, 31 -
+// still fill 8..12 MFMA row tiles).  No barrier inside the K loop: one DMA phase, one barrier, 9 taps x C/16 k-steps of
+// MFMAs whose A fragments are LDS reads at (row + tap offset) and whose B fragments (all 9 taps) live in registers.
+// Overlap of load / compute / epilogue comes from 2-3 co-resident blocks per CU.
+struct HaloK {
+  ConvK c;
+  int d, TH, TW, PT, NS, HPW, HP, nty, ntx, total_sub, rows;     // PT: slots per sub-tile (multiple of 32), rows = NS * PT
+  unsigned mHP, mHPW, mPT, mTW;                                  // ceil(2^32 / divisor): x / dv == umulhi(x, m) for x, dv < 2^16, dv > 1
+};
+__device__ __forceinline__ int fdiv(int x, unsigned m, int dv) { return dv == 1 ? x : (int)__umulhi((unsigned)x, m); }
+
+template <int C, int MAXMT>                           // MAXMT: MFMA row tiles per wave (rows <= MAXMT * 128)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXMT == 2 ? 4 : 3, MAXMT == 2 ? 4 : 3)))
+void conv_halo(const HaloK q) {
+  typedef bf16_t T;
+  static_assert(C == 32, "conv_halo: C = Cout = 32");
+  constexpr int ROWB = C * 2, SPR = ROWB / 16;        // bytes per LDS pixel row, 16-B slots per row
+  constexpr int CSTR = C + 4;
+  constexpr int KST = C / 16;                         // k-steps per tap
+  const ConvK& p = q.c;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sC = reinterpret_cast<float*>(smem);         // aliases the halo images after the MFMA phase
+  // fixed carve-up behind the halo / epilogue area (sizes from the launcher): row->pixel table, row->LDS-row table, sub-tile records
+  const int area = q.rows * CSTR * 4 > ((q.NS * q.HP * ROWB + 1023) / 1024) * 1024 ? q.rows * CSTR * 4 : ((q.NS * q.HP * ROWB + 1023) / 1024) * 1024;
+  int* rowtab = reinterpret_cast<int*>(smem + area);
+  int* r0tab = rowtab + q.rows;
+  int* subrec = r0tab + q.rows;                       // [NS][4]: n, y0, x0, valid   (halo origin in image coordinates)
+  float* sred = reinterpret_cast<float*>(subrec + 4 * 12);
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int H = p.H, W = p.W, d = q.d;
+
+  if (tid < q.NS) {
+    int t = vid * q.NS + tid;
+    const int ok = t < q.total_sub;
+    if (!ok) t = 0;
+    const int rx = t % d; t /= d;
+    const int tx = t % q.ntx; t /= q.ntx;
+    const int ry = t % d; t /= d;
+    const int ty = t % q.nty; const int n = t / q.nty;
+    subrec[tid * 4 + 0] = n;
+    subrec[tid * 4 + 1] = ry + (ty * q.TH - 1) * d;
+    subrec[tid * 4 + 2] = rx + (tx * q.TW - 1) * d;
+    subrec[tid * 4 + 3] = ok;
+  }
+  __syncthreads();
+
+  // ---- tables: tile row m -> output pixel (or -1) and -> LDS row of its tap (0,0) ---------------------------------
+  for (int m = tid; m < q.rows; m += 256) {
+    const int s_ = fdiv(m, q.mPT, q.PT), qq = m - s_ * q.PT;
+    const int i = fdiv(qq, q.mTW, q.TW), j = qq - i * q.TW;
+    const int y = subrec[s_ * 4 + 1] + (i + 1) * d, x = subrec[s_ * 4 + 2] + (j + 1) * d;
+    const bool ok = subrec[s_ * 4 + 3] && i < q.TH && y < H && x < W;
+    rowtab[m] = ok ? (subrec[s_ * 4 + 0] * H + y) * W + x : -1;
+    r0tab[m] = s_ * q.HP + (i < q.TH ? i : 0) * q.HPW + j;
+  }
+
+  // ---- weights: every wave keeps the B fragments of all 9 taps in registers -------------------------------------------
+  const int lr = lane & 31, lh = lane >> 5;
+  bf16x8 fb[9][KST];
+  {
+    const unsigned char* wp = p.seg[0].w;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KST; ++ks)
+        fb[t][ks] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)(t * C + lr) * C + ks * 16 + lh * 8) * 2);
+  }
+
+  // ---- halo images: HBM/L2 -> LDS, one pass (lane-linear destination, swizzle on the source piece) ------------------
+  {
+    const __amdgpu_buffer_rsrc_t rx_ = make_rsrc(p.seg[0].x, p.seg[0].xbytes);
+    const int hrows = q.NS * q.HP;
+    const int ninst = (hrows * SPR + 63) / 64;                 // wave-instructions in total (64 pieces = 16 rows each)
+    for (int it = wid; it < ninst; it += 4) {
+      const int g = it * 64 + lane;
+      const int row = g / SPR, slot = g % SPR;
+      const int s_ = fdiv(row, q.mHP, q.HP), hp = row - s_ * q.HP;
+      const int hi = fdiv(hp, q.mHPW, q.HPW), hj = hp - hi * q.HPW;
+      unsigned off = 0x80000000u;
+      if (row < hrows) {
+        const int y = subrec[s_ * 4 + 1] + hi * d, x = subrec[s_ * 4 + 2] + hj * d;
+        if (subrec[s_ * 4 + 3] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+          off = (unsigned)((((subrec[s_ * 4 + 0] * H + y) * W + x) * C + ((slot ^ ((row >> 2) & (SPR - 1))) * 8)) * 2);
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_void_p)(smem + it * 1024), 16, off, 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- MFMA phase: this wave's row tiles wid, wid+4, wid+8 ------------------------------------------------------------
+  const int mtb = q.rows >> 5;
+  int r0[MAXMT];
+#pragma unroll
+  for (int a = 0; a < MAXMT; ++a) {
+    const int mt = wid + a * 4;
+    r0[a] = (mt < mtb) ? r0tab[mt * 32 + lr] : 0;
+  }
+  f32x16 acc[MAXMT];
+#pragma unroll
+  for (int a = 0; a < MAXMT; ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int toff = (t / 3) * q.HPW + (t % 3);
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      bf16x8 fa[MAXMT];
+#pragma unroll
+      for (int a = 0; a < MAXMT; ++a) {
+        const int row = r0[a] + toff;
+        fa[a] = *reinterpret_cast<const bf16x8*>(smem + row * ROWB + (((ks * 2 + lh) ^ ((row >> 2) & (SPR - 1))) * 16));
+      }
+#pragma unroll
+      for (int a = 0; a < MAXMT; ++a)          // unconditional (a branch around MFMAs makes hipcc shuttle the accumulators):
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[t][ks], acc[a], 0, 0, 0);     // a missing row tile computes garbage, never stored
+    }
+  }
+  __syncthreads();                                       // every wave is done with the halo images: reuse them as the fp32 tile
+#pragma unroll
+  for (int a = 0; a < MAXMT; ++a) {
+    const int mt = wid + a * 4;
+    if (mt < mtb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        sC[row * CSTR + lr] = acc[a][i];
+      }
+    }
+  }
+  __syncthreads();
+  conv_epilogue<T, MAXMT * 128, C>(p, 0, 0, vid, sC, CSTR, sred, rowtab, q.rows);
+}
+
 #define RUA_MAX_UNITS 1024
 template <typename T, int BM, int BN> static constexpr int conv_smem() { return conv_smem_base<T, BM, BN>() + RUA_MAX_UNITS * 16; }
 
@@ -981,6 +1154,70 @@ template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, 
   return RUA_OK;
 }
 
+// ---- conv_halo launcher -------------------------------------------------------------------------------------------------
+static bool pick_halo(const rua_conv_desc* d) {
+  static const int mode = getenv("RUA_CONV_HALO") ? atoi(getenv("RUA_CONV_HALO")) : 1;      // 0: off (experiments)
+  if (!mode || d->dtype != RUA_BF16 || d->nseg != 1) return false;
+  const rua_conv_seg& g = d->seg[0];
+  return g.taps == 9 && g.up_shift == 0 && g.C == 32 && d->Cout == 32 && d->stride == 1 && d->out_stride == 1 &&
+         d->OH == d->H && d->OW == d->W && g.Hs == d->H && g.Ws == d->W && d->H >= 16 && d->W >= 16 &&
+         (long long)d->N * d->H * d->W >= 65536;
+}
+static unsigned magic_div(int dv) { return dv <= 1 ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); }
+
+// lattice tile TH x TW (slots padded to a multiple of 32) and sub-tiles per block for an H x W map at dilation d:
+// minimise padded slots (MFMA waste) with a penalty for halo bytes; at most 384 rows and 40 KiB of halo images per block
+static void halo_tiling(int H, int W, int d, int* TH_, int* TW_, int* NS_) {
+  const int ny = (H + d - 1) / d, nx = (W + d - 1) / d;
+  double best = 1e30;
+  int bth = 1, btw = 1;
+  for (int th = 1; th <= ny && th <= 32; ++th)
+    for (int tw = 1; tw <= nx && tw <= 32; ++tw) {
+      const int pt = (th * tw + 31) / 32 * 32;
+      if (pt > 384 || (th + 2) * (tw + 2) * 64 > 40 * 1024) continue;
+      const double slots = (double)((ny + th - 1) / th) * ((nx + tw - 1) / tw) * pt;
+      const double halo = (double)(th + 2) * (tw + 2) / (th * tw);
+      const double cost = slots * (1.0 + 0.35 * (halo - 1.0));
+      if (cost < best) { best = cost; bth = th; btw = tw; }
+    }
+  const int pt = (bth * btw + 31) / 32 * 32;
+  int ns = 384 / pt;
+  while (ns > 1 && ns * (bth + 2) * (btw + 2) * 64 > 40 * 1024) --ns;
+  if (ns > 12) ns = 12;
+  *TH_ = bth; *TW_ = btw; *NS_ = ns < 1 ? 1 : ns;
+}
+
+static int launch_conv_halo(const ConvK& k, int dil, hipStream_t st) {
+  HaloK q;
+  q.c = k;
+  q.d = dil;
+  halo_tiling(k.H, k.W, dil, &q.TH, &q.TW, &q.NS);
+  q.PT = (q.TH * q.TW + 31) / 32 * 32;
+  q.HPW = q.TW + 2; q.HP = (q.TH + 2) * (q.TW + 2);
+  const int ny = (k.H + dil - 1) / dil, nx = (k.W + dil - 1) / dil;
+  q.nty = (ny + q.TH - 1) / q.TH; q.ntx = (nx + q.TW - 1) / q.TW;
+  const long long total = (long long)k.N * dil * dil * q.nty * q.ntx;
+  RUA_CHECK_ARG(total < (1ll << 30), "conv_halo: too many lattice tiles");
+  q.total_sub = (int)total;
+  q.rows = q.NS * q.PT;
+  q.mHP = magic_div(q.HP); q.mHPW = magic_div(q.HPW); q.mPT = magic_div(q.PT); q.mTW = magic_div(q.TW);
+  const int halo_bytes = (q.NS * q.HP * 64 + 1023) / 1024 * 1024;
+  const int epi_bytes = q.rows * 36 * 4;
+  const int area = epi_bytes > halo_bytes ? epi_bytes : halo_bytes;
+  const int smem = area + q.rows * 8 + 4 * 12 * 4 + 4 * 4 * 16 * 4;
+  const int blocks = (int)((total + q.NS - 1) / q.NS);
+  static bool attr2 = false, attr3 = false;
+  if (q.rows <= 256) {
+    if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr2 = true; }
+    hipLaunchKernelGGL((conv_halo<32, 2>), dim3(blocks), dim3(256), smem, st, q);
+  } else {
+    if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr3 = true; }
+    hipLaunchKernelGGL((conv_halo<32, 3>), dim3(blocks), dim3(256), smem, st, q);
+  }
+  RUA_LAUNCH_CHECK("conv_halo");
+  return RUA_OK;
+}
+
 // conv_dmap eligibility: bf16, wide outputs, every segment a whole number of 64-channel stages
 static bool pick_dmap(const rua_conv_desc* d) {
   static const int mode = getenv("RUA_CONV_DMAP") ? atoi(getenv("RUA_CONV_DMAP")) : 1;      // 0: off (experiments)
@@ -1050,6 +1287,10 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.stats_R = d->stats_replicas < 1 ? 1 : d->stats_replicas;
   RUA_CHECK_ARG((k.stats_R & (k.stats_R - 1)) == 0, "rua_conv_fwd: stats_replicas must be a power of two");
   hipStream_t st = (hipStream_t)stream;
+  if (pick_halo(d)) {
+    k.nbn = 1; k.nbm = 1; k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr;
+    return launch_conv_halo(k, d->seg[0].dil, st);
+  }
   if (pick_dmap(d)) {
     // 128 x 128 tiles; split K until the grid covers the chip once (every level of the reference network then runs
     // 256 blocks of >= 18 stages: one block per CU, no tail)
@@ -1557,9 +1798,11 @@ extern "C" int rua_conv_tile_bn(const rua_conv_desc* d) {
   if (pick_dmap(d)) return 128;
   return pick_bn(d, (long long)d->N * d->H * d->W);
 }
-// 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA), 2: conv_dmap (LDS-DMA, pipelined across the stage barrier)
+// 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA), 2: conv_dmap (LDS-DMA, pipelined across the stage barrier),
+// 3: conv_halo (input + halo resident in LDS, lattice tiles)
 extern "C" int rua_conv_kernel_id(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
+  if (pick_halo(d)) return 3;
   if (pick_dmap(d)) return 2;
   return pick_dma(d, pick_bn(d, (long long)d->N * d->H * d->W)) ? 1 : 0;
 }

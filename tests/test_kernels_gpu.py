@@ -599,3 +599,52 @@ def test_metrics_and_optimizers():
     torch.cuda.synchronize()
     e_th, _ = nv.sgd_step(th.astype(np.float64), g.astype(np.float64), np.zeros(n), 0.1)
     assert np.allclose(thd.cpu().numpy(), e_th, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("H,W,dil", [(256, 256, 1), (256, 256, 3), (256, 256, 15), (256, 256, 31), (272, 248, 3), (248, 272, 15)])
+@pytest.mark.parametrize("mode", ["residual_stats", "mask_accumulate_stats2"])
+def test_conv_halo_lattice_tiles(H, W, dil, mode):
+    """The top-level kernel (C = Cout = 32, bf16): input + halo resident in LDS, dilation by lattice decomposition.
+    Every dilation of the reference's ResBlocks, ragged maps (lattice tiles that overhang the image, residue classes of
+    unequal size), and both epilogue families (forward: bias + residual + sum/sum^2; data gradient: ReLU mask from
+    aux*scale+shift, accumulate into y, sum g / sum g*aux)."""
+    dt = L.RUA_BF16
+    rng = np.random.default_rng(H + dil)
+    lib = L.lib()
+    N, Cs, Cout = 1, 32, 32
+    x = rng.standard_normal((N, H, W, Cs)).astype(np.float32)
+    w = (rng.standard_normal((9, Cout, Cs)) / np.sqrt(9 * Cs)).astype(np.float32)
+    aux = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    y0 = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    sc = (0.5 + rng.random(Cout)).astype(np.float32); sh = (0.3 * rng.standard_normal(Cout)).astype(np.float32)
+    xd, wd, ad, bd = to_dev(x, dt), to_dev(w, dt), to_dev(aux, dt), torch.from_numpy(bias).to(dev())
+    scd, shd = torch.from_numpy(sc).to(dev()), torch.from_numpy(sh).to(dev())
+    y = to_dev(y0, dt)
+    R = 8
+    stats = torch.zeros(R * 2 * Cout, dtype=torch.float64, device=dev())
+    d = L.ConvDesc()
+    d.nseg = 1
+    s = d.seg[0]
+    s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = xd.data_ptr(), wd.data_ptr(), Cs, H, W, 0, dil, 9
+    d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cout, 1, dt
+    d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+    d.stats, d.stats_replicas = stats.data_ptr(), R
+    conv = ref_conv_nhwc(rnd(dt, x), rnd(dt, w), None, dil, 9).numpy()
+    a = rnd(dt, aux).double().numpy()
+    if mode == "residual_stats":
+        d.bias, d.aux, d.aux_mode, d.stats_mode = bd.data_ptr(), ad.data_ptr(), 1, 1
+        exp = conv + bias.astype(np.float64) + a
+        s2 = (exp ** 2).sum(axis=(0, 1, 2))
+    else:
+        d.aux, d.aux_mode, d.mscale, d.mshift, d.accumulate, d.stats_mode = ad.data_ptr(), 2, scd.data_ptr(), shd.data_ptr(), 1, 2
+        exp = (conv + rnd(dt, y0).double().numpy()) * ((a * sc + sh) > 0)
+        s2 = (exp * a).sum(axis=(0, 1, 2))
+    assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 3
+    lib.call("rua_conv_fwd", C.byref(d), stream())
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy()
+    assert rel_err(got, exp) < tol(dt)
+    st = stats.cpu().numpy().reshape(R, 2 * Cout).sum(0)
+    assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
+    assert rel_err(st[Cout:], s2) < 5 * tol(dt) + 1e-4
