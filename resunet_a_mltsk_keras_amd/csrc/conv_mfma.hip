@@ -54,7 +54,7 @@ template <typename T, int BM, int BN> __host__ __device__ constexpr int conv_sme
 // SLABS: `src` is the first of p.ksplit fp32 slabs (stride M*Cout floats) whose sum is the tile (split-K finisher).
 template <typename T, int BM, int BN, bool SLABS = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int n0, int bm_i, const float* src, int sstride, float* sred,
-                                              const int* rowtab = nullptr, int nrows = BM) {
+                                              const int* rowtab = nullptr, int nrows = BM, float* carry = nullptr, bool last = true) {
   constexpr int CG = BN / 8;
   constexpr int ROWS_PP = 256 / CG;
   constexpr int EP = BM / ROWS_PP;
@@ -66,6 +66,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
   float s1[8], s2[8], bias8[8], ms8[8], mt8[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; bias8[j] = 0.f; ms8[j] = 1.f; mt8[j] = 0.f; }
+  if (carry) {                                         // statistics partials carried over several calls of one block
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = carry[j]; s2[j] = carry[8 + j]; }
+  }
   if (cok) {
     if (p.bias) {
 #pragma unroll
@@ -168,7 +172,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
       store8<T>(p.y, ooff[e], v);
     }
   }
-  if (p.stats_mode != 0) {
+  if (carry) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { carry[j] = s1[j]; carry[8 + j] = s2[j]; }
+  }
+  if (p.stats_mode != 0 && last) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -183,7 +191,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
       const int g = tid / 16, k = tid % 16;
       const float t = sred[(0 * CG + g) * 16 + k] + sred[(1 * CG + g) * 16 + k] + sred[(2 * CG + g) * 16 + k] + sred[(3 * CG + g) * 16 + k];
       const int c = n0 + g * 8 + (k & 7);
-      if (c < p.Cout) atomicAdd(&p.stats[(size_t)(bm_i & (p.stats_R - 1)) * 2 * p.Cout + (k >> 3) * p.Cout + c], (double)t);
+      if (c < p.Cout) unsafeAtomicAdd(&p.stats[(size_t)(bm_i & (p.stats_R - 1)) * 2 * p.Cout + (k >> 3) * p.Cout + c], (double)t);
     }
   }
 }
@@ -931,7 +939,8 @@ void conv_halo(const HaloK q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sC = reinterpret_cast<float*>(smem);         // aliases the halo images after the MFMA phase
   // fixed carve-up behind the halo / epilogue area (sizes from the launcher): row->pixel table, row->LDS-row table, sub-tile records
-  const int area = q.rows * CSTR * 4 > ((q.NS * q.HP * ROWB + 1023) / 1024) * 1024 ? q.rows * CSTR * 4 : ((q.NS * q.HP * ROWB + 1023) / 1024) * 1024;
+  const int halo_b = ((q.NS * q.HP * ROWB + 1023) / 1024) * 1024;
+  const int area = 128 * CSTR * 4 > halo_b ? 128 * CSTR * 4 : halo_b;       // the fp32 tile is transposed 128 rows at a time
   int* rowtab = reinterpret_cast<int*>(smem + area);
   int* r0tab = rowtab + q.rows;
   int* subrec = r0tab + q.rows;                       // [NS][4]: n, y0, x0, valid   (halo origin in image coordinates)
@@ -1031,20 +1040,22 @@ void conv_halo(const HaloK q) {
         acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[t][ks], acc[a], 0, 0, 0);     // a missing row tile computes garbage, never stored
     }
   }
-  __syncthreads();                                       // every wave is done with the halo images: reuse them as the fp32 tile
+  // ---- epilogue, 128 rows (one row tile per wave) at a time: a small fp32 tile keeps LDS per block low (more blocks per CU) --
+  float carry[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) carry[j] = 0.f;
 #pragma unroll
   for (int a = 0; a < MAXMT; ++a) {
-    const int mt = wid + a * 4;
-    if (mt < mtb) {
+    __syncthreads();                                     // a == 0: every wave is done with the halo images; else: previous pass read
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-        sC[row * CSTR + lr] = acc[a][i];
-      }
+    for (int i = 0; i < 16; ++i) {
+      const int row = wid * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+      sC[row * CSTR + lr] = acc[a][i];
     }
+    __syncthreads();
+    // tile rows of pass a: row tile (wid + 4a) of wave wid sits at LDS rows wid*32.., i.e. tile row r <-> m = (a*4 + r/32)*32 + r%32
+    conv_epilogue<T, 128, C>(p, 0, 0, vid, sC, CSTR, sred, rowtab + a * 128, q.rows - a * 128, carry, a == MAXMT - 1);
   }
-  __syncthreads();
-  conv_epilogue<T, MAXMT * 128, C>(p, 0, 0, vid, sC, CSTR, sred, rowtab, q.rows);
 }
 
 #define RUA_MAX_UNITS 1024
@@ -1202,7 +1213,7 @@ static int launch_conv_halo(const ConvK& k, int dil, hipStream_t st) {
   q.rows = q.NS * q.PT;
   q.mHP = magic_div(q.HP); q.mHPW = magic_div(q.HPW); q.mPT = magic_div(q.PT); q.mTW = magic_div(q.TW);
   const int halo_bytes = (q.NS * q.HP * 64 + 1023) / 1024 * 1024;
-  const int epi_bytes = q.rows * 36 * 4;
+  const int epi_bytes = 128 * 36 * 4;
   const int area = epi_bytes > halo_bytes ? epi_bytes : halo_bytes;
   const int smem = area + q.rows * 8 + 4 * 12 * 4 + 4 * 4 * 16 * 4;
   const int blocks = (int)((total + q.NS - 1) / q.NS);

@@ -17,46 +17,44 @@ struct StatsK { const unsigned char* x; const unsigned char* g; const float* ms;
 
 template <typename T, int MODE>   // MODE 1: sum x, sum x^2 ; MODE 2: sum g*m, sum g*m*x
 __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
+  // CG (16-byte pieces per row) is a power of two <= 256, so thread t of every block owns column piece t % CG for the whole
+  // grid-stride sweep: partial sums stay in registers, 8 independent 16-byte loads in flight per thread, lanes that share
+  // a piece are folded with wave shuffles, the four waves through LDS, and ONE fp64 atomic per channel and block goes to
+  // replica (block % R).  Same-address fp64 atomics serialise at ~180 ns each (measured), so the launcher keeps the grid
+  // at <= 512 blocks and the caller sizes R for <= ~16 adds per address.
   constexpr int VEC = ET<T>::VEC;
-  __shared__ float sred[256 * 2 * VEC];
-  const int tid = threadIdx.x;
-  const int tx = tid % p.TX, ty = tid / p.TX;
-  const int cp = blockIdx.y * p.TX + tx;
+  __shared__ float sred[4 * 64 * 2 * VEC];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int CG = p.CG;
+  const int cp = tid & (CG - 1);
+  const int rpb = 256 / CG > 0 ? 256 / CG : 1;          // rows covered by one block per step (CG <= 256)
   float s1[VEC], s2[VEC], ms[VEC], mt[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; ms[j] = 1.f; mt[j] = 0.f; }
-  if (cp < p.CG) {
-    if (MODE == 2 && p.masked) {
+  if (MODE == 2 && p.masked) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { if (p.ms) ms[j] = p.ms[cp * VEC + j]; if (p.mt) mt[j] = p.mt[cp * VEC + j]; }
+    for (int j = 0; j < VEC; ++j) { if (p.ms) ms[j] = p.ms[cp * VEC + j]; if (p.mt) mt[j] = p.mt[cp * VEC + j]; }
+  }
+  const long long rstep = (long long)gridDim.x * rpb;
+  long long r = (long long)blockIdx.x * rpb + tid / CG;
+  constexpr int UN = (MODE == 1) ? 8 : 4;
+  for (; r + (UN - 1) * rstep < p.M; r += UN * rstep) {
+    uint4 q[UN], qg[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      q[u] = ldg16(p.x + ((size_t)(r + u * rstep) * CG + cp) * 16);
+      if (MODE == 2) qg[u] = ldg16(p.g + ((size_t)(r + u * rstep) * CG + cp) * 16);
     }
-    long long r = (long long)blockIdx.x * p.rows_per_block + ty;
-    long long rend = (long long)(blockIdx.x + 1) * p.rows_per_block;
-    if (rend > p.M) rend = p.M;
-    if (MODE == 1) {
-      // four independent 16-byte loads in flight per thread
-      for (; r + 3 * p.TY < rend; r += 4 * p.TY) {
-        uint4 q[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = ldg16(p.x + ((size_t)(r + u * p.TY) * p.CG + cp) * 16);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          float xv[VEC];
-          ET<T>::unpack(q[u], xv);
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) { s1[j] += xv[j]; s2[j] = fmaf(xv[j], xv[j], s2[j]); }
-        }
-      }
-    }
-    for (; r < rend; r += p.TY) {
+    for (int u = 0; u < UN; ++u) {
       float xv[VEC];
-      ET<T>::unpack(ldg16(p.x + ((size_t)r * p.CG + cp) * 16), xv);
+      ET<T>::unpack(q[u], xv);
       if (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { s1[j] += xv[j]; s2[j] = fmaf(xv[j], xv[j], s2[j]); }
       } else {
         float gv[VEC];
-        ET<T>::unpack(ldg16(p.g + ((size_t)r * p.CG + cp) * 16), gv);
+        ET<T>::unpack(qg[u], gv);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           const float m = (!p.masked || fmaf(ms[j], xv[j], mt[j]) > 0.f) ? gv[j] : 0.f;
@@ -65,28 +63,48 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
       }
     }
   }
+  for (; r < p.M; r += rstep) {
+    float xv[VEC];
+    ET<T>::unpack(ldg16(p.x + ((size_t)r * CG + cp) * 16), xv);
+    if (MODE == 1) {
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) { sred[(tid * 2) * VEC + j] = s1[j]; sred[(tid * 2 + 1) * VEC + j] = s2[j]; }
+      for (int j = 0; j < VEC; ++j) { s1[j] += xv[j]; s2[j] = fmaf(xv[j], xv[j], s2[j]); }
+    } else {
+      float gv[VEC];
+      ET<T>::unpack(ldg16(p.g + ((size_t)r * CG + cp) * 16), gv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float m = (!p.masked || fmaf(ms[j], xv[j], mt[j]) > 0.f) ? gv[j] : 0.f;
+        s1[j] += m; s2[j] = fmaf(m, xv[j], s2[j]);
+      }
+    }
+  }
+  // lanes l and l ^ o (o = CG, 2CG, .. < 64) hold the same piece
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    for (int o = CG; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+  }
+  const int lpw = CG < 64 ? CG : 64;                     // distinct pieces held by one wave
+  if (lane < lpw) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sred[((wid * 64 + lane) * 2) * VEC + j] = s1[j]; sred[((wid * 64 + lane) * 2 + 1) * VEC + j] = s2[j]; }
+  }
   __syncthreads();
-  // threads with ty == 0 fold the TY partials of their column piece (fixed order => deterministic per block)
-  if (ty == 0 && cp < p.CG) {
-    for (int k = 1; k < p.TY; ++k) {
+  double* st = p.stats + (size_t)(blockIdx.x & (p.R - 1)) * 2 * p.C;
+  for (int t = tid; t < CG * 2 * VEC; t += 256) {
+    const int cpi = t / (2 * VEC), k = t % (2 * VEC);     // piece, (which sum, channel in piece)
+    float acc = 0.f;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { s1[j] += sred[((k * p.TX + tx) * 2) * VEC + j]; s2[j] += sred[((k * p.TX + tx) * 2 + 1) * VEC + j]; }
-    }
-    double* st = p.stats + (size_t)(blockIdx.x & (p.R - 1)) * 2 * p.C;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      atomicAdd(&st[cp * VEC + j], (double)s1[j]);
-      atomicAdd(&st[p.C + cp * VEC + j], (double)s2[j]);
-    }
+    for (int w = 0; w < 4; ++w)                          // waves whose lane (cpi % 64) holds piece cpi
+      if (((w * 64 + (cpi & 63)) & (CG - 1)) == cpi) acc += sred[((w * 64 + (cpi & 63)) * 2) * VEC + k];
+    unsafeAtomicAdd(&st[(k / VEC) * p.C + cpi * VEC + (k % VEC)], (double)acc);
   }
 }
 
 extern "C" int rua_stats_replicas(int64_t blocks) {
   int r = 1;
-  while (r < 32 && (int64_t)r * 64 < blocks) r *= 2;     // keep <= ~64 blocks per replica address
-  return r;
+  while (r < 32 && (int64_t)r * 8 < blocks) r *= 2;      // <= ~8 adds per replica address up to the cap of 32 replicas:
+  return r;                                              // same-address fp64 atomics serialise at ~180 ns each
 }
 
 template <int MODE>
@@ -100,18 +118,16 @@ static int launch_stats(const void* g, const void* x, const float* ms, const flo
   StatsK k;
   k.x = (const unsigned char*)x; k.g = (const unsigned char*)g; k.ms = ms; k.mt = mt; k.masked = masked;
   k.M = M; k.C = C; k.CG = C / vec;
-  int tx = 1; while (tx * 2 <= k.CG && tx < 256) tx *= 2;
-  k.TX = tx; k.TY = 256 / tx;
-  const int gy = (k.CG + tx - 1) / tx;
-  int64_t target_blocks = 1024 / gy; if (target_blocks < 1) target_blocks = 1;
-  int64_t rpb = (M + target_blocks - 1) / target_blocks;
-  if (rpb < k.TY * 4) rpb = k.TY * 4;
-  k.rows_per_block = (int)rpb;
+  RUA_CHECK_ARG(k.CG <= 256 && (k.CG & (k.CG - 1)) == 0, "%s: C/%d = %d must be a power of two <= 256", name, vec, k.CG);
+  k.TX = k.CG; k.TY = 256 / k.CG; k.rows_per_block = 0;
   k.stats = stats; k.R = replicas;
-  const int gx = (int)((M + rpb - 1) / rpb);
+  const int64_t pieces = M * k.CG;
+  int64_t gx = pieces / (256 * 8);                       // >= 8 pieces per thread
+  if (gx > 512) gx = 512;
+  if (gx < 1) gx = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RUA_BF16) hipLaunchKernelGGL((col_stats_kernel<bf16_t, MODE>), dim3(gx, gy), dim3(256), 0, st, k);
-  else hipLaunchKernelGGL((col_stats_kernel<float, MODE>), dim3(gx, gy), dim3(256), 0, st, k);
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((col_stats_kernel<bf16_t, MODE>), dim3((unsigned)gx), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((col_stats_kernel<float, MODE>), dim3((unsigned)gx), dim3(256), 0, st, k);
   RUA_LAUNCH_CHECK(name);
   return RUA_OK;
 }

@@ -9,7 +9,7 @@ __device__ __forceinline__ void block_atomic_add(double* dst, float v, float* sh
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) sh[slot * 4 + wid] = v;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(dst, (double)sh[slot * 4 + 0] + (double)sh[slot * 4 + 1] + (double)sh[slot * 4 + 2] + (double)sh[slot * 4 + 3]);
+  if (threadIdx.x == 0) unsafeAtomicAdd(dst, (double)sh[slot * 4 + 0] + (double)sh[slot * 4 + 1] + (double)sh[slot * 4 + 2] + (double)sh[slot * 4 + 3]);
   __syncthreads();
 }
 
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void tanimoto_sums_kernel(const float* __restr
     const int c = threadIdx.x / 6, k = threadIdx.x % 6;
     if (c < C) {
       const double t = (double)sh[threadIdx.x] + (double)sh[48 + threadIdx.x] + (double)sh[96 + threadIdx.x] + (double)sh[144 + threadIdx.x];
-      atomicAdd(&sums[((size_t)n * C + c) * 6 + k], t);
+      unsafeAtomicAdd(&sums[((size_t)n * C + c) * 6 + k], t);
     }
   }
 }

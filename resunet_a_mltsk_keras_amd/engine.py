@@ -184,7 +184,7 @@ class Ten:
 def stats_replicas(blocks: int) -> int:
     """Mirror of rua_stats_replicas(): replicas of a statistics buffer fed by `blocks` workgroups."""
     r = 1
-    while r < 32 and r * 64 < blocks:
+    while r < 32 and r * 8 < blocks:
         r *= 2
     return r
 
@@ -381,8 +381,12 @@ class Graph:
     def Wd(self, dst):
         return 0 if self.dry else self.e.Wd.data_ptr() + dst * self.e.esize
 
+    def stat_blocks(self, x: Ten) -> int:
+        """Workgroups rua_col_stats / rua_col_stats2 launch for x (>= 8 pieces per thread, at most 512)."""
+        return max(1, min(512, x.M * (x.C // self.vec) // 2048))
+
     def col_stats(self, plan: Plan, x: Ten) -> Stat:
-        s = self.stat(x.C, min(1024, (x.M + 63) // 64))
+        s = self.stat(x.C, self.stat_blocks(x))
         plan.add("rua_col_stats", x.ptr, x.M, x.C, s.ptr, s.R, self.dt)
         return s
 
@@ -535,7 +539,7 @@ class Graph:
         for bi, (d, l, a) in enumerate(zip(dils, lay, a1)):
             F.set_lane(bi); self.cur_lane = bi
             y = self.like(x)
-            st = self.stat(nf, (cnt + 127) // 128) if tr else None
+            st = self.stat(nf, (cnt + 31) // 32) if tr else None
             self.conv(F, [(a, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st)
             o2, c2l = self.bn_fwd(F, y, [l[2]], True, st, cnt)
             c2 = c2l[0]
@@ -562,14 +566,14 @@ class Graph:
                 Bp.set_lane(bi); self.cur_lane = bi
                 self.wgrad(Bp, a_2, dO, l[3]["segs"][0]["off"], 1, d, 9)
                 g2 = self.like(x)
-                s2 = self.stat(nf, (cnt + 127) // 128)
+                s2 = self.stat(nf, (cnt + 31) // 32)
                 self.dgrad(Bp, dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
                 dy1 = self.like(x)
                 self.bn_bwd(Bp, [g2], [c2], [l[2]], [s2], y, dy1, 0, cnt)
                 # no bias gradient launch: the output of a BN backward sums to zero per channel, so d b1 == 0 exactly
                 self.wgrad(Bp, a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9)
                 g1 = g2                                    # g2 is dead after bn_bwd_apply: reuse its storage
-                s1 = self.stat(nf, (cnt + 127) // 128)
+                s1 = self.stat(nf, (cnt + 31) // 32)
                 self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
                 g1s.append(g1); s1s.append(s1)
             Bp.join(len(dils)); self.cur_lane = 0
@@ -583,7 +587,7 @@ class Graph:
         F, tr = self.fwd, self.training
         lay = self.Lconv([x.C], nf, 1)
         y = self.new(x.N, x.H // 2, x.W // 2, nf)
-        st = self.stat(nf, (y.M + 127) // 128) if tr else None
+        st = self.stat(nf, (y.M + 31) // 32) if tr else None
         self.conv(F, [(x, 0, 1, 1)], lay["segs"], nf, self.P(lay["bias"]), y, stride=2, stats=st)
         y.stats = st
         if tr:
@@ -614,7 +618,7 @@ class Graph:
             Bp = self.bwd
             g = y.grad
             if not node["fused"]:
-                node["s2"] = self.stat(x.C, min(1024, (x.M + 63) // 64))
+                node["s2"] = self.stat(x.C, self.stat_blocks(x))
                 Bp.add("rua_col_stats2", g.ptr, x.ptr, coef.scale, coef.shift, 1 if relu else 0, x.M, x.C, node["s2"].ptr, node["s2"].R, self.dt)
             gx, acc = self.gacc(x)
             self.bn_bwd(Bp, [g], [coef], [bn], [node["s2"]], x, gx, acc, cnt, masked=(relu and not node["fused"]))
@@ -624,7 +628,7 @@ class Graph:
     def fuse_target(self, node):
         """dgrad epilogue arguments that make `node`'s backward fused (single consumer only)."""
         node["fused"] = True
-        node["s2"] = self.stat(node["x"].C, (node["x"].M + 127) // 128)
+        node["s2"] = self.stat(node["x"].C, (node["x"].M + 31) // 32)
         g, _ = self.gacc(node["y"])
         if node["relu"]:
             return dict(out=g, mask=(node["x"], node["coef"].scale, node["coef"].shift), stats2=node["s2"])
@@ -635,7 +639,7 @@ class Graph:
         F, tr = self.fwd, self.training
         lay = self.Lconv([t.C for t, _ in segs], cout, 1)
         y = self.new(self.B, out_hw[0], out_hw[1], cout)
-        st = self.stat(cout, (y.M + 127) // 128) if (tr and want_stats) else None
+        st = self.stat(cout, (y.M + 31) // 32) if (tr and want_stats) else None
         self.conv(F, [(t, up, 1, 1) for t, up in segs], lay["segs"], cout, self.P(lay["bias"]), y, stats=st)
         y.stats = st
         return y, lay
@@ -980,7 +984,7 @@ class Engine:
         items = np.array(rows, dtype=items.dtype)
         self.wprep_items = torch.from_numpy(np.frombuffer(items.tobytes(), dtype=np.uint8).copy()).to(self.dev)
         self.wprep_n, self.wprep_max = len(rows), mx
-        self.stats_arena = torch.zeros(1 << 20, dtype=torch.float64, device=self.dev)
+        self.stats_arena = torch.zeros(1 << 22, dtype=torch.float64, device=self.dev)
         # one split-K slab workspace and one weight-gradient partial scratch per lane: branches run concurrently
         self.workspaces = [torch.zeros(8 << 20, dtype=torch.float32, device=self.dev) for _ in range(4)]
         self.scratches = [torch.zeros(8 << 20, dtype=torch.float32, device=self.dev) for _ in range(4)]

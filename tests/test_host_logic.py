@@ -71,7 +71,8 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()
     assert lib.raw("rua_version")() >= 100
     assert lib.raw("rua_stats_replicas")(5000) == stats_replicas(5000) == 32
-    assert lib.raw("rua_stats_replicas")(10) == stats_replicas(10) == 1
+    assert lib.raw("rua_stats_replicas")(10) == stats_replicas(10) == 2
+    assert lib.raw("rua_stats_replicas")(8) == stats_replicas(8) == 1
 
 
 def test_c_abi_struct_sizes_match_header():
