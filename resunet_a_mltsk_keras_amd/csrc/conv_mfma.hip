@@ -1470,7 +1470,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = co0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-        if (co < p.Cout) unsafeAtomicAdd(&p.dw[((size_t)tap * p.Cout + co) * p.C + ci], acc[i]);
+        if (co < p.Cout) {
+          float* dst = &p.dw[((size_t)tap * p.Cout + co) * p.C + ci];
+          // one K slice = one writer per element: a plain read-modify-write (float atomics run at ~1.3 TB/s chip-wide,
+          // plain traffic at ~6; the 8x8 level writes its whole 37.7 MB gradient this way)
+          if (p.ksplit == 1) *dst += acc[i]; else unsafeAtomicAdd(dst, acc[i]);
+        }
       }
     }
   }
@@ -1478,15 +1483,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
 
 // =========================================================================================
 // All-taps weight gradient for the two top levels (Cin = Cout = CC in {32, 64}, 3x3, stride 1, W % 64 == 0; bf16).
-// A stage is a run of 64 consecutive pixels of one image row.  Per stage a pixel group (3 waves) stages dy[64][32]
-// once and a 3-row halo a[3][64+2d][CC] of the conv input; wave `tr` computes the three taps of kernel row tr
-// (dh = (tr-1)*d) for every 16-pixel k-step from shifted views of its halo row, so the nine taps cost ~3x the pixel
-// traffic instead of 9x and dy is read once.  NPG pixel groups per block run interleaved stages and are summed in
-// LDS; the block writes ONE fp32 partial (plain coalesced stores); wgrad_taps_reduce adds the partials into dW in a
-// fixed order (deterministic, no atomics).  blockIdx.y selects the 32-wide output-channel half (CC = 64).
+// A stage is a run of 64 consecutive pixels of one image row.  A pixel group (3 waves x CC/32) walks a CHAIN of stages
+// down the image: same 64-pixel column strip, rows h, h+d, h+2d, .. (one residue class mod d), so the conv-input rows
+// h-d, h, h+d it needs are a sliding window: per stage it loads ONE new halo row a[64+2d][CC] into a 3-slot LDS ring plus
+// dy[64][32], instead of three rows (measured before chaining: 132 MB fetched for 67 MB of tensors; the window makes the
+// nine taps cost ~1.3x the pixel traffic).  Wave `tr` computes the three taps of kernel row tr (dh = (tr-1)*d) for
+// every 16-pixel k-step from shifted views of ring slot (it + tr) % 3.  Chains are cut into segments so that ~1024
+// groups are busy; a segment pays two extra row loads to fill its window.  NPG pixel groups per block are summed in LDS;
+// the block writes ONE fp32 partial (plain coalesced stores); wgrad_taps_reduce adds the partials into dW in a fixed
+// order (deterministic, no atomics).  blockIdx.y selects the 32-wide output-channel half (CC = 64).
 struct WgtK {
   const unsigned char* a; const unsigned char* dy; float* scratch; float* dw;
-  int H, W, N, dil, S, NPG, workers, iters, halo, group_bytes, wshift, hshift, gx;
+  int H, W, N, dil, NPG, halo, halo4, group_bytes, gx;
+  int strips, spc, seglen, nchains;        // 64-pixel column strips per row, segments per chain, lattice rows per segment
+  int njobs, nworkers, jpw;                // (chain, segment) jobs, pixel groups in the grid, jobs per group
   unsigned abytes, dybytes;
 };
 
@@ -1498,7 +1508,7 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
   constexpr int PP = CC / 8;              // 16-byte pieces per pixel of the a image
   constexpr int AROWB = CC * 2;           // a image row bytes (CC = 64: 16-byte chunks XOR-swizzled, see swz())
   constexpr int DROWB = 64;               // dy image: this block's 32 output channels
-  constexpr int MAXP = (3 * 126 * PP + GT - 1) / GT;
+  constexpr int MAXP = (126 * PP + GT - 1) / GT;       // pieces of one halo row per thread (d <= 31)
   constexpr int DP = (256 + GT - 1) / GT; // dy piece passes
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1509,26 +1519,23 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
   unsigned char* sA = sD + 64 * DROWB;
   const int halo = p.halo, d = p.dil, W = p.W, H = p.H;
   const int co0 = blockIdx.y * 32;
-  const int worker = blockIdx.x * p.NPG + pg;
   const __amdgpu_buffer_rsrc_t ra_ = make_rsrc(p.a, p.abytes), rd_ = make_rsrc(p.dy, p.dybytes);
 
   auto swz = [](int row, int chunk) { return (CC == 64) ? (chunk ^ (((row >> 1) & 1) << 2)) : chunk; };
 
-  // ---- everything that does not depend on the stage is computed once ---------------------------------
-  // halo piece k of this thread: byte offset relative to the stage's first pixel, LDS write offset, and which
-  // border conditions would invalidate it (bit0: needs row h-d, bit1: needs row h+d, bit2: left of the run,
-  // bit3: right of the run)
+  const int worker = blockIdx.x * p.NPG + pg;
+
+  // ---- stage-invariant per-thread data: halo-row pieces (offset relative to the row's pixel x0, LDS offset inside a ring
+  // slot, border flags: bit2 left of the image, bit3 right of it) and dy pieces
   int prel[MAXP], plds[MAXP], pneed[MAXP];
-  const int total = 3 * halo * PP;
+  const int total = halo * PP;
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
     const int i = gt + k * GT;
-    const int r3 = i / (halo * PP), rem = i - r3 * halo * PP;
-    const int j = rem / PP, q = rem - j * PP;
-    const int row = r3 * halo + j;
-    prel[k] = (((r3 - 1) * d * W + (j - d)) * CC + q * 8) * 2;
-    plds[k] = (i < total) ? row * AROWB + swz(row, q) * 16 : -1;
-    pneed[k] = (r3 == 0 ? 1 : 0) | (r3 == 2 ? 2 : 0) | (j < d ? 4 : 0) | (j >= 64 + d ? 8 : 0) | (i < total ? 0 : 16);
+    const int j = i / PP, q = i - j * PP;
+    prel[k] = ((j - d) * CC + q * 8) * 2;
+    plds[k] = (i < total) ? j * AROWB + swz(j, q) * 16 : -1;
+    pneed[k] = (j < d ? 4 : 0) | (j >= 64 + d ? 8 : 0) | (i < total ? 0 : 16);
   }
   int drel[DP], dlds[DP];
 #pragma unroll
@@ -1537,7 +1544,7 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
     drel[k] = ((i >> 2) * CC + co0 + (i & 3) * 8) * 2;
     dlds[k] = (i < 256) ? (i >> 2) * DROWB + (i & 3) * 16 : -1;
   }
-  // transposing-read lane geometry (see wgrad_kernel) and the stage-invariant fragment addresses
+  // transposing-read lane geometry (see wgrad_kernel) and the stage-invariant fragment addresses (inside a ring slot)
   const int li = lane & 15, g = lane >> 4;
   const int q4 = li >> 2, pp = li & 3;
   const int chan = 16 * (g & 1) + 4 * pp;
@@ -1545,38 +1552,74 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
   typedef s16x4 __attribute__((address_space(3))) * lds4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   const unsigned char* dybase = sD + hrow * DROWB + chan * 2;
-  const unsigned char* abase[3];
+  int aoff[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int row = tr * halo + j * d + hrow;
+    const int row = j * d + hrow;                        // ring slots start at multiples of 4 rows: the swizzle bit is slot-independent
     const int ch = cih * 32 + chan;
-    abase[j] = sA + row * AROWB + swz(row, ch >> 3) * 16 + (ch & 7) * 2;     // +16 rows / +4 rows never flip the swizzle bit
+    aoff[j] = row * AROWB + swz(row, ch >> 3) * 16 + (ch & 7) * 2;     // +16 rows / +4 rows never flip the swizzle bit
   }
+  const int slot_bytes = p.halo4 * AROWB;
 
-  uint4 va[MAXP], vd[DP];
-  auto load_stage = [&](int it) {
-    const int s = worker + it * p.workers;
-    const int m0 = s * 64;
-    int h, w0;
-    if (p.wshift >= 0) { w0 = m0 & (W - 1); h = (m0 >> p.wshift) & (H - 1); }
-    else { const int rem = m0 % (H * W); h = rem / W; w0 = rem - h * W; }
-    // border conditions of this run of 64 pixels as one scalar mask (bit4: stage beyond the end)
-    const int bad = (h - d < 0 ? 1 : 0) | (h + d >= H ? 2 : 0) | (w0 == 0 ? 4 : 0) | (w0 + 64 == W ? 8 : 0) | (s < p.S ? 0 : 31) | 16;
-    const int segb = m0 * CC * 2;
-#pragma unroll
-    for (int k = 0; k < DP; ++k)
-      vd[k] = bufload16(rd_, (s < p.S && dlds[k] >= 0) ? (unsigned)(m0 * CC * 2 + drel[k]) : RUA_OOB);
-#pragma unroll
-    for (int k = 0; k < MAXP; ++k)
-      va[k] = bufload16(ra_, (pneed[k] & bad) == 0 ? (unsigned)(segb + prel[k]) : RUA_OOB);
+  // the current job of this group: image n_, column strip x0, rows h = r_ + i*d for i in [i0, i0 + nit)
+  int n_ = 0, x0 = 0, r_ = 0, i0 = 0, nit = 0, bad_lr = 31;
+  auto enter_job = [&](int job) {
+    n_ = 0; x0 = 0; r_ = 0; i0 = 0; nit = 0;
+    if (job < p.njobs) {
+      const int chain = job / p.spc, seg = job - chain * p.spc;
+      r_ = chain % d; const int t = chain / d;
+      x0 = (t % p.strips) * 64; n_ = t / p.strips;
+      const int ny = (H - r_ + d - 1) / d;
+      i0 = seg * p.seglen;
+      int i1 = i0 + p.seglen; if (i1 > ny) i1 = ny;
+      nit = i1 > i0 ? i1 - i0 : 0;
+    }
+    bad_lr = (x0 == 0 ? 4 : 0) | (x0 + 64 == W ? 8 : 0) | 16;
   };
-  auto write_stage = [&]() {
-#pragma unroll
-    for (int k = 0; k < DP; ++k)
-      if (dlds[k] >= 0) *reinterpret_cast<uint4*>(sD + dlds[k]) = vd[k];
+
+  // lattice row j (relative to i0; j = -1 .. nit) of the conv input -> registers; dy of stage jd (0 .. nit-1) -> registers.
+  // TWO register sets: a load has two stages to land (one block per CU: the only latency hiding is this depth)
+  uint4 va0[MAXP], vd0[DP], va1[MAXP], vd1[DP];
+  auto load_rows = [&](uint4* va, uint4* vd, int j, int jd) {
+    const int h = r_ + (i0 + j) * d;
+    const bool rowok = nit > 0 && j <= nit && h >= 0 && h < H;
+    const int segb = ((n_ * H + h) * W + x0) * CC * 2;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k)
-      if (plds[k] >= 0) *reinterpret_cast<uint4*>(sA + plds[k]) = va[k];
+      va[k] = bufload16(ra_, (rowok && (pneed[k] & bad_lr) == 0) ? (unsigned)(segb + prel[k]) : RUA_OOB);
+    const int hd = r_ + (i0 + jd) * d;
+    const bool dok = jd >= 0 && jd < nit;
+    const int dyb = ((n_ * H + hd) * W + x0) * CC * 2;
+#pragma unroll
+    for (int k = 0; k < DP; ++k)
+      vd[k] = bufload16(rd_, (dok && dlds[k] >= 0) ? (unsigned)(dyb + drel[k]) : RUA_OOB);
+  };
+  auto write_rows = [&](const uint4* va, const uint4* vd, int slot, bool with_dy) {
+    unsigned char* dst = sA + slot * slot_bytes;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k)
+      if (plds[k] >= 0) *reinterpret_cast<uint4*>(dst + plds[k]) = va[k];
+    if (with_dy) {
+#pragma unroll
+      for (int k = 0; k < DP; ++k)
+        if (dlds[k] >= 0) *reinterpret_cast<uint4*>(sD + dlds[k]) = vd[k];
+    }
+  };
+  auto compute = [&](f32x16* acc, int it) {
+    const unsigned char* ar = sA + ((it + tr) % 3) * slot_bytes;      // row it + tr - 1
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(dybase + ks * 16 * DROWB));
+      const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(dybase + ks * 16 * DROWB + 4 * DROWB));
+      const s16x8 fd = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const s16x4 x0_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ar + aoff[j] + ks * 16 * AROWB));
+        const s16x4 x1_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ar + aoff[j] + ks * 16 * AROWB + 4 * AROWB));
+        const s16x8 fx = {x0_[0], x0_[1], x0_[2], x0_[3], x1_[0], x1_[1], x1_[2], x1_[3]};
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc[j], 0, 0, 0);
+      }
+    }
   };
 
   f32x16 acc[3];
@@ -1585,23 +1628,26 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-  load_stage(0);
-  for (int it = 0; it < p.iters; ++it) {
-    __syncthreads();
-    write_stage();
-    __syncthreads();
-    if (it + 1 < p.iters) load_stage(it + 1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(dybase + ks * 16 * DROWB));
-      const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(dybase + ks * 16 * DROWB + 4 * DROWB));
-      const s16x8 fd = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(abase[j] + ks * 16 * AROWB));
-        const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(abase[j] + ks * 16 * AROWB + 4 * AROWB));
-        const s16x8 fx = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc[j], 0, 0, 0);
+  for (int jb = 0; jb < p.jpw; ++jb) {
+    enter_job(worker + jb * p.nworkers);
+    __syncthreads();                                     // the previous job's last stage is done with the ring
+    // window fill: rows -1 and 0 into slots 0 and 1 (row j lives in slot (j + 1) % 3), both loads in flight together;
+    // then set 0 <- (row 1, dy 0), set 1 <- (row 2, dy 1)
+    load_rows(va0, vd0, -1, -1); load_rows(va1, vd1, 0, -1);
+    write_rows(va0, vd0, 0, false); write_rows(va1, vd1, 1, false);
+    load_rows(va0, vd0, 1, 0); load_rows(va1, vd1, 2, 1);
+    for (int it = 0; it < p.seglen; it += 2) {
+      __syncthreads();                                   // everyone is done reading slot (it + 2) % 3 (row it - 1) and sD
+      write_rows(va0, vd0, (it + 2) % 3, true);          // row it + 1, dy of stage it
+      __syncthreads();
+      load_rows(va0, vd0, it + 3, it + 2);
+      compute(acc, it);
+      if (it + 1 < p.seglen) {
+        __syncthreads();
+        write_rows(va1, vd1, (it + 3) % 3, true);        // row it + 2, dy of stage it + 1
+        __syncthreads();
+        load_rows(va1, vd1, it + 4, it + 3);
+        compute(acc, it + 1);
       }
     }
   }
@@ -1665,20 +1711,26 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.scratch = (float*)d->workspace; k.dw = d->dw;
   k.H = d->H; k.W = d->W; k.N = d->N; k.dil = d->dil;
   const long long M = (long long)d->N * d->H * d->W;
-  k.S = (int)(M / 64);
   k.halo = 64 + 2 * d->dil;
-  k.group_bytes = 64 * 64 + 3 * k.halo * CC * 2;
+  k.halo4 = (k.halo + 3) / 4 * 4;
+  k.group_bytes = 64 * 64 + 3 * k.halo4 * CC * 2;
   k.NPG = (CC == 32) ? 4 : 2;                          // 12 waves per block either way (3 kernel rows x CC/32 halves per group)
   const int gy = CC / 32;
-  int gx = 256 / gy;
-  if (gx * k.NPG > k.S) gx = (k.S + k.NPG - 1) / k.NPG;
-  if (gx < 1) gx = 1;
+  const int target = (256 / gy) * k.NPG;               // pixel groups wanted: one block per CU and output-channel half
+  k.strips = d->W / 64;
+  k.nchains = d->N * k.strips * d->dil;
+  const int ny = (d->H + d->dil - 1) / d->dil;         // lattice rows of the longest chain
+  int spc = target / k.nchains;                        // segments per chain (jobs <= groups where possible: one round)
+  if (spc < 1) spc = 1;
+  if (spc > ny) spc = ny;
+  k.seglen = (ny + spc - 1) / spc;
+  k.spc = (ny + k.seglen - 1) / k.seglen;
+  k.njobs = k.nchains * k.spc;
+  int gx = (k.njobs + k.NPG - 1) / k.NPG;
+  if (gx > 256 / gy) gx = 256 / gy;                    // one block per CU and output-channel half; extra jobs are queued
   k.gx = gx;
-  k.workers = gx * k.NPG;
-  k.iters = (k.S + k.workers - 1) / k.workers;
-  auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
-  k.wshift = lg2(d->W); k.hshift = lg2(d->H);
-  if (k.wshift < 0 || k.hshift < 0) k.wshift = k.hshift = -1;
+  k.nworkers = gx * k.NPG;
+  k.jpw = (k.njobs + k.nworkers - 1) / k.nworkers;
   k.abytes = (unsigned)((size_t)M * CC * 2); k.dybytes = k.abytes;
   size_t smem = (size_t)k.group_bytes * k.NPG;
   const size_t red = (size_t)(k.NPG - 1) * 3 * (CC / 32) * 3 * 16 * 64 * 4;
@@ -1699,7 +1751,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
 
 extern "C" int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d) {
   if (!d) return 0;
-  return (int64_t)256 * 9 * 32 * (int64_t)d->C * 4;
+  return (int64_t)256 * 9 * 32 * (int64_t)d->C * 4;     // up to 256 block partials of [9][32][C] fp32
 }
 
 // which kernel a descriptor launches: 1 = all-taps (top levels), 0 = generic tiled

@@ -25,9 +25,11 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
   constexpr int VEC = ET<T>::VEC;
   __shared__ float sred[4 * 64 * 2 * VEC];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int CG = p.CG;
-  const int cp = tid & (CG - 1);
-  const int rpb = 256 / CG > 0 ? 256 / CG : 1;          // rows covered by one block per step (CG <= 256)
+  const int CGA = p.CG;                                  // pieces per row (power of two)
+  const int CG = CGA < 256 ? CGA : 256;                  // pieces handled by one block (blockIdx.y picks the 256-piece slab)
+  const int cp0 = blockIdx.y * CG;
+  const int cp = cp0 + (tid & (CG - 1));
+  const int rpb = 256 / CG;                              // rows covered by one block per step
   float s1[VEC], s2[VEC], ms[VEC], mt[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; ms[j] = 1.f; mt[j] = 0.f; }
@@ -42,8 +44,8 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
     uint4 q[UN], qg[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      q[u] = ldg16(p.x + ((size_t)(r + u * rstep) * CG + cp) * 16);
-      if (MODE == 2) qg[u] = ldg16(p.g + ((size_t)(r + u * rstep) * CG + cp) * 16);
+      q[u] = ldg16(p.x + ((size_t)(r + u * rstep) * CGA + cp) * 16);
+      if (MODE == 2) qg[u] = ldg16(p.g + ((size_t)(r + u * rstep) * CGA + cp) * 16);
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -65,13 +67,13 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
   }
   for (; r < p.M; r += rstep) {
     float xv[VEC];
-    ET<T>::unpack(ldg16(p.x + ((size_t)r * CG + cp) * 16), xv);
+    ET<T>::unpack(ldg16(p.x + ((size_t)r * CGA + cp) * 16), xv);
     if (MODE == 1) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { s1[j] += xv[j]; s2[j] = fmaf(xv[j], xv[j], s2[j]); }
     } else {
       float gv[VEC];
-      ET<T>::unpack(ldg16(p.g + ((size_t)r * CG + cp) * 16), gv);
+      ET<T>::unpack(ldg16(p.g + ((size_t)r * CGA + cp) * 16), gv);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const float m = (!p.masked || fmaf(ms[j], xv[j], mt[j]) > 0.f) ? gv[j] : 0.f;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
 #pragma unroll
     for (int w = 0; w < 4; ++w)                          // waves whose lane (cpi % 64) holds piece cpi
       if (((w * 64 + (cpi & 63)) & (CG - 1)) == cpi) acc += sred[((w * 64 + (cpi & 63)) * 2) * VEC + k];
-    unsafeAtomicAdd(&st[(k / VEC) * p.C + cpi * VEC + (k % VEC)], (double)acc);
+    unsafeAtomicAdd(&st[(k / VEC) * p.C + (cp0 + cpi) * VEC + (k % VEC)], (double)acc);
   }
 }
 
@@ -118,16 +120,17 @@ static int launch_stats(const void* g, const void* x, const float* ms, const flo
   StatsK k;
   k.x = (const unsigned char*)x; k.g = (const unsigned char*)g; k.ms = ms; k.mt = mt; k.masked = masked;
   k.M = M; k.C = C; k.CG = C / vec;
-  RUA_CHECK_ARG(k.CG <= 256 && (k.CG & (k.CG - 1)) == 0, "%s: C/%d = %d must be a power of two <= 256", name, vec, k.CG);
+  RUA_CHECK_ARG((k.CG & (k.CG - 1)) == 0, "%s: C/%d = %d must be a power of two", name, vec, k.CG);
+  const int gy = k.CG > 256 ? k.CG / 256 : 1;
   k.TX = k.CG; k.TY = 256 / k.CG; k.rows_per_block = 0;
   k.stats = stats; k.R = replicas;
   const int64_t pieces = M * k.CG;
-  int64_t gx = pieces / (256 * 8);                       // >= 8 pieces per thread
-  if (gx > 512) gx = 512;
+  int64_t gx = pieces / (256 * 8) / gy;                  // >= 8 pieces per thread
+  if (gx > 512 / gy) gx = 512 / gy;
   if (gx < 1) gx = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RUA_BF16) hipLaunchKernelGGL((col_stats_kernel<bf16_t, MODE>), dim3((unsigned)gx), dim3(256), 0, st, k);
-  else hipLaunchKernelGGL((col_stats_kernel<float, MODE>), dim3((unsigned)gx), dim3(256), 0, st, k);
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((col_stats_kernel<bf16_t, MODE>), dim3((unsigned)gx, gy), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((col_stats_kernel<float, MODE>), dim3((unsigned)gx, gy), dim3(256), 0, st, k);
   RUA_LAUNCH_CHECK(name);
   return RUA_OK;
 }
