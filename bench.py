@@ -90,7 +90,7 @@ def profile_kernels(eng, g, dtype):
                 d = args[0]._obj
                 if name == "rua_conv_fwd":
                     bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d)), lib.raw('rua_conv_tile_bn')(C.byref(d))
-                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap<{bm_},{bn_}>", "conv_halo<32>")[kid]
+                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap<{bm_},{bn_}>", f"conv_halo<{d.Cout}>")[kid]
                     kk = sum(d.seg[i].taps * d.seg[i].C for i in range(d.nseg))
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "")
                     rec.append((kn, e0, e1, conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags)))
@@ -209,6 +209,8 @@ def main():
     eng = Engine(ModelConfig(input_shape=(patch, patch, ch), num_classes=ncls, multitasking=mt, depth=depth), dtype=args.dtype, seed=0)
     heads = ["seg", "bound", "dist", "color"]
     eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in heads}, weight={h: 1.0 for h in heads}, optimizer="adam", lr=1e-3))
+    if os.environ.get("RUA_LANES"):                             # experiment: ResBlock branches on parallel graph branches
+        eng.use_lanes = True
     if world > 1 or args.force_dp:
         from resunet_a_mltsk_keras_amd.dist import DataParallel
         DataParallel(eng, bucket_mb=args.bucket_mb, overlap=not args.no_overlap)

@@ -928,25 +928,30 @@ struct HaloK {
 __device__ __forceinline__ int fdiv(int x, unsigned m, int dv) { return dv == 1 ? x : (int)__umulhi((unsigned)x, m); }
 
 template <int C, int MAXMT>                           // MAXMT: MFMA row tiles per wave (rows <= MAXMT * 128)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXMT == 2 ? 4 : 3, MAXMT == 2 ? 4 : 3)))
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(C == 64 ? 2 : (MAXMT == 2 ? 4 : 3), C == 64 ? 2 : (MAXMT == 2 ? 4 : 3))))     // = blocks per CU the LDS footprint allows
 void conv_halo(const HaloK q) {
   typedef bf16_t T;
-  static_assert(C == 32, "conv_halo: C = Cout = 32");
+  static_assert(C == 32 || C == 64, "conv_halo: C = Cout in {32, 64}");
   constexpr int ROWB = C * 2, SPR = ROWB / 16;        // bytes per LDS pixel row, 16-B slots per row
-  constexpr int CSTR = C + 4;
+  constexpr int SW = (C == 32) ? 2 : 1;               // swizzle: slot = piece ^ ((row >> SW) & (SPR - 1)) (conflict-free b128 reads)
+  constexpr int CSTR = 32 + 4;                        // a block computes 32 output channels (C = 64: blockIdx.y picks the half)
   constexpr int KST = C / 16;                         // k-steps per tap
+  constexpr bool BLDS = (C == 64);                    // weights of the block's 32 output channels: LDS (C = 64) or registers
+  constexpr int B_BYTES = BLDS ? 9 * 32 * ROWB : 0;
+  const int n0 = BLDS ? blockIdx.y * 32 : 0;
   const ConvK& p = q.c;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sC = reinterpret_cast<float*>(smem);         // aliases the halo images after the MFMA phase
   // fixed carve-up behind the halo / epilogue area (sizes from the launcher): row->pixel table, row->LDS-row table, sub-tile records
   const int halo_b = ((q.NS * q.HP * ROWB + 1023) / 1024) * 1024;
   const int area = 128 * CSTR * 4 > halo_b ? 128 * CSTR * 4 : halo_b;       // the fp32 tile is transposed 128 rows at a time
-  int* rowtab = reinterpret_cast<int*>(smem + area);
-  int* r0tab = rowtab + q.rows;
-  int* subrec = r0tab + q.rows;                       // [NS][4]: n, y0, x0, valid   (halo origin in image coordinates)
+  unsigned char* sB = smem + area;                     // [9 taps * 32 output channels][C] bf16, swizzled like the halo rows
+  int* rowtab = reinterpret_cast<int*>(smem + area + B_BYTES);
+  int* subrec = rowtab + q.rows;                      // [NS][4]: n, y0, x0, valid   (halo origin in image coordinates)
   float* sred = reinterpret_cast<float*>(subrec + 4 * 12);
 
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int nwg = gridDim.x, bid = blockIdx.x;         // (gridDim.y = output-channel halves)
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -974,19 +979,27 @@ void conv_halo(const HaloK q) {
     const int y = subrec[s_ * 4 + 1] + (i + 1) * d, x = subrec[s_ * 4 + 2] + (j + 1) * d;
     const bool ok = subrec[s_ * 4 + 3] && i < q.TH && y < H && x < W;
     rowtab[m] = ok ? (subrec[s_ * 4 + 0] * H + y) * W + x : -1;
-    r0tab[m] = s_ * q.HP + (i < q.TH ? i : 0) * q.HPW + j;
   }
 
   // ---- weights: every wave keeps the B fragments of all 9 taps in registers -------------------------------------------
   const int lr = lane & 31, lh = lane >> 5;
-  bf16x8 fb[9][KST];
-  {
+  bf16x8 fb[BLDS ? 1 : 9][BLDS ? 1 : KST];
+  if constexpr (!BLDS) {
     const unsigned char* wp = p.seg[0].w;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int ks = 0; ks < KST; ++ks)
         fb[t][ks] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)(t * C + lr) * C + ks * 16 + lh * 8) * 2);
+  } else {
+    // 288 rows (tap, output channel) x 128 B -> LDS by DMA, 8 rows per wave-instruction, same source-side swizzle
+    const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(p.seg[0].w, p.seg[0].wbytes);
+    for (int it = wid; it < 9 * 32 / 8; it += 4) {
+      const int row = it * 8 + (lane >> 3), slot = lane & 7;
+      const int t = row >> 5, co = row & 31;
+      const unsigned off = (unsigned)((((t * C + n0 + co) * C) + ((slot ^ ((row >> SW) & (SPR - 1))) * 8)) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_, (lds_void_p)(sB + it * 1024), 16, off, 0, 0, 0);
+    }
   }
 
   // ---- halo images: HBM/L2 -> LDS, one pass (lane-linear destination, swizzle on the source piece) ------------------
@@ -1003,7 +1016,7 @@ void conv_halo(const HaloK q) {
       if (row < hrows) {
         const int y = subrec[s_ * 4 + 1] + hi * d, x = subrec[s_ * 4 + 2] + hj * d;
         if (subrec[s_ * 4 + 3] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-          off = (unsigned)((((subrec[s_ * 4 + 0] * H + y) * W + x) * C + ((slot ^ ((row >> 2) & (SPR - 1))) * 8)) * 2);
+          off = (unsigned)((((subrec[s_ * 4 + 0] * H + y) * W + x) * C + ((slot ^ ((row >> SW) & (SPR - 1))) * 8)) * 2);
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_void_p)(smem + it * 1024), 16, off, 0, 0, 0);
     }
@@ -1013,11 +1026,14 @@ void conv_halo(const HaloK q) {
 
   // ---- MFMA phase: this wave's row tiles wid, wid+4, wid+8 ------------------------------------------------------------
   const int mtb = q.rows >> 5;
-  int r0[MAXMT];
+  int r0[MAXMT];                                         // LDS row of tap (0,0) for this lane's pixel of each row tile
 #pragma unroll
   for (int a = 0; a < MAXMT; ++a) {
     const int mt = wid + a * 4;
-    r0[a] = (mt < mtb) ? r0tab[mt * 32 + lr] : 0;
+    const int m = (mt < mtb ? mt : 0) * 32 + lr;
+    const int s_ = fdiv(m, q.mPT, q.PT), qq = m - s_ * q.PT;
+    const int i = fdiv(qq, q.mTW, q.TW), j = qq - i * q.TW;
+    r0[a] = s_ * q.HP + (i < q.TH ? i : 0) * q.HPW + j;
   }
   f32x16 acc[MAXMT];
 #pragma unroll
@@ -1033,11 +1049,14 @@ void conv_halo(const HaloK q) {
 #pragma unroll
       for (int a = 0; a < MAXMT; ++a) {
         const int row = r0[a] + toff;
-        fa[a] = *reinterpret_cast<const bf16x8*>(smem + row * ROWB + (((ks * 2 + lh) ^ ((row >> 2) & (SPR - 1))) * 16));
+        fa[a] = *reinterpret_cast<const bf16x8*>(smem + row * ROWB + (((ks * 2 + lh) ^ ((row >> SW) & (SPR - 1))) * 16));
       }
+      bf16x8 fbv;
+      if constexpr (BLDS) fbv = *reinterpret_cast<const bf16x8*>(sB + (t * 32 + lr) * ROWB + (((ks * 2 + lh) ^ ((lr >> SW) & (SPR - 1))) * 16));
+      else fbv = fb[t][ks];
 #pragma unroll
       for (int a = 0; a < MAXMT; ++a)          // unconditional (a branch around MFMAs makes hipcc shuttle the accumulators):
-        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[t][ks], acc[a], 0, 0, 0);     // a missing row tile computes garbage, never stored
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fbv, acc[a], 0, 0, 0);     // a missing row tile computes garbage, never stored
     }
   }
   // ---- epilogue, 128 rows (one row tile per wave) at a time: a small fp32 tile keeps LDS per block low (more blocks per CU) --
@@ -1054,7 +1073,7 @@ void conv_halo(const HaloK q) {
     }
     __syncthreads();
     // tile rows of pass a: row tile (wid + 4a) of wave wid sits at LDS rows wid*32.., i.e. tile row r <-> m = (a*4 + r/32)*32 + r%32
-    conv_epilogue<T, 128, C>(p, 0, 0, vid, sC, CSTR, sred, rowtab + a * 128, q.rows - a * 128, carry, a == MAXMT - 1);
+    conv_epilogue<T, 128, 32>(p, 0, n0, vid, sC, CSTR, sred, rowtab + a * 128, q.rows - a * 128, carry, a == MAXMT - 1);
   }
 }
 
@@ -1170,7 +1189,11 @@ static bool pick_halo(const rua_conv_desc* d) {
   static const int mode = getenv("RUA_CONV_HALO") ? atoi(getenv("RUA_CONV_HALO")) : 1;      // 0: off (experiments)
   if (!mode || d->dtype != RUA_BF16 || d->nseg != 1) return false;
   const rua_conv_seg& g = d->seg[0];
-  return g.taps == 9 && g.up_shift == 0 && g.C == 32 && d->Cout == 32 && d->stride == 1 && d->out_stride == 1 &&
+  // C = 64: measured against conv_igemm<256,64> on 128x128 maps - d = 1: 28.0 vs 30.3 us, d = 15: 46 vs 29 us (the small
+  // lattices leave 192-row blocks at two per CU), so only the small dilations take the halo kernel there
+  static const int maxd64 = getenv("RUA_HALO64_MAXD") ? atoi(getenv("RUA_HALO64_MAXD")) : 1;
+  if (g.C == 64 && g.dil > maxd64) return false;
+  return g.taps == 9 && g.up_shift == 0 && (g.C == 32 || g.C == 64) && d->Cout == g.C && d->stride == 1 && d->out_stride == 1 &&
          d->OH == d->H && d->OW == d->W && g.Hs == d->H && g.Ws == d->W && d->H >= 16 && d->W >= 16 &&
          (long long)d->N * d->H * d->W >= 65536;
 }
@@ -1178,14 +1201,15 @@ static unsigned magic_div(int dv) { return dv <= 1 ? 0u : (unsigned)(((1ull << 3
 
 // lattice tile TH x TW (slots padded to a multiple of 32) and sub-tiles per block for an H x W map at dilation d:
 // minimise padded slots (MFMA waste) with a penalty for halo bytes; at most 384 rows and 40 KiB of halo images per block
-static void halo_tiling(int H, int W, int d, int* TH_, int* TW_, int* NS_) {
+static void halo_tiling(int H, int W, int d, int rowb, int* TH_, int* TW_, int* NS_) {
   const int ny = (H + d - 1) / d, nx = (W + d - 1) / d;
+  const int lim = 41 * 1024;                           // halo images per block (C = 64: + 36 KiB of weights = 2 blocks per CU)
   double best = 1e30;
   int bth = 1, btw = 1;
   for (int th = 1; th <= ny && th <= 32; ++th)
     for (int tw = 1; tw <= nx && tw <= 32; ++tw) {
       const int pt = (th * tw + 31) / 32 * 32;
-      if (pt > 384 || (th + 2) * (tw + 2) * 64 > 40 * 1024) continue;
+      if (pt > 384 || (th + 2) * (tw + 2) * rowb > lim) continue;
       const double slots = (double)((ny + th - 1) / th) * ((nx + tw - 1) / tw) * pt;
       const double halo = (double)(th + 2) * (tw + 2) / (th * tw);
       const double cost = slots * (1.0 + 0.35 * (halo - 1.0));
@@ -1193,7 +1217,7 @@ static void halo_tiling(int H, int W, int d, int* TH_, int* TW_, int* NS_) {
     }
   const int pt = (bth * btw + 31) / 32 * 32;
   int ns = 384 / pt;
-  while (ns > 1 && ns * (bth + 2) * (btw + 2) * 64 > 40 * 1024) --ns;
+  while (ns > 1 && ns * (bth + 2) * (btw + 2) * rowb > lim) --ns;
   if (ns > 12) ns = 12;
   *TH_ = bth; *TW_ = btw; *NS_ = ns < 1 ? 1 : ns;
 }
@@ -1202,7 +1226,8 @@ static int launch_conv_halo(const ConvK& k, int dil, hipStream_t st) {
   HaloK q;
   q.c = k;
   q.d = dil;
-  halo_tiling(k.H, k.W, dil, &q.TH, &q.TW, &q.NS);
+  const int Cc = k.seg[0].C, rowb = Cc * 2;
+  halo_tiling(k.H, k.W, dil, rowb, &q.TH, &q.TW, &q.NS);
   q.PT = (q.TH * q.TW + 31) / 32 * 32;
   q.HPW = q.TW + 2; q.HP = (q.TH + 2) * (q.TW + 2);
   const int ny = (k.H + dil - 1) / dil, nx = (k.W + dil - 1) / dil;
@@ -1212,13 +1237,21 @@ static int launch_conv_halo(const ConvK& k, int dil, hipStream_t st) {
   q.total_sub = (int)total;
   q.rows = q.NS * q.PT;
   q.mHP = magic_div(q.HP); q.mHPW = magic_div(q.HPW); q.mPT = magic_div(q.PT); q.mTW = magic_div(q.TW);
-  const int halo_bytes = (q.NS * q.HP * 64 + 1023) / 1024 * 1024;
+  const int halo_bytes = (q.NS * q.HP * rowb + 1023) / 1024 * 1024;
   const int epi_bytes = 128 * 36 * 4;
   const int area = epi_bytes > halo_bytes ? epi_bytes : halo_bytes;
-  const int smem = area + q.rows * 8 + 4 * 12 * 4 + 4 * 4 * 16 * 4;
+  const int smem = area + (Cc == 64 ? 9 * 32 * 128 : 0) + q.rows * 4 + 4 * 12 * 4 + 4 * 4 * 16 * 4;
   const int blocks = (int)((total + q.NS - 1) / q.NS);
-  static bool attr2 = false, attr3 = false;
-  if (q.rows <= 256) {
+  static bool attr2 = false, attr3 = false, attr642 = false, attr643 = false;
+  if (Cc == 64) {
+    if (q.rows <= 256) {
+      if (!attr642) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr642 = true; }
+      hipLaunchKernelGGL((conv_halo<64, 2>), dim3(blocks, 2), dim3(256), smem, st, q);
+    } else {
+      if (!attr643) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr643 = true; }
+      hipLaunchKernelGGL((conv_halo<64, 3>), dim3(blocks, 2), dim3(256), smem, st, q);
+    }
+  } else if (q.rows <= 256) {
     if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr2 = true; }
     hipLaunchKernelGGL((conv_halo<32, 2>), dim3(blocks), dim3(256), smem, st, q);
   } else {

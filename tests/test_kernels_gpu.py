@@ -601,17 +601,18 @@ def test_metrics_and_optimizers():
     assert np.allclose(thd.cpu().numpy(), e_th, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("H,W,dil", [(256, 256, 1), (256, 256, 3), (256, 256, 15), (256, 256, 31), (272, 248, 3), (248, 272, 15)])
+@pytest.mark.parametrize("H,W,dil,Cs", [(256, 256, 1, 32), (256, 256, 3, 32), (256, 256, 15, 32), (256, 256, 31, 32), (272, 248, 3, 32),
+                                        (248, 272, 15, 32), (256, 256, 1, 64), (256, 256, 3, 64), (264, 256, 15, 64), (256, 256, 31, 64)])
 @pytest.mark.parametrize("mode", ["residual_stats", "mask_accumulate_stats2"])
-def test_conv_halo_lattice_tiles(H, W, dil, mode):
-    """The top-level kernel (C = Cout = 32, bf16): input + halo resident in LDS, dilation by lattice decomposition.
+def test_conv_halo_lattice_tiles(H, W, dil, Cs, mode):
+    """The kernel of the two top levels (C = Cout in {32, 64}, bf16): input + halo resident in LDS, dilation by lattice decomposition.
     Every dilation of the reference's ResBlocks, ragged maps (lattice tiles that overhang the image, residue classes of
     unequal size), and both epilogue families (forward: bias + residual + sum/sum^2; data gradient: ReLU mask from
     aux*scale+shift, accumulate into y, sum g / sum g*aux)."""
     dt = L.RUA_BF16
     rng = np.random.default_rng(H + dil)
     lib = L.lib()
-    N, Cs, Cout = 1, 32, 32
+    N, Cout = 1, Cs
     x = rng.standard_normal((N, H, W, Cs)).astype(np.float32)
     w = (rng.standard_normal((9, Cout, Cs)) / np.sqrt(9 * Cs)).astype(np.float32)
     aux = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
