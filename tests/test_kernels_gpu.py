@@ -641,7 +641,9 @@ def test_conv_halo_lattice_tiles(H, W, dil, Cs, mode):
         d.aux, d.aux_mode, d.mscale, d.mshift, d.accumulate, d.stats_mode = ad.data_ptr(), 2, scd.data_ptr(), shd.data_ptr(), 1, 2
         exp = (conv + rnd(dt, y0).double().numpy()) * ((a * sc + sh) > 0)
         s2 = (exp * a).sum(axis=(0, 1, 2))
-    assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 3
+    # (C = 64 takes conv_halo only at d = 1 by default, where it wins; RUA_HALO64_MAXD=31 routes the other dilations through it)
+    if Cs == 32 or dil == 1:
+        assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 3
     lib.call("rua_conv_fwd", C.byref(d), stream())
     torch.cuda.synchronize()
     got = y.float().cpu().numpy()
