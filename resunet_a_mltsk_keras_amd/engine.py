@@ -189,6 +189,16 @@ def stats_replicas(blocks: int) -> int:
     return r
 
 
+def conv_stats_replicas(blocks: int) -> int:
+    """Replicas for statistics produced by a convolution epilogue: its workgroups finish spread over the kernel's run
+    time, so ~64 adds per address do not queue up (same-address fp64 atomics serialise at ~180 ns) - and every replica
+    costs each consumer block of the fused BatchNorm kernels a dependent round trip per 4 replicas in its prologue."""
+    r = 1
+    while r < 32 and r * 64 < blocks:
+        r *= 2
+    return r
+
+
 class Stat:
     """fp64 statistics buffer [R][2][C] in the per-step arena."""
     __slots__ = ("ptr", "R")
@@ -350,8 +360,9 @@ class Graph:
         assert self.stats_used <= self.e.stats_arena.numel(), "statistics arena exhausted"
         return self.e.stats_arena.data_ptr() + off * 8
 
-    def stat(self, C: int, blocks: int) -> Stat:
-        R = stats_replicas(blocks)
+    def stat(self, C: int, blocks: int, burst: bool = False) -> Stat:
+        """burst: the producer's workgroups all finish together (rua_col_stats*); else a convolution epilogue."""
+        R = stats_replicas(blocks) if burst else conv_stats_replicas(blocks)
         return Stat(self.salloc(R * 2 * C), R)
 
     def gacc(self, x: Ten) -> Tuple[Ten, int]:
@@ -386,7 +397,7 @@ class Graph:
         return max(1, min(512, x.M * (x.C // self.vec) // 2048))
 
     def col_stats(self, plan: Plan, x: Ten) -> Stat:
-        s = self.stat(x.C, self.stat_blocks(x))
+        s = self.stat(x.C, self.stat_blocks(x), burst=True)
         plan.add("rua_col_stats", x.ptr, x.M, x.C, s.ptr, s.R, self.dt)
         return s
 
@@ -539,7 +550,7 @@ class Graph:
         for bi, (d, l, a) in enumerate(zip(dils, lay, a1)):
             F.set_lane(bi); self.cur_lane = bi
             y = self.like(x)
-            st = self.stat(nf, (cnt + 31) // 32) if tr else None
+            st = self.stat(nf, (cnt + 127) // 128) if tr else None
             self.conv(F, [(a, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st)
             o2, c2l = self.bn_fwd(F, y, [l[2]], True, st, cnt)
             c2 = c2l[0]
@@ -566,14 +577,14 @@ class Graph:
                 Bp.set_lane(bi); self.cur_lane = bi
                 self.wgrad(Bp, a_2, dO, l[3]["segs"][0]["off"], 1, d, 9)
                 g2 = self.like(x)
-                s2 = self.stat(nf, (cnt + 31) // 32)
+                s2 = self.stat(nf, (cnt + 127) // 128)
                 self.dgrad(Bp, dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
                 dy1 = self.like(x)
                 self.bn_bwd(Bp, [g2], [c2], [l[2]], [s2], y, dy1, 0, cnt)
                 # no bias gradient launch: the output of a BN backward sums to zero per channel, so d b1 == 0 exactly
                 self.wgrad(Bp, a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9)
                 g1 = g2                                    # g2 is dead after bn_bwd_apply: reuse its storage
-                s1 = self.stat(nf, (cnt + 31) // 32)
+                s1 = self.stat(nf, (cnt + 127) // 128)
                 self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
                 g1s.append(g1); s1s.append(s1)
             Bp.join(len(dils)); self.cur_lane = 0
@@ -587,7 +598,7 @@ class Graph:
         F, tr = self.fwd, self.training
         lay = self.Lconv([x.C], nf, 1)
         y = self.new(x.N, x.H // 2, x.W // 2, nf)
-        st = self.stat(nf, (y.M + 31) // 32) if tr else None
+        st = self.stat(nf, (y.M + 127) // 128) if tr else None
         self.conv(F, [(x, 0, 1, 1)], lay["segs"], nf, self.P(lay["bias"]), y, stride=2, stats=st)
         y.stats = st
         if tr:
@@ -618,7 +629,7 @@ class Graph:
             Bp = self.bwd
             g = y.grad
             if not node["fused"]:
-                node["s2"] = self.stat(x.C, self.stat_blocks(x))
+                node["s2"] = self.stat(x.C, self.stat_blocks(x), burst=True)
                 Bp.add("rua_col_stats2", g.ptr, x.ptr, coef.scale, coef.shift, 1 if relu else 0, x.M, x.C, node["s2"].ptr, node["s2"].R, self.dt)
             gx, acc = self.gacc(x)
             self.bn_bwd(Bp, [g], [coef], [bn], [node["s2"]], x, gx, acc, cnt, masked=(relu and not node["fused"]))
@@ -628,7 +639,7 @@ class Graph:
     def fuse_target(self, node):
         """dgrad epilogue arguments that make `node`'s backward fused (single consumer only)."""
         node["fused"] = True
-        node["s2"] = self.stat(node["x"].C, (node["x"].M + 31) // 32)
+        node["s2"] = self.stat(node["x"].C, (node["x"].M + 127) // 128)
         g, _ = self.gacc(node["y"])
         if node["relu"]:
             return dict(out=g, mask=(node["x"], node["coef"].scale, node["coef"].shift), stats2=node["s2"])
@@ -639,7 +650,7 @@ class Graph:
         F, tr = self.fwd, self.training
         lay = self.Lconv([t.C for t, _ in segs], cout, 1)
         y = self.new(self.B, out_hw[0], out_hw[1], cout)
-        st = self.stat(cout, (y.M + 31) // 32) if (tr and want_stats) else None
+        st = self.stat(cout, (y.M + 127) // 128) if (tr and want_stats) else None
         self.conv(F, [(t, up, 1, 1) for t, up in segs], lay["segs"], cout, self.P(lay["bias"]), y, stats=st)
         y.stats = st
         return y, lay
