@@ -54,8 +54,14 @@ def measured_traffic(kernel, args):
     t = json.load(open(path))
     if t.get("workload") != args.workload or t.get("dtype") != args.dtype:
         return None
-    k = t["kernels"].get(kernel.split("+")[0])
-    return k["bytes_per_launch"] if k else None
+    name = kernel.split("+")[0]
+    k = t["kernels"].get(name)
+    if k:
+        return k["bytes_per_launch"]
+    # template instantiations the bench name folds together (conv_halo<32> = conv_halo<32,2> + conv_halo<32,3>, ...)
+    fam = [v for kk, v in t["kernels"].items() if kk.startswith(name[:-1] + ",")]
+    n = sum(v["launches_seen"] for v in fam)
+    return round(sum(v["bytes_per_launch"] * v["launches_seen"] for v in fam) / n) if n else None
 
 
 def profile_kernels(eng, g, dtype):
@@ -90,7 +96,8 @@ def profile_kernels(eng, g, dtype):
                 d = args[0]._obj
                 if name == "rua_conv_fwd":
                     bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d)), lib.raw('rua_conv_tile_bn')(C.byref(d))
-                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap<{bm_},{bn_}>", f"conv_halo<{d.Cout}>")[kid]
+                    split = lib.raw("rua_conv_last_ksplit")() > 1
+                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap<{bm_},{bn_}>", f"conv_halo<{d.Cout}>")[kid] + ("+splitk_finish" if split else "")
                     kk = sum(d.seg[i].taps * d.seg[i].C for i in range(d.nseg))
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "")
                     rec.append((kn, e0, e1, conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags)))

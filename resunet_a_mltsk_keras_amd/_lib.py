@@ -66,6 +66,7 @@ _SIGS = {
     "rua_conv_tile_bn": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_tile_bm": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_kernel_id": ([C.POINTER(ConvDesc)], i32),
+    "rua_conv_last_ksplit": ([], i32),
     "rua_conv_workspace_bytes": ([C.POINTER(ConvDesc)], i64),
     "rua_conv_wgrad": ([C.POINTER(WgradDesc), vp], i32),
     "rua_wgrad_workspace_bytes": ([C.POINTER(WgradDesc)], i64),

@@ -1283,6 +1283,9 @@ template <typename T> static int dispatch_conv(const ConvK& k, int bm, int bn, i
   return bn == 32 ? launch_conv<T, 128, 32>(k, nbm, st) : launch_conv<T, 128, 64>(k, nbm, st);
 }
 
+static thread_local int g_last_ksplit = 1;
+extern "C" int rua_conv_last_ksplit(void) { return g_last_ksplit; }    // K slices of this thread's latest rua_conv_fwd launch (1: no finisher ran)
+
 extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   RUA_CHECK_ARG(d && d->nseg >= 1 && d->nseg <= RUA_MAX_SEG, "rua_conv_fwd: nseg out of range");
   RUA_CHECK_ARG(d->dtype == RUA_F32 || d->dtype == RUA_BF16, "rua_conv_fwd: bad dtype");
@@ -1333,6 +1336,7 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (pick_halo(d)) {
     k.nbn = 1; k.nbm = 1; k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr;
+    g_last_ksplit = 1;
     return launch_conv_halo(k, d->seg[0].dil, st);
   }
   if (pick_dmap(d)) {
@@ -1355,6 +1359,7 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     k.ws = (float*)d->workspace;
     k.stages_per_split = (nstages + want - 1) / want;
     k.ksplit = (nstages + k.stages_per_split - 1) / k.stages_per_split;
+    g_last_ksplit = k.ksplit;
     static const int rowb = env_int("RUA_DMAP_ROWB") == 128 ? 128 : 64;
     return rowb == 128 ? launch_conv_dmap<128, 128, 128>(k, st) : launch_conv_dmap<128, 128, 64>(k, st);
   }
@@ -1368,6 +1373,7 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.ksplit = (d->workspace && bm == 128) ? pick_ksplit((long long)nbm * k.nbn, nstages, k.M, d->Cout, (size_t)d->workspace_bytes) : 1;
   k.stages_per_split = (nstages + k.ksplit - 1) / k.ksplit;
   k.ksplit = (nstages + k.stages_per_split - 1) / k.stages_per_split;
+  g_last_ksplit = k.ksplit;
   // Kernel choice (measured per level, scratch/bench_conv.py): the LDS-DMA kernel wins where K is long and the grid is
   // small (Cout >= 128: 5-12 %); the register-staged kernel wins on the two top levels (short K, occupancy-bound) and,
   // with 128-wide tiles, on the very long K of the multi-branch convs at Cout >= 256.

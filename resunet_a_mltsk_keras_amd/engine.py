@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -1006,6 +1007,7 @@ class Engine:
         self.use_graph = True
         self._captured: Dict[int, object] = {}
         self._captured_dp: Dict[int, list] = {}
+        self.dp_graph = os.environ.get("RUA_DP_GRAPH", "1") != "0"      # data-parallel step as HIP-graph pieces (else eager launches)
         self.scalars_ptr = self.stats_arena.data_ptr()
         self.t = 0
         self.weights_dirty = True
@@ -1217,22 +1219,32 @@ class Engine:
             cuts = sorted(marks)
             nb = len(g.bwd.calls)
             pieces, first = [], 0
-            for ci, idx in enumerate(cuts + [nb - 1]):
-                if ci == len(cuts) and first >= nb:
-                    break
-                cap = torch.cuda.CUDAGraph()
-                # thread_local: the process group's watchdog thread may query events while we capture
-                with torch.cuda.graph(cap, capture_error_mode="thread_local"):
-                    s = self._stream()
-                    if first == 0:
-                        self._zero_arena(g, s); self.weights_dirty = True; self._prep_weights(s)
-                        g.fwd.run(s); g.loss_plan.run(s)
-                    g.bwd.run(s, first=first, last=idx + 1)
-                pieces.append((cap, marks.get(idx, []) if ci < len(cuts) else []))
-                first = idx + 1
-            opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(opt, capture_error_mode="thread_local"):
-                self._launch_optimizer(1.0 / self.world, self._stream())
+            try:
+                for ci, idx in enumerate(cuts + [nb - 1]):
+                    if ci == len(cuts) and first >= nb:
+                        break
+                    cap = torch.cuda.CUDAGraph()
+                    # thread_local: the process group's watchdog thread may query events while we capture
+                    with torch.cuda.graph(cap, capture_error_mode="thread_local"):
+                        s = self._stream()
+                        if first == 0:
+                            self._zero_arena(g, s); self.weights_dirty = True; self._prep_weights(s)
+                            g.fwd.run(s); g.loss_plan.run(s)
+                        g.bwd.run(s, first=first, last=idx + 1)
+                    pieces.append((cap, marks.get(idx, []) if ci < len(cuts) else []))
+                    first = idx + 1
+                opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(opt, capture_error_mode="thread_local"):
+                    self._launch_optimizer(1.0 / self.world, self._stream())
+            except RuntimeError as exc:
+                # Capture is an optimisation: the eager launch sequence issues the same kernels and the same collectives in
+                # the same order (so ranks may even disagree on which path they run).  Say so loudly and carry on.
+                import sys
+                print(f"[resunet_a] HIP-graph capture of the data-parallel step failed ({exc}); running it eagerly", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                self.dp_graph = False
+                self.weights_dirty = True
+                return g
             self._captured_dp[B] = pieces
             self._opt_graph = opt
             self.weights_dirty = True
@@ -1253,7 +1265,7 @@ class Engine:
         if self.use_graph and self.dist is None:
             g = self._graph_step(x, y)
             return self._results(g) if fetch else None
-        if self.use_graph and not self.dist.host_staged and not self.use_lanes:
+        if self.use_graph and self.dp_graph and not self.dist.host_staged and not self.use_lanes:
             g = self._graph_step_dp(x, y)
             return self._results(g) if fetch else None
         g = self.forward_backward(x, y)
