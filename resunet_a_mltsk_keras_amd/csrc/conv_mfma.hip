@@ -929,7 +929,7 @@ __device__ __forceinline__ int fdiv(int x, unsigned m, int dv) { return dv == 1 
 
 template <int C, int MAXMT>                           // MAXMT: MFMA row tiles per wave (rows <= MAXMT * 128)
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(C == 64 ? 2 : (MAXMT == 2 ? 4 : 3), C == 64 ? 2 : (MAXMT == 2 ? 4 : 3))))     // = blocks per CU the LDS footprint allows
+__attribute__((amdgpu_waves_per_eu(C == 64 ? 2 : (MAXMT == 2 ? 4 : 4), C == 64 ? 2 : (MAXMT == 2 ? 6 : 4))))     // = blocks per CU the LDS footprint allows
 void conv_halo(const HaloK q) {
   typedef bf16_t T;
   static_assert(C == 32 || C == 64, "conv_halo: C = Cout in {32, 64}");
@@ -983,14 +983,16 @@ void conv_halo(const HaloK q) {
 
   // ---- weights: every wave keeps the B fragments of all 9 taps in registers -------------------------------------------
   const int lr = lane & 31, lh = lane >> 5;
-  bf16x8 fb[BLDS ? 1 : 9][BLDS ? 1 : KST];
+  // C = 32: B fragments of ONE kernel row (3 taps) live in registers; the fragment of tap t + 3 is loaded into the
+  // registers of tap t right after the MFMAs that consumed it (72 -> 24 VGPRs: one to two more blocks per CU)
+  bf16x8 fb[BLDS ? 1 : 3][BLDS ? 1 : KST];
+  const unsigned char* wlane = p.seg[0].w + ((size_t)lr * C + lh * 8) * 2;      // this lane's (cout row, k half) in tap 0
   if constexpr (!BLDS) {
-    const unsigned char* wp = p.seg[0].w;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int ks = 0; ks < KST; ++ks)
-        fb[t][ks] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)(t * C + lr) * C + ks * 16 + lh * 8) * 2);
+        fb[t][ks] = *reinterpret_cast<const bf16x8*>(wlane + ((size_t)t * C * C + ks * 16) * 2);
   } else {
     // 288 rows (tap, output channel) x 128 B -> LDS by DMA, 8 rows per wave-instruction, same source-side swizzle
     const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(p.seg[0].w, p.seg[0].wbytes);
@@ -1053,10 +1055,13 @@ void conv_halo(const HaloK q) {
       }
       bf16x8 fbv;
       if constexpr (BLDS) fbv = *reinterpret_cast<const bf16x8*>(sB + (t * 32 + lr) * ROWB + (((ks * 2 + lh) ^ ((lr >> SW) & (SPR - 1))) * 16));
-      else fbv = fb[t][ks];
+      else fbv = fb[t % 3][ks];
 #pragma unroll
       for (int a = 0; a < MAXMT; ++a)          // unconditional (a branch around MFMAs makes hipcc shuttle the accumulators):
         acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fbv, acc[a], 0, 0, 0);     // a missing row tile computes garbage, never stored
+      if constexpr (!BLDS) {
+        if (t < 6) fb[t % 3][ks] = *reinterpret_cast<const bf16x8*>(wlane + ((size_t)(t + 3) * C * C + ks * 16) * 2);
+      }
     }
   }
   // ---- epilogue, 128 rows (one row tile per wave) at a time: a small fp32 tile keeps LDS per block low (more blocks per CU) --
@@ -1355,6 +1360,9 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
       if (want > 32) want = 32;
       if (want > slabs) want = (int)slabs;
       if (want < 1) want = 1;
+      // half the chip busy for a short K beats two slices + slab traffic + a finisher launch
+      // (measured at the 32x32 level: 28.4 vs 32.5 us for K = 36 stages; the 108-stage convs still split: 46 vs 68)
+      if (tiles * 2 >= target && nstages <= 40) want = 1;
     }
     k.ws = (float*)d->workspace;
     k.stages_per_split = (nstages + want - 1) / want;
