@@ -1082,7 +1082,9 @@ class Engine:
                 src = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32))
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError(f"expected shape {tuple(dst.shape)}, got {tuple(src.shape)}")
-            dst.copy_(src)            # blocking: the source may be a temporary pageable host tensor
+            # pageable sources may be temporaries: blocking copy.  Pinned tensors (loader.PrefetchLoader slots, which stay
+            # alive and untouched until the step has returned its metrics) go up asynchronously on the compute stream.
+            dst.copy_(src, non_blocking=bool(src.is_pinned()) if isinstance(src, torch.Tensor) else False)
         put(g.x_in.t, x)
         if y is not None:
             if isinstance(y, dict):

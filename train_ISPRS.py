@@ -109,12 +109,6 @@ class ScalarLog:
         self.f.flush()
 
 
-def load_batch(x_paths, y_paths, idx, x_buf, y_bufs):
-    for b, i in enumerate(idx):
-        x_buf[b] = np.load(x_paths[i])
-        for h, buf in y_bufs.items():
-            buf[b] = np.load(y_paths[h][i]).astype(np.float32)
-
 
 def train_model(args, net, x_tr, y_tr, x_va, y_va, batch_size, epochs, x_shape, n_classes, patience=10, delta=0.001,
                 metrics_names=None, rank=0):
@@ -123,22 +117,22 @@ def train_model(args, net, x_tr, y_tr, x_va, y_va, batch_size, epochs, x_shape, 
     say(f"Training on {len(x_tr)} images\nValidating on {len(x_va)} images\n" + "=" * 60 + f"\nTotal Epochs: {epochs}")
     tw = ScalarLog(os.path.join(args.results_path, "logs", "train")) if rank == 0 else None
     vw = ScalarLog(os.path.join(args.results_path, "logs", "val")) if rank == 0 else None
-    heads = list(y_tr)
-    mk = lambda c: np.zeros(x_shape[:3] + (c,), np.float32)
-    xb, yb = np.zeros(x_shape, np.float32), {h: mk(3 if h == "color" else n_classes) for h in heads}
+    from resunet_a_mltsk_keras_amd.loader import PrefetchLoader
+    # the reference loads 5*B .npy files serially before every step (train_ISPRS.py:115-141); here worker threads read
+    # two batches ahead into pinned buffers
+    ld_tr = PrefetchLoader(x_tr, y_tr, batch_size)
+    ld_va = PrefetchLoader(x_va, y_va, batch_size)
     min_loss, cont = float("inf"), 0
     rng = np.random.default_rng(args.seed)
     say(net.output_names)
     for epoch in range(epochs):
         acc_tr = np.zeros(len(metrics_names)); acc_va = np.zeros(len(metrics_names))
-        order = rng.permutation(len(x_tr))
-        n_tr, n_va = len(x_tr) // batch_size, len(x_va) // batch_size
-        for b in range(n_tr):
-            load_batch(x_tr, y_tr, order[b * batch_size:(b + 1) * batch_size], xb, yb)
+        ld_tr.set_order(rng.permutation(len(x_tr)))
+        n_tr, n_va = len(ld_tr), len(ld_va)
+        for xb, yb in ld_tr:
             acc_tr += np.asarray(net.train_on_batch(x=xb, y=yb if args.multitasking else yb["seg"], return_dict=False))
         acc_tr /= max(n_tr, 1)
-        for b in range(n_va):
-            load_batch(x_va, y_va, range(b * batch_size, (b + 1) * batch_size), xb, yb)
+        for xb, yb in ld_va:
             acc_va += np.asarray(net.test_on_batch(x=xb, y=yb if args.multitasking else yb["seg"]))
         acc_va /= max(n_va, 1)
         tm, vm = dict(zip(metrics_names, acc_tr)), dict(zip(metrics_names, acc_va))
