@@ -208,3 +208,39 @@ def test_data_parallel_graph_pieces_match_single_process_step():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_evaluation_script_end_to_end(tmp_path):
+    """test_ISPRS.py: tile -> predict -> argmax -> metrics -> mosaic on a synthetic test tile; the numbers must
+    equal what the same model gives through predict() directly."""
+    import importlib.util
+    from ResUnet_a.model2 import Resunet_a
+    spec = importlib.util.spec_from_file_location("eval_isprs", os.path.join(ROOT, "test_ISPRS.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+
+    class A:
+        multitasking = True
+        gpu_parallel = False
+    ps, ncls = 64, 5
+    net = Resunet_a((ps, ps, 3), ncls, A()).model
+    path = str(tmp_path / "m.h5")
+    net.save(path)
+    rng = np.random.default_rng(0)
+    colours = np.array([eval(k) for k in ev.LABEL_DICT], np.uint8)
+    cls = rng.integers(0, 5, size=(2 * ps + 10, 3 * ps))                       # 2 x 3 patches + a border that is dropped
+    os.makedirs(tmp_path / "data")
+    np.save(tmp_path / "data" / "Image_Test.npy", rng.integers(0, 256, size=(3,) + cls.shape).astype(np.uint8))
+    np.save(tmp_path / "data" / "Reference_Test.npy", colours[cls].transpose(2, 0, 1))
+    out = ev.main(["--use_multitasking", "--model_path", path, "--dataset_path", str(tmp_path / "data"), "-ps", str(ps),
+                   "--num_classes", str(ncls), "--output_path", str(tmp_path / "preds")])
+    img = np.load(tmp_path / "data" / "Image_Test.npy").astype(np.float32).transpose(1, 2, 0) / 255.0
+    patches = ev.extract_patches_train(img, ps)
+    direct = np.argmax(net.predict(patches, batch_size=2)["seg"], axis=-1)
+    ref = ev.extract_patches_test(cls.astype(np.uint8), ps)
+    assert out["accuracy"] == pytest.approx(100.0 * (direct.reshape(-1) == ref.reshape(-1)).mean(), abs=1e-9)
+    mosaic = np.load(tmp_path / "preds" / "pred_seg_reconstructed.npy")
+    assert mosaic.shape == cls.shape and np.array_equal(mosaic[:ps, ps:2 * ps], direct[1])
+    assert out["confusion_matrix"].sum() == 6 * ps * ps
+    assert os.path.getsize(tmp_path / "preds" / "pred_seg_reconstructed.ppm") > 3 * cls.size
+    assert np.load(tmp_path / "preds" / "pred_color.npy").shape == (6, ps, ps, 3)
