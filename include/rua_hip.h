@@ -64,9 +64,12 @@ typedef struct rua_conv_desc {
   int32_t out_stride, OH, OW;
   double* stats;               /* [stats_replicas][2][Cout] atomically accumulated, or NULL */
   int32_t stats_mode;          /* 1: sum v, sum v^2   2: sum v, sum v*aux */
-  void* workspace;             /* optional fp32 scratch, >= 2 * rua_conv_workspace_bytes(): enables split-K for small output
-                                  grids (one N*H*W*Cout slab per K slice, plain stores, summed in a fixed order by the
-                                  finisher: deterministic).  Contents on entry are irrelevant and undefined on return */
+  void* workspace;             /* optional fp32 scratch, >= 2 * rua_conv_workspace_bytes() + 4096: enables split-K for small
+                                  output grids (one N*H*W*Cout slab per K slice, plain stores, summed in a fixed order:
+                                  deterministic).  The LAST 4096 bytes are reserved for the tile ticket counters of the
+                                  optional in-launch reduction (RUA_DMAP_FUSED_FINISH=1): zero them once (e.g. allocate
+                                  the workspace zero-filled); every call leaves them zero.  The rest: contents on entry
+                                  irrelevant, undefined on return */
   int64_t workspace_bytes;
   int32_t stats_replicas;      /* power of two >= 1: block b adds into replica b % R (spreads atomic contention);
                                   the finalize kernels sum the replicas */

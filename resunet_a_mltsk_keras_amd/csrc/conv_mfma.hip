@@ -22,6 +22,7 @@ struct ConvK {
   const float* bias; const unsigned char* aux; int aux_mode; const float* mscale; const float* mshift;
   int out_relu, accumulate; unsigned char* y; int out_stride, OH, OW; double* stats; int stats_mode; int stats_R;
   int nbn, nbm, ksplit, stages_per_split; float* ws;
+  int* cnt;      // per-tile ticket counters (all zero between launches) for the in-launch split-K reduction, or null
 };
 
 template <typename T> __device__ __forceinline__ void load8(const unsigned char* base, size_t elem_off, float* f) {
@@ -880,6 +881,30 @@ __global__ __launch_bounds__(256) void conv_dmap(const ConvK p) {
           const int c = n0 + wn * (BN / WN) + b * 32 + lr;
           if (m < p.M && c < p.Cout) p.ws[((size_t)ks_i * p.M + m) * p.Cout + c] = acc[a][b][i];
         }
+    if (p.cnt == nullptr) return;                      // a separate conv_splitk_finish launch sums the slabs
+    // In-launch reduction: the slice that arrives LAST at this tile's ticket counter sums the slabs (fixed order) and runs
+    // the epilogue.  Publication: every wave's slab stores complete (vmcnt) -> block barrier -> one agent-scope release +
+    // relaxed ticket; the last arriver takes one agent-scope acquire (the other XCDs' L2s are not coherent with ours)
+    // before any slab load.  The ticket word lives in the kernel's one dynamic LDS array (a second __shared__ object
+    // beside LDS-DMA buffers makes hipcc drain vmcnt(0) before every ds_read of the K loop).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    int* cnt = p.cnt + (bm_i * p.nbn + bn_i);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *flag = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*flag != p.ksplit - 1) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
+    __syncthreads();
+    conv_epilogue<T, BM, BN, true>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sC + BM * CSTR);
     return;
   }
 #pragma unroll
@@ -1182,7 +1207,7 @@ template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, 
   constexpr int smem = conv_dmap_smem<BM, BN>();
   hipLaunchKernelGGL((conv_dmap<BM, BN, ROWB>), dim3(k.nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
   RUA_LAUNCH_CHECK("conv_dmap");
-  if (k.ksplit > 1) {
+  if (k.ksplit > 1 && k.cnt == nullptr) {
     launch_splitk_finish<bf16_t>(k, st);
     RUA_LAUNCH_CHECK("conv_splitk_finish");
   }
@@ -1340,7 +1365,7 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   RUA_CHECK_ARG((k.stats_R & (k.stats_R - 1)) == 0, "rua_conv_fwd: stats_replicas must be a power of two");
   hipStream_t st = (hipStream_t)stream;
   if (pick_halo(d)) {
-    k.nbn = 1; k.nbm = 1; k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr;
+    k.nbn = 1; k.nbm = 1; k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr; k.cnt = nullptr;
     g_last_ksplit = 1;
     return launch_conv_halo(k, d->seg[0].dil, st);
   }
@@ -1353,7 +1378,14 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     const int nstages = units / 2;
     const long long tiles = (long long)k.nbm * k.nbn;
     int want = 1;
-    const long long slabs = d->workspace ? (long long)((size_t)d->workspace_bytes / ((size_t)k.M * d->Cout * sizeof(float))) : 0;
+    // the last 4 KiB of the workspace hold the tile ticket counters of the in-launch reduction (zero between launches:
+    // the caller zero-fills the workspace once, every last arriver resets its counter)
+    // OFF by default - measured: the single last-arriving block reads ksplit x 64 KB of slabs serially (8x8 level: 45 vs 26 us,
+    // 16x16: 39 vs 28 us); the separate finisher spreads the same bytes over 1024 blocks.  Kept (and tested) as an option.
+    static const int fused = getenv("RUA_DMAP_FUSED_FINISH") ? atoi(getenv("RUA_DMAP_FUSED_FINISH")) : 0;
+    const size_t ws_usable = d->workspace_bytes > 4096 ? (size_t)d->workspace_bytes - 4096 : 0;
+    const long long slabs = d->workspace ? (long long)(ws_usable / ((size_t)k.M * d->Cout * sizeof(float))) : 0;
+    k.cnt = (fused && d->workspace && tiles <= 1024) ? reinterpret_cast<int*>((char*)d->workspace + ws_usable) : nullptr;
     if (slabs >= 2 && tiles < target) {
       want = (int)((target + tiles - 1) / tiles);
       if (want > nstages / 4) want = nstages / 4;
@@ -1378,7 +1410,9 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.nbm = nbm;
   const int nstages = (units + 1) / 2;
   k.ws = (float*)d->workspace;
-  k.ksplit = (d->workspace && bm == 128) ? pick_ksplit((long long)nbm * k.nbn, nstages, k.M, d->Cout, (size_t)d->workspace_bytes) : 1;
+  k.cnt = nullptr;
+  k.ksplit = (d->workspace && bm == 128) ? pick_ksplit((long long)nbm * k.nbn, nstages, k.M, d->Cout,
+                                                       d->workspace_bytes > 4096 ? (size_t)d->workspace_bytes - 4096 : 0) : 1;
   k.stages_per_split = (nstages + k.ksplit - 1) / k.ksplit;
   k.ksplit = (nstages + k.stages_per_split - 1) / k.stages_per_split;
   g_last_ksplit = k.ksplit;

@@ -125,7 +125,8 @@ def test_conv_split_k_matches_single_pass(dt):
     xd, wd, ad, bd = to_dev(x, dt), to_dev(w, dt), to_dev(aux, dt), torch.from_numpy(bias).to(dev())
     y = torch.empty((N, H, W, Cout), dtype=tdt(dt), device=dev())
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev())
-    ws = torch.full((16 * N * H * W * Cout,), float("nan"), dtype=torch.float32, device=dev())   # contents on entry are irrelevant
+    ws = torch.full((16 * N * H * W * Cout + 1024,), float("nan"), dtype=torch.float32, device=dev())   # slab contents on entry are irrelevant
+    ws[-1024:] = 0                                            # ... except the ticket counters in the last 4 KiB: zero once
     d = L.ConvDesc()
     d.nseg = 1
     s = d.seg[0]
@@ -135,7 +136,7 @@ def test_conv_split_k_matches_single_pass(dt):
     d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
     d.stats, d.stats_mode, d.stats_replicas = stats.data_ptr(), 2, 1
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    assert lib.raw("rua_conv_workspace_bytes")(C.byref(d)) * 16 == ws.numel() * 4
+    assert lib.raw("rua_conv_workspace_bytes")(C.byref(d)) * 16 + 4096 == ws.numel() * 4
     lib.call("rua_conv_fwd", C.byref(d), stream())
     torch.cuda.synchronize()
     y1 = y.clone()
@@ -143,6 +144,7 @@ def test_conv_split_k_matches_single_pass(dt):
     lib.call("rua_conv_fwd", C.byref(d), stream())
     torch.cuda.synchronize()
     assert torch.equal(y1.view(torch.uint8), y.view(torch.uint8))
+    assert int(ws[-1024:].view(torch.int32).abs().max()) == 0          # counters (RUA_DMAP_FUSED_FINISH=1 only) are back to zero
     a = rnd(dt, aux).double().numpy()
     exp = (ref_conv_nhwc(rnd(dt, x), rnd(dt, w), torch.from_numpy(bias), 1, 9).numpy()) * (a > 0)
     assert rel_err(y.float().cpu().numpy(), exp) < tol(dt)
