@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned char* x, c
   }
 }
 
-template <typename T>
+template <typename T, int CO>      // CO: output channels held in registers (exact for the reference's 6 classes / 3 colour bands, else 8)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, const float* __restrict__ dz, const float* __restrict__ w,
                                                         unsigned char* dx, int accumulate_dx, float* dw, float* db, float* partial,
                                                         long long M, int Cin, int Cout, int rows_per_block) {
@@ -169,32 +169,51 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
   const int CGI = Cin / VEC;
   const int cp = threadIdx.x % CGI, pl = threadIdx.x / CGI, PL = 256 / CGI;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  float wr[8][VEC], acc[8][VEC], bs[8];
+  float wr[CO][VEC], acc[CO][VEC], bs[CO];
 #pragma unroll
-  for (int co = 0; co < 8; ++co) { bs[co] = 0.f;
+  for (int co = 0; co < CO; ++co) { bs[co] = 0.f;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { wr[co][j] = co < Cout ? w[co * Cin + cp * VEC + j] : 0.f; acc[co][j] = 0.f; } }
   long long r = (long long)blockIdx.x * rows_per_block + pl;
   long long rend = (long long)(blockIdx.x + 1) * rows_per_block; if (rend > M) rend = M;
-  for (; r < rend; r += PL) {
-    float xv[VEC], g[8], o[VEC];
-    ET<T>::unpack(ldg16(x + ((size_t)r * CGI + cp) * 16), xv);
-#pragma unroll
-    for (int co = 0; co < 8; ++co) g[co] = co < Cout ? dz[r * Cout + co] : 0.f;
+  auto row = [&](const uint4& xq, const float* g, const uint4& oq, long long rr) {
+    float xv[VEC], o[VEC];
+    ET<T>::unpack(xq, xv);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o[j] = 0.f;
-    if (dx && accumulate_dx) ET<T>::unpack(ldg16(dx + ((size_t)r * CGI + cp) * 16), o);
+    if (dx && accumulate_dx) ET<T>::unpack(oq, o);
 #pragma unroll
-    for (int co = 0; co < 8; ++co) {
+    for (int co = 0; co < CO; ++co) {
       bs[co] += g[co];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { o[j] = fmaf(g[co], wr[co][j], o[j]); acc[co][j] = fmaf(g[co], xv[j], acc[co][j]); }
     }
-    if (dx) stg16(dx + ((size_t)r * CGI + cp) * 16, ET<T>::pack(o));
+    if (dx) stg16(dx + ((size_t)rr * CGI + cp) * 16, ET<T>::pack(o));
+  };
+  // two rows per iteration, every load of both issued before the first use
+  for (; r + PL < rend; r += 2 * PL) {
+    const long long r1 = r + PL;
+    const uint4 x0 = ldg16(x + ((size_t)r * CGI + cp) * 16), x1 = ldg16(x + ((size_t)r1 * CGI + cp) * 16);
+    float g0[CO], g1[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) { g0[co] = co < Cout ? dz[r * Cout + co] : 0.f; g1[co] = co < Cout ? dz[r1 * Cout + co] : 0.f; }
+    uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+    if (dx && accumulate_dx) { o0 = ldg16(dx + ((size_t)r * CGI + cp) * 16); o1 = ldg16(dx + ((size_t)r1 * CGI + cp) * 16); }
+    row(x0, g0, o0, r);
+    row(x1, g1, o1, r1);
+  }
+  for (; r < rend; r += PL) {
+    const uint4 x0 = ldg16(x + ((size_t)r * CGI + cp) * 16);
+    float g0[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) g0[co] = co < Cout ? dz[r * Cout + co] : 0.f;
+    uint4 o0 = make_uint4(0, 0, 0, 0);
+    if (dx && accumulate_dx) o0 = ldg16(dx + ((size_t)r * CGI + cp) * 16);
+    row(x0, g0, o0, r);
   }
   // lanes that share a channel piece (same lane % CGI) are folded with shuffles, then one LDS slot per wave
 #pragma unroll
-  for (int co = 0; co < 8; ++co) {
+  for (int co = 0; co < CO; ++co) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
       for (int o = CGI; o < 64; o <<= 1) acc[co][j] += __shfl_xor(acc[co][j], o, 64);
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
   }
   if (lane < CGI) {
 #pragma unroll
-    for (int co = 0; co < 8; ++co) {
+    for (int co = 0; co < CO; ++co) {
       if (co < Cout) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) red[wid * NE + co * Cin + lane * VEC + j] = acc[co][j];
@@ -262,8 +281,11 @@ extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void
   const size_t smem = (size_t)4 * ne * 4;
   float* partial = (scratch && scratch_bytes >= (int64_t)g * ne * 4) ? scratch : nullptr;   // else: fp32 atomics
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RUA_BF16) hipLaunchKernelGGL((head_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb);
-  else hipLaunchKernelGGL((head_bwd_kernel<float>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb);
+#define RUA_HEAD_BWD(TT, CO_) hipLaunchKernelGGL((head_bwd_kernel<TT, CO_>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, \
+    (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb)
+  if (dtype == RUA_BF16) { if (Cout == 6) RUA_HEAD_BWD(bf16_t, 6); else if (Cout == 3) RUA_HEAD_BWD(bf16_t, 3); else RUA_HEAD_BWD(bf16_t, 8); }
+  else { if (Cout == 6) RUA_HEAD_BWD(float, 6); else if (Cout == 3) RUA_HEAD_BWD(float, 3); else RUA_HEAD_BWD(float, 8); }
+#undef RUA_HEAD_BWD
   RUA_LAUNCH_CHECK("rua_head_bwd");
   if (partial) {
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((ne + 15) / 16), dim3(256), 0, st, (const float*)partial, ne, g, dw, Cout * Cin, db);
