@@ -2,6 +2,7 @@
 // model2.py:101) and the heads (32 -> num_classes / 3 with softmax / sigmoid, model2.py:145-188).
 // Both are HBM-bound; weights live in LDS / registers, one thread per pixel (or pixel x piece).
 #include "common.h"
+#include <stdlib.h>
 
 template <typename T> __device__ __forceinline__ void st8(unsigned char* base, size_t elem_off, const float* f) {
   if constexpr (sizeof(T) == 2) stg16(base + elem_off * 2, ET<T>::pack(f));
@@ -39,11 +40,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 template <typename T, int CINP>
 __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ x, const unsigned char* dy, float* dw, float* db,
                                                         long long M, int Cin, int Cout, int rows_per_block) {
-  extern __shared__ float red[];                      // [Cout][CINP+1]
-  for (int i = threadIdx.x; i < Cout * (CINP + 1); i += 256) red[i] = 0.f;
-  __syncthreads();
-  const int CG8 = Cout / 8;
+  extern __shared__ float red[];                      // [4 waves][Cout][CINP+1]
+  const int CG8 = Cout / 8;                           // power of two <= 32 (checked by the launcher)
   const int cg = threadIdx.x % CG8, pl = threadIdx.x / CG8, PL = 256 / CG8;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int NE = Cout * (CINP + 1);
   float acc[8][CINP], bs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { bs[j] = 0.f;
@@ -51,29 +52,50 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     for (int c = 0; c < CINP; ++c) acc[j][c] = 0.f; }
   long long r = (long long)blockIdx.x * rows_per_block + pl;
   long long rend = (long long)(blockIdx.x + 1) * rows_per_block; if (rend > M) rend = M;
-  if (pl < PL) {
-    for (; r < rend; r += PL) {
-      float g[8], xv[CINP];
-      ld8<T>(dy, (size_t)r * Cout + cg * 8, g);
+  auto fma_row = [&](const float* g, const float* xv) {
 #pragma unroll
-      for (int c = 0; c < CINP; ++c) xv[c] = c < Cin ? x[r * Cin + c] : 0.f;
+    for (int j = 0; j < 8; ++j) { bs[j] += g[j];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { bs[j] += g[j];
+      for (int c = 0; c < CINP; ++c) acc[j][c] = fmaf(g[j], xv[c], acc[j][c]); }
+  };
+  for (; r + PL < rend; r += 2 * PL) {                 // two rows per iteration, all loads before the first use
+    float g0[8], g1[8], x0[CINP], x1[CINP];
+    ld8<T>(dy, (size_t)r * Cout + cg * 8, g0);
+    ld8<T>(dy, (size_t)(r + PL) * Cout + cg * 8, g1);
 #pragma unroll
-        for (int c = 0; c < CINP; ++c) acc[j][c] = fmaf(g[j], xv[c], acc[j][c]); }
-    }
+    for (int c = 0; c < CINP; ++c) { x0[c] = c < Cin ? x[r * Cin + c] : 0.f; x1[c] = c < Cin ? x[(r + PL) * Cin + c] : 0.f; }
+    fma_row(g0, x0); fma_row(g1, x1);
+  }
+  for (; r < rend; r += PL) {
+    float g[8], xv[CINP];
+    ld8<T>(dy, (size_t)r * Cout + cg * 8, g);
+#pragma unroll
+    for (int c = 0; c < CINP; ++c) xv[c] = c < Cin ? x[r * Cin + c] : 0.f;
+    fma_row(g, xv);
+  }
+  // lanes l and l ^ o (o = CG8 .. 32) hold the same 8 output channels: fold with shuffles (the previous version sent 72 LDS
+  // float atomics per thread into 9 x Cout addresses: 88 us for a 46 MB pass), then one LDS slot per wave
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int c = 0; c < CINP; ++c)
+      for (int o = CG8; o < 64; o <<= 1) acc[j][c] += __shfl_xor(acc[j][c], o, 64);
+    for (int o = CG8; o < 64; o <<= 1) bs[j] += __shfl_xor(bs[j], o, 64);
+  }
+  if (lane < CG8) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
-      for (int c = 0; c < CINP; ++c) if (c < Cin) atomicAdd(&red[(cg * 8 + j) * (CINP + 1) + c], acc[j][c]);
-      atomicAdd(&red[(cg * 8 + j) * (CINP + 1) + CINP], bs[j]);
+      for (int c = 0; c < CINP; ++c) red[wid * NE + (lane * 8 + j) * (CINP + 1) + c] = acc[j][c];
+      red[wid * NE + (lane * 8 + j) * (CINP + 1) + CINP] = bs[j];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < Cout * (CINP + 1); i += 256) {
+  for (int i = threadIdx.x; i < NE; i += 256) {
     const int co = i / (CINP + 1), c = i - co * (CINP + 1);
-    if (c < Cin) unsafeAtomicAdd(&dw[co * Cin + c], red[i]);
-    else if (c == CINP && db) unsafeAtomicAdd(&db[co], red[i]);
+    const float v = red[i] + red[NE + i] + red[2 * NE + i] + red[3 * NE + i];
+    if (c < Cin) unsafeAtomicAdd(&dw[co * Cin + c], v);
+    else if (c == CINP && db) unsafeAtomicAdd(&db[co], v);
   }
 }
 
@@ -94,16 +116,18 @@ extern "C" int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db
   RUA_CHECK_ARG(x && dy && dw && M > 0, "rua_stem_bwd: bad arguments");
   RUA_CHECK_ARG(Cin >= 1 && Cin <= 16, "rua_stem_bwd: Cin=%d must be in 1..16", Cin);
   RUA_CHECK_ARG(Cout % 8 == 0 && Cout <= 256 && 256 % (Cout / 8) == 0, "rua_stem_bwd: unsupported Cout=%d", Cout);
-  int64_t blocks = 1024; int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
+  // every block ends with one float atomic per weight: same-address float atomics serialise (~25 ns each), so few blocks
+  static const int64_t nblk = getenv("RUA_STEM_BLOCKS") ? atoi(getenv("RUA_STEM_BLOCKS")) : 256;
+  int64_t blocks = nblk; int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
   const int g = (int)((M + rpb - 1) / rpb);
   hipStream_t st = (hipStream_t)stream;
   const unsigned char* d = (const unsigned char*)dy;
   if (Cin <= 8) {
-    const size_t smem = (size_t)Cout * 9 * 4;
+    const size_t smem = (size_t)4 * Cout * 9 * 4;
     if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, 8>), dim3(g), dim3(256), smem, st, x, d, dw, db, (long long)M, Cin, Cout, (int)rpb);
     else hipLaunchKernelGGL((stem_bwd_kernel<float, 8>), dim3(g), dim3(256), smem, st, x, d, dw, db, (long long)M, Cin, Cout, (int)rpb);
   } else {
-    const size_t smem = (size_t)Cout * 17 * 4;
+    const size_t smem = (size_t)4 * Cout * 17 * 4;
     if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, 16>), dim3(g), dim3(256), smem, st, x, d, dw, db, (long long)M, Cin, Cout, (int)rpb);
     else hipLaunchKernelGGL((stem_bwd_kernel<float, 16>), dim3(g), dim3(256), smem, st, x, d, dw, db, (long long)M, Cin, Cout, (int)rpb);
   }
