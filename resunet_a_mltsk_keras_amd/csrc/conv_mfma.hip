@@ -1888,33 +1888,60 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
 template <typename T>
 __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ master, T* __restrict__ wf, T* __restrict__ wd,
                                                     const rua_wprep_item* __restrict__ items) {
-  // one 32(co) x 32(ci) tile of one tap per block iteration: coalesced fp32 reads along ci, coalesced writes of the
-  // forward copy (same layout) and, through an LDS transpose, of the data-gradient copy [taps reversed][ci][co]
-  __shared__ float tile[32][33];
+  // one 64(co) x 64(ci) tile of one tap per block iteration: 16-byte fp32 reads along ci, 4-element writes of the forward
+  // copy (same layout) and, through an LDS transpose, of the data-gradient copy [taps reversed][ci][co].  Every slice of
+  // the flat buffers is 64-byte aligned and C, Cout are multiples of 4 wherever the fast path is taken.
+  __shared__ float tile[64][65];
   const rua_wprep_item it = items[blockIdx.y];
-  const int tco = (it.Cout + 31) / 32, tci = (it.C + 31) / 32;
+  const int tco = (it.Cout + 63) / 64, tci = (it.C + 63) / 64;
   const int ntiles = it.taps * tco * tci;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // 16 x 16: 4 elements per thread and pass
+  const bool vec = (it.C % 4 == 0) && (it.Cout % 4 == 0);
+  auto put4 = [](T* dst, const float* v) {
+    if constexpr (sizeof(T) == 2) {
+      const uint2 q = make_uint2(ET<bf16_t>::pk(v[0], v[1]), ET<bf16_t>::pk(v[2], v[3]));
+      *reinterpret_cast<uint2*>(dst) = q;
+    } else {
+      *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int tap = t / (tco * tci), r = t - tap * tco * tci;
-    const int co0 = (r / tci) * 32, ci0 = (r % tci) * 32;
+    const int co0 = (r / tci) * 64, ci0 = (r % tci) * 64;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int co = co0 + ty + k * 8, ci = ci0 + tx;
-      float v = 0.f;
-      if (co < it.Cout && ci < it.C) {
+      const int co = co0 + ty + k * 16, ci = ci0 + tx * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (co < it.Cout) {
         const size_t o = (size_t)tap * it.Cout * it.C + (size_t)co * it.C + ci;
-        v = master[it.src_off + o];
-        wf[it.dst_off + o] = (T)v;
+        if (vec && ci + 3 < it.C) {
+          const float4 q = *reinterpret_cast<const float4*>(master + it.src_off + o);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+          put4(wf + it.dst_off + o, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (ci + j < it.C) { v[j] = master[it.src_off + o + j]; wf[it.dst_off + o + j] = (T)v[j]; }
+        }
       }
-      tile[ty + k * 8][tx] = v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[ty + k * 16][tx * 4 + j] = v[j];
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int ci = ci0 + ty + k * 8, co = co0 + tx;
-      if (co < it.Cout && ci < it.C)
-        wd[it.dst_off + (size_t)(it.taps - 1 - tap) * it.Cout * it.C + (size_t)ci * it.Cout + co] = (T)tile[tx][ty + k * 8];
+      const int ci = ci0 + ty + k * 16, co = co0 + tx * 4;
+      if (ci < it.C) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = tile[tx * 4 + j][ty + k * 16];
+        T* dst = wd + it.dst_off + (size_t)(it.taps - 1 - tap) * it.Cout * it.C + (size_t)ci * it.Cout + co;
+        if (vec && co + 3 < it.Cout) put4(dst, v);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (co + j < it.Cout) dst[j] = (T)v[j];
+        }
+      }
     }
     __syncthreads();
   }
@@ -1923,7 +1950,7 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ ma
 extern "C" int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev,
                                int n_items, int max_elems, int dtype, void* stream) {
   RUA_CHECK_ARG(master && w_fwd && w_dgrad && items_dev && n_items > 0, "rua_weight_prep: bad arguments");
-  int gx = rua_div_up(max_elems, 1024 * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
+  int gx = rua_div_up(max_elems, 4096 * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RUA_BF16) hipLaunchKernelGGL((wprep_kernel<bf16_t>), dim3(gx, n_items), dim3(256), 0, st, master, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, items_dev);
   else hipLaunchKernelGGL((wprep_kernel<float>), dim3(gx, n_items), dim3(256), 0, st, master, (float*)w_fwd, (float*)w_dgrad, items_dev);
