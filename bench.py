@@ -283,7 +283,7 @@ def main():
                                  for k, v in sorted(prof.items())},
             "whole_step_frac_of_peak": round(value / world * gflop_patch / 1e3 / peak, 4),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:            # the CPU oracle is timed at N=1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
