@@ -253,3 +253,25 @@ def test_d7_512_fp32_loss_and_logits():
     for h, z in eng.logits(True, 1).items():
         assert rel(z, trainer.last_taps[h + "_logits"]) < 1e-3, h
     assert eng.count_params() > 150e6
+
+
+def test_odd_batch_partial_tiles_fp32():
+    """B = 3 on 64x64: 12288 pixels at the top level, 3 at the 1x1-pooled PSP branch - none of the tile sizes (32, 64, 128,
+    256 rows) divides every level, so the ragged-tile paths of every kernel run (and batch statistics over 3 samples)."""
+    shape, C = (64, 64, 3), 4
+    trainer, eng = make_pair(shape, C, True, 32, "weighted_cross_entropy", "sgd", cw=[1.0, 2.0, 0.5, 1.5])
+    x, y = make_batch(3, 64, 3, C, True, seed=23, block=16)
+    check_step(trainer, eng, x, y, True, 1e-3, 1e-3, 5e-3, 2e-3)
+
+
+def test_odd_batch_bf16_graph_steps():
+    """Same ragged shapes through the bf16 kernels (conv_dmap / conv_halo are bf16-only) and the whole-step HIP graph:
+    three Adam steps must track the oracle's loss within bf16 storage error and stay finite."""
+    shape, C = (128, 128, 6), 6
+    trainer, eng = make_pair(shape, C, True, 32, "tanimoto", "adam", dtype="bf16", split_k=True)
+    for step in range(3):
+        x, y = make_batch(3, 128, 6, C, True, seed=50 + step)
+        exp = trainer.train_on_batch(x, y)
+        got = eng.train_step(x, y)
+        assert np.all(np.isfinite(got))
+        assert abs(got[0] - exp[0]) <= 5e-2 * max(1.0, abs(exp[0])), (step, got[0], exp[0])
