@@ -4,3 +4,7 @@ from resunet_a_mltsk_keras_amd.keras_api import Tanimoto_dual_loss, TanimotoDual
 
 def Tanimoto_loss(label, pred):
     raise NotImplementedError("only the dual form is on the training path: use Tanimoto_dual_loss()")
+
+
+# Label synthesis of the reference module (multitasking_utils.py:6-35), without cv2: see resunet_a_mltsk_keras_amd/labels.py
+from resunet_a_mltsk_keras_amd.labels import get_boundary_label, get_distance_label  # noqa: E402,F401

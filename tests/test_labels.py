@@ -1,0 +1,67 @@
+"""Hand-derived pins of the label synthesis (parity with cv2 itself is unpinned: cv2 is not installed)."""
+import numpy as np
+
+from resunet_a_mltsk_keras_amd import labels as lb
+
+
+def square_mask(n=16, a=5, b=11):
+    m = np.zeros((n, n), np.uint8)
+    m[a:b, a:b] = 1
+    return m
+
+
+def test_canny_of_a_binary_square_is_a_closed_one_pixel_contour():
+    e = lb.canny_u8(square_mask(), 0, 1)
+    assert set(np.unique(e)) <= {0, 255}
+    ys, xs = np.nonzero(e)
+    assert ys.min() in (4, 5) and ys.max() in (10, 11) and xs.min() in (4, 5) and xs.max() in (10, 11)
+    assert e[7:9, 7:9].sum() == 0 and e[:3].sum() == 0                      # nothing inside, nothing far outside
+    # one-pixel-wide: every edge pixel of a straight side has exactly two 4/8-neighbours on that side
+    row = e[:, 8]
+    assert (row > 0).sum() == 2                                             # the vertical scan line crosses the contour twice
+    assert lb.canny_u8(np.zeros((8, 8), np.uint8), 0, 1).sum() == 0
+    assert lb.canny_u8(np.ones((8, 8), np.uint8), 0, 1).sum() == 0
+
+
+def test_boundary_label_is_the_dilated_contour_in_unit_range():
+    lab = np.stack([square_mask(), 1 - square_mask()], axis=-1).astype(np.float32)
+    b = lb.get_boundary_label(lab)
+    assert b.shape == lab.shape and b.dtype == np.float32 and set(np.unique(b)) <= {0.0, 1.0}
+    e = lb.canny_u8(square_mask(), 0, 1) > 0
+    assert np.array_equal(b[:, :, 0] > 0, lb.dilate_cross3(e.astype(np.uint8)) > 0)
+    assert b[:, :, 0].sum() > e.sum()                                       # the cross thickens the contour
+    assert b[8, 8, 0] == 0 and b[0, 0, 0] == 0
+
+
+def test_distance_label_matches_brute_force_and_degenerate_channels_are_zero():
+    m = np.zeros((12, 12), np.uint8)
+    m[2:10, 3:9] = 1
+    lab = np.stack([m, np.ones_like(m), np.zeros_like(m)], axis=-1).astype(np.float32)
+    d = lb.get_distance_label(lab)
+    zy, zx = np.nonzero(m == 0)
+    brute = np.zeros((12, 12))
+    for y, x in zip(*np.nonzero(m)):
+        brute[y, x] = np.sqrt(((zy - y) ** 2 + (zx - x) ** 2).min())
+    assert np.allclose(d[:, :, 0], brute / brute.max(), atol=1e-6)
+    assert d[:, :, 0].max() == 1.0 and d[0, 0, 0] == 0.0
+    assert not d[:, :, 1].any() and not d[:, :, 2].any()                     # full / absent class: constant image -> 0
+
+
+def test_rgb_to_hsv_known_colours():
+    rgb = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128], [255, 255, 0], [0, 255, 255], [255, 0, 255], [200, 100, 50]]], np.uint8)
+    hsv = lb.rgb_to_hsv_u8(rgb)[0]
+    assert hsv[0].tolist() == [0, 255, 255] and hsv[1].tolist() == [60, 255, 255] and hsv[2].tolist() == [120, 255, 255]
+    assert hsv[3].tolist() == [0, 0, 255] and hsv[4].tolist() == [0, 0, 0] and hsv[5].tolist() == [0, 0, 128]
+    assert hsv[6].tolist() == [30, 255, 255] and hsv[7].tolist() == [90, 255, 255] and hsv[8].tolist() == [150, 255, 255]
+    assert hsv[9].tolist() == [10, 191, 200]                                 # h = 60*(50/150)/2 = 10, s = 150/200*255 = 191.25
+    c = lb.color_label(rgb, 1)
+    assert c.dtype == np.float32 and c.max() <= 1.0 and np.isclose(c[0, 2, 0], 120 / 179)
+
+
+def test_multitask_labels_shapes():
+    seg = np.stack([square_mask(), 1 - square_mask()], axis=-1)
+    rgb = np.random.default_rng(0).integers(0, 256, size=(16, 16, 3)).astype(np.uint8)
+    out = lb.multitask_labels(seg, rgb)
+    assert set(out) == {"seg", "bound", "dist", "color"}
+    assert all(v.dtype == np.float32 for v in out.values())
+    assert out["bound"].shape == out["dist"].shape == (16, 16, 2) and out["color"].shape == (16, 16, 3)
