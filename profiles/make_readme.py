@@ -1,4 +1,34 @@
-# profiles/
+"""Regenerates the tables of profiles/README.md from r01_final/{kernel_stats.csv,bench.json} and traffic.json.
+usage: python profiles/make_readme.py   (prose sections are kept in this file)"""
+import csv, json, re, subprocess
+
+rows = list(csv.DictReader(open('profiles/r01_final/kernel_stats.csv')))
+b = json.load(open('profiles/r01_final/bench.json'))
+tr = json.load(open('profiles/traffic.json'))['kernels']
+n = b['steps'] + b['warmup'] + 4 + 1
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+
+
+def short(nm):
+    if nm.startswith('_Z'):
+        nm = subprocess.run(['c++filt', nm.replace('DF16b', 'u6__bf16')], capture_output=True, text=True).stdout.strip() or nm
+    nm = re.sub(r'^void\s+', '', nm)
+    return re.sub(r'\(.*$', '', nm).replace('__bf16', 'bf16').replace(' ', '')
+
+
+lines, rp = [], {}
+for r in rows[:22]:
+    nm = short(r['Name'])
+    rp[nm] = float(r['AverageNs']) / 1e3
+    t = tr.get(nm)
+    tb = "%.1f / %.1f" % (t['read_bytes_per_launch'] / 1e6, t['write_bytes_per_launch'] / 1e6) if t else ""
+    lines.append("| `%s` | %.1f | %.3f | %.1f | %.1f | %s |" % (nm[:48], int(r['Calls']) / n, float(r['TotalDurationNs']) / 1e6 / n,
+                                                            float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot, tb))
+table = "\n".join(lines)
+rf = b['roofline']
+fam = "\n".join("| `%s` | %d | %.1f | %.0f |" % (k, v['launches'], 1e3 * v['ms_per_step'] / v['launches'], v['tflops']) for k, v in rf['all_mfma_kernels'].items())
+dom_rp = rp.get(rf['kernel'].split('+')[0], float('nan'))
+txt = f'''# profiles/
 
 rocprofv3 summaries of `python bench.py` on one MI355X (cfg3: 256×256×6, multitask Tanimoto-dual, bs 8, bf16).  One
 sub-directory per stage of round 1, each with the `rocprofv3 --kernel-trace --stats` kernel table (`kernel_stats.csv`) and
@@ -12,7 +42,7 @@ Commands (on the GPU box):
 | dir | state | ms/step | patches/s |
 |---|---|---:|---:|
 | `r01_first/` | first correct path (contended fp64 statistics atomics, no split-K, eager launches) | 37.1 | 216 |
-| `r01_final/` | end of round 1 | 10.8 | 743 |
+| `r01_final/` | end of round 1 | {b['ms_per_step']:.1f} | {b['value']:.0f} |
 
 The ladder between the two, each step measured with the same command (see `git log`): replicated statistics buffers
 36.4→24.0 ms; split-K for small output grids + one HIP graph per step →22.0; branch-free range-checked buffer loads,
@@ -25,64 +55,32 @@ serialisation of same-address fp64 atomics →11.2; sliding-window all-taps weig
 K is not split →11.1; rolling B fragments in `conv_halo`, shuffle reductions in the stem / head gradients, vectorised weight
 prep, BN grids →10.8.
 
-## r01_final: kernel table (per training step; 18 steps in the trace incl. warm-up and the instrumented step)
+## r01_final: kernel table (per training step; {n} steps in the trace incl. warm-up and the instrumented step)
 
 | kernel | launches/step | ms/step | avg µs | % of GPU time | HBM MB/launch read / write (PMC) |
 |---|---:|---:|---:|---:|---|
-| `conv_dmap<128,128,64>` | 86.0 | 1.851 | 21.5 | 17.2 | 12.9 / 7.1 |
-| `wgrad_kernel<bf16>` | 70.0 | 1.711 | 24.4 | 15.9 | 22.3 / 6.6 |
-| `bn_bwd_kernel<bf16>` | 63.0 | 0.790 | 12.5 | 7.3 | 32.8 / 12.2 |
-| `conv_igemm<bf16,256,64>` | 24.0 | 0.713 | 29.7 | 6.6 | 31.3 / 17.2 |
-| `conv_halo<32,3>` | 18.0 | 0.669 | 37.2 | 6.2 | 57.8 / 36.2 |
-| `bn_fwd_kernel<bf16>` | 63.0 | 0.658 | 10.4 | 6.1 | 12.4 / 17.8 |
-| `wgrad_taps_kernel<32>` | 21.0 | 0.577 | 27.5 | 5.4 | 76.0 / 9.2 |
-| `conv_igemm<bf16,256,32>` | 18.0 | 0.561 | 31.2 | 5.2 | 52.6 / 21.4 |
-| `conv_halo<32,2>` | 16.0 | 0.444 | 27.8 | 4.1 | 46.6 / 33.9 |
-| `wgrad_taps_kernel<64>` | 16.0 | 0.391 | 24.4 | 3.6 | 36.6 / 18.3 |
-| `wgrad_taps_reduce` | 37.0 | 0.246 | 6.6 | 2.3 | 26.4 / 0.1 |
-| `adam_kernel` | 1.0 | 0.211 | 211.2 | 2.0 | 683.4 / 683.3 |
-| `col_stats_kernel<bool_Accum,int,E>` | 27.0 | 0.188 | 7.0 | 1.7 | 16.0 / 0.4 |
-| `conv_splitk_finish<bf16,32>` | 32.0 | 0.182 | 5.7 | 1.7 | 10.4 / 1.4 |
-| `conv_halo<64,2>` | 6.0 | 0.168 | 28.0 | 1.6 | 51.9 / 19.8 |
-| `head_bwd_kernel<bf16,6>` | 3.0 | 0.148 | 49.2 | 1.4 | 46.3 / 34.4 |
-| `col_stats_kernel<bf16,2>` | 8.0 | 0.123 | 15.3 | 1.1 | 33.4 / 0.4 |
-| `stats_to_f32_kernel` | 21.0 | 0.100 | 4.7 | 0.9 | 0.0 / 0.0 |
-| `sumpool_kernel<bf16>` | 11.0 | 0.093 | 8.5 | 0.9 | 15.4 / 2.5 |
-| `head_fwd_kernel<bf16>` | 4.0 | 0.087 | 21.7 | 0.8 | 43.4 / 22.0 |
-| `relu_kernel<bf16,0>` | 5.0 | 0.085 | 17.0 | 0.8 | 67.1 / 33.6 |
-| `wprep_kernel<bf16>` | 1.0 | 0.079 | 78.9 | 0.7 | 170.8 / 170.7 |
+{table}
 
-Total GPU time per step 10.77 ms ≈ wall 10.77 ms: the step is GPU-bound, launch gaps are gone (one HIP graph).
+Total GPU time per step {tot/1e6/n:.2f} ms ≈ wall {b['ms_per_step']:.2f} ms: the step is GPU-bound, launch gaps are gone (one HIP graph).
 
 ## Roofline line of `bench.json`
 
-Dominant kernel by total time: `wgrad_kernel<bf16>` — 70 launches/step, 24.13 µs average (live
-HIP-event timing inside bench.py, GPU kept busy, measured event-pair overhead of 5.16 µs
-subtracted; rocprofv3 average for the same kernel in `kernel_stats.csv`: 24.4 µs), 4.367
-algorithmic GFLOP per launch ⇒ **180.96 TFLOP/s = 7.2 % of the 2.5 PFLOP/s dense bf16 MFMA peak**;
-HBM traffic 28.9 MB per launch (PMC).  Whole step: 187.46 TFLOP/s of model FLOPs
-(7.5 % of peak).
+Dominant kernel by total time: `{rf['kernel']}` — {rf['launches_per_step']} launches/step, {rf['avg_launch_us']} µs average (live
+HIP-event timing inside bench.py, GPU kept busy, measured event-pair overhead of {rf['event_pair_overhead_us_subtracted']} µs
+subtracted; rocprofv3 average for the same kernel in `kernel_stats.csv`: {dom_rp:.1f} µs), {rf['algorithmic_gflop_per_launch']}
+algorithmic GFLOP per launch ⇒ **{rf['achieved']} TFLOP/s = {100*rf['frac']:.1f} % of the 2.5 PFLOP/s dense bf16 MFMA peak**;
+HBM traffic {rf['traffic']/1e6:.1f} MB per launch (PMC).  Whole step: {b['model_tflops_per_s']} TFLOP/s of model FLOPs
+({100*rf['whole_step_frac_of_peak']:.1f} % of peak).
 
 Per kernel family, same run (`all_mfma_kernels` in bench.json; "+splitk"/"+reduce" = the second launch of the same C-ABI
 call is inside the bracket):
 
 | kernel | launches | avg µs | TFLOP/s |
 |---|---:|---:|---:|
-| `conv_dma<128,64>` | 1 | 10.0 | 26 |
-| `conv_dmap<128,128>` | 54 | 25.6 | 299 |
-| `conv_dmap<128,128>+splitk` | 32 | 21.6 | 264 |
-| `conv_halo<32>` | 34 | 32.9 | 294 |
-| `conv_halo<64>` | 6 | 27.8 | 347 |
-| `conv_igemm<bf16,128,32>` | 8 | 8.0 | 7 |
-| `conv_igemm<bf16,128,64>` | 3 | 11.7 | 27 |
-| `conv_igemm<bf16,256,32>` | 18 | 30.8 | 161 |
-| `conv_igemm<bf16,256,64>` | 24 | 29.5 | 359 |
-| `wgrad_kernel<bf16>` | 70 | 24.1 | 181 |
-| `wgrad_taps_kernel<32>+reduce` | 21 | 32.5 | 297 |
-| `wgrad_taps_kernel<64>+reduce` | 16 | 32.3 | 299 |
+{fam}
 
-CPU baseline in the same JSON: 0.976 patches/s on 16 host cores
-(2 full train steps (fwd+loss+bwd+Adam) of config 1 (256x256x3, 6 classes, bs 4, fp32) after 1 warm-up step, PyTorch-CPU oracle standing in for Keras-CPU).
+CPU baseline in the same JSON: {b['cpu_baseline']['value']} patches/s on {b['cpu_baseline']['cores']} host cores
+({b['cpu_baseline']['sample']}).
 
 ## What the counters say (why these are the numbers)
 
@@ -103,3 +101,6 @@ CPU baseline in the same JSON: 0.976 patches/s on 16 host cores
 
 cfg2 (single-task) 814 patches/s (9.83 ms); cfg5 (128²×7, bs 32) 3 305 patches/s (9.68 ms); cfg4 (d7, 512², bs 4) 218 patches/s
 (18.4 ms, 233 TFLOP/s of model FLOPs).  Data-parallel step on one GPU with a one-rank RCCL group (`bench.py --force-dp`): +0.5 ms.
+'''
+open('profiles/README.md', 'w').write(txt)
+print("written", len(lines), "rows; dominant rocprof avg", dom_rp)
