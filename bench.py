@@ -102,7 +102,7 @@ def profile_kernels(eng, g, dtype):
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "")
                     rec.append((kn, e0, e1, conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags)))
                 else:
-                    wn = f"wgrad_taps_kernel<{d.C}>+reduce" if lib.raw('rua_wgrad_kind')(C.byref(d)) == 1 else f"wgrad_kernel<{tname}>"
+                    wk = lib.raw("rua_wgrad_kind")(C.byref(d)); wn = (f"wgrad_kernel<{tname}>", f"wgrad_taps_kernel<{d.C}>+reduce", "wgrad_dmap")[wk]
                     rec.append((wn, e0, e1, wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, "")))
             else:
                 rc = fn(*args, sp)

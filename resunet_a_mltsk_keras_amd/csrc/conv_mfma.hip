@@ -1563,6 +1563,181 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
 }
 
 // =========================================================================================
+// wgrad_dmap: the weight gradient of the wide levels (C, Cout multiples of 128, bf16, stride 1, power-of-two maps) on the
+// conv_dmap structure.  wgrad_kernel's 64x64 tiles (32x32 per wave: four LDS reads per MFMA, 0.031 staged bytes per FLOP,
+// one barrier per 4 MFMAs) are bound by the L2->LDS staging rate like every implicit GEMM here; this one uses 128 (co) x
+// 128 (ci) tiles with 64x64 wave tiles (two transposing LDS reads per MFMA, half the staged bytes), 64-pixel stages filled
+// by LDS-DMA into three buffers with a counted vmcnt and ONE barrier per 16 MFMAs, and the fragment prefetch across the
+// barrier.  LDS image of a stage: [64 pixels][256 B = 128 channels] for dy and for the (tap-shifted, zero-padded) input; the
+// 64-byte quarter of a row is XOR-swizzled with (pixel & 3) - applied to the per-lane SOURCE chunk of the DMA - so that the
+// ds_read_b64_tr_b16 fragment reads (4 pixel rows x 64 B per 32-lane group) hit four different bank quarters.
+struct WgdK {
+  const unsigned char* a; const unsigned char* dy; float* dw;
+  int C, Cout, H, W, dil, taps, wsh;
+  long long M;
+  int ntc, nti, ksplit, stages_per_split;
+  unsigned abytes, dybytes;
+};
+
+// Transposing LDS read that hipcc's wait insertion cannot see (it puts s_waitcnt vmcnt(0) in front of a ds_read_b64_tr_b16
+// builtin whenever an LDS-DMA is in flight, which would drain the stage pipeline at every k-step): the caller orders these
+// reads itself with counted lgkmcnt waits that name the destination registers.
+__device__ __forceinline__ s16x4 lds_tr_raw(const unsigned char* p) {
+  s16x4 v;
+  const unsigned a = (unsigned)(size_t)(lds_void_p)const_cast<unsigned char*>(p);
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+
+__global__ __launch_bounds__(256) void wgrad_dmap(const WgdK p) {
+  constexpr int NBUF = 3, PX = 64, ROWB = 256, KS = 4;
+  constexpr int D_BYTES = PX * ROWB, STAGE = 2 * D_BYTES;
+  constexpr int PER_STAGE = 8;                                      // DMA instructions per wave per stage (4 dy + 4 a)
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ks_i = vid % p.ksplit; vid /= p.ksplit;
+  const int ti = vid % p.nti; vid /= p.nti;
+  const int tc = vid % p.ntc;
+  const int tap = vid / p.ntc;
+  const int co0 = tc * 128, ci0 = ti * 128;
+  int dh = 0, dw_ = 0;
+  if (p.taps == 9) { dh = (tap / 3 - 1) * p.dil; dw_ = (tap % 3 - 1) * p.dil; }
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int H = p.H, W = p.W;
+
+  const int st_begin = ks_i * p.stages_per_split;
+  const int k_begin = st_begin * PX;                               // pixel indices fit 32 bits (checked by the launcher)
+  int k_end = k_begin + p.stages_per_split * PX;
+  if (k_end > (int)p.M) k_end = (int)p.M;
+  const int nst = k_end > k_begin ? (k_end - k_begin + PX - 1) / PX : 0;
+
+  // DMA geometry of this lane: instruction j of this wave covers pixel rows (wid*4 + j)*4 .. +3 of the stage
+  const int rl = lane >> 4, c16 = lane & 15;
+  int drow[4], dchan[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    drow[j] = (wid * 4 + j) * 4 + rl;
+    dchan[j] = (c16 ^ ((drow[j] & 3) << 2)) * 8;                   // source chunk that lands in LDS slot c16
+  }
+  const __amdgpu_buffer_rsrc_t rd_ = make_rsrc(p.dy, p.dybytes), ra_ = make_rsrc(p.a, p.abytes);
+  const int shift_px = dh * W + dw_;
+  int st_next = 0;                                                  // next stage of this block to issue
+  auto issue_next = [&](int buf) {
+    unsigned char* sD = smem + buf * STAGE;
+    unsigned char* sA = sD + D_BYTES;
+    const int p0 = k_begin + st_next * PX;                          // past the end of the K range: every pixel >= k_end => zeros
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // branch-free: offsets are computed for every lane and replaced by the out-of-range offset where invalid (a branch
+      // here would execute the DMA under a partial exec mask and leave stale LDS bytes instead of zeros)
+      const int pi = p0 + drow[j];
+      const unsigned offd = (unsigned)((pi * p.Cout + co0 + dchan[j]) * 2);
+      const unsigned okd = (unsigned)(pi < k_end);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rd_, (lds_void_p)(sD + (wid * 4 + j) * 1024), 16, okd ? offd : OOB, 0, 0, 0);
+      const int w = pi & (W - 1), h = (pi >> p.wsh) & (H - 1);
+      const unsigned oka = okd & (unsigned)((unsigned)(h + dh) < (unsigned)H) & (unsigned)((unsigned)(w + dw_) < (unsigned)W);
+      const unsigned offa = (unsigned)(((pi + shift_px) * p.C + ci0 + dchan[j]) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void_p)(sA + (wid * 4 + j) * 1024), 16, oka ? offa : OOB, 0, 0, 0);
+    }
+    ++st_next;
+  };
+
+  // fragment geometry (transposing reads, see wgrad_kernel): a 32-channel x 16-pixel fragment = two ds_read_b64_tr_b16
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int li = lane & 15, g = lane >> 4;
+  const int q4 = li >> 2, pp = li & 3;
+  const int chan = 16 * (g & 1) + 4 * pp;
+  const int hrow = 8 * (g >> 1) + q4;
+  typedef s16x4 __attribute__((address_space(3))) * lds4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  unsigned fa_off[2], fb_off[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    fa_off[t] = hrow * ROWB + (((wm * 2 + t) ^ q4) * 64) + chan * 2;             // (row & 3) == q4 for every row this lane reads
+    fb_off[t] = D_BYTES + hrow * ROWB + (((wn * 2 + t) ^ q4) * 64) + chan * 2;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  // a fragment set = 8 raw transposing reads (2 co blocks + 2 ci blocks, two 4-pixel-row halves each), in flight until
+  // the caller's counted wait
+  struct Frags { s16x4 a[2][2], b[2][2]; };
+  auto load_frags = [&](int buf, int kk, Frags& f) {
+    const unsigned char* sS = smem + buf * STAGE + kk * 16 * ROWB;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f.a[t][0] = lds_tr_raw(sS + fa_off[t]);
+      f.a[t][1] = lds_tr_raw(sS + fa_off[t] + 4 * ROWB);
+      f.b[t][0] = lds_tr_raw(sS + fb_off[t]);
+      f.b[t][1] = lds_tr_raw(sS + fb_off[t] + 4 * ROWB);
+    }
+  };
+#define RUA_FRAG_OPS(f) "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1])
+  auto mfma_set = [&](const Frags& f) {
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+      for (int b_ = 0; b_ < 2; ++b_) {
+        const s16x8 va = {f.a[a_][0][0], f.a[a_][0][1], f.a[a_][0][2], f.a[a_][0][3], f.a[a_][1][0], f.a[a_][1][1], f.a[a_][1][2], f.a[a_][1][3]};
+        const s16x8 vb = {f.b[b_][0][0], f.b[b_][0][1], f.b[b_][0][2], f.b[b_][0][3], f.b[b_][1][0], f.b[b_][1][1], f.b[b_][1][2], f.b[b_][1][3]};
+        acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, vb), acc[a_][b_], 0, 0, 0);
+      }
+  };
+
+  issue_next(0);
+  issue_next(1);
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STAGE) : "memory");
+  __builtin_amdgcn_s_barrier();
+  issue_next(2);
+  Frags f0, f1;
+  load_frags(0, 0, f0);
+  int buf = 0;
+  for (int st = 0; st < nst; ++st) {
+    int nxt = buf + 1; if (nxt == NBUF) nxt = 0;
+    // k-steps 0..3 alternate between the two fragment sets; the set of k-step kk+1 is requested before the MFMAs of kk
+    load_frags(buf, 1, f1);
+    asm volatile("s_waitcnt lgkmcnt(8)" : RUA_FRAG_OPS(f0) :: "memory");      // the 8 older reads (f0) have landed
+    mfma_set(f0);
+    load_frags(buf, 2, f0);
+    asm volatile("s_waitcnt lgkmcnt(8)" : RUA_FRAG_OPS(f1) :: "memory");
+    mfma_set(f1);
+    load_frags(buf, 3, f1);
+    asm volatile("s_waitcnt lgkmcnt(8)" : RUA_FRAG_OPS(f0) :: "memory");
+    mfma_set(f0);
+    // stage st+1 landed (this wave's part), every read of this stage's buffer is complete -> barrier -> refill it
+    asm volatile("s_waitcnt vmcnt(%[ps])\n\ts_waitcnt lgkmcnt(0)" : RUA_FRAG_OPS(f1) : [ps] "n"(PER_STAGE) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_next(buf);
+    load_frags(nxt, 0, f0);
+    mfma_set(f1);
+    buf = nxt;
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" : RUA_FRAG_OPS(f0) :: "memory");
+#undef RUA_FRAG_OPS
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = co0 + wm * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        const int ci = ci0 + wn * 64 + b * 32 + lr;
+        float* dst = &p.dw[((size_t)tap * p.Cout + co) * p.C + ci];
+        if (p.ksplit == 1) *dst += acc[a][b][i]; else unsafeAtomicAdd(dst, acc[a][b][i]);
+      }
+}
+
+// =========================================================================================
 // All-taps weight gradient for the two top levels (Cin = Cout = CC in {32, 64}, 3x3, stride 1, W % 64 == 0; bf16).
 // A stage is a run of 64 consecutive pixels of one image row.  A pixel group (3 waves x CC/32) walks a CHAIN of stages
 // down the image: same 64-pixel column strip, rows h, h+d, h+2d, .. (one residue class mod d), so the conv-input rows
@@ -1836,8 +2011,46 @@ extern "C" int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d) {
 }
 
 // which kernel a descriptor launches: 1 = all-taps (top levels), 0 = generic tiled
+static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
+  WgdK k;
+  k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.dw = d->dw;
+  k.C = d->C; k.Cout = d->Cout; k.H = d->H; k.W = d->W; k.dil = d->dil; k.taps = d->taps;
+  k.M = (long long)d->N * d->H * d->W;
+  int wsh = 0; while ((1 << wsh) < d->W) ++wsh;
+  k.wsh = wsh;
+  k.ntc = d->Cout / 128; k.nti = d->C / 128;
+  const long long tiles = (long long)k.ntc * k.nti * d->taps;
+  const int stages = (int)((k.M + 63) / 64);
+  static const int target = env_int("RUA_WGD_BLOCKS") > 0 ? env_int("RUA_WGD_BLOCKS") : 256;
+  long long want = target / tiles; if (want < 1) want = 1;
+  if (want > stages / 4) want = stages / 4;             // >= 4 stages per K slice
+  if (want < 1) want = 1;
+  k.stages_per_split = (int)((stages + want - 1) / want);
+  k.ksplit = (stages + k.stages_per_split - 1) / k.stages_per_split;
+  k.abytes = (unsigned)((size_t)k.M * d->C * 2); k.dybytes = (unsigned)((size_t)k.M * d->Cout * 2);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+  hipLaunchKernelGGL(wgrad_dmap, dim3((unsigned)(tiles * k.ksplit)), dim3(256), 96 * 1024, st, k);
+  RUA_LAUNCH_CHECK("wgrad_dmap");
+  return RUA_OK;
+}
+
 extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
   if (!d) return RUA_ERR_ARG;
+  {
+    static const int on = getenv("RUA_WGRAD_DMAP") ? atoi(getenv("RUA_WGRAD_DMAP")) : 1;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (on && d->dtype == RUA_BF16 && (d->taps == 9 || d->taps == 1) && d->stride == 1 && d->C % 128 == 0 && d->Cout % 128 == 0 &&
+        d->Hs == d->H && d->Ws == d->W && pow2(d->H) && pow2(d->W) && d->dil >= 1 &&
+        ((long long)d->N * d->H * d->W + 64 * 64) * (d->C > d->Cout ? d->C : d->Cout) * 2 < (1ll << 31)) {
+      // measured per level of the reference network (us, wgrad_dmap vs wgrad_kernel): 64x64x128 33.1 / 32.5 (9 tiles: the
+      // 28 K slices pay 16 MB of float atomics), 32x32x256 25.9 / 35.1, 16x16x512 41.9 / 33.3 (144 tiles: no K split, half
+      // the CUs idle), 8x8x1024 75 / 32 (576 short-K blocks at one per CU).  So: a few dozen tiles and a long K.
+      const long long tiles = (long long)d->taps * (d->Cout / 128) * (d->C / 128);
+      const long long stages = ((long long)d->N * d->H * d->W + 63) / 64;
+      if (on == 2 || (tiles >= 16 && tiles <= 64 && stages >= 64)) return 2;
+    }
+  }
   const bool ok = d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->C == d->Cout && (d->C == 32 || d->C == 64) &&
                   d->W % 64 == 0 && d->Hs == d->H && d->Ws == d->W && d->dil >= 1 && d->dil <= 31 && d->workspace &&
                   d->workspace_bytes >= rua_wgrad_workspace_bytes(d) && (long long)d->N * d->H * d->W * d->C * 2 < (1ll << 31);
@@ -1851,6 +2064,7 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   RUA_CHECK_ARG(d->C % vec == 0 && d->Cout % vec == 0, "rua_conv_wgrad: C=%d Cout=%d must be multiples of %d", d->C, d->Cout, vec);
   RUA_CHECK_ARG(d->taps == 1 || d->taps == 9, "rua_conv_wgrad: taps must be 1 or 9");
   if (rua_wgrad_kind(d) == 1) return launch_wgrad_taps(d, (hipStream_t)stream);
+  if (rua_wgrad_kind(d) == 2) return launch_wgrad_dmap(d, (hipStream_t)stream);
   RUA_CHECK_ARG((long long)(d->H - 1) * d->stride < d->Hs && (long long)(d->W - 1) * d->stride < d->Ws,
                 "rua_conv_wgrad: input %dx%d too small for gradient %dx%d stride %d", d->Hs, d->Ws, d->H, d->W, d->stride);
   WgK k;

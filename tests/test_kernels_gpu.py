@@ -214,6 +214,14 @@ WGRAD_CASES = [
     (2, 16, 16, 32, 64, 2, 1, 1),
     (3, 8, 8, 128, 72, 1, 1, 1),
     (1, 12, 12, 8, 8, 1, 1, 9),
+    # wide levels (bf16: wgrad_dmap, 128 x 128 tiles, LDS-DMA stages; power-of-two maps)
+    (2, 16, 16, 128, 128, 1, 1, 9),
+    (1, 32, 32, 128, 256, 1, 3, 9),
+    (1, 16, 16, 256, 128, 1, 15, 9),
+    (2, 8, 8, 256, 128, 1, 1, 1),
+    (3, 4, 4, 128, 128, 1, 1, 9),
+    (4, 32, 32, 256, 256, 1, 3, 9),      # 36 tiles, 64 stages: the shape class the dispatch gives to wgrad_dmap
+    (8, 32, 32, 256, 128, 1, 15, 9),
 ]
 
 
@@ -232,6 +240,8 @@ def test_conv_wgrad(case, dt):
     d.dy, d.Cout, d.H, d.W = dyd.data_ptr(), Cout, H, W
     d.N, d.stride, d.dil, d.taps, d.dtype = N, stride, dil, taps, dt
     d.dw = dw.data_ptr()
+    if dt == L.RUA_BF16 and case[:5] == (4, 32, 32, 256, 256):
+        assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 2
     L.lib().call("rua_conv_wgrad", C.byref(d), stream())
     torch.cuda.synchronize()
     w = torch.zeros((taps, Cout, Cs), dtype=torch.float64, requires_grad=True)
