@@ -64,6 +64,18 @@ def measured_traffic(kernel, args):
     return round(sum(v["bytes_per_launch"] * v["launches_seen"] for v in fam) / n) if n else None
 
 
+def committed_rocprof_avg(kernel, args):
+    """rocprofv3's average duration (us) of `kernel` in the committed profile (profiles/rocprof_avg.json, written by
+    profiles/make_readme.py from r01_final/kernel_stats.csv) - printed beside the live figure, never used in it."""
+    path = os.path.join(ROOT, "profiles", "rocprof_avg.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    if t.get("workload") != args.workload or t.get("dtype") != args.dtype:
+        return None
+    return t["avg_us"].get(kernel)
+
+
 def profile_kernels(eng, g, dtype):
     """One extra (untimed) step with an event pair around every conv / wgrad launch on the launch stream.
     Returns per-kernel-instantiation totals: {name: [launches, seconds, flops]}."""
@@ -73,59 +85,95 @@ def profile_kernels(eng, g, dtype):
     sp = C.c_void_p(s)
     tname = "bf16" if dtype == "bf16" else "f32"
     rec = []
+    mid = lib.raw("rua_profile_mid_event")
+    ev_new, ev_rec, ev_us, ev_del = (lib.raw("rua_prof_event_" + n) for n in ("create", "record", "elapsed_us", "destroy"))
+    events = []
+
+    def mark(record=True):                                  # timing event without the system-scope release (include/rua_hip.h)
+        e = C.c_void_p(ev_new())
+        if not e.value:
+            lib.check(-1, "rua_prof_event_create")
+        events.append(e)
+        if record:
+            ev_rec(e, sp)
+        return e
+
+    def us(a, b):
+        v = C.c_double()
+        lib.check(ev_us(a, b, C.byref(v)), "rua_prof_event_elapsed_us")
+        return v.value
+
     # Keep the GPU busy while the instrumented step is enqueued, so every launch is already queued when its turn comes and
     # the event pair brackets GPU execution only (bracketing a launch into an idle queue adds ~10 us of dispatch latency
     # per kernel and would disagree with rocprofv3's per-kernel durations).
     for _ in range(4):
         eng.train_step(None, None, fetch=False)
+    # Bracket overhead, calibrated on an idempotent library kernel (the statistics-arena fill): T1 = bracket around one
+    # launch, T2 = around two back-to-back launches, so T2 - T1 is what one more kernel costs IN the stream and
+    # 2*T1 - T2 is what the two markers add.  (An empty marker pair over-estimates it: ~5 us, part of which overlaps
+    # the kernel when there is one.)
+    cal1, cal2 = [], []
+    for _ in range(12):
+        a = mark(); eng._zero_arena(g, s); b = mark(); cal1.append((a, b))
+        a = mark(); eng._zero_arena(g, s); eng._zero_arena(g, s); b = mark(); cal2.append((a, b))
     eng._zero_arena(g, s)
     eng._prep_weights(s)
     empty = []
     for plan in (g.fwd, g.loss_plan, g.bwd):
         for ci, (fn, name, args, _lane) in enumerate(plan.calls):
             if ci % 16 == 0:                                # empty event pairs: the marker-to-marker cost to subtract
-                z0, z1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                z0.record(); z1.record(); empty.append((z0, z1))
+                empty.append((mark(), mark()))
             if fn is None:
                 continue                                    # fork / join markers: this pass runs everything on one stream
             if name in ("rua_conv_fwd", "rua_conv_wgrad"):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                em = mark(False)                            # recorded by the library between the main kernel and the
+                mid(em)                                     # second launch of a two-launch call
+                e0 = mark()
                 rc = fn(*args, sp)
-                e1.record()
+                e1 = mark()
+                mid(None)
                 d = args[0]._obj
                 if name == "rua_conv_fwd":
                     bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d)), lib.raw('rua_conv_tile_bn')(C.byref(d))
-                    split = lib.raw("rua_conv_last_ksplit")() > 1
-                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap<{bm_},{bn_}>", f"conv_halo<{d.Cout}>")[kid] + ("+splitk" if split else "")
+                    two = lib.raw("rua_conv_last_ksplit")() > 1
+                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap<{bm_},{bn_}>", f"conv_halo<{d.Cout}>")[kid]
                     kk = sum(d.seg[i].taps * d.seg[i].C for i in range(d.nseg))
-                    flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "")
-                    rec.append((kn, e0, e1, conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags)))
+                    flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "") + (" splitk" if two else "")
+                    fl, tag, second = conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags), f"conv_splitk_finish<{tname}>"
                 else:
-                    wk = lib.raw("rua_wgrad_kind")(C.byref(d)); wn = (f"wgrad_kernel<{tname}>", f"wgrad_taps_kernel<{d.C}>+reduce", "wgrad_dmap")[wk]
-                    rec.append((wn, e0, e1, wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, "")))
+                    wk = lib.raw("rua_wgrad_kind")(C.byref(d)); kn = (f"wgrad_kernel<{tname}>", f"wgrad_taps_kernel<{d.C}>", "wgrad_dmap")[wk]
+                    two = wk == 1
+                    fl, tag, second = wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, ""), "wgrad_taps_reduce"
+                if two:                                     # per-kernel rows, as rocprofv3 names them
+                    rec.append((kn, e0, em, fl, tag)); rec.append((second, em, e1, 0.0, tag))
+                else:
+                    rec.append((kn, e0, e1, fl, tag))
             else:
                 rc = fn(*args, sp)
             if rc != 0:
                 lib.check(rc, name)
     eng.optimizer_step(1.0 / eng.world)
     torch.cuda.synchronize()
-    ov = sorted(z0.elapsed_time(z1) for z0, z1 in empty)
-    ov = ov[len(ov) // 2] * 1e-3 if ov else 0.0          # median seconds per empty bracket
+    med = lambda pairs: sorted(us(a, b) for a, b in pairs)[len(pairs) // 2]
+    t1, t2, empty_us = med(cal1), med(cal2), med(empty)
+    ov = max(2 * t1 - t2, 0.0) * 1e-6                    # seconds the two markers add to a bracket with a kernel inside
     out = {}
     for kn, e0, e1, fl, _ in rec:
         t = out.setdefault(kn, [0, 0.0, 0.0])
-        t[0] += 1; t[1] += max(e0.elapsed_time(e1) * 1e-3 - ov, 1e-7); t[2] += fl
+        t[0] += 1; t[1] += max(us(e0, e1) * 1e-6 - ov, 1e-7); t[2] += fl
     out["_event_overhead_us"] = ov * 1e6
+    log(f"event bracket calibration: one fill {t1:.2f} us, two fills {t2:.2f} us, empty pair {empty_us:.2f} us -> overhead {ov * 1e6:.2f} us")
     if os.environ.get("RUA_BENCH_DETAIL"):
         groups = {}
         for kn, e0, e1, fl, tag in rec:
             gkey = (kn,) + tag
             t = groups.setdefault(gkey, [0, 0.0, 0.0])
-            t[0] += 1; t[1] += e0.elapsed_time(e1) * 1e-3; t[2] += fl
+            t[0] += 1; t[1] += us(e0, e1) * 1e-6; t[2] += fl
         log("per-shape MFMA kernel table (kernel, M, Cout, K, dil, flags): launches, total ms, avg us, TFLOP/s")
         for gkey, (n, sec, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
             log(f"  {str(gkey):90s} n={n:3d} {1e3 * sec:8.3f} ms {1e6 * sec / n:8.1f} us {fl / sec / 1e12:7.1f} TF/s")
+    for e in events:
+        ev_del(e)
     return out
 
 
@@ -271,7 +319,7 @@ def main():
     if rank == 0:
         peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
         ev_ov = prof.pop("_event_overhead_us")
-        dom = max(prof.items(), key=lambda kv: kv[1][1])
+        dom = max((kv for kv in prof.items() if kv[1][2] > 0), key=lambda kv: kv[1][1])   # second launches (no FLOPs) are rows, not candidates
         kn, (n, sec, fl) = dom
         out["roofline"] = {
             "bound": "mfma", "kernel": kn, "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
@@ -279,6 +327,7 @@ def main():
             "achieved": round(fl / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4),
             "traffic": measured_traffic(kn, args), "traffic_unit": "HBM bytes per launch (profiles/traffic.json: rocprofv3 PMC)",
             "event_pair_overhead_us_subtracted": round(ev_ov, 2),
+            "rocprof_avg_us_committed_profile": committed_rocprof_avg(kn, args),
             "all_mfma_kernels": {k: {"launches": v[0], "ms_per_step": round(1e3 * v[1], 3), "tflops": round(v[2] / v[1] / 1e12, 2)}
                                  for k, v in sorted(prof.items())},
             "whole_step_frac_of_peak": round(value / world * gflop_patch / 1e3 / peak, 4),

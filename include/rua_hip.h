@@ -77,6 +77,13 @@ typedef struct rua_conv_desc {
 int rua_conv_fwd(const rua_conv_desc* d, void* stream);
 int rua_conv_smem_bytes(const rua_conv_desc* d);
 int64_t rua_conv_workspace_bytes(const rua_conv_desc* d);   /* bytes of ONE slab (N*H*W*Cout fp32); split-K uses up to 32 */
+/* profiling only (bench.py): timing events without the system-scope release a default event performs when recorded */
+void* rua_prof_event_create(void);
+int rua_prof_event_record(void* ev, void* hip_stream);
+int rua_prof_event_elapsed_us(void* start, void* stop, double* us);   /* waits for `stop` */
+void rua_prof_event_destroy(void* ev);
+void rua_profile_mid_event(void* hip_event);    /* profiling only: the calling thread's NEXT two-launch call (split-K conv, all-taps weight
+                                                   gradient) records this hipEvent_t between its main kernel and its second launch; one shot */
 int rua_conv_last_ksplit(void);                  /* K slices of the calling thread's latest rua_conv_fwd (1: single pass, no finisher) */
 int rua_conv_tile_bn(const rua_conv_desc* d);   /* 32 / 64 / 128 and */
 int rua_conv_kernel_id(const rua_conv_desc* d); /* 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA, bf16), 2: conv_dmap (LDS-DMA, pipelined across the stage barrier) */

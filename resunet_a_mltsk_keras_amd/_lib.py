@@ -67,6 +67,11 @@ _SIGS = {
     "rua_conv_tile_bm": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_kernel_id": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_last_ksplit": ([], i32),
+    "rua_profile_mid_event": ([vp], None),
+    "rua_prof_event_create": ([], vp),
+    "rua_prof_event_record": ([vp, vp], i32),
+    "rua_prof_event_elapsed_us": ([vp, vp, C.POINTER(f64)], i32),
+    "rua_prof_event_destroy": ([vp], None),
     "rua_conv_workspace_bytes": ([C.POINTER(ConvDesc)], i64),
     "rua_conv_wgrad": ([C.POINTER(WgradDesc), vp], i32),
     "rua_wgrad_workspace_bytes": ([C.POINTER(WgradDesc)], i64),

@@ -457,7 +457,15 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK p) {
   const int n0 = bn_i * 64;
   conv_epilogue<T, FM, 64, true>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sred);
 }
+// Profiling hook (bench.py): an event recorded BETWEEN the main kernel of a call and its second launch (split-K finisher,
+// wgrad_taps_reduce), so that per-kernel durations can be compared with rocprofv3's per-kernel-name averages.  One shot.
+static thread_local hipEvent_t g_mid_event = nullptr;
+extern "C" void rua_profile_mid_event(void* ev) { g_mid_event = (hipEvent_t)ev; }
+static inline void record_mid_event(hipStream_t st) {
+  if (g_mid_event) { (void)hipEventRecord(g_mid_event, st); g_mid_event = nullptr; }
+}
 template <typename T> static void launch_splitk_finish(const ConvK& k, hipStream_t st) {
+  record_mid_event(st);
   const int nbn = (k.Cout + 63) / 64;
   const long long t128 = ((k.M + 127) / 128) * nbn;
   if (t128 >= 512) hipLaunchKernelGGL((conv_splitk_finish<T, 128>), dim3((unsigned)t128), dim3(256), 0, st, k);
@@ -2000,6 +2008,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_taps_kernel<64>), dim3(gx, gy), dim3(768), smem, st, k);
   }
   RUA_LAUNCH_CHECK("wgrad_taps_kernel");
+  record_mid_event(st);
   hipLaunchKernelGGL(wgrad_taps_reduce, dim3(rua_div_up(9 * CC * CC, 16)), dim3(256), 0, st, (const float*)k.scratch, d->dw, CC, gx);
   RUA_LAUNCH_CHECK("wgrad_taps_reduce");
   return RUA_OK;
