@@ -289,6 +289,49 @@ class Model:
     def set_weights_dict(self, w: Dict[str, np.ndarray]):
         self.engine.set_weights(w)
 
+    # -- weight exchange with the reference.  h5py is not in this image, so the carrier is an .npz of
+    #    Keras variable names -> arrays in Keras layout (kernel HWIO, BN gamma/beta/moving_mean/moving_variance); on the
+    #    TensorFlow side that is `np.savez(path, **{w.name: w.numpy() for w in model.weights})`.
+    def save_weights(self, path):
+        np.savez(path, **{k + ":0": v for k, v in self.engine.get_weights().items()})
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.engine.set_weights(canonical_keras_names({k: z[k] for k in z.files}, self.engine.get_weights()))
+
+
+def canonical_keras_names(given: Dict[str, np.ndarray], want: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Maps a dict of Keras variables onto this model's names.  Keras numbers layers per process (`conv2d_85/kernel:0`
+    if other models were built before), so layers are matched by their ORDER within a layer type, not by the absolute
+    index; a `:0` suffix is dropped.  Any missing / extra variable or shape mismatch is an error naming the variable."""
+    def split(name):
+        layer, _, var = name.split(":")[0].rpartition("/")
+        base, _, idx = layer.rpartition("_")
+        return (base, int(idx), var) if base and idx.isdigit() else (layer, 0, var)
+
+    def ranked(names):
+        seen: Dict[str, list] = {}
+        for n in names:
+            b, i, _ = split(n)
+            if i not in seen.setdefault(b, []):
+                seen[b].append(i)
+        rank = {b: {i: r for r, i in enumerate(sorted(v))} for b, v in seen.items()}
+        return {(split(n)[0], rank[split(n)[0]][split(n)[1]], split(n)[2]): n for n in names}
+
+    g, w = ranked(given), ranked(want)
+    missing = [w[k] for k in w if k not in g]
+    extra = [g[k] for k in g if k not in w]
+    if missing or extra:
+        raise ValueError(f"weights do not match the model: missing {missing[:4]}{'...' if len(missing) > 4 else ''}, "
+                         f"unexpected {extra[:4]}{'...' if len(extra) > 4 else ''}")
+    out = {}
+    for k, name in w.items():
+        a = np.asarray(given[g[k]], np.float32)
+        if a.shape != want[name].shape:
+            raise ValueError(f"{g[k]}: shape {a.shape}, the model's {name} is {want[name].shape}")
+        out[name] = a
+    return out
+
 
 def load_model(path, compile=True, custom_objects=None, dtype=None, **_):
     blob = torch.load(path, map_location="cpu", weights_only=False)

@@ -103,6 +103,23 @@ def test_keras_style_model_roundtrip(tmp_path):
     assert abs(a[0] - b[0]) < 1e-4                             # same state (weights, Adam moments, step count) continues
     m3 = load_model(path, compile=False)
     assert np.abs(m3.predict(x)["dist"] - pred["dist"]).max() < 1e-6
+    # weight exchange with the reference: .npz of Keras variable names, layer numbers shifted as in a
+    # Keras process that built another model first
+    w = m3.get_weights_dict()
+    shifted = {}
+    for k, v in w.items():
+        layer, var = k.rsplit("/", 1)
+        base, _, idx = layer.rpartition("_")
+        n = int(idx) if base and idx.isdigit() else 0
+        base = base if base and idx.isdigit() else layer
+        shifted[f"{base}_{n + 7}/{var}:0"] = v
+    np.savez(str(tmp_path / "from_keras.npz"), **shifted)
+    net4 = Resunet_a((64, 64, 3), 4, Args())
+    net4.model.load_weights(str(tmp_path / "from_keras.npz"))
+    assert np.abs(net4.model.predict(x)["seg"] - m3.predict(x)["seg"]).max() < 1e-6
+    net4.model.save_weights(str(tmp_path / "to_keras.npz"))
+    with np.load(str(tmp_path / "to_keras.npz")) as z:
+        assert set(z.files) == {k + ":0" for k in w} and all(np.array_equal(z[k + ":0"], w[k]) for k in w)
 
 
 def test_cli_end_to_end_on_synthetic_dataset(tmp_path):

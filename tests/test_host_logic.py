@@ -165,3 +165,26 @@ def test_goldens_pin_the_oracle():
     nchw = lambda a: torch.from_numpy(a).permute(0, 3, 1, 2)
     assert np.allclose(ref.tanimoto_dual_loss(nchw(k["y_swap"]), nchw(k["p_swap"])).numpy(), k["l_swap"], rtol=1e-5)
     assert np.allclose(ref.tanimoto_dual_loss(nchw(k["y_rand"]), nchw(k["p_rand"])).numpy(), k["l_rand"], rtol=1e-5)
+
+
+def test_keras_variable_names_are_matched_by_order_within_a_layer_type():
+    """keras_api.canonical_keras_names: `conv2d_85/kernel:0` of a process that built other models first."""
+    from resunet_a_mltsk_keras_amd.keras_api import canonical_keras_names
+    want = {"conv2d/kernel": np.zeros((1, 1, 3, 8), np.float32), "conv2d/bias": np.zeros(8, np.float32),
+            "conv2d_1/kernel": np.zeros((3, 3, 8, 8), np.float32), "batch_normalization/gamma": np.zeros(8, np.float32),
+            "batch_normalization/moving_variance": np.ones(8, np.float32)}
+    given = {"conv2d_84/kernel:0": np.full((1, 1, 3, 8), 1.0), "conv2d_84/bias:0": np.full(8, 2.0),
+             "conv2d_85/kernel:0": np.full((3, 3, 8, 8), 3.0), "batch_normalization_9/gamma:0": np.full(8, 4.0),
+             "batch_normalization_9/moving_variance:0": np.full(8, 5.0)}
+    out = canonical_keras_names(given, want)
+    assert set(out) == set(want) and out["conv2d_1/kernel"][0, 0, 0, 0] == 3.0 and out["batch_normalization/gamma"][0] == 4.0
+    assert all(v.dtype == np.float32 for v in out.values())
+    bad = dict(given); bad["conv2d_85/kernel:0"] = np.zeros((3, 3, 8, 4))
+    with pytest.raises(ValueError, match="conv2d_85/kernel"):
+        canonical_keras_names(bad, want)
+    short = dict(given); del short["conv2d_84/bias:0"]
+    with pytest.raises(ValueError, match="conv2d/bias"):
+        canonical_keras_names(short, want)
+    extra = dict(given); extra["dense/kernel:0"] = np.zeros(3)
+    with pytest.raises(ValueError, match="dense/kernel"):
+        canonical_keras_names(extra, want)
