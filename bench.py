@@ -141,7 +141,7 @@ def profile_kernels(eng, g, dtype):
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "") + (" splitk" if two else "")
                     fl, tag, second = conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags), f"conv_splitk_finish<{tname}>"
                 else:
-                    wk = lib.raw("rua_wgrad_kind")(C.byref(d)); kn = (f"wgrad_kernel<{tname}>", f"wgrad_taps_kernel<{d.C}>", "wgrad_dmap")[wk]
+                    wk = lib.raw("rua_wgrad_kind")(C.byref(d)); kn = (f"wgrad_kernel<{tname}>", f"wgrad_taps_kernel<{d.C}>", "wgrad_dmap", "wgrad_pw")[wk]
                     two = wk == 1
                     fl, tag, second = wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, ""), "wgrad_taps_reduce"
                 if two:                                     # per-kernel rows, as rocprofv3 names them

@@ -98,12 +98,17 @@ typedef struct rua_wgrad_desc {
   const void* dy; int32_t Cout, H, W;       /* out-gradient [N][H][W][Cout] */
   int32_t N, stride, dil, taps, dtype;
   float* dw;                                /* [taps][Cout][C] fp32, accumulated */
-  void* workspace;                          /* optional fp32 scratch of rua_wgrad_workspace_bytes(): enables the all-taps */
-  int64_t workspace_bytes;                  /* kernel of the two top levels (C = Cout in {32,64}, 3x3, W % 64 == 0, bf16) */
+  void* workspace;                          /* optional fp32 scratch of rua_wgrad_workspace_bytes(): enables the all-taps kernel of */
+  int64_t workspace_bytes;                  /* the two top levels (C = Cout in {32,64}, 3x3, W % 64 == 0, bf16; uses the front of it,
+                                               contents on entry irrelevant) and the per-wave kernel of the narrow 1x1 convolutions
+                                               (taps 1, C * Cout <= 4096, bf16), whose replica accumulators and ticket counters are the
+                                               LAST 264 KiB (16 * 16 KiB + 8 KiB): zero them once before the first call, every call
+                                               leaves them zero.  One workspace per concurrently running stream. */
 } rua_wgrad_desc;
 int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream);
 int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d);
-int rua_wgrad_kind(const rua_wgrad_desc* d);   /* 1: all-taps kernel + deterministic partial reduce, 0: generic tiled kernel */
+int rua_wgrad_kind(const rua_wgrad_desc* d);   /* 0: generic tiled kernel, 1: all-taps kernel + deterministic partial reduce,
+                                                  2: wgrad_dmap (wide levels), 3: wgrad_pw (narrow 1x1) */
 
 /* Master fp32 weights [taps][Cout][C] -> activation-dtype copies: forward layout (same) and
  * data-gradient layout [taps reversed][C][Cout].  One launch for the whole parameter table. */

@@ -2014,9 +2014,292 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   return RUA_OK;
 }
 
+// =========================================================================================
+// wgrad_pw: the weight gradient of the narrow 1x1 convolutions (C, Cout <= 64: stem, PSP branches, combine / upsampling
+// convs of the top levels).  These are memory-bound (67 MB in for a 4 KB..16 KB dW at 256x256x32) and were slow on
+// wgrad_kernel for two reasons: one 64x64 tile per block with two block barriers per 64 pixels, and up to 512 blocks
+// adding the SAME few hundred dW addresses with float atomics (same-address atomics serialise at ~25 ns: 13 us).
+// Here every WAVE streams its own pixel range with no block barrier at all: 16-byte coalesced loads (two iterations
+// in flight in registers) -> the wave's private LDS tile -> transposing fragment reads -> MFMA 32x32x16; LDS operations
+// of one wave execute in order, so write -> read -> next write needs no barrier.  The four waves of a block add their
+// accumulators in LDS, the block adds the result into one of R replica buffers (atomic chain nblocks / R long), and the
+// block that draws the last ticket sums the replicas into dW (one writer, plain +=) and leaves replicas and ticket
+// zero for the next launch.
+struct WgpK {
+  const unsigned char* a; const unsigned char* dy; float* dw; float* rep; int* cnt;
+  int C, Cout, Hs, Ws, H, W, stride, wshift, hshift, dense, R;
+  int M, px_per_wave;
+  unsigned abytes, dybytes;
+};
+constexpr int WG_PW_REPLICAS = 16;
+constexpr int64_t WG_PW_TAIL = (int64_t)WG_PW_REPLICAS * 64 * 64 * 4 + 8192;   // replicas + two ticket pages at the end of the workspace
+
+template <int NCO, int NCI> static constexpr int wgrad_pw_smem() {
+  constexpr int PXW = (NCO + NCI <= 2) ? 32 : 16;
+  constexpr int WAVE_LDS = PXW * ((NCO == 2 ? 192 : 64) + (NCI == 2 ? 192 : 64));
+  constexpr int RED = 4 * NCO * 32 * (NCI * 32 + 1) * 4;
+  return (16 * WAVE_LDS > RED ? 16 * WAVE_LDS : RED) + 16;
+}
+
+template <int NCO, int NCI>
+__global__ __launch_bounds__(1024) void wgrad_pw(const WgpK p) {
+  constexpr int NW = 16, NT = NW * 64;                           // waves / threads per block
+  constexpr int PXW = (NCO + NCI <= 2) ? 32 : 16;                  // pixels per wave iteration
+  constexpr int ROWB_D = NCO == 2 ? 192 : 64, ROWB_A = NCI == 2 ? 192 : 64;   // 64 ch + pad / 32 ch: conflict-free tr reads
+  constexpr int WAVE_LDS = PXW * (ROWB_D + ROWB_A);
+  constexpr int NLD = PXW * NCO * 4 / 64, NLA = PXW * NCI * 4 / 64;          // 16-byte pieces per lane per iteration
+  constexpr int RED = 4 * NCO * 32 * (NCI * 32 + 1) * 4;            // four padded fp32 slots for the block sum
+  constexpr int SMEM = wgrad_pw_smem<NCO, NCI>() - 16;
+  static_assert(SMEM >= NW * WAVE_LDS && SMEM >= RED, "LDS size");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int& s_ticket = *reinterpret_cast<int*>(smem + SMEM);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  unsigned char* sD = smem + wid * WAVE_LDS;
+  unsigned char* sA = sD + PXW * ROWB_D;
+
+  const int gw = blockIdx.x * NW + wid;
+  const int k_begin = gw * p.px_per_wave;
+  int k_end = k_begin + p.px_per_wave; if (k_end > p.M) k_end = p.M;
+
+  // loop-invariant piece geometry of this lane
+  const int PD = p.Cout >> 3, PA = p.C >> 3;
+  int dpx[NLD], doff[NLD], dlds[NLD], apx[NLA], apc[NLA], alds[NLA];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int e = lane + 64 * j, px = e / PD, pc = e - px * PD;
+    dpx[j] = px < PXW ? px : (1 << 30);                            // idle lane: never in range
+    doff[j] = (px * p.Cout + pc * 8) * 2; dlds[j] = px * ROWB_D + pc * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+    const int e = lane + 64 * j, px = e / PA, pc = e - px * PA;
+    apx[j] = px < PXW ? px : (1 << 30);
+    apc[j] = pc * 8; alds[j] = px * ROWB_A + pc * 16;
+  }
+  const __amdgpu_buffer_rsrc_t rd_ = make_rsrc(p.dy, p.dybytes), ra_ = make_rsrc(p.a, p.abytes);
+  uint4 rd[2][NLD], rx[2][NLA];
+  auto load = [&](int set, int k0) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const bool in = (long long)k0 + dpx[j] < k_end;
+      rd[set][j] = bufload16(rd_, in ? (unsigned)(k0 * p.Cout * 2 + doff[j]) : RUA_OOB);
+    }
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) {
+      const bool in = (long long)k0 + apx[j] < k_end;
+      const int mm = k0 + (apx[j] & 31);
+      const int w = mm & (p.W - 1), h = (mm >> p.wshift) & (p.H - 1), n = mm >> (p.wshift + p.hshift);
+      const int gen = ((n * p.Hs + h * p.stride) * p.Ws + w * p.stride) * p.C;   // only meaningful when !dense (power-of-two maps)
+      const int pix = p.dense ? mm * p.C : gen;
+      rx[set][j] = bufload16(ra_, in ? (unsigned)((pix + apc[j]) * 2) : RUA_OOB);
+    }
+  };
+  f32x16 acc[NCO][NCI];
+#pragma unroll
+  for (int a = 0; a < NCO; ++a)
+#pragma unroll
+    for (int b = 0; b < NCI; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  const int li = lane & 15, g = lane >> 4;
+  const int chan = 16 * (g & 1) + 4 * (li & 3), hrow = 8 * (g >> 1) + (li >> 2);
+  typedef s16x4 __attribute__((address_space(3))) * lds4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto consume = [&](int set) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j)
+      if (dpx[j] < PXW) *reinterpret_cast<uint4*>(sD + dlds[j]) = rd[set][j];
+#pragma unroll
+    for (int j = 0; j < NLA; ++j)
+      if (apx[j] < PXW) *reinterpret_cast<uint4*>(sA + alds[j]) = rx[set][j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int kk = 0; kk < PXW / 16; ++kk) {
+      bf16x8 fa[NCO], fb[NCI];
+#pragma unroll
+      for (int a = 0; a < NCO; ++a) {
+        const unsigned char* ad = sD + (kk * 16 + hrow) * ROWB_D + (a * 32 + chan) * 2;
+        const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ad));
+        const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ad + 4 * ROWB_D));
+        const s16x8 f = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+        fa[a] = __builtin_bit_cast(bf16x8, f);
+      }
+#pragma unroll
+      for (int b = 0; b < NCI; ++b) {
+        const unsigned char* ax = sA + (kk * 16 + hrow) * ROWB_A + (b * 32 + chan) * 2;
+        const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ax));
+        const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ax + 4 * ROWB_A));
+        const s16x8 f = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        fb[b] = __builtin_bit_cast(bf16x8, f);
+      }
+#pragma unroll
+      for (int a = 0; a < NCO; ++a)
+#pragma unroll
+        for (int b = 0; b < NCI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  // channels beyond C / Cout of a 32-wide MFMA tile read LDS bytes no load ever wrote: zero the wave's tile once so that
+  // they are zeros (a NaN pattern there would only reach output elements that are never stored, but zeros cost nothing)
+  for (int o = lane * 16; o < WAVE_LDS; o += 64 * 16) *reinterpret_cast<uint4*>(sD + o) = make_uint4(0, 0, 0, 0);
+  __builtin_amdgcn_wave_barrier();
+  // two iterations in flight; out-of-range iterations load zeros (range-checked offsets), so the loop needs no tail
+  load(0, k_begin);
+  load(1, k_begin + PXW);
+  for (int k0 = k_begin; k0 < k_end; k0 += 2 * PXW) {
+    consume(0);
+    load(0, k0 + 2 * PXW);
+    consume(1);
+    load(1, k0 + 3 * PXW);
+  }
+  // Block sum of the 16 waves' accumulators through four LDS slots with plain stores (ds_add_f32 from several waves on the
+  // same words took ~20 us per launch): wave w uses slot w & 3 in round w >> 2 (round 0 stores, rounds 1-3 add); every
+  // thread then sums the four slots of its elements.
+  __syncthreads();
+  constexpr int RW = NCI * 32 + 1;                                 // padded row
+  constexpr int SLOT = NCO * 32 * RW;
+  float* slot = reinterpret_cast<float*>(smem) + (wid & 3) * SLOT;
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int round = 0; round < NW / 4; ++round) {
+    if ((wid >> 2) == round) {
+#pragma unroll
+      for (int a = 0; a < NCO; ++a)
+#pragma unroll
+        for (int b = 0; b < NCI; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float* q = &slot[(a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh) * RW + b * 32 + lr];
+            *q = round == 0 ? acc[a][b][i] : *q + acc[a][b][i];
+          }
+    }
+    __syncthreads();
+  }
+  const int nel = p.Cout * p.C;
+  // The block adds its sum into replica (block % R) with RETURNING atomics: when the old values are back the adds have
+  // been performed at the device's coherence point, so the ticket below needs no release fence (an agent-scope release
+  // would write back this XCD's whole L2), and the last block reads the replicas with atomic exchanges (read and reset
+  // in one round trip, all R in flight), which needs no acquire fence either.
+  const float* s0 = reinterpret_cast<const float*>(smem);
+  float* rep = p.rep + (size_t)(blockIdx.x % p.R) * nel;
+  constexpr int NPT = NCO * NCI;                                   // elements per thread at the full tile width
+  float olds[NPT];
+#pragma unroll
+  for (int e = 0; e < NPT; ++e) {                                  // unrolled: all of a thread's adds are in flight together
+    const int o = tid + e * NT;
+    const int co = o / p.C, ci = o - co * p.C;
+    olds[e] = 0.f;
+    if (o < nel) { const float* q = s0 + co * RW + ci; olds[e] = unsafeAtomicAdd(rep + o, (q[0] + q[SLOT]) + (q[2 * SLOT] + q[3 * SLOT])); }
+  }
+#pragma unroll
+  for (int e = 0; e < NPT; ++e) asm volatile("" : "+v"(olds[e]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // Two-level ticket (one counter for all blocks is a same-address chain of ~13 ns per block: 13 us at 1024 blocks, and so
+  // are 16 counters in one cache line): the group counters sit 256 B apart, the last block of each replica group draws
+  // from the top counter (its own page), the last of those finishes.
+  if (tid == 0) {
+    const int G = (int)gridDim.x < p.R ? (int)gridDim.x : p.R;
+    const int g = blockIdx.x % p.R;
+    const int gsize = ((int)gridDim.x - g + p.R - 1) / p.R;
+    int last = 0;
+    int* cg = p.cnt + g * 64;
+    int* ctop = p.cnt + WG_PW_REPLICAS * 64;
+    if (__hip_atomic_fetch_add(cg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+      __hip_atomic_store(cg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(ctop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+        __hip_atomic_store(ctop, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    }
+    s_ticket = last;
+  }
+  __syncthreads();
+  if (!s_ticket) return;
+  constexpr int OB = 2;                                            // elements per thread per round: 2 x R exchanges in flight
+  for (int o0 = tid; o0 < nel; o0 += NT * OB) {
+    float v[OB][WG_PW_REPLICAS];
+#pragma unroll
+    for (int e = 0; e < OB; ++e)
+#pragma unroll
+      for (int r = 0; r < WG_PW_REPLICAS; ++r) {
+        const int o = o0 + e * NT;
+        v[e][r] = 0.f;
+        if (o < nel && r < p.R) v[e][r] = __hip_atomic_exchange(p.rep + (size_t)r * nel + o, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+    for (int e = 0; e < OB; ++e) {
+      const int o = o0 + e * NT;
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < WG_PW_REPLICAS; ++r) sum += v[e][r];
+      if (o < nel) p.dw[o] += sum;
+    }
+  }
+}
+
+static int64_t wg_taps_bytes(const rua_wgrad_desc* d) { return (int64_t)256 * 9 * 32 * (int64_t)d->C * 4; }   // 256 block partials of [9][32][C] fp32
+
+static bool pick_wgrad_pw(const rua_wgrad_desc* d) {
+  static const int on = getenv("RUA_WGRAD_PW") ? atoi(getenv("RUA_WGRAD_PW")) : 1;
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  const long long M = (long long)d->N * d->H * d->W;
+  const bool dense = d->stride == 1 && d->Hs == d->H && d->Ws == d->W;
+  return on && d->dtype == RUA_BF16 && d->taps == 1 && d->C <= 64 && d->Cout <= 64 && d->C % 8 == 0 && d->Cout % 8 == 0 &&
+         (dense || (pow2(d->H) && pow2(d->W))) && M >= 2048 && d->workspace &&
+         d->workspace_bytes >= wg_taps_bytes(d) + WG_PW_TAIL && M * d->Cout * 2 < (1ll << 31) &&
+         (long long)d->N * d->Hs * d->Ws * d->C * 2 < (1ll << 31) &&
+         (long long)(d->H - 1) * d->stride < d->Hs && (long long)(d->W - 1) * d->stride < d->Ws;
+}
+
+static int launch_wgrad_pw(const rua_wgrad_desc* d, hipStream_t st) {
+  WgpK k;
+  k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.dw = d->dw;
+  char* tail = (char*)d->workspace + d->workspace_bytes - WG_PW_TAIL;
+  k.rep = (float*)tail; k.cnt = (int*)(tail + WG_PW_TAIL - 8192);
+  k.C = d->C; k.Cout = d->Cout; k.Hs = d->Hs; k.Ws = d->Ws; k.H = d->H; k.W = d->W; k.stride = d->stride;
+  k.dense = (d->stride == 1 && d->Hs == d->H && d->Ws == d->W) ? 1 : 0;
+  int ws = 0, hs = 0; while ((1 << ws) < d->W) ++ws; while ((1 << hs) < d->H) ++hs;
+  k.wshift = ws; k.hshift = hs;
+  k.M = (int)((long long)d->N * d->H * d->W);
+  k.abytes = (unsigned)((size_t)d->N * d->Hs * d->Ws * d->C * 2); k.dybytes = (unsigned)((size_t)k.M * d->Cout * 2);
+  const int nco = d->Cout > 32 ? 2 : 1, nci = d->C > 32 ? 2 : 1;
+  const int pxw = (nco + nci <= 2) ? 32 : 16;
+  static const int target = env_int("RUA_WGPW_BLOCKS") > 0 ? env_int("RUA_WGPW_BLOCKS") : 256;    // blocks of 16 waves
+  long long waves = (long long)target * 16;
+  if (waves > k.M / 128) waves = k.M / 128;                // >= 128 pixels per wave
+  if (waves < 16) waves = 16;
+  long long ppw = (k.M + waves - 1) / waves;
+  ppw = (ppw + 2 * pxw - 1) / (2 * pxw) * (2 * pxw);       // whole double iterations
+  k.px_per_wave = (int)ppw;
+  {   // replicas: atomic chains of ~64 blocks per address; fewer replicas = fewer exchanges for the finishing block
+    const long long nblk = (k.M + ppw * 16 - 1) / (ppw * 16);
+    k.R = (int)(nblk / 32); if (k.R < 1) k.R = 1; if (k.R > WG_PW_REPLICAS) k.R = WG_PW_REPLICAS;
+    if (env_int("RUA_WGPW_R") > 0) k.R = env_int("RUA_WGPW_R") > WG_PW_REPLICAS ? WG_PW_REPLICAS : env_int("RUA_WGPW_R");
+  }
+  const unsigned grid = (unsigned)((k.M + ppw * 16 - 1) / (ppw * 16));
+  constexpr int s11 = wgrad_pw_smem<1, 1>(), s21 = wgrad_pw_smem<2, 1>(), s12 = wgrad_pw_smem<1, 2>(), s22 = wgrad_pw_smem<2, 2>();
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pw<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, s21);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pw<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, s12);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pw<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, s22);
+    attr = true;
+  }
+  if (nco == 1 && nci == 1) hipLaunchKernelGGL((wgrad_pw<1, 1>), dim3(grid), dim3(1024), s11, st, k);
+  else if (nco == 2 && nci == 1) hipLaunchKernelGGL((wgrad_pw<2, 1>), dim3(grid), dim3(1024), s21, st, k);
+  else if (nco == 1 && nci == 2) hipLaunchKernelGGL((wgrad_pw<1, 2>), dim3(grid), dim3(1024), s12, st, k);
+  else hipLaunchKernelGGL((wgrad_pw<2, 2>), dim3(grid), dim3(1024), s22, st, k);
+  RUA_LAUNCH_CHECK("wgrad_pw");
+  return RUA_OK;
+}
+
 extern "C" int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d) {
   if (!d) return 0;
-  return (int64_t)256 * 9 * 32 * (int64_t)d->C * 4;     // up to 256 block partials of [9][32][C] fp32
+  return wg_taps_bytes(d) + WG_PW_TAIL;                 // all-taps block partials + wgrad_pw's replicas and ticket (the tail)
 }
 
 // which kernel a descriptor launches: 1 = all-taps (top levels), 0 = generic tiled
@@ -2046,6 +2329,7 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
 
 extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
   if (!d) return RUA_ERR_ARG;
+  if (pick_wgrad_pw(d)) return 3;
   {
     static const int on = getenv("RUA_WGRAD_DMAP") ? atoi(getenv("RUA_WGRAD_DMAP")) : 1;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
@@ -2062,7 +2346,7 @@ extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
   }
   const bool ok = d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->C == d->Cout && (d->C == 32 || d->C == 64) &&
                   d->W % 64 == 0 && d->Hs == d->H && d->Ws == d->W && d->dil >= 1 && d->dil <= 31 && d->workspace &&
-                  d->workspace_bytes >= rua_wgrad_workspace_bytes(d) && (long long)d->N * d->H * d->W * d->C * 2 < (1ll << 31);
+                  d->workspace_bytes >= wg_taps_bytes(d) && (long long)d->N * d->H * d->W * d->C * 2 < (1ll << 31);
   return ok ? 1 : 0;
 }
 
@@ -2074,6 +2358,7 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   RUA_CHECK_ARG(d->taps == 1 || d->taps == 9, "rua_conv_wgrad: taps must be 1 or 9");
   if (rua_wgrad_kind(d) == 1) return launch_wgrad_taps(d, (hipStream_t)stream);
   if (rua_wgrad_kind(d) == 2) return launch_wgrad_dmap(d, (hipStream_t)stream);
+  if (rua_wgrad_kind(d) == 3) return launch_wgrad_pw(d, (hipStream_t)stream);
   RUA_CHECK_ARG((long long)(d->H - 1) * d->stride < d->Hs && (long long)(d->W - 1) * d->stride < d->Ws,
                 "rua_conv_wgrad: input %dx%d too small for gradient %dx%d stride %d", d->Hs, d->Ws, d->H, d->W, d->stride);
   WgK k;

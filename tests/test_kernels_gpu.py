@@ -283,6 +283,48 @@ def test_wgrad_all_taps_kernel(case):
     assert rel_err(outs[0] - base, w.grad.numpy()) < 2e-3
 
 
+PW_CASES = [
+    # N, Hs, Ws, C, Cout, stride
+    (2, 64, 64, 32, 32, 1), (1, 128, 128, 32, 8, 1), (2, 64, 64, 8, 32, 1), (2, 64, 64, 64, 64, 1), (2, 64, 64, 32, 64, 2),
+    (1, 64, 64, 16, 64, 1), (3, 40, 24, 32, 32, 1), (2, 64, 64, 48, 24, 1), (4, 64, 64, 64, 16, 2), (8, 64, 64, 64, 40, 1),
+    (1, 64, 32, 8, 8, 1),
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_wgrad_pointwise_kernel(case):
+    """Narrow 1x1 weight gradients (C, Cout <= 64, bf16: wgrad_pw): per-wave streaming, replica accumulators and a ticket in
+    the tail of the workspace, which must be zero before the first call and is left zero by every call."""
+    N, Hs, Ws, Cs, Cout, stride = case
+    H, W = Hs // stride, Ws // stride
+    dt = L.RUA_BF16
+    rng = np.random.default_rng(17)
+    a = rng.standard_normal((N, Hs, Ws, Cs)).astype(np.float32)
+    dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    ad, dyd = to_dev(a, dt), to_dev(dy, dt)
+    base = rng.standard_normal((1, Cout, Cs)).astype(np.float32)
+    dw = torch.from_numpy(base).to(dev())
+    d = L.WgradDesc()
+    d.a, d.C, d.Hs, d.Ws = ad.data_ptr(), Cs, Hs, Ws
+    d.dy, d.Cout, d.H, d.W = dyd.data_ptr(), Cout, H, W
+    d.N, d.stride, d.dil, d.taps, d.dtype = N, stride, 1, 1, dt
+    d.dw = dw.data_ptr()
+    assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 0       # no workspace: the generic kernel
+    nbytes = L.lib().raw("rua_wgrad_workspace_bytes")(C.byref(d))
+    ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev())
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 3
+    w = torch.zeros((1, Cout, Cs), dtype=torch.float64, requires_grad=True)
+    y = ref_conv_nhwc(rnd(dt, a).double(), w, None, 1, 1, stride)
+    y.backward(rnd(dt, dy).double())
+    for rep in range(2):                                        # the second call runs on what the first left behind
+        dw.copy_(torch.from_numpy(base))
+        L.lib().call("rua_conv_wgrad", C.byref(d), stream())
+        torch.cuda.synchronize()
+        assert rel_err(dw.cpu().numpy() - base, w.grad.numpy()) < 2e-3
+        assert float(ws[-(16 * 64 * 64 + 2048):].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
 def test_weight_prep_layouts(dt):
     rng = np.random.default_rng(4)
