@@ -132,17 +132,18 @@ def profile_kernels(eng, g, dtype):
                 rc = fn(*args, sp)
                 e1 = mark()
                 mid(None)
+                fired = lib.raw("rua_profile_mid_event_fired")() == 1
                 d = args[0]._obj
                 if name == "rua_conv_fwd":
                     bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d)), lib.raw('rua_conv_tile_bn')(C.byref(d))
-                    two = lib.raw("rua_conv_last_ksplit")() > 1
+                    two = fired
                     kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap<{bm_},{bn_}>", f"conv_halo<{d.Cout}>")[kid]
                     kk = sum(d.seg[i].taps * d.seg[i].C for i in range(d.nseg))
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "") + (" splitk" if two else "")
                     fl, tag, second = conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags), f"conv_splitk_finish<{tname}>"
                 else:
                     wk = lib.raw("rua_wgrad_kind")(C.byref(d)); kn = (f"wgrad_kernel<{tname}>", f"wgrad_taps_kernel<{d.C}>", "wgrad_dmap", "wgrad_pw")[wk]
-                    two = wk == 1
+                    two = fired
                     fl, tag, second = wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, ""), "wgrad_taps_reduce"
                 if two:                                     # per-kernel rows, as rocprofv3 names them
                     rec.append((kn, e0, em, fl, tag)); rec.append((second, em, e1, 0.0, tag))

@@ -82,7 +82,8 @@ void* rua_prof_event_create(void);
 int rua_prof_event_record(void* ev, void* hip_stream);
 int rua_prof_event_elapsed_us(void* start, void* stop, double* us);   /* waits for `stop` */
 void rua_prof_event_destroy(void* ev);
-void rua_profile_mid_event(void* hip_event);    /* profiling only: the calling thread's NEXT two-launch call (split-K conv, all-taps weight
+void rua_profile_mid_event(void* hip_event);
+int rua_profile_mid_event_fired(void);          /* 1 if the call made since the event was armed recorded it (had a second launch) */    /* profiling only: the calling thread's NEXT two-launch call (split-K conv, all-taps weight
                                                    gradient) records this hipEvent_t between its main kernel and its second launch; one shot */
 int rua_conv_last_ksplit(void);                  /* K slices of the calling thread's latest rua_conv_fwd (1: single pass, no finisher) */
 int rua_conv_tile_bn(const rua_conv_desc* d);   /* 32 / 64 / 128 and */

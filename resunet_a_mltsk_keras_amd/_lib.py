@@ -68,6 +68,7 @@ _SIGS = {
     "rua_conv_kernel_id": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_last_ksplit": ([], i32),
     "rua_profile_mid_event": ([vp], None),
+    "rua_profile_mid_event_fired": ([], i32),
     "rua_prof_event_create": ([], vp),
     "rua_prof_event_record": ([vp, vp], i32),
     "rua_prof_event_elapsed_us": ([vp, vp, C.POINTER(f64)], i32),

@@ -460,9 +460,11 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK p) {
 // Profiling hook (bench.py): an event recorded BETWEEN the main kernel of a call and its second launch (split-K finisher,
 // wgrad_taps_reduce), so that per-kernel durations can be compared with rocprofv3's per-kernel-name averages.  One shot.
 static thread_local hipEvent_t g_mid_event = nullptr;
-extern "C" void rua_profile_mid_event(void* ev) { g_mid_event = (hipEvent_t)ev; }
+static thread_local int g_mid_fired = 0;
+extern "C" void rua_profile_mid_event(void* ev) { g_mid_event = (hipEvent_t)ev; if (ev) g_mid_fired = 0; }
+extern "C" int rua_profile_mid_event_fired(void) { return g_mid_fired; }     // 1: the call since the last arm had a second launch
 static inline void record_mid_event(hipStream_t st) {
-  if (g_mid_event) { (void)hipEventRecord(g_mid_event, st); g_mid_event = nullptr; }
+  if (g_mid_event) { (void)hipEventRecord(g_mid_event, st); g_mid_event = nullptr; g_mid_fired = 1; }
 }
 template <typename T> static void launch_splitk_finish(const ConvK& k, hipStream_t st) {
   record_mid_event(st);
@@ -1741,6 +1743,8 @@ __global__ __launch_bounds__(256) void wgrad_dmap(const WgdK p) {
         const int co = co0 + wm * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
         const int ci = ci0 + wn * 64 + b * 32 + lr;
         float* dst = &p.dw[((size_t)tap * p.Cout + co) * p.C + ci];
+        // K slices add with float atomics: per-slice partial tiles in a workspace + a reduce launch were measured and are no
+        // faster (64x64x128 level 32.8 vs 35.6 us, still behind wgrad_kernel's 33.7; 32x32x256 level 27.9 vs 27.0)
         if (p.ksplit == 1) *dst += acc[a][b][i]; else unsafeAtomicAdd(dst, acc[a][b][i]);
       }
 }
