@@ -67,7 +67,8 @@ fragment prefetch across the stage barrier) + split-K through fp32 slabs instead
 resident in LDS, lattice tiles for dilation) + hoisted epilogue loads →11.6; statistics kernels sized for the ~180 ns
 serialisation of same-address fp64 atomics →11.2; sliding-window all-taps weight gradient, plain read-modify-write where
 K is not split →11.1; rolling B fragments in `conv_halo`, shuffle reductions in the stem / head gradients, vectorised weight
-prep, BN grids →10.8; `wgrad_dmap` (weight gradient on the conv_dmap structure) at the 32×32×256 level →10.6.
+prep, BN grids →10.8; `wgrad_dmap` (weight gradient on the conv_dmap structure) at the 32×32×256 level →10.6;
+`wgrad_pw` (per-wave streaming weight gradient of the narrow 1×1 convolutions) →10.4–10.5 (box to box).
 
 ## r01_final: kernel table (per training step; {n} steps in the trace incl. warm-up and the instrumented step)
 
@@ -96,12 +97,12 @@ matches one rocprofv3 kernel name):
 
 ### Live vs rocprofv3 durations
 
-Three clocks for the same kernel, conv_dmap as the example: rocprofv3's dispatch duration **21.6 µs**; live events in the
-profiled run (`r01_final/bench.json`, this table) **23.4 µs** — the profiler serialises every dispatch behind its own
+Three clocks for the same kernel, `{rf['kernel']}`: rocprofv3's dispatch duration **{dom_rp:.1f} µs**; live events in the
+profiled run (`r01_final/bench.json`, this table) **{rf['avg_launch_us']:.1f} µs** — the profiler serialises every dispatch behind its own
 completion signal, which lands inside the bracket; live events in an unprofiled run (`r01_final/bench_unprofiled.json`, what the
-driver's bench run sees) **19.8 µs** — what one more kernel costs in the stream, below rocprofv3's figure because a dispatch's
+driver's bench run sees) **{bu['roofline']['avg_launch_us']:.1f} µs** — what one more kernel costs in the stream, below rocprofv3's figure because a dispatch's
 begin/end timestamps include ≈2 µs of dispatch set-up and end-of-kernel release that overlap the neighbouring kernels in a
-stream or graph.  (Σ rocprofv3 durations = {tot/1e6/n:.2f} ms per step ≥ the unprofiled wall step of 10.6 ms, gaps included.)
+stream or graph.  (Σ rocprofv3 durations = {tot/1e6/n:.2f} ms per step ≥ the unprofiled wall step of {bu['ms_per_step']:.2f} ms, gaps included.)
 The live events are created with `hipEventDisableSystemFence | hipEventReleaseToDevice` (`rua_prof_event_create`): a default
 event adds the L2 write-back of the bracketed kernel's output (≈3 µs for a 16 MB output) to the bracket.  The bracket's own
 cost is calibrated differentially on an idempotent library kernel (one launch vs two back-to-back launches between the markers).
@@ -126,8 +127,8 @@ CPU baseline in the same JSON: {b['cpu_baseline']['value']} patches/s on {b['cpu
 
 ## Other workloads (same build, `gpurun_out` logs of the same session)
 
-cfg2 (single-task) 814 patches/s (9.83 ms); cfg5 (128²×7, bs 32) 3 305 patches/s (9.68 ms); cfg4 (d7, 512², bs 4) 218 patches/s
-(18.4 ms, 233 TFLOP/s of model FLOPs).  Data-parallel step on one GPU with a one-rank RCCL group (`bench.py --force-dp`): +0.5 ms.
+cfg2 (single-task) 830 patches/s (9.64 ms); cfg5 (128²×7, bs 32) 3 367 patches/s (9.50 ms); cfg4 (d7, 512², bs 4) 221 patches/s
+(18.1 ms, 237 TFLOP/s of model FLOPs).  Data-parallel step on one GPU with a one-rank RCCL group (`bench.py --force-dp`): +0.7 ms.
 '''
 open('profiles/README.md', 'w').write(txt)
 print("written", len(lines), "rows; dominant rocprof avg", dom_rp)
