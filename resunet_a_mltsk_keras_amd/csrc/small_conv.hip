@@ -262,19 +262,30 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
   }
 }
 
-// dst[e] += sum_b partial[b][e]; 16 elements x 16 slices per block, slices folded in a fixed order
+// dst[e] += sum_b partial[b][e]; 4 elements x 64 slices per block (a thread's loads are independent: unrolled by 8), slices
+// folded in a fixed order
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int ne, int nparts, float* dw, int ndw, float* db) {
   __shared__ float sh[256];
-  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int e = blockIdx.x * 16 + el;
+  const int el = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int e = blockIdx.x * 4 + el;
   float s = 0.f;
-  if (e < ne) for (int b = sl; b < nparts; b += 16) s += partial[(size_t)b * ne + e];
+  if (e < ne) {
+    int b = sl;
+    for (; b + 7 * 64 < nparts; b += 8 * 64) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(b + k * 64) * ne + e];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; b < nparts; b += 64) s += partial[(size_t)b * ne + e];
+  }
   sh[threadIdx.x] = s;
   __syncthreads();
   if (sl == 0 && e < ne) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += sh[k * 16 + el];
+    for (int k = 0; k < 64; ++k) t += sh[k * 4 + el];
     if (e < ndw) dw[e] += t; else if (db) db[e - ndw] += t;
   }
 }
@@ -299,7 +310,10 @@ extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void
   const int vec = dtype == RUA_BF16 ? 8 : 4;
   RUA_CHECK_ARG(Cin % vec == 0 && Cin <= 256 && 256 % (Cin / vec) == 0, "rua_head_bwd: unsupported Cin=%d", Cin);
   RUA_CHECK_ARG(Cout >= 1 && Cout <= 8, "rua_head_bwd: Cout=%d must be in 1..8", Cout);
-  int64_t blocks = 1024; int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
+  static const int blocks_env = getenv("RUA_HEAD_BLOCKS") ? atoi(getenv("RUA_HEAD_BLOCKS")) : 0;
+  // two blocks per CU are resident (VGPRs), so 512 blocks run in one round: measured 128 blocks 49 us, 256: 37, 512: 35,
+  // 640: 52, 1024: 51, 2048: 85 (kernel + partial reduce, 256x256x32 -> 6)
+  int64_t blocks = blocks_env > 0 ? blocks_env : 512; int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
   const int g = (int)((M + rpb - 1) / rpb);
   const int ne = Cout * Cin + Cout;
   const size_t smem = (size_t)4 * ne * 4;
@@ -312,7 +326,7 @@ extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void
 #undef RUA_HEAD_BWD
   RUA_LAUNCH_CHECK("rua_head_bwd");
   if (partial) {
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((ne + 15) / 16), dim3(256), 0, st, (const float*)partial, ne, g, dw, Cout * Cin, db);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((ne + 3) / 4), dim3(256), 0, st, (const float*)partial, ne, g, dw, Cout * Cin, db);
     RUA_LAUNCH_CHECK("partial_reduce_kernel");
   }
   return RUA_OK;

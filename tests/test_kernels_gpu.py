@@ -486,6 +486,25 @@ def test_bn_fused_forward_backward_two_branches(dt):
         assert rel_err(dbet[b].cpu().numpy(), gm.sum(0)) < 5 * tol(dt) + 1e-4
 
 
+@pytest.mark.parametrize("Cc", [6, 3, 2, 5])
+def test_tanimoto_sums_match_numpy(Cc):
+    """rua_tanimoto_sums: sums[n][c] = {sum p, sum (1-l), sum p*l, sum p^2+l^2, sum (1-p)(1-l), sum (1-p)^2+(1-l)^2}
+    (multitasking_utils.py:38-85); C in {6, 3, 2} take the 16-byte-load kernel, 5 the scalar one."""
+    rng = np.random.default_rng(31)
+    B, HW = 3, 72 * 60
+    p = rng.uniform(0, 1, (B, HW, Cc)).astype(np.float32)
+    l = (rng.uniform(0, 1, (B, HW, Cc)) > 0.7).astype(np.float32)
+    pd, ld = torch.from_numpy(p).to(dev()), torch.from_numpy(l).to(dev())
+    sums = torch.zeros(B * Cc * 6, dtype=torch.float64, device=dev())
+    L.lib().call("rua_tanimoto_sums", pd.data_ptr(), ld.data_ptr(), B, HW, Cc, sums.data_ptr(), stream())
+    torch.cuda.synchronize()
+    P, Y = p.astype(np.float64), l.astype(np.float64)
+    want = np.stack([P.sum(1), (1 - Y).sum(1), (P * Y).sum(1), (P * P + Y * Y).sum(1), ((1 - P) * (1 - Y)).sum(1),
+                     ((1 - P) ** 2 + (1 - Y) ** 2).sum(1)], axis=-1)            # [B][C][6]
+    got = sums.cpu().numpy().reshape(B, Cc, 6)
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
 def test_pooling_family(dt):
     rng = np.random.default_rng(7)
@@ -625,17 +644,17 @@ def test_metrics_and_optimizers():
     from oracle import naive_ops as nv
     rng = np.random.default_rng(10)
     lib = L.lib()
-    M, Cc = 777, 6
-    p = rng.uniform(0, 1, (M, Cc)).astype(np.float32); p /= p.sum(1, keepdims=True)
-    y = np.eye(Cc, dtype=np.float32)[rng.integers(0, Cc, M)]
     f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
-    out = torch.zeros(5, dtype=torch.float64, device=dev())
-    pd, yd = f(p), f(y)
-    lib.call("rua_seg_metrics", pd.data_ptr(), yd.data_ptr(), M, Cc, out.data_ptr(), stream())
-    torch.cuda.synchronize()
-    t, q = y > 0.5, p > 0.5
-    exp = [(p.argmax(1) == y.argmax(1)).sum(), (t & q).sum(), (~t & q).sum(), (~t & ~q).sum(), (t & ~q).sum()]
-    assert np.array_equal(out.cpu().numpy(), np.array(exp, np.float64))
+    for M, Cc in ((777, 6), (70000, 6), (4096, 2), (4096, 5)):   # odd M / C = 5: scalar kernel; even M with C in {6, 2}: 16-byte loads
+        p = rng.uniform(0, 1, (M, Cc)).astype(np.float32); p /= p.sum(1, keepdims=True)
+        y = np.eye(Cc, dtype=np.float32)[rng.integers(0, Cc, M)]
+        out = torch.zeros(5, dtype=torch.float64, device=dev())
+        pd, yd = f(p), f(y)
+        lib.call("rua_seg_metrics", pd.data_ptr(), yd.data_ptr(), M, Cc, out.data_ptr(), stream())
+        torch.cuda.synchronize()
+        t, q = y > 0.5, p > 0.5
+        exp = [(p.argmax(1) == y.argmax(1)).sum(), (t & q).sum(), (~t & q).sum(), (~t & ~q).sum(), (t & ~q).sum()]
+        assert np.array_equal(out.cpu().numpy(), np.array(exp, np.float64)), (M, Cc)
     n = 1000
     th = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32)
     thd, gd, md, vd = f(th), f(g), f(np.zeros(n)), f(np.zeros(n))
