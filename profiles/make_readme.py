@@ -68,7 +68,8 @@ resident in LDS, lattice tiles for dilation) + hoisted epilogue loads →11.6; s
 serialisation of same-address fp64 atomics →11.2; sliding-window all-taps weight gradient, plain read-modify-write where
 K is not split →11.1; rolling B fragments in `conv_halo`, shuffle reductions in the stem / head gradients, vectorised weight
 prep, BN grids →10.8; `wgrad_dmap` (weight gradient on the conv_dmap structure) at the 32×32×256 level →10.6;
-`wgrad_pw` (per-wave streaming weight gradient of the narrow 1×1 convolutions) →10.4–10.5 (box to box).
+`wgrad_pw` (per-wave streaming weight gradient of the narrow 1×1 convolutions) →10.4–10.5 (box to box); loss-side kernels
+(head gradient in one resident round of blocks, 16-byte-load Tanimoto sums / metrics, wider partial reduce) →10.3–10.4.
 
 ## r01_final: kernel table (per training step; {n} steps in the trace incl. warm-up and the instrumented step)
 
