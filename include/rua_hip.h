@@ -224,6 +224,9 @@ int rua_seg_metrics(const float* p, const float* y, int64_t M, int C, double* ou
 /* ---- optimizers on the flat parameter buffer (train_ISPRS.py:404-407) --------------------- */
 /* Keras Adam: theta -= lr_t * m / (sqrt(v) + eps); g is read as g*grad_scale and zeroed if zero_grad.
  * lr_t_dev (optional): device scalar overriding lr_t, so a captured HIP graph can be replayed every step */
+/* state[0] += 1 (optimizer steps taken), lr_out[0] = state[1] (base rate) [* sqrt(1 - beta2^t) / (1 - beta1^t) for Adam]:
+ * the step-dependent rate is produced on the device so that a captured step replays without host-side scalar updates */
+int rua_lr_step(double* state, float* lr_out, int adam, double beta1, double beta2, void* stream);
 int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1, float beta2,
                   float eps, float grad_scale, int zero_grad, void* stream);
 int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, const float* lr_dev, float momentum, float grad_scale,

@@ -107,6 +107,7 @@ _SIGS = {
     "rua_pixel_loss": ([i32, vp, vp, vp, vp, i64, i32, vp, vp, vp], i32),
     "rua_head_dz": ([i32, i32, vp, vp, vp, vp, f32, i32, i64, i32, vp, vp], i32),
     "rua_seg_metrics": ([vp, vp, i64, i32, vp, vp], i32),
+    "rua_lr_step": ([vp, vp, i32, f64, f64, vp], i32),
     "rua_adam_step": ([vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, i32, vp], i32),
     "rua_sgd_step": ([vp, vp, vp, i64, f32, vp, f32, f32, i32, vp], i32),
 }

@@ -434,6 +434,24 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ th, float*
     if (zero) g[i] = 0.f;
   }
 }
+// Step-dependent learning rate on the device, so that a captured training step needs no host-side scalar update between
+// replays: state[0] = optimizer steps taken (advanced here), state[1] = base learning rate; lr_out[0] = the rate the
+// optimizer kernel launched next reads (Adam: Keras' lr * sqrt(1 - beta2^t) / (1 - beta1^t), train_ISPRS.py:404-407).
+__global__ void lr_step_kernel(double* state, float* lr_out, int adam, double beta1, double beta2) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double t = state[0] + 1.0;
+    state[0] = t;
+    double lr = state[1];
+    if (adam) lr = lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t));
+    lr_out[0] = (float)lr;
+  }
+}
+extern "C" int rua_lr_step(double* state, float* lr_out, int adam, double beta1, double beta2, void* stream) {
+  RUA_CHECK_ARG(state && lr_out, "rua_lr_step: null pointer");
+  hipLaunchKernelGGL(lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr_out, adam, beta1, beta2);
+  RUA_LAUNCH_CHECK("rua_lr_step");
+  return RUA_OK;
+}
 extern "C" int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1, float beta2,
                              float eps, float grad_scale, int zero_grad, void* stream) {
   RUA_CHECK_ARG(theta && g && m && v && n > 0, "rua_adam_step: bad arguments");

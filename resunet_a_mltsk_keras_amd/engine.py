@@ -1004,6 +1004,8 @@ class Engine:
         self.side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(3)]
         self.use_lanes = False      # measured: no gain (13.5 vs 14.0 ms/step), the step is bound by shared memory-side resources
         self.lr_dev = torch.zeros(16, dtype=torch.float32, device=self.dev)               # step-dependent optimizer scalars
+        self.lr_state = torch.zeros(2, dtype=torch.float64, device=self.dev)              # [steps taken, base learning rate]
+        self._t_dev, self._lr_base_dev = -1, None                                         # what lr_state holds (host shadow)
         self.use_graph = True
         self._captured: Dict[int, object] = {}
         self._captured_dp: Dict[int, list] = {}
@@ -1148,16 +1150,20 @@ class Engine:
         return g._hooks
 
     def _set_lr(self):
-        """Advance the step counter and put the step-dependent learning rate into device memory."""
+        """Advance the step counter.  The step-dependent learning rate is produced on the device by the optimizer launch
+        (`rua_lr_step`), so a captured step replays with no host-side scalar update in between; the host only pushes the
+        base rate / the counter when they were changed from outside (K.set_value(optimizer.lr), a loaded checkpoint)."""
         sp = self.loss
+        if self._t_dev != self.t or self._lr_base_dev != sp.lr:
+            self.lr_state.copy_(torch.tensor([float(self.t), float(sp.lr)], dtype=torch.float64))
+            self._t_dev, self._lr_base_dev = self.t, sp.lr
         self.t += 1
-        lr = sp.lr
-        if sp.optimizer == "adam":
-            lr = sp.lr * math.sqrt(1.0 - sp.beta_2 ** self.t) / (1.0 - sp.beta_1 ** self.t)
-        self.lr_dev[:1].fill_(lr)
+        self._t_dev += 1                                    # the optimizer launch of this step advances the device counter
 
     def _launch_optimizer(self, grad_scale, s):
         sp = self.loss
+        L.lib().call("rua_lr_step", self.lr_state.data_ptr(), self.lr_dev.data_ptr(), 1 if sp.optimizer == "adam" else 0,
+                     float(sp.beta_1), float(sp.beta_2), C.c_void_p(s))
         if sp.optimizer == "adam":
             L.lib().call("rua_adam_step", self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.V1.data_ptr(), self.params.n,
                          0.0, self.lr_dev.data_ptr(), sp.beta_1, sp.beta_2, KERAS_EPS, grad_scale, 1, C.c_void_p(s))
