@@ -552,9 +552,12 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
 
 // ---------------------------------------------------------------------------------------
 // pooling / resampling: one thread per output (or input) piece
-template <typename T>
-__global__ void maxpool_fwd_kernel(const unsigned char* x, unsigned char* y, uint8_t* idx, int N, int H, int W, int CG, int k) {
+// K > 0: window size known at compile time - the K loads of a window row are issued together (the runtime-k loop did
+// k*k dependent loads per output: 22 us for the 8x8 windows of the PSP pyramids); K == 0: any k.
+template <typename T, int K>
+__global__ void maxpool_fwd_kernel(const unsigned char* x, unsigned char* y, uint8_t* idx, int N, int H, int W, int CG, int k_rt) {
   constexpr int VEC = ET<T>::VEC;
+  const int k = K > 0 ? K : k_rt;
   const int Ho = H / k, Wo = W / k;
   const long long total = (long long)N * Ho * Wo * CG;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -564,13 +567,28 @@ __global__ void maxpool_fwd_kernel(const unsigned char* x, unsigned char* y, uin
     float best[VEC]; int bi[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
-    for (int a = 0; a < k; ++a)
-      for (int b = 0; b < k; ++b) {
-        float v[VEC];
-        ET<T>::unpack(ldg16(x + ((((size_t)n * H + ho * k + a) * W + wo * k + b) * CG + cp) * 16), v);
+    if constexpr (K > 0) {
+      for (int a = 0; a < K; ++a) {
+        uint4 q[K];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) if (v[j] > best[j]) { best[j] = v[j]; bi[j] = a * k + b; }   // first maximum wins
+        for (int b = 0; b < K; ++b) q[b] = ldg16(x + ((((size_t)n * H + ho * K + a) * W + wo * K + b) * CG + cp) * 16);
+#pragma unroll
+        for (int b = 0; b < K; ++b) {
+          float v[VEC];
+          ET<T>::unpack(q[b], v);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) if (v[j] > best[j]) { best[j] = v[j]; bi[j] = a * K + b; }   // first maximum wins
+        }
       }
+    } else {
+      for (int a = 0; a < k; ++a)
+        for (int b = 0; b < k; ++b) {
+          float v[VEC];
+          ET<T>::unpack(ldg16(x + ((((size_t)n * H + ho * k + a) * W + wo * k + b) * CG + cp) * 16), v);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) if (v[j] > best[j]) { best[j] = v[j]; bi[j] = a * k + b; }   // first maximum wins
+        }
+    }
     stg16(y + i * 16, ET<T>::pack(best));
 #pragma unroll
     for (int j = 0; j < VEC; ++j) idx[i * VEC + j] = (uint8_t)bi[j];
@@ -603,9 +621,10 @@ __global__ void maxpool_bwd_kernel(const unsigned char* dy, const uint8_t* idx, 
   }
 }
 
-template <typename T>
-__global__ void sumpool_kernel(const unsigned char* x, unsigned char* y, int N, int H, int W, int CG, int k) {
+template <typename T, int K>
+__global__ void sumpool_kernel(const unsigned char* x, unsigned char* y, int N, int H, int W, int CG, int k_rt) {
   constexpr int VEC = ET<T>::VEC;
+  const int k = K > 0 ? K : k_rt;
   const int Ho = H / k, Wo = W / k;
   const long long total = (long long)N * Ho * Wo * CG;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -615,13 +634,28 @@ __global__ void sumpool_kernel(const unsigned char* x, unsigned char* y, int N, 
     float s[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s[j] = 0.f;
-    for (int a = 0; a < k; ++a)
-      for (int b = 0; b < k; ++b) {
-        float v[VEC];
-        ET<T>::unpack(ldg16(x + ((((size_t)n * H + ho * k + a) * W + wo * k + b) * CG + cp) * 16), v);
+    if constexpr (K > 0) {
+      for (int a = 0; a < K; ++a) {
+        uint4 q[K];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) s[j] += v[j];
+        for (int b = 0; b < K; ++b) q[b] = ldg16(x + ((((size_t)n * H + ho * K + a) * W + wo * K + b) * CG + cp) * 16);
+#pragma unroll
+        for (int b = 0; b < K; ++b) {
+          float v[VEC];
+          ET<T>::unpack(q[b], v);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) s[j] += v[j];
+        }
       }
+    } else {
+      for (int a = 0; a < k; ++a)
+        for (int b = 0; b < k; ++b) {
+          float v[VEC];
+          ET<T>::unpack(ldg16(x + ((((size_t)n * H + ho * k + a) * W + wo * k + b) * CG + cp) * 16), v);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) s[j] += v[j];
+        }
+    }
     stg16(y + i * 16, ET<T>::pack(s));
   }
 }
@@ -649,8 +683,10 @@ extern "C" int rua_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int 
   POOL_ARGS_CHECK("rua_maxpool_fwd");
   RUA_CHECK_ARG(idx && H % k == 0 && W % k == 0 && k * k <= 256, "rua_maxpool_fwd: H,W must be divisible by k");
   const int g = grid_for((int64_t)N * (H / k) * (W / k) * CG);
-  if (dtype == RUA_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, idx, N, H, W, CG, k);
-  else hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, idx, N, H, W, CG, k);
+#define RUA_MAXPOOL(TT, KK) hipLaunchKernelGGL((maxpool_fwd_kernel<TT, KK>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, idx, N, H, W, CG, k)
+  if (dtype == RUA_BF16) { if (k == 2) RUA_MAXPOOL(bf16_t, 2); else if (k == 4) RUA_MAXPOOL(bf16_t, 4); else if (k == 8) RUA_MAXPOOL(bf16_t, 8); else RUA_MAXPOOL(bf16_t, 0); }
+  else { if (k == 2) RUA_MAXPOOL(float, 2); else if (k == 4) RUA_MAXPOOL(float, 4); else if (k == 8) RUA_MAXPOOL(float, 8); else RUA_MAXPOOL(float, 0); }
+#undef RUA_MAXPOOL
   RUA_LAUNCH_CHECK("rua_maxpool_fwd");
   return RUA_OK;
 }
@@ -667,8 +703,10 @@ extern "C" int rua_sumpool(const void* x, void* y, int N, int H, int W, int C, i
   POOL_ARGS_CHECK("rua_sumpool");
   RUA_CHECK_ARG(H % k == 0 && W % k == 0, "rua_sumpool: H,W must be divisible by k");
   const int g = grid_for((int64_t)N * (H / k) * (W / k) * CG);
-  if (dtype == RUA_BF16) hipLaunchKernelGGL((sumpool_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, N, H, W, CG, k);
-  else hipLaunchKernelGGL((sumpool_kernel<float>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, N, H, W, CG, k);
+#define RUA_SUMPOOL(TT, KK) hipLaunchKernelGGL((sumpool_kernel<TT, KK>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, N, H, W, CG, k)
+  if (dtype == RUA_BF16) { if (k == 2) RUA_SUMPOOL(bf16_t, 2); else if (k == 4) RUA_SUMPOOL(bf16_t, 4); else if (k == 8) RUA_SUMPOOL(bf16_t, 8); else RUA_SUMPOOL(bf16_t, 0); }
+  else { if (k == 2) RUA_SUMPOOL(float, 2); else if (k == 4) RUA_SUMPOOL(float, 4); else if (k == 8) RUA_SUMPOOL(float, 8); else RUA_SUMPOOL(float, 0); }
+#undef RUA_SUMPOOL
   RUA_LAUNCH_CHECK("rua_sumpool");
   return RUA_OK;
 }

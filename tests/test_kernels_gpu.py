@@ -512,11 +512,11 @@ def test_tanimoto_sums_match_numpy(Cc):
 def test_pooling_family(dt):
     rng = np.random.default_rng(7)
     lib = L.lib()
-    N, H, W, Cc = 2, 16, 16, 16
+    N, H, W, Cc = 2, 48, 48, 16
     x = rng.standard_normal((N, H, W, Cc)).astype(np.float32)
     xd = to_dev(x, dt)
     xr = rnd(dt, x)
-    for k in (2, 4, 8):
+    for k in (2, 4, 8, 3, 1):                                # 2 / 4 / 8: compile-time windows; 3, 1: the any-k kernel
         y = torch.empty((N, H // k, W // k, Cc), dtype=tdt(dt), device=dev())
         idx = torch.empty(y.numel(), dtype=torch.uint8, device=dev())
         lib.call("rua_maxpool_fwd", xd.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, Cc, k, dt, stream())
