@@ -73,6 +73,8 @@ typedef struct rua_conv_desc {
   int64_t workspace_bytes;
   int32_t stats_replicas;      /* power of two >= 1: block b adds into replica b % R (spreads atomic contention);
                                   the finalize kernels sum the replicas */
+  const float* bias_more[3];   /* further [Cout] bias vectors (or NULL) added after `bias`, in this order: the branch-final convs
+                                  of a ResBlock run as ONE concatenated conv whose bias is the sum of the branches' biases */
 } rua_conv_desc;
 int rua_conv_fwd(const rua_conv_desc* d, void* stream);
 int rua_conv_smem_bytes(const rua_conv_desc* d);

@@ -24,7 +24,8 @@ class ConvDesc(C.Structure):
     _fields_ = [("seg", ConvSeg * RUA_MAX_SEG), ("nseg", i32), ("N", i32), ("H", i32), ("W", i32), ("Cout", i32),
                 ("stride", i32), ("dtype", i32), ("bias", vp), ("aux", vp), ("aux_mode", i32), ("mscale", vp),
                 ("mshift", vp), ("out_relu", i32), ("accumulate", i32), ("y", vp), ("out_stride", i32), ("OH", i32),
-                ("OW", i32), ("stats", vp), ("stats_mode", i32), ("workspace", vp), ("workspace_bytes", i64), ("stats_replicas", i32)]
+                ("OW", i32), ("stats", vp), ("stats_mode", i32), ("workspace", vp), ("workspace_bytes", i64), ("stats_replicas", i32),
+                ("bias_more", vp * 3)]
 
 
 class WgradDesc(C.Structure):

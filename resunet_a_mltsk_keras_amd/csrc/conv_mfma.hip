@@ -19,7 +19,7 @@ struct ConvK {
   int nseg, nunits;
   int N, H, W, Cout, stride;
   long long M;
-  const float* bias; const unsigned char* aux; int aux_mode; const float* mscale; const float* mshift;
+  const float* bias; const float* bias_more[3]; const unsigned char* aux; int aux_mode; const float* mscale; const float* mshift;
   int out_relu, accumulate; unsigned char* y; int out_stride, OH, OW; double* stats; int stats_mode; int stats_R;
   int nbn, nbm, ksplit, stages_per_split; float* ws;
   int* cnt;      // per-tile ticket counters (all zero between launches) for the in-launch split-K reduction, or null
@@ -75,6 +75,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
     if (p.bias) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) bias8[j] = p.bias[co + j];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (p.bias_more[q]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bias8[j] += p.bias_more[q][co + j];
+        }
     }
     if (p.aux_mode == 2) {
       if (p.mscale) {
@@ -1368,6 +1374,7 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.N = d->N; k.H = d->H; k.W = d->W; k.Cout = d->Cout; k.stride = d->stride;
   k.M = (long long)d->N * d->H * d->W;
   k.bias = d->bias; k.aux = (const unsigned char*)d->aux; k.aux_mode = d->aux_mode;
+  for (int q = 0; q < 3; ++q) k.bias_more[q] = d->bias ? d->bias_more[q] : nullptr;
   k.mscale = d->mscale; k.mshift = d->mshift; k.out_relu = d->out_relu; k.accumulate = d->accumulate;
   k.y = (unsigned char*)d->y; k.out_stride = d->out_stride; k.OH = d->OH; k.OW = d->OW;
   k.stats = d->stats; k.stats_mode = d->stats_mode;

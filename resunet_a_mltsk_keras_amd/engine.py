@@ -452,7 +452,7 @@ class Graph:
         plan.add("rua_bn_bwd", C.byref(d))
 
     def conv(self, plan: Plan, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual: Optional[Ten] = None,
-             out_relu=False, stats=None):
+             out_relu=False, stats=None, bias_more=()):
         """segs: [(Ten, up_shift, dil, taps)], layer_segs: [param seg dict] (same order)."""
         d = L.ConvDesc()
         d.nseg = len(segs)
@@ -462,6 +462,8 @@ class Graph:
             s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = t.ptr, self.Wf(ps["dst"]), t.C, t.H, t.W, up, dil, taps
         d.N, d.H, d.W, d.Cout, d.stride, d.dtype = out.N, out.H, out.W, cout, stride, self.dt
         d.bias = bias_ptr
+        for i, b in enumerate(bias_more):                  # added after `bias` in this order (<= 3)
+            d.bias_more[i] = b
         if residual is not None:
             d.aux, d.aux_mode = residual.ptr, 1
         d.out_relu = 1 if out_relu else 0
@@ -558,13 +560,10 @@ class Graph:
             y1.append(y); coef2.append(c2)
             a2.append(o2[0])
         F.join(len(dils)); self.cur_lane = 0
-        bsum = self.alloc(((nf + 15) // 16 * 16,), torch.float32, zero=True)
-        bl = L.ptr_array([self.P(l[3]["bias"]) for l in lay])
-        F.keep += [bsum, bl]
-        F.add("rua_add_n", len(lay), bl, bsum.data_ptr(), 0, nf, L.RUA_F32)
         out = self.like(x)
-        self.conv(F, [(a, 0, d, 9) for a, d in zip(a2, dils)], [l[3]["segs"][0] for l in lay], nf, bsum.data_ptr(), out,
-                  residual=x if v2 else None)
+        biases = [self.P(l[3]["bias"]) for l in lay]        # the concatenated conv's bias = sum of the branches' biases
+        self.conv(F, [(a, 0, d, 9) for a, d in zip(a2, dils)], [l[3]["segs"][0] for l in lay], nf, biases[0], out,
+                  residual=x if v2 else None, bias_more=biases[1:])
         if not tr:
             return out
 

@@ -93,8 +93,13 @@ def test_conv_fwd(case, dt):
         s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = xd.data_ptr(), wd.data_ptr(), Cs, Hs, Ws, up, dil, taps
         exp = exp + ref_conv_nhwc(rnd(dt, x), rnd(dt, w), None, dil, taps, stride, up)
     bias = rng.standard_normal(Cout).astype(np.float32)
+    more = [rng.standard_normal(Cout).astype(np.float32) for _ in range(2)]          # bias_more: added after `bias`, in order
+    md = [torch.from_numpy(m).to(dev()) for m in more]
+    for i, m in enumerate(md):
+        d.bias_more[i] = m.data_ptr()
     res = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
     bd, rd = torch.from_numpy(bias).to(dev()), to_dev(res, dt)
+    bias = (bias + more[0]) + more[1]
     y = torch.empty((N, H, W, Cout), dtype=tdt(dt), device=dev())
     stats = torch.zeros(2 * 2 * Cout, dtype=torch.float64, device=dev())
     d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cout, stride, dt
