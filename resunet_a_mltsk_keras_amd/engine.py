@@ -1007,6 +1007,8 @@ class Engine:
         self._t_dev, self._lr_base_dev = -1, None                                         # what lr_state holds (host shadow)
         self.use_graph = True
         self._captured: Dict[int, object] = {}
+        self._captured_eval: Dict[int, object] = {}        # batch -> graph of the inference forward (False: capture failed)
+        self._eval_seen = set()
         self._captured_dp: Dict[int, list] = {}
         self.dp_graph = os.environ.get("RUA_DP_GRAPH", "1") != "0"      # data-parallel step as HIP-graph pieces (else eager launches)
         self.scalars_ptr = self.stats_arena.data_ptr()
@@ -1293,11 +1295,34 @@ class Engine:
         return self._results(g)
 
     def predict(self, x):
-        g = self.graph(x.shape[0], False)
+        """Inference forward (moving BN statistics).  The forward launch list of a batch size is captured into a HIP graph
+        on its second use (the reference's evaluation calls predict(batch_size=1) per patch, test_ISPRS.py:28: ~250
+        launches of host time per patch otherwise)."""
+        B = x.shape[0]
+        g = self.graph(B, False)
         s = self._stream()
         self._upload(g, x, None)
         self._prep_weights(s)
-        g.fwd.run(s)
+        cap = self._captured_eval.get(B) if self.use_graph else None
+        if cap is None or self.use_lanes:
+            g.fwd.run(s)
+            if self.use_graph and not self.use_lanes and B in self._eval_seen:
+                try:
+                    torch.cuda.synchronize()
+                    cap = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(cap):
+                        g.fwd.run(self._stream())
+                    self._captured_eval[B] = cap           # capture launched nothing: this call's results are the eager run's
+                except RuntimeError as exc:
+                    import sys
+                    print(f"[resunet_a] HIP-graph capture of the inference forward failed ({exc}); staying eager", file=sys.stderr, flush=True)
+                    torch.cuda.synchronize()
+                    self._captured_eval[B] = False
+            self._eval_seen.add(B)
+        elif cap is False:
+            g.fwd.run(s)
+        else:
+            cap.replay()
         outs = {h["name"]: h["p"].t.cpu().numpy() for h in g.heads}
         return outs if self.cfg.multitasking else outs["seg"]
 

@@ -91,6 +91,10 @@ def test_keras_style_model_roundtrip(tmp_path):
     pred = model.predict(x, batch_size=1)
     assert set(pred) == set(HEADS) and pred["seg"].shape == (2, 64, 64, 4) and pred["color"].shape == (2, 64, 64, 3)
     assert np.allclose(pred["seg"].sum(-1), 1.0, atol=1e-5)
+    for _ in range(2):                                         # later calls replay the captured inference forward
+        again = model.predict(x, batch_size=1)
+        assert all(np.array_equal(again[h], pred[h]) for h in HEADS)
+    assert model.engine._captured_eval.get(1) not in (None, False)
     path = str(tmp_path / "best_model.h5")
     model.save(path)
     m2 = load_model(path)
