@@ -69,7 +69,10 @@ serialisation of same-address fp64 atomics →11.2; sliding-window all-taps weig
 K is not split →11.1; rolling B fragments in `conv_halo`, shuffle reductions in the stem / head gradients, vectorised weight
 prep, BN grids →10.8; `wgrad_dmap` (weight gradient on the conv_dmap structure) at the 32×32×256 level →10.6;
 `wgrad_pw` (per-wave streaming weight gradient of the narrow 1×1 convolutions) →10.4–10.5 (box to box); loss-side kernels
-(head gradient in one resident round of blocks, 16-byte-load Tanimoto sums / metrics, wider partial reduce) →10.3–10.4.
+(head gradient in one resident round of blocks, 16-byte-load Tanimoto sums / metrics, wider partial reduce) →10.3–10.4;
+`conv_dmap` with 64-row tiles where 128×128 tiles leave half the CUs idle →10.2; pooling kernels with compile-time windows (a
+window row's loads issued together), learning rate advanced on the device, branch biases summed in the conv epilogue
+→10.05–10.3 (box to box; the committed run is on a 10.3 box).
 
 ## r01_final: kernel table (per training step; {n} steps in the trace incl. warm-up and the instrumented step)
 
@@ -128,8 +131,9 @@ CPU baseline in the same JSON: {b['cpu_baseline']['value']} patches/s on {b['cpu
 
 ## Other workloads (same build, `gpurun_out` logs of the same session)
 
-cfg2 (single-task) 830 patches/s (9.64 ms); cfg5 (128²×7, bs 32) 3 367 patches/s (9.50 ms); cfg4 (d7, 512², bs 4) 221 patches/s
-(18.1 ms, 237 TFLOP/s of model FLOPs).  Data-parallel step on one GPU with a one-rank RCCL group (`bench.py --force-dp`): +0.7 ms.
+On a 10.09 ms box (cfg3 793 patches/s): cfg2 (single-task) 863 patches/s (9.27 ms); cfg5 (128²×7, bs 32) 3 492 patches/s (9.17 ms);
+cfg4 (d7, 512², bs 4) 230 patches/s (17.4 ms, 247 TFLOP/s of model FLOPs).  Data-parallel step on one GPU with a one-rank RCCL
+group (`bench.py --force-dp`): 10.68 ms (+0.6 ms).
 '''
 open('profiles/README.md', 'w').write(txt)
 print("written", len(lines), "rows; dominant rocprof avg", dom_rp)
