@@ -2359,7 +2359,8 @@ extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
       // the CUs idle), 8x8x1024 75 / 32 (576 short-K blocks at one per CU).  So: a few dozen tiles and a long K.
       const long long tiles = (long long)d->taps * (d->Cout / 128) * (d->C / 128);
       const long long stages = ((long long)d->N * d->H * d->W + 63) / 64;
-      if (on == 2 || (tiles >= 16 && tiles <= 64 && stages >= 64)) return 2;
+      static const int mint = getenv("RUA_WGD_MINTILES") ? atoi(getenv("RUA_WGD_MINTILES")) : 9;    // 9: the 64x64x128 level too (A/B in the step: -0.03 ms)
+      if (on == 2 || (tiles >= mint && tiles <= 64 && stages >= 64)) return 2;
     }
   }
   const bool ok = d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->C == d->Cout && (d->C == 32 || d->C == 64) &&

@@ -230,6 +230,7 @@ WGRAD_CASES = [
     (3, 4, 4, 128, 128, 1, 1, 9),
     (4, 32, 32, 256, 256, 1, 3, 9),      # 36 tiles, 64 stages: the shape class the dispatch gives to wgrad_dmap
     (8, 32, 32, 256, 128, 1, 15, 9),
+    (4, 64, 64, 128, 128, 1, 3, 9),      # 9 tiles, 256 stages: the 64x64x128 level's class
 ]
 
 
@@ -248,7 +249,7 @@ def test_conv_wgrad(case, dt):
     d.dy, d.Cout, d.H, d.W = dyd.data_ptr(), Cout, H, W
     d.N, d.stride, d.dil, d.taps, d.dtype = N, stride, dil, taps, dt
     d.dw = dw.data_ptr()
-    if dt == L.RUA_BF16 and case[:5] == (4, 32, 32, 256, 256):
+    if dt == L.RUA_BF16 and case[:5] in ((4, 32, 32, 256, 256), (4, 64, 64, 128, 128)):
         assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 2
     L.lib().call("rua_conv_wgrad", C.byref(d), stream())
     torch.cuda.synchronize()
