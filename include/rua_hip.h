@@ -126,9 +126,11 @@ int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db, int64_t M
 /* heads: Conv2D(num_classes,(1,1)) + softmax / sigmoid (model2.py:145-146,160-162,169-171,181-183,186-188).
  * act: 0 none, 1 softmax over channels, 2 sigmoid.  z (logits) and p are fp32 [M][Cout<=8]. */
 int rua_head_fwd(const void* x, const float* w, const float* b, float* z, float* p, int64_t M, int Cin, int Cout, int act, int dtype, void* stream);
-/* scratch (optional, >= 1024*(Cout*Cin+Cout)*4 bytes): per-block partials + fixed-order reduce instead of fp32 atomics */
+/* scratch (optional, >= 1024*(Cout*Cin+Cout)*4 bytes): per-block partials + fixed-order reduce instead of fp32 atomics.
+ * mask_dx: x is the output of a fused ReLU (the heads' 3x3 conv + relu, model2.py:153-158): dx *= (x > 0), i.e. the ReLU's
+ * backward is applied here instead of in a pass of its own */
 int rua_head_bwd(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db,
-                 float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, void* stream);
+                 float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, int mask_dx, void* stream);
 
 /* ---- BatchNormalization (model2.py:17,21,38,86,93; Keras eps 1e-3, momentum .99) -------- */
 /* per-channel sum / sum of squares over all rows of x [M][C] -> stats[R][2][C] (fp64, accumulated over R replicas) */

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned char* x, c
 template <typename T, int CO>      // CO: output channels held in registers (exact for the reference's 6 classes / 3 colour bands, else 8)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, const float* __restrict__ dz, const float* __restrict__ w,
                                                         unsigned char* dx, int accumulate_dx, float* dw, float* db, float* partial,
-                                                        long long M, int Cin, int Cout, int rows_per_block) {
+                                                        long long M, int Cin, int Cout, int rows_per_block, int mask_dx) {
   constexpr int VEC = ET<T>::VEC;
   extern __shared__ float red[];                      // [4 waves][Cout*Cin + Cout]
   const int NE = Cout * Cin + Cout;
@@ -211,6 +211,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
       bs[co] += g[co];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { o[j] = fmaf(g[co], wr[co][j], o[j]); acc[co][j] = fmaf(g[co], xv[j], acc[co][j]); }
+    }
+    if (mask_dx) {                                      // x is the output of a fused ReLU: dx *= (x > 0)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = xv[j] > 0.f ? o[j] : 0.f;
     }
     if (dx) stg16(dx + ((size_t)rr * CGI + cp) * 16, ET<T>::pack(o));
   };
@@ -305,7 +309,7 @@ extern "C" int rua_head_fwd(const void* x, const float* w, const float* b, float
 }
 
 extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db,
-                            float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, void* stream) {
+                            float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, int mask_dx, void* stream) {
   RUA_CHECK_ARG(x && dz && w && dw && M > 0, "rua_head_bwd: bad arguments");
   const int vec = dtype == RUA_BF16 ? 8 : 4;
   RUA_CHECK_ARG(Cin % vec == 0 && Cin <= 256 && 256 % (Cin / vec) == 0, "rua_head_bwd: unsupported Cin=%d", Cin);
@@ -320,7 +324,7 @@ extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void
   float* partial = (scratch && scratch_bytes >= (int64_t)g * ne * 4) ? scratch : nullptr;   // else: fp32 atomics
   hipStream_t st = (hipStream_t)stream;
 #define RUA_HEAD_BWD(TT, CO_) hipLaunchKernelGGL((head_bwd_kernel<TT, CO_>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, \
-    (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb)
+    (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb, mask_dx)
   if (dtype == RUA_BF16) { if (Cout == 6) RUA_HEAD_BWD(bf16_t, 6); else if (Cout == 3) RUA_HEAD_BWD(bf16_t, 3); else RUA_HEAD_BWD(bf16_t, 8); }
   else { if (Cout == 6) RUA_HEAD_BWD(float, 6); else if (Cout == 3) RUA_HEAD_BWD(float, 3); else RUA_HEAD_BWD(float, 8); }
 #undef RUA_HEAD_BWD

@@ -168,7 +168,7 @@ class ParamStore:
 # ---------------------------------------------------------------------------------------
 class Ten:
     """A device activation tensor [N][H][W][C] (storage owned by a torch tensor)."""
-    __slots__ = ("N", "H", "W", "C", "t", "ptr", "grad", "gw", "stats", "f32")
+    __slots__ = ("N", "H", "W", "C", "t", "ptr", "grad", "gw", "stats", "f32", "relu_out", "masked_w", "plain_w")
 
     def __init__(self, t: torch.Tensor, N, H, W, C, f32=False):
         self.t, self.N, self.H, self.W, self.C, self.f32 = t, N, H, W, C, f32
@@ -176,6 +176,9 @@ class Ten:
         self.grad: Optional["Ten"] = None
         self.gw = False
         self.stats: Optional[int] = None
+        self.relu_out = False      # output of a fused ReLU: gradient writers that know how apply the (t > 0) mask themselves
+        self.masked_w = 0          # gradient writers that applied it / that did not
+        self.plain_w = 0
 
     @property
     def M(self):
@@ -366,12 +369,17 @@ class Graph:
         R = stats_replicas(blocks) if burst else conv_stats_replicas(blocks)
         return Stat(self.salloc(R * 2 * C), R)
 
-    def gacc(self, x: Ten) -> Tuple[Ten, int]:
-        """Gradient buffer of x and whether the next writer must accumulate."""
+    def gacc(self, x: Ten, masked: bool = False) -> Tuple[Ten, int]:
+        """Gradient buffer of x and whether the next writer must accumulate.  masked: this writer applies x's ReLU mask to
+        what it writes (the mask is idempotent on a masked sum, so it commutes with accumulation)."""
         if x.grad is None:
             x.grad = self.like(x)
         acc = 1 if x.gw else 0
         x.gw = True
+        if masked:
+            x.masked_w += 1
+        else:
+            x.plain_w += 1
         return x.grad, acc
 
     # -- primitive recorders ------------------------------------------------------------------
@@ -823,20 +831,25 @@ class Graph:
         return self.relu_cat_conv_v1(z, 1, skip, nf, want_stats=True)
 
     def conv3x3_relu(self, x: Ten, nf: int, name=None):
-        """ZeroPadding2D(1)+Conv2D(32,(3,3),relu,valid) of the heads (model2.py:153-158) == same-pad 3x3 + ReLU."""
+        """ZeroPadding2D(1)+Conv2D(32,(3,3),relu,valid) of the heads (model2.py:153-158) == same-pad 3x3 + ReLU.
+        The ReLU's backward mask is applied by whoever writes y.grad (the next conv's data gradient or the head's), so no
+        separate masking pass over dy runs; it is launched only if some writer could not."""
         F, tr = self.fwd, self.training
         lay = self.Lconv([x.C], nf, 9, name=name)
         y = self.new(x.N, x.H, x.W, nf)
+        y.relu_out = True
         self.conv(F, [(x, 0, 1, 9)], lay["segs"], nf, self.P(lay["bias"]), y, out_relu=True)
         if tr:
             def back():
                 Bp = self.bwd
                 dy = y.grad
-                Bp.add("rua_relu_mask", dy.ptr, y.ptr, y.t.numel(), self.dt)
+                assert not (y.masked_w and y.plain_w), "mixed masked / unmasked writers of a ReLU output's gradient"
+                if y.plain_w:
+                    Bp.add("rua_relu_mask", dy.ptr, y.ptr, y.t.numel(), self.dt)
                 self.bias_grad(Bp, dy, [lay["bias"]])
                 self.wgrad(Bp, x, dy, lay["segs"][0]["off"], 1, 1, 9)
-                gx, acc = self.gacc(x)
-                self.dgrad(Bp, dy, self.Wd(lay["segs"][0]["dst"]), x.C, 1, 9, gx, acc)
+                gx, acc = self.gacc(x, masked=x.relu_out)
+                self.dgrad(Bp, dy, self.Wd(lay["segs"][0]["dst"]), x.C, 1, 9, gx, acc, mask=(x, None, None) if x.relu_out else None)
             self.back_steps.append(back)
         return y
 
@@ -879,10 +892,12 @@ class Graph:
             gs = wgt / B if kind == L.LOSS_TANIMOTO else wgt / M
             Bp.add("rua_head_dz", kind, h["act"], h["p"].ptr, h["y"].ptr, coef.data_ptr() if coef is not None else None,
                    self.e.class_w_ptr, gs, B, HW, Cc, dz.ptr)
-            gx, acc = self.gacc(h["x"])
+            hx = h["x"]
+            gx, acc = self.gacc(hx, masked=hx.relu_out)
             lay = h["lay"]
-            Bp.add("rua_head_bwd", h["x"].ptr, dz.ptr, self.P(lay["segs"][0]["off"]), gx.ptr, acc, self.G(lay["segs"][0]["off"]),
-                   self.G(lay["bias"]), self.e.scratch.data_ptr(), self.e.scratch.numel() * 4, M, h["x"].C, Cc, self.dt)
+            Bp.add("rua_head_bwd", hx.ptr, dz.ptr, self.P(lay["segs"][0]["off"]), gx.ptr, acc, self.G(lay["segs"][0]["off"]),
+                   self.G(lay["bias"]), self.e.scratch.data_ptr(), self.e.scratch.numel() * 4, M, hx.C, Cc, self.dt,
+                   1 if hx.relu_out else 0)
         self.back_steps.append(back)
 
     # -- whole network ---------------------------------------------------------------------------------

@@ -583,12 +583,13 @@ def test_stem_and_head_kernels():
         dx = torch.empty((M, Ci), dtype=tdt(dt), device=dev())
         dwh = torch.zeros((Co, Ci), device=dev()); dbh = torch.zeros(Co, device=dev())
         scr = torch.empty(1024 * (Co * Ci + Co), device=dev())
-        for scratch in (None, scr):                        # fp32-atomic path and deterministic partial path
+        for scratch, mask_dx in ((None, 0), (scr, 0), (scr, 1)):   # fp32-atomic path, deterministic partial path, fused ReLU mask
             dwh.zero_(); dbh.zero_()
             lib.call("rua_head_bwd", hxd.data_ptr(), dzd.data_ptr(), hwd.data_ptr(), dx.data_ptr(), 0, dwh.data_ptr(), dbh.data_ptr(),
-                     None if scratch is None else scratch.data_ptr(), 0 if scratch is None else scratch.numel() * 4, M, Ci, Co, dt, stream())
+                     None if scratch is None else scratch.data_ptr(), 0 if scratch is None else scratch.numel() * 4, M, Ci, Co, dt,
+                     mask_dx, stream())
             torch.cuda.synchronize()
-            assert rel_err(dx.float().cpu().numpy(), dz @ hw) < tol(dt)
+            assert rel_err(dx.float().cpu().numpy(), (dz @ hw) * ((rnd(dt, hx).numpy() > 0) if mask_dx else 1.0)) < tol(dt)
             assert rel_err(dwh.cpu().numpy(), dz.T @ rnd(dt, hx).numpy()) < 1e-4
             assert rel_err(dbh.cpu().numpy(), dz.sum(0)) < 1e-4
 
