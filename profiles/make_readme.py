@@ -72,7 +72,8 @@ prep, BN grids →10.8; `wgrad_dmap` (weight gradient on the conv_dmap structure
 (head gradient in one resident round of blocks, 16-byte-load Tanimoto sums / metrics, wider partial reduce) →10.3–10.4;
 `conv_dmap` with 64-row tiles where 128×128 tiles leave half the CUs idle →10.2; pooling kernels with compile-time windows (a
 window row's loads issued together), learning rate advanced on the device, branch biases summed in the conv epilogue
-→10.05–10.3 (box to box; the committed run is on a 10.3 box).
+→10.1; the ReLU masks of the head convs applied by the
+gradient writers instead of five masking passes, `wgrad_dmap` at the 64×64×128 level →10.0 (boxes differ by up to ±1.5 %).
 
 ## r01_final: kernel table (per training step; {n} steps in the trace incl. warm-up and the instrumented step)
 
@@ -131,7 +132,7 @@ CPU baseline in the same JSON: {b['cpu_baseline']['value']} patches/s on {b['cpu
 
 ## Other workloads (same build, `gpurun_out` logs of the same session)
 
-On a 10.09 ms box (cfg3 793 patches/s): cfg2 (single-task) 863 patches/s (9.27 ms); cfg5 (128²×7, bs 32) 3 492 patches/s (9.17 ms);
+Before the last two steps, on a 10.09 ms box (cfg3 793 patches/s): cfg2 (single-task) 863 patches/s (9.27 ms); cfg5 (128²×7, bs 32) 3 492 patches/s (9.17 ms);
 cfg4 (d7, 512², bs 4) 230 patches/s (17.4 ms, 247 TFLOP/s of model FLOPs).  Data-parallel step on one GPU with a one-rank RCCL
 group (`bench.py --force-dp`): 10.68 ms (+0.6 ms).
 '''
