@@ -89,7 +89,8 @@ int rua_profile_mid_event_fired(void);          /* 1 if the call made since the 
                                                    gradient) records this hipEvent_t between its main kernel and its second launch; one shot */
 int rua_conv_last_ksplit(void);                  /* K slices of the calling thread's latest rua_conv_fwd (1: single pass, no finisher) */
 int rua_conv_tile_bn(const rua_conv_desc* d);   /* 32 / 64 / 128 and */
-int rua_conv_kernel_id(const rua_conv_desc* d); /* 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA, bf16), 2: conv_dmap (LDS-DMA, pipelined across the stage barrier) */
+int rua_conv_kernel_id(const rua_conv_desc* d); /* 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA, bf16), 2: conv_dmap (LDS-DMA, pipelined across the stage barrier),
+                                                   3: conv_halo (input + halo resident in LDS), 4: conv_pw (narrow 1x1, per-wave streaming) */
 int rua_conv_tile_bm(const rua_conv_desc* d);   /* 128 / 256: which conv_igemm<T,BM,BN> instantiation a descriptor launches */
 
 /* ---- weight gradient (MFMA, split over pixels, fp32 atomic accumulation) ----------------

@@ -1230,6 +1230,233 @@ template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, 
   return RUA_OK;
 }
 
+// =========================================================================================
+// conv_pw: the narrow 1x1 convolutions of the two top levels (Cout <= 32, K <= 96: combine / PSP / upsampling convs and their
+// data gradients) are memory-bound, and on conv_igemm they streamed at ~2.8 TB/s (one 256-row tile per block: load ->
+// LDS -> MFMA -> LDS -> epilogue, serial, 8-12 waves per CU).  Here every WAVE streams its own pixel range in 32-pixel
+// tiles with no LDS and no barrier in the loop: the transposed product D^T[co][px] = W[co][k] * X^T[k][px] makes BOTH MFMA
+// operands plain 16-byte loads (a-operand: weight rows, held in registers for the whole kernel; b-operand: lane = pixel,
+// k-slice = 8 consecutive channels), the next tile's loads (input, aux, old output) are in flight while the current tile
+// computes, and one 32-lane exchange per register pair turns the accumulator layout (lane = pixel, 4-channel groups
+// interleaved between the wave halves) into 8-channel pieces for the shared epilogue semantics (bias, accumulate, residual /
+// mask, ReLU, statistics) and 16-byte stores.  Statistics stay in registers over all tiles of a wave and leave through
+// shuffles -> LDS -> one fp64 atomic per channel and block, like everywhere else.
+struct PwStep { const unsigned char* x; const unsigned char* w; unsigned xbytes, wbytes; int C, kofs, up, Hs, Ws, dense; };
+template <int KS> struct PwK { ConvK c; PwStep st[KS]; int px_per_wave, wsh, hsh; };
+
+template <int KS, bool DENSE>
+__global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_pw(const PwK<KS> q) {      // >= 3 waves per SIMD for K <= 64
+  const ConvK& p = q.c;
+  __shared__ float tab[3 * 32];                       // bias sum, mask scale, mask shift per output channel
+  __shared__ float sred[4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int pl = lane & 31, lh = lane >> 5;
+  if (tid < 32) {
+    float b = 0.f, ms = 1.f, mt = 0.f;
+    if (tid < p.Cout) {
+      if (p.bias) { b = p.bias[tid]; for (int r = 0; r < 3; ++r) if (p.bias_more[r]) b += p.bias_more[r][tid]; }
+      if (p.aux_mode == 2) { if (p.mscale) ms = p.mscale[tid]; if (p.mshift) mt = p.mshift[tid]; }
+    }
+    tab[tid] = b; tab[32 + tid] = ms; tab[64 + tid] = mt;
+  }
+  __syncthreads();
+  const int M = (int)p.M;
+  const int gw = blockIdx.x * 4 + wid;
+  const int k_begin = gw * q.px_per_wave;
+  int k_end = k_begin + q.px_per_wave; if (k_end > M) k_end = M;
+
+  // weight fragments: a-operand row = output channel pl, k-slice 8*lh of step ks
+  bf16x8 wf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const PwStep& s = q.st[ks];
+    const int kk = s.kofs + 8 * lh;
+    const bool ok = pl < p.Cout && kk < s.C;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(s.w, s.wbytes);
+    wf[ks] = __builtin_bit_cast(bf16x8, bufload16(rw, ok ? (unsigned)((pl * s.C + kk) * 2) : RUA_OOB));
+  }
+  const __amdgpu_buffer_rsrc_t raux = make_rsrc(p.aux ? p.aux : p.y, (unsigned)((size_t)M * p.Cout * 2));
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, (unsigned)((size_t)M * p.Cout * 2));
+  const bool cok0 = 8 * lh < p.Cout, cok1 = 16 + 8 * lh < p.Cout;       // this lane's two 8-channel pieces exist
+
+  struct Tile { uint4 x[KS], a[2], o[2]; };           // the loads of one 32-pixel tile: input k-steps, aux pieces, old-output pieces
+  auto load_tile = [&](Tile& T, int t0) {
+    const int m = t0 + pl;
+    const bool in = m < k_end;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const PwStep& s = q.st[ks];
+      const int kk = s.kofs + 8 * lh;
+      int px = m;
+      if constexpr (!DENSE) {                           // some segment is upsampled on read (power-of-two maps, checked by the launcher)
+        const int w = m & (p.W - 1), h = (m >> q.wsh) & (p.H - 1), n = m >> (q.wsh + q.hsh);
+        const int gen = (n * s.Hs + (h >> s.up)) * s.Ws + (w >> s.up);
+        px = s.dense ? m : gen;
+      }
+      const __amdgpu_buffer_rsrc_t rx = make_rsrc(s.x, s.xbytes);
+      T.x[ks] = bufload16(rx, (in && kk < s.C) ? (unsigned)((px * s.C + kk) * 2) : RUA_OOB);
+    }
+    const unsigned o0 = (unsigned)((m * p.Cout + 8 * lh) * 2), o1 = o0 + 32;
+    T.a[0] = bufload16(raux, (in && cok0 && p.aux_mode != 0) ? o0 : RUA_OOB);
+    T.a[1] = bufload16(raux, (in && cok1 && p.aux_mode != 0) ? o1 : RUA_OOB);
+    T.o[0] = bufload16(ry, (in && cok0 && p.accumulate) ? o0 : RUA_OOB);
+    T.o[1] = bufload16(ry, (in && cok1 && p.accumulate) ? o1 : RUA_OOB);
+  };
+  float s1[2][8], s2[2][8];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[g][j] = 0.f; s2[g][j] = 0.f; }
+
+  auto process = [&](const Tile& T, int t0) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], __builtin_bit_cast(bf16x8, T.x[ks]), acc, 0, 0, 0);
+    // acc[r]: channel (r & 3) + 8 * (r >> 2) + 4 * lh of pixel pl.  v_permlane32_swap(A, B) exchanges the upper half of A with
+    // the lower half of B: with A = group 2g and B = group 2g+1 every lane ends up with channels 16g + 8*lh .. +7 of its pixel
+    // (lower half: own group 2g + the upper half's group 2g; upper half: the lower half's group 2g+1 + own group 2g+1).
+    float v[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // (inline asm: the builtin form of this exchange was miscompiled here - every pair collapsed onto acc[0].  The asm
+        // reads MFMA results directly, a hazard hipcc does not track for inline asm: the s_nops before the first exchange
+        // cover the 19 wait states an 8/16-pass MFMA needs before a VALU read of its destination.)
+        float a = acc[(2 * g) * 4 + j], b = acc[(2 * g + 1) * 4 + j];
+        if (g == 0 && j == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        else asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v[g][j] = a;
+        v[g][4 + j] = b;
+      }
+    const int m = t0 + pl;
+    if (m < k_end) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int co = 16 * g + 8 * lh;
+        if (co < p.Cout) {
+          float a8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[g][j] += tab[co + j];
+          if (p.accumulate) {
+            float o8[8];
+            ET<bf16_t>::unpack(T.o[g], o8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g][j] += o8[j];
+          }
+          if (p.aux_mode != 0) ET<bf16_t>::unpack(T.a[g], a8);
+          if (p.aux_mode == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g][j] += a8[j];
+          } else if (p.aux_mode == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g][j] = (fmaf(tab[32 + co + j], a8[j], tab[64 + co + j]) > 0.f) ? v[g][j] : 0.f;
+          }
+          if (p.out_relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g][j] = fmaxf(v[g][j], 0.f);
+          }
+          if (p.stats_mode == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], v[g][j], s2[g][j]); }
+          } else if (p.stats_mode == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], a8[j], s2[g][j]); }
+          }
+          stg16(p.y + ((size_t)m * p.Cout + co) * 2, ET<bf16_t>::pack(v[g]));
+        }
+      }
+    }
+  };
+  // ping-pong: the next tile's loads are in flight while this one computes (a tile past the range loads zeros and stores
+  // nothing).  Three tiles in flight were measured and are no faster (18.2 vs 17.2 us at 256x256x32->32): the loop is bound by
+  // its own VALU work (address arithmetic, the half-wave exchange, unpack / pack), not by bytes in flight.
+  Tile T0, T1;
+  load_tile(T0, k_begin);
+  for (int t0 = k_begin; t0 < k_end; t0 += 64) {
+    load_tile(T1, t0 + 32); process(T0, t0);
+    load_tile(T0, t0 + 64); process(T1, t0 + 32);
+  }
+  if (p.stats_mode != 0) {
+    // fold the 32 pixel lanes of each half, then the four waves through LDS: sred[wave][channel 0..31][2]
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        for (int o = 1; o < 32; o <<= 1) { s1[g][j] += __shfl_xor(s1[g][j], o, 64); s2[g][j] += __shfl_xor(s2[g][j], o, 64); }
+    if (pl == 0) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sred[wid * 64 + (16 * g + 8 * lh + j) * 2] = s1[g][j]; sred[wid * 64 + (16 * g + 8 * lh + j) * 2 + 1] = s2[g][j]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int c = tid >> 1, k = tid & 1;
+      const float t = sred[tid] + sred[64 + tid] + sred[128 + tid] + sred[192 + tid];
+      if (c < p.Cout) unsafeAtomicAdd(&p.stats[(size_t)(blockIdx.x & (p.stats_R - 1)) * 2 * p.Cout + k * p.Cout + c], (double)t);
+    }
+  }
+}
+
+static int pw_steps(const rua_conv_desc* d) {             // 16-channel k-steps of all segments; 0: not a conv_pw shape
+  int n = 0;
+  for (int s = 0; s < d->nseg; ++s) {
+    const rua_conv_seg& g = d->seg[s];
+    if (g.taps != 1 || g.C % 8 != 0 || g.C > 64) return 0;
+    n += (g.C + 15) / 16;
+  }
+  return n;
+}
+static bool pick_pw(const rua_conv_desc* d) {
+  static const int on = getenv("RUA_CONV_PW") ? atoi(getenv("RUA_CONV_PW")) : 1;
+  static const long long minm = getenv("RUA_CONV_PW_MINM") ? atoll(getenv("RUA_CONV_PW_MINM")) : 65536;
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  if (!on || d->dtype != RUA_BF16 || d->Cout > 32 || d->stride != 1 || d->out_stride != 1 || d->OH != d->H || d->OW != d->W) return false;
+  const long long M = (long long)d->N * d->H * d->W;
+  if (M < minm || M * d->Cout * 2 >= (1ll << 31)) return false;
+  const int ks = pw_steps(d);
+  if (ks < 1 || ks > 6) return false;
+  for (int s = 0; s < d->nseg; ++s) {
+    const rua_conv_seg& g = d->seg[s];
+    const bool dense = g.up_shift == 0 && g.Hs == d->H && g.Ws == d->W;
+    if (!dense && !(pow2(d->H) && pow2(d->W))) return false;
+  }
+  return true;
+}
+template <int KS> static int launch_conv_pw(const ConvK& k, const rua_conv_desc* d, hipStream_t st) {
+  PwK<KS> q;
+  q.c = k;
+  int n = 0;
+  for (int s = 0; s < d->nseg; ++s) {
+    const SegK& g = k.seg[s];
+    for (int k0 = 0; k0 < g.C; k0 += 16) {
+      PwStep& t = q.st[n++];
+      t.x = g.x; t.w = g.w; t.xbytes = g.xbytes; t.wbytes = g.wbytes; t.C = g.C; t.kofs = k0; t.up = g.up; t.Hs = g.Hs; t.Ws = g.Ws;
+      t.dense = (g.up == 0 && g.Hs == k.H && g.Ws == k.W) ? 1 : 0;
+    }
+  }
+  for (; n < KS; ++n) { PwStep& t = q.st[n]; t = q.st[0]; t.C = 0; t.kofs = 0; }       // padding steps: every load out of range
+  int wsh = 0, hsh = 0; while ((1 << wsh) < k.W) ++wsh; while ((1 << hsh) < k.H) ++hsh;
+  q.wsh = wsh; q.hsh = hsh;
+  static const int target = env_int("RUA_CONV_PW_BLOCKS") > 0 ? env_int("RUA_CONV_PW_BLOCKS") : 2048;
+  long long waves = (long long)target * 4;
+  if (waves > k.M / 128) waves = k.M / 128;                // >= 4 tiles per wave
+  if (waves < 4) waves = 4;
+  long long ppw = (k.M + waves - 1) / waves;
+  ppw = (ppw + 31) / 32 * 32;
+  q.px_per_wave = (int)ppw;
+  const unsigned grid = (unsigned)((k.M + ppw * 4 - 1) / (ppw * 4));
+  bool all_dense = true;
+  for (int i = 0; i < KS; ++i) all_dense = all_dense && (q.st[i].dense || q.st[i].C == 0);
+  if (all_dense) hipLaunchKernelGGL((conv_pw<KS, true>), dim3(grid), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((conv_pw<KS, false>), dim3(grid), dim3(256), 0, st, q);
+  RUA_LAUNCH_CHECK("conv_pw");
+  return RUA_OK;
+}
+
 // ---- conv_halo launcher -------------------------------------------------------------------------------------------------
 static bool pick_halo(const rua_conv_desc* d) {
   static const int mode = getenv("RUA_CONV_HALO") ? atoi(getenv("RUA_CONV_HALO")) : 1;      // 0: off (experiments)
@@ -1385,6 +1612,12 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     k.nbn = 1; k.nbm = 1; k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr; k.cnt = nullptr;
     g_last_ksplit = 1;
     return launch_conv_halo(k, d->seg[0].dil, st);
+  }
+  if (pick_pw(d)) {
+    k.nbn = 1; k.nbm = 1; k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr; k.cnt = nullptr;
+    g_last_ksplit = 1;
+    const int ks = pw_steps(d);
+    return ks <= 2 ? launch_conv_pw<2>(k, d, st) : ks <= 4 ? launch_conv_pw<4>(k, d, st) : launch_conv_pw<6>(k, d, st);
   }
   if (pick_dmap(d)) {
     // 128 x 128 tiles; split K until the grid covers the chip once (every level of the reference network then runs
@@ -2501,6 +2734,7 @@ extern "C" int rua_conv_tile_bn(const rua_conv_desc* d) {
 extern "C" int rua_conv_kernel_id(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
   if (pick_halo(d)) return 3;
+  if (pick_pw(d)) return 4;
   if (pick_dmap(d)) return 2;
   return pick_dma(d, pick_bn(d, (long long)d->N * d->H * d->W)) ? 1 : 0;
 }

@@ -70,6 +70,11 @@ CONV_CASES = [
     (1, 16, 16, [(32, 0, 1, 9), (32, 0, 3, 9), (32, 0, 15, 9)], 32, 1),
     (3, 8, 8, [(40, 0, 1, 9)], 8, 1),
     (8, 32, 32, [(128, 0, 3, 9)], 256, 1),     # bf16: conv_dmap with 64-row tiles (128 tiles of 128 x 128 would leave half the CUs idle)
+    # bf16: conv_pw (narrow 1x1 convs, >= 65536 pixels: per-wave streaming, no LDS in the loop)
+    (1, 256, 256, [(16, 1, 1, 1), (32, 0, 1, 1)], 32, 1),
+    (1, 256, 256, [(8, 0, 1, 1), (8, 1, 1, 1), (8, 2, 1, 1), (8, 3, 1, 1), (32, 0, 1, 1)], 32, 1),
+    (2, 256, 128, [(32, 0, 1, 1)], 8, 1),
+    (1, 320, 224, [(64, 0, 1, 1)], 24, 1),     # not a power of two: dense segments only
 ]
 
 
@@ -108,6 +113,8 @@ def test_conv_fwd(case, dt):
     d.stats, d.stats_mode, d.stats_replicas = stats.data_ptr(), 1, 2
     if dt == L.RUA_BF16 and case[:3] == (8, 32, 32):
         assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 2 and lib.raw("rua_conv_tile_bm")(C.byref(d)) == 64
+    if dt == L.RUA_BF16 and N * H * W >= 65536 and all(t == 1 for _, _, _, t in segs):
+        assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 4
     lib.call("rua_conv_fwd", C.byref(d), stream())
     torch.cuda.synchronize()
     exp = (exp + torch.from_numpy(bias).double() + rnd(dt, res).double()).numpy()
