@@ -73,7 +73,9 @@ prep, BN grids →10.8; `wgrad_dmap` (weight gradient on the conv_dmap structure
 `conv_dmap` with 64-row tiles where 128×128 tiles leave half the CUs idle →10.2; pooling kernels with compile-time windows (a
 window row's loads issued together), learning rate advanced on the device, branch biases summed in the conv epilogue
 →10.1; the ReLU masks of the head convs applied by the
-gradient writers instead of five masking passes, `wgrad_dmap` at the 64×64×128 level →10.0 (boxes differ by up to ±1.5 %).
+gradient writers instead of five masking passes, `wgrad_dmap` at the 64×64×128 level →10.0; `conv_pw` (per-wave streaming
+kernel for the narrow 1×1 convolutions of the top levels) →9.95 on the same box (A/B 10.04 → 9.96); boxes differ by up to
+±1.5 % (the committed run is on a 10.1 box).
 
 ## r01_final: kernel table (per training step; {n} steps in the trace incl. warm-up and the instrumented step)
 
