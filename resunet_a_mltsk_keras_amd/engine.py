@@ -1020,6 +1020,7 @@ class Engine:
         self.lr_dev = torch.zeros(16, dtype=torch.float32, device=self.dev)               # step-dependent optimizer scalars
         self.lr_state = torch.zeros(2, dtype=torch.float64, device=self.dev)              # [steps taken, base learning rate]
         self._t_dev, self._lr_base_dev = -1, None                                         # what lr_state holds (host shadow)
+        self._dp_fence = torch.zeros(16, dtype=torch.float32, device=self.dev)            # see _graph_step_dp
         self.use_graph = True
         self._captured: Dict[int, object] = {}
         self._captured_eval: Dict[int, object] = {}        # batch -> graph of the inference forward (False: capture failed)
@@ -1277,6 +1278,13 @@ class Engine:
         red.begin()
         for cap, buckets in pieces:
             cap.replay()
+            # One eager kernel between a graph launch and the event choreography of the collectives.  Measured on this
+            # stack (ROCm 7.0 / torch 2.10): a graph launch followed DIRECTLY by cross-stream event record / wait operations
+            # (what an all-reduce is at the stream level; with one rank it is nothing else) corrupted the step in 40-60 % of
+            # 13-step runs (NaN parameters), with or without bucket overlap and even behind a device synchronise; with an
+            # ordinary kernel launch after every replay: 0 of 20.  The eager data-parallel path and the single-GPU graph
+            # (no collectives between graphs) were never affected.
+            self._dp_fence.zero_()
             for b in buckets:
                 red.ready(b)
         self.dist.reduce_gradients(self)

@@ -226,6 +226,14 @@ def test_data_parallel_graph_pieces_match_single_process_step():
         pa, pb = a.P.cpu().numpy(), b.P.cpu().numpy()          # same bar as test_graph_replay_equals_eager_launches:
         d = np.abs(pa - pb)                                      # atomic-order noise only, no systematic difference
         assert d.mean() < 1e-4 * np.abs(pa).mean() and d.max() < 2e-3, (float(d.mean()), float(d.max()))
+        # back-to-back replays with nothing fetched in between (what bench.py and a fed training loop do): graph launches
+        # directly followed by the collectives' stream events corrupted steps on this stack until an eager kernel was put
+        # between them (engine._graph_step_dp); the parameters must stay finite and the loss must keep falling
+        for _ in range(24):
+            b.train_step(None, None, fetch=False)
+        torch.cuda.synchronize()
+        last = b._results(b.graph(4, True))[0]
+        assert bool(torch.isfinite(b.P).all()) and bool(torch.isfinite(b.S).all()) and np.isfinite(last) and last < lb[-1]
     finally:
         if created:
             dist.destroy_process_group()
