@@ -217,6 +217,7 @@ def test_data_parallel_graph_pieces_match_single_process_step():
     try:
         b = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=True), dtype="f32", seed=3, split_k=False)
         b.compile(spec())
+        b.dp_graph = True                                         # opt-in path (default: eager launches)
         dp = DataParallel(b, bucket_mb=4.0)                       # small buckets => several pieces
         assert len(dp.buckets) > 3
         lb = [b.train_step(x, y)[0] for _ in range(4)]
