@@ -136,7 +136,7 @@ CPU baseline in the same JSON: {b['cpu_baseline']['value']} patches/s on {b['cpu
 
 Before the last two steps, on a 10.09 ms box (cfg3 793 patches/s): cfg2 (single-task) 863 patches/s (9.27 ms); cfg5 (128²×7, bs 32) 3 492 patches/s (9.17 ms);
 cfg4 (d7, 512², bs 4) 230 patches/s (17.4 ms, 247 TFLOP/s of model FLOPs).  Data-parallel step on one GPU with a one-rank RCCL
-group (`bench.py --force-dp`, end of round 1): 10.4 ms vs 9.9 ms for the single whole-step graph.
+group (`bench.py --force-dp`, end of round 1): 10.08 ms vs 9.95 ms for the single whole-step graph on the same box.
 '''
 open('profiles/README.md', 'w').write(txt)
 print("written", len(lines), "rows; dominant rocprof avg", dom_rp)

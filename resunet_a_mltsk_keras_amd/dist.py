@@ -4,12 +4,14 @@ Semantics follow tf.distribute.MirroredStrategy as the reference uses it (train_
 every replica runs the step on its local shard with LOCAL BatchNorm batch statistics and LOCAL
 Tanimoto class volumes, gradients are summed and divided by the number of replicas, BN moving
 statistics are mean-aggregated.  The only data-path collective is the gradient all-reduce: the flat
-fp32 gradient buffer is cut into contiguous buckets; a bucket is reduced on a side HIP stream as soon
-as the backward plan has issued the last launch that writes into it, so the all-reduce of the deep
-(parameter-heavy) stages overlaps the backward of the shallow (FLOP-heavy) ones.
+fp32 gradient buffer is cut into contiguous buckets; a bucket's asynchronous all-reduce is issued (it runs
+on the process group's own stream) as soon as the backward plan has issued the last launch that writes
+into it, so the all-reduce of the deep (parameter-heavy) stages overlaps the backward of the shallow
+(FLOP-heavy) ones.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -92,7 +94,12 @@ class DataParallel:
         self.host_staged = backend == "gloo" and eng.P.is_cuda
         entries = [(e["off"], e["size"]) for e in eng.params.entries]
         self.buckets = make_buckets(entries, eng.params.n, int(bucket_mb * (1 << 20) / 4))
-        self.reducer = GradReducer(eng.G[:eng.params.n], self.buckets, group, use_side_stream=overlap, host_staged=self.host_staged)
+        # No side stream of our own: an async all-reduce already runs on the process group's internal stream (which waits for
+        # the launch stream at the call and is joined again by work.wait()), so issuing it from the launch stream at the
+        # bucket's hook overlaps it with the rest of the backward.  A second stream of ours in between cost 0.3 ms per step on
+        # one GPU (10.42 vs 10.14 ms: event record + wait + stream switch per bucket) for nothing.
+        side = os.environ.get("RUA_DP_SIDE_STREAM", "0") == "1"
+        self.reducer = GradReducer(eng.G[:eng.params.n], self.buckets, group, use_side_stream=overlap and side, host_staged=self.host_staged)
         self._bcast(eng.P); self._bcast(eng.S)
         eng.weights_dirty = True
 
