@@ -20,14 +20,22 @@ import torch.distributed as dist
 
 def make_buckets(entries: List[Tuple[int, int]], total: int, bucket_elems: int) -> List[Tuple[int, int]]:
     """Contiguous [begin, end) slices of the flat buffer, walking parameters from the END of the buffer
-    (the order backward produces them), each at least bucket_elems long except the last."""
+    (the order backward produces them), each at least bucket_elems long except the last two (the front of the buffer)."""
     bounds = sorted(set([0, total] + [o for o, _ in entries]))
     buckets, end = [], total
-    cur = total
     for b in reversed(bounds[:-1]):
         if end - b >= bucket_elems or b == 0:
             buckets.append((b, end))
             end = b
+    # The front bucket is complete only when backward ends, so its all-reduce is the one nothing can hide: keep it small
+    # (the first parameters of the buffer = the top encoder levels, ~1/16 of a bucket) and give the rest its own bucket,
+    # which completes a couple of levels earlier.
+    tail = max(bucket_elems // 16, 1)
+    b0, e0 = buckets[-1]
+    if e0 - b0 > 2 * tail:
+        cut = next((b for b in bounds if b >= tail and b < e0), None)
+        if cut is not None and cut > b0:
+            buckets[-1:] = [(cut, e0), (b0, cut)]
     return buckets
 
 

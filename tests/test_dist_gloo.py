@@ -24,7 +24,8 @@ def test_buckets_cover_flat_buffer_back_to_front():
     b = make_buckets(entries, ps.n, int(25 * (1 << 20) / 4))
     assert b[0][1] == ps.n and b[-1][0] == 0
     assert all(b[i][0] == b[i + 1][1] for i in range(len(b) - 1))           # contiguous, descending
-    assert all(e - s >= 25 * (1 << 20) // 4 for s, e in b[:-1])
+    assert all(e - s >= 25 * (1 << 20) // 4 for s, e in b[:-2])              # all but the split front of the buffer
+    assert b[-1][1] - b[-1][0] <= 2 * (25 * (1 << 20) // 4) // 16 + max(sz for _, sz in entries if _ < b[-1][1])   # small last-completing bucket
     starts = {o for o, _ in entries}
     assert all(s in starts or s == 0 for s, _ in b)                         # cut only at parameter boundaries
     assert 5 <= len(b) <= 8                                                 # 171 MB of fp32 gradients / 25 MB
