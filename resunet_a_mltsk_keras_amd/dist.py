@@ -123,12 +123,24 @@ class DataParallel:
                 return i
         raise ValueError(off)
 
+    def start_state_reduce(self, eng):
+        """BN moving statistics are final once the forward has been issued: their (small) all-reduce starts here and hides
+        behind the backward instead of standing between the last gradient bucket and the optimizer."""
+        self._s_work = None
+        if self.overlap and not self.host_staged:
+            self._s_work = dist.all_reduce(eng.S, group=self.group, async_op=True)
+
     def reduce_gradients(self, eng):
         """Called after the backward plan (buckets already fired by the plan's markers when overlap is on)."""
         self.reducer.finish()
         S = eng.S
+        work = getattr(self, "_s_work", None)
+        self._s_work = None
         if self.host_staged:
             h = S.cpu(); dist.all_reduce(h, group=self.group); S.copy_(h / self.world)
+        elif work is not None:
+            work.wait()
+            S.div_(self.world)
         else:
             dist.all_reduce(S, group=self.group)
             S.div_(self.world)

@@ -1142,6 +1142,7 @@ class Engine:
         g.loss_plan.run(s)
         hooks = None
         if self.dist is not None:
+            self.dist.start_state_reduce(self)
             self.dist.reducer.begin()
             if self.dist.overlap:
                 hooks = self._bucket_hooks(g)
