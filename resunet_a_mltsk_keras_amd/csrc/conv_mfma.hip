@@ -2193,30 +2193,42 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
 // dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 16 elements x 16 slices:
 // every thread has all its loads in flight at once, slices are folded through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void wgrad_taps_reduce(const float* __restrict__ scratch, float* __restrict__ dw, int CC, int gx) {
-  __shared__ float sh[256];
-  const int total = 9 * CC * CC;
+  // 16 float4 columns x 16 partial slices per block: a 16-lane group reads 256 contiguous bytes of one partial (the scalar
+  // version read 64-byte runs: 6.7 us per launch, 37 launches per step), four loads in flight, slices folded in a fixed order
+  __shared__ float4 sh[256];
+  const int total4 = 9 * CC * CC / 4;
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int e = blockIdx.x * 16 + el;
-  float s = 0.f;
-  if (e < total) {
+  const int e4 = blockIdx.x * 16 + el;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e4 < total4) {
+    const int e = e4 * 4;
     const int tap = e / (CC * CC), r = e - tap * CC * CC, co = r / CC, ci = r - co * CC;
     const float* src = scratch + ((size_t)(co >> 5) * gx * 9 + tap) * 32 * CC + (co & 31) * CC + ci;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    const size_t pstride = (size_t)9 * 32 * CC;
+    float4 t0 = s, t1 = s, t2 = s, t3 = s;
+    auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
     int b = sl;
     for (; b + 48 < gx; b += 64) {
-      t0 += src[(size_t)b * 9 * 32 * CC]; t1 += src[(size_t)(b + 16) * 9 * 32 * CC];
-      t2 += src[(size_t)(b + 32) * 9 * 32 * CC]; t3 += src[(size_t)(b + 48) * 9 * 32 * CC];
+      const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)b * pstride);
+      const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(b + 16) * pstride);
+      const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(b + 32) * pstride);
+      const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(b + 48) * pstride);
+      add4(t0, v0); add4(t1, v1); add4(t2, v2); add4(t3, v3);
     }
-    for (; b < gx; b += 16) t0 += src[(size_t)b * 9 * 32 * CC];
-    s = (t0 + t1) + (t2 + t3);
+    for (; b < gx; b += 16) add4(t0, *reinterpret_cast<const float4*>(src + (size_t)b * pstride));
+    s.x = (t0.x + t1.x) + (t2.x + t3.x); s.y = (t0.y + t1.y) + (t2.y + t3.y);
+    s.z = (t0.z + t1.z) + (t2.z + t3.z); s.w = (t0.w + t1.w) + (t2.w + t3.w);
   }
   sh[threadIdx.x] = s;
   __syncthreads();
-  if (sl == 0 && e < total) {
-    float t = 0.f;
+  if (sl == 0 && e4 < total4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += sh[k * 16 + el];
-    dw[e] += t;
+    for (int k = 0; k < 16; ++k) { const float4 v = sh[k * 16 + el]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    float4* d = reinterpret_cast<float4*>(dw + (size_t)e4 * 4);
+    float4 o = *d;
+    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+    *d = o;
   }
 }
 
@@ -2260,7 +2272,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   }
   RUA_LAUNCH_CHECK("wgrad_taps_kernel");
   record_mid_event(st);
-  hipLaunchKernelGGL(wgrad_taps_reduce, dim3(rua_div_up(9 * CC * CC, 16)), dim3(256), 0, st, (const float*)k.scratch, d->dw, CC, gx);
+  hipLaunchKernelGGL(wgrad_taps_reduce, dim3(rua_div_up(9 * CC * CC / 4, 16)), dim3(256), 0, st, (const float*)k.scratch, d->dw, CC, gx);
   RUA_LAUNCH_CHECK("wgrad_taps_reduce");
   return RUA_OK;
 }
