@@ -119,12 +119,24 @@ def profile_kernels(eng, g, dtype):
     eng._zero_arena(g, s)
     eng._prep_weights(s)
     empty = []
-    for plan in (g.fwd, g.loss_plan, g.bwd):
+    scopes = {}                                             # (pass, scope) -> [first event, last event, conv+wgrad FLOPs]
+    for pname, plan in (("fwd", g.fwd), ("loss", g.loss_plan), ("bwd", g.bwd)):
+        cur = None
         for ci, (fn, name, args, _lane) in enumerate(plan.calls):
             if ci % 16 == 0:                                # empty event pairs: the marker-to-marker cost to subtract
                 empty.append((mark(), mark()))
+            sc = plan.scopes[ci]
+            if sc != cur:                                   # a composite's launches are contiguous in the plan: one marker
+                ev = mark()                                 # closes the block before it and opens this one
+                if cur is not None:
+                    scopes[(pname, cur)][1] = ev
+                if sc is not None:
+                    scopes[(pname, sc)] = [ev, None, 0.0]
+                cur = sc
             if fn is None:
                 continue                                    # fork / join markers: this pass runs everything on one stream
+            if sc is not None and name in ("rua_conv_fwd", "rua_conv_wgrad"):
+                scopes[(pname, sc)][2] += conv_flops(args[0]._obj) if name == "rua_conv_fwd" else wgrad_flops(args[0]._obj)
             if name in ("rua_conv_fwd", "rua_conv_wgrad"):
                 em = mark(False)                            # recorded by the library between the main kernel and the
                 mid(em)                                     # second launch of a two-launch call
@@ -153,6 +165,8 @@ def profile_kernels(eng, g, dtype):
                 rc = fn(*args, sp)
             if rc != 0:
                 lib.check(rc, name)
+        if cur is not None:
+            scopes[(pname, cur)][1] = mark()
     eng.optimizer_step(1.0 / eng.world)
     torch.cuda.synchronize()
     med = lambda pairs: sorted(us(a, b) for a, b in pairs)[len(pairs) // 2]
@@ -163,6 +177,8 @@ def profile_kernels(eng, g, dtype):
         t = out.setdefault(kn, [0, 0.0, 0.0])
         t[0] += 1; t[1] += max(us(e0, e1) * 1e-6 - ov, 1e-7); t[2] += fl
     out["_event_overhead_us"] = ov * 1e6
+    # whole composites (every launch of a ResBlock: BN passes, convolutions, weight / data gradients), forward and backward
+    out["_blocks"] = {f"{pn}:{sc}": (max(us(e0, e1) * 1e-6 - ov, 1e-7), fl) for (pn, sc), (e0, e1, fl) in scopes.items() if e1 is not None}
     log(f"event bracket calibration: one fill {t1:.2f} us, two fills {t2:.2f} us, empty pair {empty_us:.2f} us -> overhead {ov * 1e6:.2f} us")
     if os.environ.get("RUA_BENCH_DETAIL"):
         groups = {}
@@ -230,11 +246,12 @@ def cpu_baseline(sample_steps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each; the median block is reported (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=25.0)
@@ -289,27 +306,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.train_step(None, None, fetch=False)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # SURVEY 8d protocol: 10 warm-up steps, then 3 timed blocks of >= 50 steps, each bracketed by barrier + device
+    # synchronise on both sides and taken as the MAX over ranks; the MEDIAN block is the reported one.
+    block_dt = []
+    for _ in range(max(args.blocks, 1)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.train_step(None, None, fetch=False)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        block_dt.append(dt)
+    dt = sorted(block_dt)[len(block_dt) // 2]
     res = eng._results(eng.graph(B, True))
     value = B * world * args.steps / dt
     if rank == 0:
-        log(f"{args.steps} steps in {dt:.3f} s -> {value:.1f} patches/s")
+        log(f"{len(block_dt)} blocks of {args.steps} steps: {[round(1e3 * d / args.steps, 3) for d in block_dt]} ms/step; median block "
+            f"{dt:.3f} s -> {value:.1f} patches/s")
 
     out = {
         "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] if args.workload in ("cfg3", "cfg2")
                   else f"training patches/sec ({patch}x{patch}, {ch}-ch, bs={B}/GPU)",
         "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic", "timed_blocks": len(block_dt),
+        "block_ms_per_step": [round(1e3 * d / args.steps, 3) for d in block_dt],
         "config": {"workload": f"{args.workload}: ResUnet-a d{depth} {'multitask (seg+bound+dist+color) Tanimoto-dual' if mt else 'single-task seg Tanimoto-dual'}, "
                                f"{patch}x{patch}x{ch}, {ncls} classes, Adam, full train step (fwd+loss+bwd+allreduce+update)",
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss_last_step": round(res[0], 5)},
@@ -320,6 +345,7 @@ def main():
     if rank == 0:
         peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
         ev_ov = prof.pop("_event_overhead_us")
+        blocks = prof.pop("_blocks")
         dom = max((kv for kv in prof.items() if kv[1][2] > 0), key=lambda kv: kv[1][1])   # second launches (no FLOPs) are rows, not candidates
         kn, (n, sec, fl) = dom
         out["roofline"] = {
@@ -333,6 +359,22 @@ def main():
                                  for k, v in sorted(prof.items())},
             "whole_step_frac_of_peak": round(value / world * gflop_patch / 1e3 / peak, 4),
         }
+        # north-star sub-metric: the d6 residual atrous block = ResBlock(32,[1,3,15,31]) at full resolution (model2.py:102),
+        # its 8 convolutions + BatchNorm passes, forward; and the same for every ResBlock of the network (SURVEY 7 hard-part 2:
+        # per-level fractions), forward and backward.  FLOPs: conv (fwd), data + weight gradient (bwd), nothing else counted.
+        lv = []
+        for key in sorted(k for k in blocks if k.startswith("fwd:")):
+            sec, fl = blocks[key]
+            row = {"block": key[4:], "fwd_gflop": round(fl / 1e9, 2), "fwd_us": round(1e6 * sec, 1), "fwd_frac": round(fl / sec / 1e12 / peak, 4)}
+            if "bwd:" + key[4:] in blocks:
+                bsec, bfl = blocks["bwd:" + key[4:]]
+                row.update({"bwd_gflop": round(bfl / 1e9, 2), "bwd_us": round(1e6 * bsec, 1), "bwd_frac": round(bfl / bsec / 1e12 / peak, 4)})
+            lv.append(row)
+        top = next((r for r in lv if r["block"].startswith("enc1:")), None)
+        if top is not None:
+            out["roofline"]["d6_block"] = {"block": top["block"], "gflop": top["fwd_gflop"], "us": top["fwd_us"], "frac": top["fwd_frac"],
+                                           "target_frac": 0.40, "pass": "forward, batch %d, every launch of the block (BN + 8 convs)" % B}
+        out["roofline"]["resblocks"] = lv
         if not args.no_cpu_baseline and world == 1:            # the CPU oracle is timed at N=1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -8,7 +8,7 @@
  * type of activations (RUA_F32 or RUA_BF16); accumulation is always fp32 (statistics fp64).
  * Every function returns 0 on success or a negative code (text via rua_last_error()), takes
  * the HIP stream as its last argument (`void*` = hipStream_t), allocates nothing and keeps no
- * global state.  Nothing here depends on PyTorch.
+ * global state besides the opt-in tuning switches (rua_set_tuning).  Nothing here depends on PyTorch.
  */
 #ifndef RUA_HIP_H
 #define RUA_HIP_H
@@ -216,6 +216,10 @@ int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t HW, int C, 
  * per_sample[B] (optional): the (B,) vector the reference's loss function returns (multitasking_utils.py:84) */
 int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,
                           float* per_sample, void* stream);
+/* Tanimoto_loss(label, pred) itself (multitasking_utils.py:38-68), shape (B,): take the sums with p := label, y := pred
+ * (rua_tanimoto_sums(label, pred, ...)), then per_sample[n] = (sum_c w_c*Spl + 1e-5) / (sum_c w_c*(Ssq - Spl) + 1e-5) with
+ * w_c = 1 / (mean_n volume of the FIRST argument)^2, inf -> largest finite weight (:46-53); mean_out[0] = mean_n. */
+int rua_tanimoto_ratio(const double* sums, int B, int C, double* mean_out, float* per_sample, void* stream);
 /* loss_out[0] += sum over pixels of the per-pixel loss of kind 1..4 (caller divides);
  * per_pixel[M] (optional): the (B,H,W) map the reference's loss function returns (utils.py:486) */
 int rua_pixel_loss(int kind, const float* p, const float* z, const float* y, const float* class_w,
@@ -236,6 +240,24 @@ int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float l
                   float eps, float grad_scale, int zero_grad, void* stream);
 int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, const float* lr_dev, float momentum, float grad_scale,
                  int zero_grad, void* stream);
+
+/* ---- data parallel: gradient all-reduce over RCCL / xGMI (train_ISPRS.py:347,432: the implicit NCCL all-reduce of
+ * tf.distribute.MirroredStrategy).  One process per GPU.  rua_comm_unique_id() on rank 0 -> ship the 128 bytes to the
+ * other ranks by any host channel -> rua_comm_init() on every rank (collective) -> rua_allreduce_bucket() per contiguous
+ * slice of the flat fp32 gradient buffer, in place, sum, asynchronous on `stream` (issue it on a side stream as soon as
+ * the backward has produced the slice; it may be captured into a HIP graph) -> rua_comm_destroy().  RCCL is bound with
+ * dlopen at first use: hosts that never call these need no RCCL. */
+int rua_comm_unique_id(void* id128);
+int rua_comm_init(void** comm, int world, int rank, const void* id128);
+int rua_comm_destroy(void* comm);
+int rua_allreduce_bucket(void* comm, float* grads, int64_t count, void* stream);
+
+/* ---- tuning switches (experiments, A/B runs).  The launchers never read the environment and keep no other global
+ * state: a heuristic changes only through this call.  Keys: rua_tuning_key(0..) until NULL.  Grid-size keys
+ * ("*_blocks", "*_target", "*_grid") default to 0 = derived from the device's compute-unit count. */
+int rua_set_tuning(const char* key, int64_t value);
+int rua_get_tuning(const char* key, int64_t* value);
+const char* rua_tuning_key(int index);
 
 #ifdef __cplusplus
 }

@@ -2,8 +2,7 @@
 from resunet_a_mltsk_keras_amd.keras_api import Tanimoto_dual_loss, TanimotoDualLoss  # noqa: F401
 
 
-def Tanimoto_loss(label, pred):
-    raise NotImplementedError("only the dual form is on the training path: use Tanimoto_dual_loss()")
+from resunet_a_mltsk_keras_amd.keras_api import Tanimoto_loss  # noqa: E402,F401
 
 
 # Label synthesis of the reference module (multitasking_utils.py:6-35), without cv2: see resunet_a_mltsk_keras_amd/labels.py

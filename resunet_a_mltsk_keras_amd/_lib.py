@@ -105,12 +105,20 @@ _SIGS = {
     "rua_fill_zero": ([vp, i64, vp], i32),
     "rua_tanimoto_sums": ([vp, vp, i32, i64, i32, vp, vp], i32),
     "rua_tanimoto_finalize": ([vp, i32, i64, i32, f32, vp, vp, vp, vp], i32),
+    "rua_tanimoto_ratio": ([vp, i32, i32, vp, vp, vp], i32),
     "rua_pixel_loss": ([i32, vp, vp, vp, vp, i64, i32, vp, vp, vp], i32),
     "rua_head_dz": ([i32, i32, vp, vp, vp, vp, f32, i32, i64, i32, vp, vp], i32),
     "rua_seg_metrics": ([vp, vp, i64, i32, vp, vp], i32),
     "rua_lr_step": ([vp, vp, i32, f64, f64, vp], i32),
     "rua_adam_step": ([vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, i32, vp], i32),
     "rua_sgd_step": ([vp, vp, vp, i64, f32, vp, f32, f32, i32, vp], i32),
+    "rua_comm_unique_id": ([vp], i32),
+    "rua_comm_init": ([C.POINTER(vp), i32, i32, vp], i32),
+    "rua_comm_destroy": ([vp], i32),
+    "rua_allreduce_bucket": ([vp, vp, i64, vp], i32),
+    "rua_set_tuning": ([C.c_char_p, i64], i32),
+    "rua_get_tuning": ([C.c_char_p, C.POINTER(i64)], i32),
+    "rua_tuning_key": ([i32], C.c_char_p),
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["rua_last_error"])
@@ -134,6 +142,27 @@ class _Lib:
             fn.argtypes = args
             fn.restype = res
             setattr(self, "_" + name, fn)
+
+        # Experiment switches: the library itself never reads the environment (include/rua_hip.h, rua_set_tuning); this
+        # host-side shim forwards RUA_TUNE_<KEY>=<int> variables once at load time so A/B runs need no code change.
+        i = 0
+        while True:
+            key = self.dll.rua_tuning_key(i) if hasattr(self.dll, "rua_tuning_key") else None
+            if not key:
+                break
+            v = os.environ.get("RUA_TUNE_" + key.decode().upper())
+            if v is not None:
+                self.check(self.dll.rua_set_tuning(key, int(v)), "rua_set_tuning")
+            i += 1
+
+    def set_tuning(self, **kv):
+        for k, v in kv.items():
+            self.check(self.dll.rua_set_tuning(k.encode(), int(v)), "rua_set_tuning")
+
+    def get_tuning(self, key: str) -> int:
+        v = i64()
+        self.check(self.dll.rua_get_tuning(key.encode(), C.byref(v)), "rua_get_tuning")
+        return int(v.value)
 
     def raw(self, name):
         return getattr(self, "_" + name)

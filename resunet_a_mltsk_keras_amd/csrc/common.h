@@ -66,4 +66,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Tuning switches for experiments and A/B runs.  The launchers never read the environment: values change only through
+// rua_set_tuning() (include/rua_hip.h); 0 in a "*_blocks" / "*_target" / "*_grid" field = derive it from the device's CU count.
+struct RuaTuning {
+  int conv_force_bn = 0, conv_force_bm = 0, conv_dma = -1, conv_pw = 1;
+  long long conv_pw_minm = 65536;
+  int conv_pw_blocks = 0, conv_halo = 1, halo64_maxd = 1, conv_dmap = 1, dmap_target = 0, dmap_fused_finish = 0, dmap_rowb = 64, dmap_bm64 = 1;
+  int wgrad_pw = 1, wgpw_blocks = 0, wgpw_r = 0, wgd_blocks = 0, wgrad_dmap = 1, wgd_mintiles = 9, wgrad_blocks = 0;
+  int bn_grid = 0, tani_vec = 1, metrics_blocks = 0, stem_blocks = 0, head_blocks = 0;
+  int halo_fuse_bn = 1, halo_group = 1;
+};
+extern RuaTuning g_tune;
+int rua_cu_count();          // compute units of the current device (queried once per device, cached)
+
 static inline int rua_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -9,9 +9,6 @@
 // Epilogue: accumulators -> LDS fp32 tile -> 8-channel pieces per thread: bias, residual /
 // ReLU-mask from `aux`, per-channel statistics (fp32 partials, fp64 atomics), 16-byte stores.
 #include "common.h"
-#include <stdlib.h>
-
-static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
 
 struct SegK { const unsigned char* x; const unsigned char* w; int C, Hs, Ws, up, dil, taps, nchunk, ubegin; unsigned xbytes, wbytes; };
 struct ConvK {
@@ -1160,7 +1157,7 @@ static int pick_ksplit(long long tiles, int nstages, long long M, int Cout, size
 
 
 static int pick_bn(const rua_conv_desc* d, long long M) {
-  static const int force = env_int("RUA_CONV_FORCE_BN");          // experiments only
+  const int force = g_tune.conv_force_bn;          // experiments only
   if (force == 32 || force == 64 || force == 128) return (d->Cout <= 32) ? 32 : (force == 128 && d->Cout < 128) ? 64 : (force == 32 ? 64 : force);
   if (d->Cout <= 32) return 32;
   if (d->Cout <= 64) return 64;
@@ -1173,14 +1170,14 @@ static int pick_bn(const rua_conv_desc* d, long long M) {
 }
 // pixel-tile height: 256 only where the grid stays large (the two top levels) and the N tile is narrow
 static int pick_bm(const rua_conv_desc* d, long long M, int bn) {
-  static const int force = env_int("RUA_CONV_FORCE_BM");
+  const int force = g_tune.conv_force_bm;
   if (bn == 128) return 128;
   if (force == 128 || force == 256) return force;
   return (M >= 65536) ? 256 : 128;
 }
 
 static bool pick_dma(const rua_conv_desc* d, int bn) {
-  static const int use_dma = getenv("RUA_CONV_DMA") ? atoi(getenv("RUA_CONV_DMA")) : -1;    // 0 / 1: force (experiments)
+  const int use_dma = g_tune.conv_dma;    // 0 / 1: force (experiments)
   bool dma = d->dtype == RUA_BF16 && d->Cout >= 128 && !(bn == 128);
   if (use_dma == 0) dma = false;
   if (use_dma == 1 && d->dtype == RUA_BF16) dma = true;
@@ -1411,8 +1408,8 @@ static int pw_steps(const rua_conv_desc* d) {             // 16-channel k-steps 
   return n;
 }
 static bool pick_pw(const rua_conv_desc* d) {
-  static const int on = getenv("RUA_CONV_PW") ? atoi(getenv("RUA_CONV_PW")) : 1;
-  static const long long minm = getenv("RUA_CONV_PW_MINM") ? atoll(getenv("RUA_CONV_PW_MINM")) : 65536;
+  const int on = g_tune.conv_pw;
+  const long long minm = g_tune.conv_pw_minm;
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   if (!on || d->dtype != RUA_BF16 || d->Cout > 32 || d->stride != 1 || d->out_stride != 1 || d->OH != d->H || d->OW != d->W) return false;
   const long long M = (long long)d->N * d->H * d->W;
@@ -1441,7 +1438,7 @@ template <int KS> static int launch_conv_pw(const ConvK& k, const rua_conv_desc*
   for (; n < KS; ++n) { PwStep& t = q.st[n]; t = q.st[0]; t.C = 0; t.kofs = 0; }       // padding steps: every load out of range
   int wsh = 0, hsh = 0; while ((1 << wsh) < k.W) ++wsh; while ((1 << hsh) < k.H) ++hsh;
   q.wsh = wsh; q.hsh = hsh;
-  static const int target = env_int("RUA_CONV_PW_BLOCKS") > 0 ? env_int("RUA_CONV_PW_BLOCKS") : 2048;
+  const int target = g_tune.conv_pw_blocks > 0 ? g_tune.conv_pw_blocks : 8 * rua_cu_count();      // 2048 on MI355X
   long long waves = (long long)target * 4;
   if (waves > k.M / 128) waves = k.M / 128;                // >= 4 tiles per wave
   if (waves < 4) waves = 4;
@@ -1459,12 +1456,12 @@ template <int KS> static int launch_conv_pw(const ConvK& k, const rua_conv_desc*
 
 // ---- conv_halo launcher -------------------------------------------------------------------------------------------------
 static bool pick_halo(const rua_conv_desc* d) {
-  static const int mode = getenv("RUA_CONV_HALO") ? atoi(getenv("RUA_CONV_HALO")) : 1;      // 0: off (experiments)
+  const int mode = g_tune.conv_halo;      // 0: off (experiments)
   if (!mode || d->dtype != RUA_BF16 || d->nseg != 1) return false;
   const rua_conv_seg& g = d->seg[0];
   // C = 64: measured against conv_igemm<256,64> on 128x128 maps - d = 1: 28.0 vs 30.3 us, d = 15: 46 vs 29 us (the small
   // lattices leave 192-row blocks at two per CU), so only the small dilations take the halo kernel there
-  static const int maxd64 = getenv("RUA_HALO64_MAXD") ? atoi(getenv("RUA_HALO64_MAXD")) : 1;
+  const int maxd64 = g_tune.halo64_maxd;
   if (g.C == 64 && g.dil > maxd64) return false;
   return g.taps == 9 && g.up_shift == 0 && (g.C == 32 || g.C == 64) && d->Cout == g.C && d->stride == 1 && d->out_stride == 1 &&
          d->OH == d->H && d->OW == d->W && g.Hs == d->H && g.Ws == d->W && d->H >= 16 && d->W >= 16 &&
@@ -1537,7 +1534,7 @@ static int launch_conv_halo(const ConvK& k, int dil, hipStream_t st) {
 
 // conv_dmap eligibility: bf16, wide outputs, every segment a whole number of 64-channel stages
 static bool pick_dmap(const rua_conv_desc* d) {
-  static const int mode = getenv("RUA_CONV_DMAP") ? atoi(getenv("RUA_CONV_DMAP")) : 1;      // 0: off (experiments)
+  const int mode = g_tune.conv_dmap;      // 0: off (experiments)
   if (!mode || d->dtype != RUA_BF16 || d->Cout < 128) return false;
   for (int s_ = 0; s_ < d->nseg; ++s_)
     if (d->seg[s_].C % 64 != 0) return false;
@@ -1622,7 +1619,7 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   if (pick_dmap(d)) {
     // 128 x 128 tiles; split K until the grid covers the chip once (every level of the reference network then runs
     // 256 blocks of >= 18 stages: one block per CU, no tail)
-    static const int target = env_int("RUA_DMAP_TARGET") > 0 ? env_int("RUA_DMAP_TARGET") : 256;
+    const int target = g_tune.dmap_target > 0 ? g_tune.dmap_target : rua_cu_count();      // one block per CU
     k.nbn = (d->Cout + 127) / 128;
     k.nbm = (int)((k.M + 127) / 128);
     const int nstages = units / 2;
@@ -1632,7 +1629,7 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     // the caller zero-fills the workspace once, every last arriver resets its counter)
     // OFF by default - measured: the single last-arriving block reads ksplit x 64 KB of slabs serially (8x8 level: 45 vs 26 us,
     // 16x16: 39 vs 28 us); the separate finisher spreads the same bytes over 1024 blocks.  Kept (and tested) as an option.
-    static const int fused = getenv("RUA_DMAP_FUSED_FINISH") ? atoi(getenv("RUA_DMAP_FUSED_FINISH")) : 0;
+    const int fused = g_tune.dmap_fused_finish;
     const size_t ws_usable = d->workspace_bytes > 4096 ? (size_t)d->workspace_bytes - 4096 : 0;
     const long long slabs = d->workspace ? (long long)(ws_usable / ((size_t)k.M * d->Cout * sizeof(float))) : 0;
     k.cnt = (fused && d->workspace && tiles <= 1024) ? reinterpret_cast<int*>((char*)d->workspace + ws_usable) : nullptr;
@@ -1650,10 +1647,10 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     k.stages_per_split = (nstages + want - 1) / want;
     k.ksplit = (nstages + k.stages_per_split - 1) / k.stages_per_split;
     g_last_ksplit = k.ksplit;
-    static const int rowb = env_int("RUA_DMAP_ROWB") == 128 ? 128 : 64;
+    const int rowb = g_tune.dmap_rowb == 128 ? 128 : 64;
     // the unsplit half-chip case (32x32 level: 128 tiles of 128 x 128, 36 stages): 64-row tiles put a block on every CU
     // (measured there: 25.5 / 23.7 / 22.6 us vs 30.1 / 30.0 / 28.6 for d = 1 / d = 15 / plain)
-    static const int bm64 = getenv("RUA_DMAP_BM64") ? atoi(getenv("RUA_DMAP_BM64")) : 1;
+    const int bm64 = g_tune.dmap_bm64;
     if (bm64 && k.ksplit == 1 && tiles < target && tiles * 2 >= target) {
       k.nbm = (int)((k.M + 63) / 64);
       return launch_conv_dmap<64, 128, 64>(k, st);
@@ -2243,7 +2240,8 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   k.group_bytes = 64 * 64 + 3 * k.halo4 * CC * 2;
   k.NPG = (CC == 32) ? 4 : 2;                          // 12 waves per block either way (3 kernel rows x CC/32 halves per group)
   const int gy = CC / 32;
-  const int target = (256 / gy) * k.NPG;               // pixel groups wanted: one block per CU and output-channel half
+  const int ncu = rua_cu_count();
+  const int target = (ncu / gy) * k.NPG;               // pixel groups wanted: one block per CU and output-channel half
   k.strips = d->W / 64;
   k.nchains = d->N * k.strips * d->dil;
   const int ny = (d->H + d->dil - 1) / d->dil;         // lattice rows of the longest chain
@@ -2254,7 +2252,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   k.spc = (ny + k.seglen - 1) / k.seglen;
   k.njobs = k.nchains * k.spc;
   int gx = (k.njobs + k.NPG - 1) / k.NPG;
-  if (gx > 256 / gy) gx = 256 / gy;                    // one block per CU and output-channel half; extra jobs are queued
+  if (gx > ncu / gy) gx = ncu / gy;                    // one block per CU and output-channel half; extra jobs are queued
   k.gx = gx;
   k.nworkers = gx * k.NPG;
   k.jpw = (k.njobs + k.nworkers - 1) / k.nworkers;
@@ -2504,10 +2502,10 @@ __global__ __launch_bounds__(1024) void wgrad_pw(const WgpK p) {
   }
 }
 
-static int64_t wg_taps_bytes(const rua_wgrad_desc* d) { return (int64_t)256 * 9 * 32 * (int64_t)d->C * 4; }   // 256 block partials of [9][32][C] fp32
+static int64_t wg_taps_bytes(const rua_wgrad_desc* d) { return (int64_t)rua_cu_count() * 9 * 32 * (int64_t)d->C * 4; }   // one block partial of [9][32][C] fp32 per CU
 
 static bool pick_wgrad_pw(const rua_wgrad_desc* d) {
-  static const int on = getenv("RUA_WGRAD_PW") ? atoi(getenv("RUA_WGRAD_PW")) : 1;
+  const int on = g_tune.wgrad_pw;
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   const long long M = (long long)d->N * d->H * d->W;
   const bool dense = d->stride == 1 && d->Hs == d->H && d->Ws == d->W;
@@ -2531,7 +2529,7 @@ static int launch_wgrad_pw(const rua_wgrad_desc* d, hipStream_t st) {
   k.abytes = (unsigned)((size_t)d->N * d->Hs * d->Ws * d->C * 2); k.dybytes = (unsigned)((size_t)k.M * d->Cout * 2);
   const int nco = d->Cout > 32 ? 2 : 1, nci = d->C > 32 ? 2 : 1;
   const int pxw = (nco + nci <= 2) ? 32 : 16;
-  static const int target = env_int("RUA_WGPW_BLOCKS") > 0 ? env_int("RUA_WGPW_BLOCKS") : 256;    // blocks of 16 waves
+  const int target = g_tune.wgpw_blocks > 0 ? g_tune.wgpw_blocks : rua_cu_count();    // blocks of 16 waves, one per CU
   long long waves = (long long)target * 16;
   if (waves > k.M / 128) waves = k.M / 128;                // >= 128 pixels per wave
   if (waves < 16) waves = 16;
@@ -2541,7 +2539,7 @@ static int launch_wgrad_pw(const rua_wgrad_desc* d, hipStream_t st) {
   {   // replicas: atomic chains of ~64 blocks per address; fewer replicas = fewer exchanges for the finishing block
     const long long nblk = (k.M + ppw * 16 - 1) / (ppw * 16);
     k.R = (int)(nblk / 32); if (k.R < 1) k.R = 1; if (k.R > WG_PW_REPLICAS) k.R = WG_PW_REPLICAS;
-    if (env_int("RUA_WGPW_R") > 0) k.R = env_int("RUA_WGPW_R") > WG_PW_REPLICAS ? WG_PW_REPLICAS : env_int("RUA_WGPW_R");
+    if (g_tune.wgpw_r > 0) k.R = g_tune.wgpw_r > WG_PW_REPLICAS ? WG_PW_REPLICAS : g_tune.wgpw_r;
   }
   const unsigned grid = (unsigned)((k.M + ppw * 16 - 1) / (ppw * 16));
   constexpr int s11 = wgrad_pw_smem<1, 1>(), s21 = wgrad_pw_smem<2, 1>(), s12 = wgrad_pw_smem<1, 2>(), s22 = wgrad_pw_smem<2, 2>();
@@ -2576,7 +2574,7 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
   k.ntc = d->Cout / 128; k.nti = d->C / 128;
   const long long tiles = (long long)k.ntc * k.nti * d->taps;
   const int stages = (int)((k.M + 63) / 64);
-  static const int target = env_int("RUA_WGD_BLOCKS") > 0 ? env_int("RUA_WGD_BLOCKS") : 256;
+  const int target = g_tune.wgd_blocks > 0 ? g_tune.wgd_blocks : rua_cu_count();
   long long want = target / tiles; if (want < 1) want = 1;
   if (want > stages / 4) want = stages / 4;             // >= 4 stages per K slice
   if (want < 1) want = 1;
@@ -2594,7 +2592,7 @@ extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
   if (!d) return RUA_ERR_ARG;
   if (pick_wgrad_pw(d)) return 3;
   {
-    static const int on = getenv("RUA_WGRAD_DMAP") ? atoi(getenv("RUA_WGRAD_DMAP")) : 1;
+    const int on = g_tune.wgrad_dmap;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     if (on && d->dtype == RUA_BF16 && (d->taps == 9 || d->taps == 1) && d->stride == 1 && d->C % 128 == 0 && d->Cout % 128 == 0 &&
         d->Hs == d->H && d->Ws == d->W && pow2(d->H) && pow2(d->W) && d->dil >= 1 &&
@@ -2604,7 +2602,7 @@ extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
       // the CUs idle), 8x8x1024 75 / 32 (576 short-K blocks at one per CU).  So: a few dozen tiles and a long K.
       const long long tiles = (long long)d->taps * (d->Cout / 128) * (d->C / 128);
       const long long stages = ((long long)d->N * d->H * d->W + 63) / 64;
-      static const int mint = getenv("RUA_WGD_MINTILES") ? atoi(getenv("RUA_WGD_MINTILES")) : 9;    // 9: the 64x64x128 level too (A/B in the step: -0.03 ms)
+      const int mint = g_tune.wgd_mintiles;    // 9: the 64x64x128 level too (A/B in the step: -0.03 ms)
       if (on == 2 || (tiles >= mint && tiles <= 64 && stages >= 64)) return 2;
     }
   }
@@ -2639,7 +2637,7 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   const long long tiles = (long long)k.ntc * k.nti * d->taps;
   // K split: every slice adds the whole dW tile with fp32 atomics (~1.3 TB/s chip-wide), so slices x |dW| must stay
   // small: ~512 blocks fill the chip; 2048 blocks meant 33 MB of atomics (~25 us) per launch.
-  static const int target = env_int("RUA_WGRAD_BLOCKS") > 0 ? env_int("RUA_WGRAD_BLOCKS") : 512;
+  const int target = g_tune.wgrad_blocks > 0 ? g_tune.wgrad_blocks : 2 * rua_cu_count();      // 512 on MI355X
   long long want = target / tiles; if (want < 1) want = 1;
   long long stages = (k.M + 63) / 64;
   if (want > stages) want = stages;
@@ -2754,8 +2752,8 @@ extern "C" int rua_conv_tile_bm(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
   const long long M = (long long)d->N * d->H * d->W;
   if (pick_dmap(d)) {                                   // mirrors the launcher: 64-row tiles in the unsplit half-chip case
-    static const int target = env_int("RUA_DMAP_TARGET") > 0 ? env_int("RUA_DMAP_TARGET") : 256;
-    static const int bm64 = getenv("RUA_DMAP_BM64") ? atoi(getenv("RUA_DMAP_BM64")) : 1;
+    const int target = g_tune.dmap_target > 0 ? g_tune.dmap_target : rua_cu_count();
+    const int bm64 = g_tune.dmap_bm64;
     const long long tiles = ((M + 127) / 128) * ((d->Cout + 127) / 128);
     int units = 0;
     for (int i = 0; i < d->nseg; ++i) units += d->seg[i].taps * (d->seg[i].C / 32);

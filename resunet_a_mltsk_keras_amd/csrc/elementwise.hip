@@ -451,7 +451,7 @@ extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream) {
   const int CG = d->C / vec;
   const long long pieces = d->M * CG;
   int g = grid_for(pieces);
-  static const int cap = getenv("RUA_BN_GRID") ? atoi(getenv("RUA_BN_GRID")) : 512;
+  const int cap = g_tune.bn_grid > 0 ? g_tune.bn_grid : 2 * rua_cu_count();      // 512 on MI355X
   if ((long long)d->replicas * d->C >= 512 && g > cap) g = cap;      // the prologue re-reads replicas*C*2 doubles per block
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == RUA_BF16) hipLaunchKernelGGL((bn_fwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, *d, pieces, CG);
@@ -540,8 +540,8 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
   const long long pieces = d->M * CG;
   int g = grid_for(pieces);
   // measured (4 branches): 256x256x32 53 -> 46 us, 128x128x64 35 -> 31 us with 1024 blocks; smaller tensors prefer 512
-  static const int cap_env = getenv("RUA_BN_GRID") ? atoi(getenv("RUA_BN_GRID")) : 0;
-  const int cap = cap_env > 0 ? cap_env : (pieces >= (1ll << 20) ? 1024 : 512);
+  const int cap_env = g_tune.bn_grid;
+  const int cap = cap_env > 0 ? cap_env : (pieces >= (1ll << 20) ? 4 : 2) * rua_cu_count();      // 1024 / 512 on MI355X
   if ((long long)rmax * d->C * d->nb >= 512 && g > cap) g = cap;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == RUA_BF16) hipLaunchKernelGGL((bn_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, *d, pieces, CG);

@@ -119,7 +119,7 @@ static void launch_tanimoto_vec(const float* p, const float* y, int B, int64_t H
 extern "C" int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t HW, int C, double* sums, void* stream) {
   RUA_CHECK_ARG(p && y && sums && B > 0 && HW > 0, "rua_tanimoto_sums: bad arguments");
   RUA_CHECK_ARG(C >= 1 && C <= 8, "rua_tanimoto_sums: C=%d must be in 1..8", C);
-  static const int vec_on = getenv("RUA_TANI_VEC") ? atoi(getenv("RUA_TANI_VEC")) : 1;
+  const int vec_on = g_tune.tani_vec;
   if (vec_on && HW % 4 == 0 && ((size_t)p & 15) == 0 && ((size_t)y & 15) == 0 && (C == 6 || C == 3 || C == 2)) {
     if (C == 6) launch_tanimoto_vec<6, 2>(p, y, B, HW, sums, (hipStream_t)stream);
     else if (C == 3) launch_tanimoto_vec<3, 4>(p, y, B, HW, sums, (hipStream_t)stream);
@@ -137,7 +137,10 @@ extern "C" int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t 
 
 // One block.  Follows Tanimoto_dual_loss: loss1 = T(label:=pred, pred:=label) so the class weights of
 // the first term come from the PREDICTION volumes (and carry gradient); loss2 = T(1-label, 1-pred).
-__global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B, int C, float grad_scale, double* loss_out, float* coef, float* per_sample) {
+// single != 0: Tanimoto_loss(label, pred) itself (multitasking_utils.py:38-68) for sums taken with p := label, y := pred -
+// the first term's ratio (N1 + 1e-5) / (D1 + 1e-5) with the class weights from the volumes of the FIRST argument.
+__global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B, int C, float grad_scale, double* loss_out, float* coef, float* per_sample,
+                                         int single) {
   __shared__ double w1[8], w2[8], v1[8], kap[8];
   __shared__ double E1[256], F1[256], E2[256], F2[256];
   __shared__ int inf1[8];
@@ -173,7 +176,7 @@ __global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B,
       N2 += w2[c] * s[4]; D2 += w2[c] * (s[5] - s[4]);
     }
     E1[n] = D1 + smooth; F1[n] = N1 + smooth; E2[n] = D2 + smooth; F2[n] = N2 + smooth;
-    const double ln = 1.0 - 0.5 * (F1[n] / E1[n] + F2[n] / E2[n]);
+    const double ln = single ? F1[n] / E1[n] : 1.0 - 0.5 * (F1[n] / E1[n] + F2[n] / E2[n]);
     if (per_sample) per_sample[n] = (float)ln;
     lsum += ln;
   }
@@ -208,8 +211,16 @@ extern "C" int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int 
   RUA_CHECK_ARG(sums && loss_out && B > 0 && B <= 256, "rua_tanimoto_finalize: B must be in 1..256");
   RUA_CHECK_ARG(C >= 1 && C <= 8, "rua_tanimoto_finalize: C=%d must be in 1..8", C);
   (void)HW;
-  hipLaunchKernelGGL(tanimoto_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, B, C, grad_scale, loss_out, coef, per_sample);
+  hipLaunchKernelGGL(tanimoto_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, B, C, grad_scale, loss_out, coef, per_sample, 0);
   RUA_LAUNCH_CHECK("rua_tanimoto_finalize");
+  return RUA_OK;
+}
+
+extern "C" int rua_tanimoto_ratio(const double* sums, int B, int C, double* mean_out, float* per_sample, void* stream) {
+  RUA_CHECK_ARG(sums && mean_out && per_sample && B > 0 && B <= 256, "rua_tanimoto_ratio: B must be in 1..256");
+  RUA_CHECK_ARG(C >= 1 && C <= 8, "rua_tanimoto_ratio: C=%d must be in 1..8", C);
+  hipLaunchKernelGGL(tanimoto_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, B, C, 0.f, mean_out, (float*)nullptr, per_sample, 1);
+  RUA_LAUNCH_CHECK("rua_tanimoto_ratio");
   return RUA_OK;
 }
 
@@ -405,7 +416,7 @@ extern "C" int rua_seg_metrics(const float* p, const float* y, int64_t M, int C,
   }
   // the five counters share one cache line and every block ends in five same-line fp64 atomics (serialised): measured
   // 64 blocks 36 us, 128: 23, 256: 24, 512: 37
-  static const int cap = getenv("RUA_METRICS_BLOCKS") ? atoi(getenv("RUA_METRICS_BLOCKS")) : 128;
+  const int cap = g_tune.metrics_blocks > 0 ? g_tune.metrics_blocks : rua_cu_count() / 2;      // 128 on MI355X
   int64_t g = (M + 255) / 256; if (g > cap) g = cap;
   hipLaunchKernelGGL(seg_metrics_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p, y, (long long)M, C, out);
   RUA_LAUNCH_CHECK("rua_seg_metrics");

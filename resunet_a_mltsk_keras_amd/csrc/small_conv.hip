@@ -117,7 +117,7 @@ extern "C" int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db
   RUA_CHECK_ARG(Cin >= 1 && Cin <= 16, "rua_stem_bwd: Cin=%d must be in 1..16", Cin);
   RUA_CHECK_ARG(Cout % 8 == 0 && Cout <= 256 && 256 % (Cout / 8) == 0, "rua_stem_bwd: unsupported Cout=%d", Cout);
   // every block ends with one float atomic per weight: same-address float atomics serialise (~25 ns each), so few blocks
-  static const int64_t nblk = getenv("RUA_STEM_BLOCKS") ? atoi(getenv("RUA_STEM_BLOCKS")) : 256;
+  const int64_t nblk = g_tune.stem_blocks > 0 ? g_tune.stem_blocks : rua_cu_count();
   int64_t blocks = nblk; int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
   const int g = (int)((M + rpb - 1) / rpb);
   hipStream_t st = (hipStream_t)stream;
@@ -314,10 +314,10 @@ extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void
   const int vec = dtype == RUA_BF16 ? 8 : 4;
   RUA_CHECK_ARG(Cin % vec == 0 && Cin <= 256 && 256 % (Cin / vec) == 0, "rua_head_bwd: unsupported Cin=%d", Cin);
   RUA_CHECK_ARG(Cout >= 1 && Cout <= 8, "rua_head_bwd: Cout=%d must be in 1..8", Cout);
-  static const int blocks_env = getenv("RUA_HEAD_BLOCKS") ? atoi(getenv("RUA_HEAD_BLOCKS")) : 0;
+  const int blocks_env = g_tune.head_blocks;
   // two blocks per CU are resident (VGPRs), so 512 blocks run in one round: measured 128 blocks 49 us, 256: 37, 512: 35,
   // 640: 52, 1024: 51, 2048: 85 (kernel + partial reduce, 256x256x32 -> 6)
-  int64_t blocks = blocks_env > 0 ? blocks_env : 512; int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
+  int64_t blocks = blocks_env > 0 ? blocks_env : 2 * rua_cu_count(); int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
   const int g = (int)((M + rpb - 1) / rpb);
   const int ne = Cout * Cin + Cout;
   const size_t smem = (size_t)4 * ne * 4;

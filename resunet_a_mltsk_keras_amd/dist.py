@@ -117,6 +117,38 @@ class DataParallel:
         else:
             dist.broadcast(t, 0, group=self.group)
 
+    def broadcast_optimizer_state(self):
+        """Rank 0's optimizer moments and step count become everyone's (a checkpoint restored on every rank, or only on
+        rank 0: train_ISPRS.py:474-480 resume)."""
+        eng = self.eng
+        self._bcast(eng.M1); self._bcast(eng.V1)
+        t = torch.tensor([float(eng.t)], dtype=torch.float64)
+        if self.host_staged or not eng.P.is_cuda:
+            dist.broadcast(t, 0, group=self.group)
+        else:
+            t = t.to(eng.P.device); dist.broadcast(t, 0, group=self.group)
+        eng.t = int(t.item())
+        eng._t_dev = -1                                       # the device-side counter is pushed again at the next step
+
+    def reduce_scalars(self, sc: torch.Tensor) -> torch.Tensor:
+        """Sum over the replicas of the step's loss / metric scalars ("all-reduce of ~10 floats"); returns a
+        new tensor, the arena itself stays local."""
+        if self.host_staged:
+            h = sc.cpu()
+            dist.all_reduce(h, group=self.group)
+            return h
+        t = sc.clone()
+        dist.all_reduce(t, group=self.group)
+        return t
+
+    def all_ranks_ok(self, ok: int) -> int:
+        """MIN over the ranks of a 0/1 flag (collective: every rank calls it at the same point)."""
+        t = torch.tensor([int(ok)], dtype=torch.int32)
+        if not self.host_staged and self.eng.P.is_cuda:
+            t = t.to(self.eng.P.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item())
+
     def bucket_of(self, off: int) -> int:
         for i, (a, b) in enumerate(self.buckets):
             if a <= off < b:

@@ -242,20 +242,25 @@ class Plan:
         self.dry = dry
         self.lane = 0
         self.open_fork = 0
+        self.scope: Optional[str] = None     # composite the next launches belong to (per-block timing in bench.py)
+        self.scopes: List[Optional[str]] = []  # scope of calls[i]
 
     def add(self, name: str, *args):
         if not self.dry:
             self.calls.append((L.lib().raw(name), name, args, self.lane))
+            self.scopes.append(self.scope)
 
     def fork(self, n: int):
         if not self.dry and n > 1:
             self.calls.append((None, Plan.FORK, n, 0))
+            self.scopes.append(self.scope)
         self.open_fork = n
 
     def join(self, n: int):
         self.lane = 0
         if not self.dry and n > 1:
             self.calls.append((None, Plan.JOIN, n, 0))
+            self.scopes.append(self.scope)
         self.open_fork = 0
 
     def set_lane(self, lane: int):
@@ -335,6 +340,7 @@ class Graph:
         self.back_steps: List = []
         self.grad_touch: Dict[int, int] = {}
         self.cur_lane = 0
+        self.block_tag = ""
         self.allocs: List[torch.Tensor] = []
         self.stats_used = 16                 # the first 16 doubles of the arena are the loss / metric scalars
         self.act_bytes = 0
@@ -551,6 +557,8 @@ class Graph:
         """model2.py:15-34.  BN1 statistics are shared by all branches (same input)."""
         tr, F = self.training, self.fwd
         v2 = self.cfg.variant == "model2"
+        scope = f"{self.block_tag}:ResBlock({nf},{dils})@{x.H}x{x.W}"
+        F.scope = scope
         lay = [(self.Lbn(nf), self.Lconv([nf], nf, 9), self.Lbn(nf), self.Lconv([nf], nf, 9)) for _ in dils]
         cnt = x.M
         if tr and x.stats is None:
@@ -572,11 +580,13 @@ class Graph:
         biases = [self.P(l[3]["bias"]) for l in lay]        # the concatenated conv's bias = sum of the branches' biases
         self.conv(F, [(a, 0, d, 9) for a, d in zip(a2, dils)], [l[3]["segs"][0] for l in lay], nf, biases[0], out,
                   residual=x if v2 else None, bias_more=biases[1:])
+        F.scope = None
         if not tr:
             return out
 
         def back():
             Bp = self.bwd
+            Bp.scope = scope
             dO = out.grad
             self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
             g1s, s1s = [], []
@@ -598,6 +608,7 @@ class Graph:
             Bp.join(len(dils)); self.cur_lane = 0
             gx, acc = self.gacc(x)
             self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None)
+            Bp.scope = None
         self.back_steps.append(back)
         return out
 
@@ -924,12 +935,14 @@ class Graph:
         for i, (nf, dils) in enumerate(lv):
             if i > 0:
                 x = self.down(x, nf)
+            self.block_tag = f"enc{i + 1}"
             x = self.resblock(x, nf, dils)
             skips.append(x)
         x = self.psp(x, lv[-1][0]) if v2 else self.psp_v1(x, lv[-1][0])
         for i in range(len(lv) - 2, -1, -1):
             nf, dils = lv[i]
             x = self.up_combine(x, skips[i], nf) if v2 else self.up_combine_v1(x, skips[i], nf)
+            self.block_tag = f"dec{i + 1}"
             x = self.resblock(x, nf, dils)
         x_comb = self.final_combine(x, c1, w0) if v2 else self.relu_cat_conv_v1(x, 0, c1, w0, want_stats=False)
         x_psp = self.psp(x_comb, w0) if v2 else self.psp_v1(x_comb, w0)
@@ -1063,6 +1076,15 @@ class Engine:
         return self.graphs[key]
 
     def compile(self, spec: LossSpec):
+        if self.dev is not None and (self.graphs or self._captured or self._captured_eval or self._captured_dp):
+            # a re-compile (Keras fine-tune pattern, or predict()'s auto-compile followed by compile): the captured HIP graphs
+            # hold raw pointers into the old plan's buffers and bake in the old loss / optimizer - drop them with the plan
+            torch.cuda.synchronize()
+        self._captured, self._captured_eval, self._captured_dp = {}, {}, {}
+        self._eval_seen = set()
+        self._opt_graph = None
+        if self.loss is not None and (self.loss.optimizer != spec.optimizer):
+            self._t_dev, self._lr_base_dev = -1, None          # device-side step counter / base rate are pushed again
         self.loss = spec
         self.graphs = {}
         if spec.class_weights is not None:
@@ -1119,10 +1141,17 @@ class Engine:
         L.lib().call("rua_fill_zero", self.stats_arena.data_ptr(), g.stats_used * 8, C.c_void_p(s))
 
     def _results(self, g: Graph):
-        sc = self.stats_arena[:16].cpu().numpy()
-        per = [float(sc[h["slot"]] * h["norm"]) for h in g.heads]
+        """Metric list of the step in the reference's order.  Under data parallel the scalars are summed over the replicas
+        first (one all-reduce of 16 doubles), so every rank returns the SAME numbers, aggregated the way
+        MirroredStrategy reports them (train_ISPRS.py:347,432): losses = mean of the replicas' means, accuracy over all
+        replicas' pixels, TP/FP/TN/FN summed.  Every rank must therefore fetch results in the same steps."""
+        sc, w = self.stats_arena[:16], 1
+        if self.dist is not None and self.world > 1:
+            sc, w = self.dist.reduce_scalars(sc), self.world
+        sc = sc.cpu().numpy()
+        per = [float(sc[h["slot"]] * h["norm"] / w) for h in g.heads]
         total = sum(self.loss.weight[h["name"]] * v for h, v in zip(g.heads, per))
-        M = g.outputs["seg"]["x"].M
+        M = g.outputs["seg"]["x"].M * w
         mets = [float(sc[8] / M), float(sc[9]), float(sc[10]), float(sc[11]), float(sc[12])]
         if self.cfg.multitasking:
             return [total] + per + mets
@@ -1265,12 +1294,16 @@ class Engine:
                 opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(opt, capture_error_mode="thread_local"):
                     self._launch_optimizer(1.0 / self.world, self._stream())
+                ok = 1
             except RuntimeError as exc:
-                # Capture is an optimisation: the eager launch sequence issues the same kernels and the same collectives in
-                # the same order (so ranks may even disagree on which path they run).  Say so loudly and carry on.
+                # Capture is an optimisation: the eager launch sequence issues the same kernels and the same collectives
+                # (BN state first, then the buckets in the same order - see the replay below).  Say so loudly and carry on.
                 import sys
                 print(f"[resunet_a] HIP-graph capture of the data-parallel step failed ({exc}); running it eagerly", file=sys.stderr, flush=True)
                 torch.cuda.synchronize()
+                ok = 0
+            # the ranks switch TOGETHER: the fallback is decided by a MIN over the ranks' capture results
+            if self.dist.all_ranks_ok(ok) == 0:
                 self.dp_graph = False
                 self.weights_dirty = True
                 return g
@@ -1280,7 +1313,7 @@ class Engine:
             return g
         self._set_lr()
         red.begin()
-        for cap, buckets in pieces:
+        for pi, (cap, buckets) in enumerate(pieces):
             cap.replay()
             # One eager kernel between a graph launch and the event choreography of the collectives.  Measured on this
             # stack (ROCm 7.0 / torch 2.10): a graph launch followed DIRECTLY by cross-stream event record / wait operations
@@ -1289,6 +1322,10 @@ class Engine:
             # ordinary kernel launch after every replay: 0 of 20.  The eager data-parallel path and the single-GPU graph
             # (no collectives between graphs) were never affected.
             self._dp_fence.zero_()
+            if pi == 0:
+                # same collective order as the eager path (forward_backward): BN moving statistics first - they are final
+                # once the forward (inside the first piece) has run - then the gradient buckets
+                self.dist.start_state_reduce(self)
             for b in buckets:
                 red.ready(b)
         self.dist.reduce_gradients(self)

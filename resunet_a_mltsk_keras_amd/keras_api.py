@@ -106,6 +106,26 @@ def Tanimoto_dual_loss():
     return TanimotoDualLoss()
 
 
+def Tanimoto_loss(label, pred):
+    """multitasking_utils.py:38-68: the (B,) Tanimoto ratio with class weights 1/V^2 from the volumes of `label`
+    (inf -> largest finite weight), on the GPU: the moments kernel of the training path with the arguments in the
+    reference's order, finished by rua_tanimoto_ratio."""
+    label, pred = np.asarray(label, np.float32), np.asarray(pred, np.float32)
+    if label.shape != pred.shape:
+        raise ValueError(f"label {label.shape} and pred {pred.shape} differ")
+    B, Cc = label.shape[0], label.shape[-1]
+    HW = int(np.prod(label.shape[1:-1]))
+    lib = L.lib()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a, b = _dev_f32(label), _dev_f32(pred)
+    sums = torch.zeros(B * Cc * 6, dtype=torch.float64, device="cuda")
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    per = torch.zeros(B, dtype=torch.float32, device="cuda")
+    lib.call("rua_tanimoto_sums", a.data_ptr(), b.data_ptr(), B, HW, Cc, sums.data_ptr(), s)      # p := label, y := pred
+    lib.call("rua_tanimoto_ratio", sums.data_ptr(), B, Cc, out.data_ptr(), per.data_ptr(), s)
+    return per.cpu().numpy()
+
+
 class WeightedCategoricalCrossentropy:
     """Returned by weighted_categorical_crossentropy(weights) (utils.py:466-491); calling it gives the (B,H,W) map."""
     kind = L.LOSS_WCE
@@ -222,10 +242,17 @@ class Model:
                         beta_1=getattr(optimizer, "beta_1", 0.9), beta_2=getattr(optimizer, "beta_2", 0.999),
                         momentum=getattr(optimizer, "momentum", 0.0))
         self.engine.compile(spec)
+        self._finish_compile()
+
+    def _finish_compile(self, restored_optimizer_state: bool = False):
+        """Shared tail of compile() and load_model(compile=True): attach data parallel when the process is one rank of a
+        torch.distributed job (MirroredStrategy scope of train_ISPRS.py:347,432), name the returned metrics."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             from .dist import DataParallel
-            DataParallel(self.engine)
+            dp = DataParallel(self.engine)                   # broadcasts rank 0's weights and BN state
+            if restored_optimizer_state:
+                dp.broadcast_optimizer_state()               # ... and rank 0's Adam moments / step count on resume
         m = ["accuracy", "true_positives", "false_positives", "true_negatives", "false_negatives"]
         if self.cfg.multitasking:
             self.metrics_names = ["loss"] + [h + "_loss" for h in HEADS] + ["seg_" + x for x in m]
@@ -236,10 +263,11 @@ class Model:
     def _sync_lr(self):
         self.engine.loss.lr = self.optimizer.lr.value          # K.set_value(model.optimizer.lr, ...) takes effect
 
-    def _local_batch(self, x, y):
-        """Under DP `-bs` is the GLOBAL batch (train_ISPRS.py:314,347): each rank takes its contiguous shard."""
+    def _local_batch(self, x, y, local_shard=False):
+        """Under DP `-bs` is the GLOBAL batch (train_ISPRS.py:314,347): each rank takes its contiguous shard.
+        local_shard=True: the caller already holds only this rank's shard (loader.PrefetchLoader(rank=, world=))."""
         w = self.engine.world
-        if w == 1:
+        if w == 1 or local_shard:
             return x, y
         import torch.distributed as dist
         r, B = dist.get_rank(), x.shape[0]
@@ -248,16 +276,16 @@ class Model:
         sl = slice(r * (B // w), (r + 1) * (B // w))
         return x[sl], ({k: v[sl] for k, v in y.items()} if isinstance(y, dict) else (None if y is None else y[sl]))
 
-    def train_on_batch(self, x, y=None, return_dict=False, **_):
+    def train_on_batch(self, x, y=None, return_dict=False, local_shard=False, **_):
         assert self._compiled, "compile() first"
         self._sync_lr()
-        x, y = self._local_batch(x, y)
+        x, y = self._local_batch(x, y, local_shard)
         res = self.engine.train_step(x, y)
         return dict(zip(self.metrics_names, res)) if return_dict else res
 
-    def test_on_batch(self, x, y=None, return_dict=False, **_):
+    def test_on_batch(self, x, y=None, return_dict=False, local_shard=False, **_):
         assert self._compiled, "compile() first"
-        x, y = self._local_batch(x, y)
+        x, y = self._local_batch(x, y, local_shard)
         res = self.engine.test_step(x, y)
         return dict(zip(self.metrics_names, res)) if return_dict else res
 
@@ -349,9 +377,7 @@ def load_model(path, compile=True, custom_objects=None, dtype=None, **_):
         m.engine.compile(LossSpec(kind={k: int(v) for k, v in lo["kind"].items()}, weight=lo["weight"], class_weights=lo["class_weights"],
                                   optimizer=lo["optimizer"], lr=lo["lr"], beta_1=lo["beta_1"], beta_2=lo["beta_2"], momentum=lo["momentum"]))
         m.engine.M1.copy_(blob["opt_m"]); m.engine.V1.copy_(blob["opt_v"]); m.engine.t = meta["t"]
-        mm = ["accuracy", "true_positives", "false_positives", "true_negatives", "false_negatives"]
-        m.metrics_names = (["loss"] + [h + "_loss" for h in HEADS] + ["seg_" + x for x in mm]) if cfg.multitasking else ["loss"] + mm
-        m._compiled = True
+        m._finish_compile(restored_optimizer_state=True)
     return m
 
 

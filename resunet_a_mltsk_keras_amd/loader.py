@@ -25,12 +25,21 @@ class PrefetchLoader:
     depth:   batches read ahead (ring slots = depth + 1: the slot handed to the caller is reused only after the
              caller has asked for the NEXT batch, i.e. after its training step has returned).
     workers: threads reading files (np.load releases the GIL while it reads).
+    rank, world: data-parallel shard.  `batch_size` stays the GLOBAL batch (train_ISPRS.py:314 under MirroredStrategy);
+             rank r reads and yields only samples [r*B/world, (r+1)*B/world) of every global batch - the contiguous
+             split Keras makes - so N ranks read each file once between them instead of N times.
     """
 
     def __init__(self, x_paths: Sequence[str], y_paths: Dict[str, Sequence[str]], batch_size: int,
-                 order: Optional[Sequence[int]] = None, depth: int = 2, workers: int = 4, pin: Optional[bool] = None):
+                 order: Optional[Sequence[int]] = None, depth: int = 2, workers: int = 4, pin: Optional[bool] = None,
+                 rank: int = 0, world: int = 1):
         if batch_size < 1:
             raise ValueError("batch_size must be >= 1")
+        if world < 1 or not (0 <= rank < world):
+            raise ValueError(f"rank {rank} outside world {world}")
+        if batch_size % world:
+            raise ValueError(f"global batch {batch_size} not divisible by {world} replicas")
+        self.rank, self.world, self.local_B = int(rank), int(world), int(batch_size) // int(world)
         for h, lst in y_paths.items():
             if len(lst) != len(x_paths):
                 raise ValueError(f"label list '{h}' has {len(lst)} entries for {len(x_paths)} patches")
@@ -44,7 +53,7 @@ class PrefetchLoader:
         if self.x_paths:
             x0 = np.load(self.x_paths[0])
             shapes = {h: np.load(v[0]).shape for h, v in self.y_paths.items()}
-            mk = lambda shp: torch.empty((self.B,) + tuple(shp), dtype=torch.float32, pin_memory=self.pin)
+            mk = lambda shp: torch.empty((self.local_B,) + tuple(shp), dtype=torch.float32, pin_memory=self.pin)
             self._slots = [(mk(x0.shape), {h: mk(s) for h, s in shapes.items()}) for _ in range(self.depth + 1)]
 
     def __len__(self) -> int:
@@ -73,7 +82,8 @@ class PrefetchLoader:
                     slot = free.get()
                     if slot is None or self._stop.is_set():
                         return
-                    self._fill(slot, self.order[k * self.B:(k + 1) * self.B], pool)
+                    first = k * self.B + self.rank * self.local_B
+                    self._fill(slot, self.order[first:first + self.local_B], pool)
                     ready.put(slot)
             ready.put(None)
         except BaseException as exc:                          # hand the error to the consumer instead of dying silently

@@ -58,6 +58,61 @@ def test_loss_factories_evaluate_on_gpu():
     assert out.shape == (1, 2, 2) and np.allclose(out, (y * w).sum(-1) * np.log(3), rtol=1e-6)
 
 
+def test_standalone_tanimoto_loss_matches_reference_definition():
+    """multitasking_utils.py:38-68 `Tanimoto_loss(label, pred)` -> (B,), weights from the LABEL volumes, inf -> largest finite
+    weight (:46-53), all-inf -> 1e-5/1e-5; on the GPU through rua_tanimoto_sums + rua_tanimoto_ratio, against both CPU
+    restatements and the hand computation of tests/test_oracle_kat.py."""
+    from multitasking_utils import Tanimoto_dual_loss, Tanimoto_loss
+    from oracle import naive_ops as nv
+    rng = np.random.default_rng(4)
+    ids = rng.integers(0, 2, size=(3, 16, 16))
+    y = np.eye(3, dtype=np.float32)[ids]                       # class 2 absent everywhere -> its weight = max finite weight
+    p = rng.uniform(0.05, 0.95, y.shape).astype(np.float32)
+    got = Tanimoto_loss(y, p)
+    assert got.shape == (3,) and np.allclose(got, nv.tanimoto_loss(y, p), rtol=1e-5)
+    v = y.sum(axis=(1, 2)).mean(axis=0)
+    w = np.array([1 / v[0] ** 2, 1 / v[1] ** 2, 0]); w[2] = w[:2].max()
+    sp, ss = (p * y).sum(axis=(1, 2)), (p ** 2 + y ** 2).sum(axis=(1, 2))
+    assert np.allclose(got, ((w * sp).sum(-1) + 1e-5) / ((w * (ss - sp)).sum(-1) + 1e-5), rtol=1e-5)
+    z = np.zeros((2, 8, 8, 3), np.float32)
+    assert np.allclose(Tanimoto_loss(z, z), 1.0)
+    # the dual is built from it exactly as the reference does (:79-84), with the swapped first term
+    dual = 1.0 - 0.5 * (Tanimoto_loss(p, y) + Tanimoto_loss(1 - y, 1 - p))
+    assert np.allclose(Tanimoto_dual_loss()(y, p), dual, rtol=1e-5, atol=1e-6)
+
+
+def test_c_abi_allreduce_bucket_one_rank_and_graph_capture():
+    """rua_comm_* / rua_allreduce_bucket: a C embedder's whole data-parallel surface.  One rank on the test box:
+    the sum over one replica is the identity, issued eagerly and from inside a captured HIP graph (how a whole-step graph
+    would carry it)."""
+    import ctypes
+    from resunet_a_mltsk_keras_amd import _lib as L
+    lib = L.lib()
+    uid = ctypes.create_string_buffer(128)
+    lib.call("rua_comm_unique_id", uid)
+    comm = ctypes.c_void_p()
+    lib.call("rua_comm_init", ctypes.byref(comm), 1, 0, uid)
+    try:
+        g = torch.randn(1 << 20, device="cuda")
+        ref = g.clone()
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            lib.call("rua_allreduce_bucket", comm, g.data_ptr(), g.numel(), ctypes.c_void_p(st.cuda_stream))
+        st.synchronize()
+        assert torch.equal(g, ref)
+        cap = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cap):
+            s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            g.mul_(2.0)
+            lib.call("rua_allreduce_bucket", comm, g.data_ptr(), g.numel(), s)
+        cap.replay(); cap.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref * 4.0)
+    finally:
+        lib.call("rua_comm_destroy", comm)
+
+
 class Args:
     multitasking = True
     gpu_parallel = False
@@ -193,6 +248,83 @@ def test_two_replica_semantics_on_one_gpu():
         e = (p[k].detach() - 0.05 * p[k].grad).numpy()        # first SGD-momentum step: v = -lr*g
         worst = max(worst, float((np.abs(w[k] - e).max() - 1e-6) / (np.abs(e).max() + 1e-6)))
     assert worst < 2e-3, worst
+
+
+def _run_ranks(tmp_path, tag, extra=()):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = tmp_path / tag
+    os.makedirs(out)
+    worker = os.path.join(ROOT, "tests", "_dp_rank_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(out), *extra], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return [np.load(out / f"rank{r}.npz") for r in range(2)]
+
+
+def test_two_process_data_parallel_engine(tmp_path):
+    """Two real ranks (two processes sharing cuda:0, gloo host-staged collectives) against one process playing both
+    MirroredStrategy replicas (train_ISPRS.py:347,432): rank-0 weights broadcast, local BN statistics / Tanimoto volumes,
+    gradients summed / world, BN moving statistics averaged, and the returned metrics replica-aggregated and IDENTICAL on
+    both ranks (reference :280-292 takes one decision from them).  Then resume from a checkpoint under DP (-cp path)."""
+    from resunet_a_mltsk_keras_amd import _lib as L
+    from resunet_a_mltsk_keras_amd.engine import Engine, LossSpec, ModelConfig
+    from resunet_a_mltsk_keras_amd.synthetic import make_batch
+    r0, r1 = _run_ranks(tmp_path, "fresh")
+    assert np.array_equal(r0["res"], r1["res"]) and np.array_equal(r0["ev"], r1["ev"])        # same numbers on every rank
+    assert np.array_equal(r0["P"], r1["P"]) and np.array_equal(r0["S"], r1["S"])              # replicas stay in lock-step
+    # single process emulating the two replicas, from rank 0's initial weights (seed 11)
+    C = 4
+    lw = {h: 1.0 for h in HEADS}
+    eng = Engine(ModelConfig(input_shape=(64, 64, 3), num_classes=C, multitasking=True), dtype="f32", seed=11, split_k=False)
+    eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in HEADS}, weight=lw, optimizer="sgd", lr=0.05, momentum=0.8))
+    x, y = make_batch(4, 64, 3, C, True, seed=21, block=16)
+    shards = [(x[:2], {h: v[:2] for h, v in y.items()}), (x[2:], {h: v[2:] for h, v in y.items()})]
+    exp = []
+    for _ in range(2):
+        S0, Ss, rs = eng.S.clone(), [], []
+        for xs, ys in shards:
+            eng.S.copy_(S0)
+            g = eng.forward_backward(xs, ys)
+            torch.cuda.synchronize()
+            rs.append(eng._results(g)); Ss.append(eng.S.clone())
+        eng.S.copy_((Ss[0] + Ss[1]) / 2)
+        eng.optimizer_step(grad_scale=0.5)
+        rs = np.asarray(rs)
+        exp.append(np.concatenate([rs[:, :6].mean(0), rs[:, 6:].sum(0)]))     # losses + accuracy: mean; TP/FP/TN/FN: summed
+    torch.cuda.synchronize()
+    assert np.allclose(r0["res"], np.asarray(exp), rtol=2e-5, atol=1e-6), (r0["res"], exp)
+    P = eng.P.cpu().numpy()
+    assert np.abs(P - r0["P"]).max() < 1e-5 * max(1.0, np.abs(P).max())
+    assert np.abs(eng.S.cpu().numpy() - r0["S"]).max() < 1e-5
+    ev = [eng.test_step(xs, ys) for xs, ys in shards]
+    ev = np.asarray(ev)
+    assert np.allclose(r0["ev"], np.concatenate([ev[:, :6].mean(0), ev[:, 6:].sum(0)]), rtol=2e-5, atol=1e-6)
+    # resume: only the file is shared; every rank restores it, attaches DP, rank 0's state wins, training continues in step
+    from resunet_a_mltsk_keras_amd import keras_api as ka
+    m = ka.Model(ModelConfig(input_shape=(64, 64, 3), num_classes=C, multitasking=True), dtype="f32", seed=11)
+    m.compile(optimizer=ka.SGD(lr=0.05, momentum=0.8), loss={h: ka.Tanimoto_dual_loss() for h in HEADS}, loss_weights=lw)
+    m.engine.split_k = False
+    m.engine.P.copy_(torch.from_numpy(r0["P"])); m.engine.S.copy_(torch.from_numpy(r0["S"]))
+    m.engine.M1.copy_(torch.from_numpy(r0["M1"])); m.engine.t = int(r0["t"])
+    ck = str(tmp_path / "resume.h5")
+    m.save(ck)
+    q0, q1 = _run_ranks(tmp_path, "resumed", extra=(ck,))
+    assert np.array_equal(q0["res"], q1["res"]) and np.array_equal(q0["P"], q1["P"])
+    assert int(q0["t"]) == int(r0["t"]) + 2
+    assert q0["res"][0][0] < r0["res"][0][0]                   # continues from the trained state, not from a fresh init
 
 
 def test_data_parallel_graph_pieces_match_single_process_step():

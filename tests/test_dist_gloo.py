@@ -62,3 +62,66 @@ def test_bucketed_reducer_two_ranks_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, 5003, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+class _FakeNet:
+    """Keras-Model stand-in whose validation loss would differ per rank if nothing reconciled it."""
+    output_names = ["softmax"]
+
+    def __init__(self, rank):
+        self.rank, self.epoch_calls, self.saved, self.seen = rank, 0, 0, []
+
+    def train_on_batch(self, x, y, return_dict=False, local_shard=False):
+        assert local_shard and x.shape[0] == 2                    # the loader handed over this rank's shard only
+        self.seen.append(float(x[0, 0, 0, 0]))
+        dist.all_reduce(torch.zeros(1))                           # the gradient all-reduce every rank must take part in
+        return [1.0, 0.5, 1, 1, 1, 1]
+
+    def test_on_batch(self, x, y, local_shard=False):
+        # rank 1 sees an ever-improving loss, rank 0 a rising one: rank-local decisions would stop rank 0 alone
+        v = 1.0 + 0.01 * self.epoch_calls if self.rank == 0 else 1.0 / (1 + self.epoch_calls)
+        self.epoch_calls += 1
+        return [v, 0.5, 1, 1, 1, 1]
+
+    def save(self, path):
+        self.saved += 1
+
+
+def _cli_worker(rank, world, port, root, out):
+    import sys
+    import types
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import train_ISPRS as cli
+    xs = [os.path.join(root, "train", f"patch_{i}.npy") for i in range(8)]
+    ys = {"seg": [os.path.join(root, "labels", "seg", f"patch_{i}.npy") for i in range(8)]}
+    args = types.SimpleNamespace(results_path=os.path.join(root, "run"), seed=0, multitasking=False)
+    net = _FakeNet(rank)
+    names = ["loss", "accuracy", "true_positives", "false_positives", "true_negatives", "false_negatives"]
+    ret = cli.train_model(args, net, xs[:4], {"seg": ys["seg"][:4]}, xs[4:], {"seg": ys["seg"][4:]}, 4, 50, None, 3,
+                          patience=3, metrics_names=names, rank=rank, world=world)
+    out[rank] = (ret is net, net.epoch_calls, net.saved, list(net.seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cli_epoch_loop_stops_on_every_rank_together(tmp_path):
+    """the early-stop / best-model decision is ONE decision for all replicas (reference
+    train_ISPRS.py:280-292 under MirroredStrategy).  Two gloo ranks run train_model() to early stop with a model whose
+    validation loss differs per rank; both must leave the loop in the same epoch (a rank that left alone would leave the
+    other one hanging in its next collective and this test would time out)."""
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "train")); os.makedirs(os.path.join(root, "labels", "seg"))
+    for i in range(8):
+        np.save(os.path.join(root, "train", f"patch_{i}.npy"), np.full((4, 4, 3), float(i), np.float32))
+        np.save(os.path.join(root, "labels", "seg", f"patch_{i}.npy"), np.zeros((4, 4, 3), np.float32))
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_cli_worker, args=(world, port, root, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0[0] and r1[0]                                        # both returned through the early-stop branch
+    assert r0[1] == r1[1] == 4                                    # epoch 0 sets the minimum, 3 more without improvement (rank 0's view)
+    assert r0[2] == 1 and r1[2] == 0                              # only rank 0 writes the checkpoint
+    assert len(r0[3]) == len(r1[3]) == 4 and all(a != b for a, b in zip(r0[3], r1[3]))      # each step: disjoint shards of one global batch

@@ -76,3 +76,34 @@ def test_prefetch_loader_reports_missing_file(tmp_path):
             pass
     with pytest.raises(ValueError):
         PrefetchLoader(xs, {"seg": ys["seg"][:-1]}, 4, pin=False)
+
+
+def test_prefetch_loader_shards_the_global_batch(tmp_path):
+    """Data parallel: `batch_size` is the global batch; rank r reads samples [r*B/world, (r+1)*B/world) of every global
+    batch (contiguous split, keras_api.Model._local_batch) and nothing else."""
+    xs, ys = make_dataset(str(tmp_path), n=13)
+    order = list(np.random.default_rng(5).permutation(len(xs)))
+    exp = list(serial_batches(xs, ys, order, 4))
+    opened = []
+    real_load = np.load
+
+    def spy(path, *a, **k):
+        opened.append(str(path))
+        return real_load(path, *a, **k)
+
+    shards = []
+    for r in range(2):
+        ld = PrefetchLoader(xs, ys, 4, order=order, rank=r, world=2, pin=False, workers=1)
+        assert len(ld) == 3 and ld.local_B == 2
+        opened.clear()
+        import unittest.mock as mock
+        with mock.patch.object(np, "load", spy):
+            shards.append([(x.numpy().copy(), {h: t.numpy().copy() for h, t in y.items()}) for x, y in ld])
+        mine = {xs[i] for k in range(3) for i in order[k * 4 + r * 2:k * 4 + r * 2 + 2]}
+        assert {p for p in opened if os.sep + "train" + os.sep in p} == mine          # no other rank's files were read
+    for k, (ex, ey) in enumerate(exp):
+        assert np.array_equal(np.concatenate([shards[0][k][0], shards[1][k][0]]), ex)
+        for h in ey:
+            assert np.array_equal(np.concatenate([shards[0][k][1][h], shards[1][k][1][h]]), ey[h])
+    with pytest.raises(ValueError):
+        PrefetchLoader(xs, ys, 5, rank=0, world=2, pin=False)

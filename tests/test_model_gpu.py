@@ -73,9 +73,13 @@ def check_step(trainer, eng, x, y, mt, tol_loss, tol_logit, tol_grad, tol_w, che
     # gradients, tensor by tensor.  Biases (and BN betas) that feed a 1x1 conv + training-mode BN, or a BN
     # directly, have an exactly-zero true gradient: both sides then hold ~1e-10 rounding noise.
     if check_grads and exact is not None:
-        # Ill-conditioned case (the model.py graph has no identity path, so every gradient passes through chains of
-        # BatchNorm backward passes that cancel most of it): the fp32 ORACLE itself is then ~1e-2 away from the exact
-        # gradient.  Bar: the HIP gradient is as close to the float64 gradient as the fp32 oracle is.
+        # Anchor: the same step evaluated in float64.  Two fp32 evaluations of this graph differ from each other by more
+        # than rounding wherever a ReLU pre-activation sits within ~1e-7 of zero (batch-normalised values; the two sides
+        # sum the statistics in different orders) and, in the model.py graph (no identity path: gradients pass through
+        # chains of cancelling BatchNorm backward passes), by conditioning: the fp32 ORACLE itself is then ~1e-2 away
+        # from the exact gradient.  Bar for every graph variant: the HIP gradient is as close to the float64 gradient as
+        # the fp32 oracle is (median within 2x + 1e-3, no tensor off by 0.5 of its scale, at most 4 % of the tensors
+        # further than tol_grad + 3x the oracle's own distance).
         grads = eng.grads_keras()
         gmax = max(float(np.abs(exact[k]).max()) for k in trainer.order)
         r_hip, r_ref = [], []
@@ -91,30 +95,7 @@ def check_step(trainer, eng, x, y, mt, tol_loss, tol_logit, tol_grad, tol_w, che
         assert r_hip.max() < 0.5
         assert (r_hip > tol_grad + 3.0 * r_ref).sum() <= max(2, len(r_hip) // 25), (r_hip.max(), r_ref.max())
     elif check_grads:
-        grads = eng.grads_keras()
-        gmax = max(float(np.abs(trainer.last_grads[k].numpy()).max()) for k in trainer.order)
-        # A ReLU whose pre-activation is within ~1e-7 of zero can take different sides in two fp32 evaluation
-        # orders; one such flip perturbs one channel's BN-backward sums and shows up (amplified) in that branch's
-        # conv centre tap.  So: every tensor within 0.5, and at most 4% of the tensors above tol_grad.
-        bad, rs = [], []
-        for k in trainer.order:
-            e = trainer.last_grads[k].numpy()
-            if np.abs(e).max() < 1e-5 * gmax:
-                assert np.abs(grads[k]).max() < 1e-4 * gmax, (k, float(np.abs(grads[k]).max()))
-                continue
-            r = float(np.abs(grads[k] - e).max() / np.abs(e).max())
-            assert r < 0.5, (k, r)      # a flip at the 2x2 bottleneck (8 samples per channel) moves a whole kernel row
-            rs.append(r)
-            if r > tol_grad:
-                bad.append((k, r))
-        rs = np.array(rs)
-        if len(bad) > max(2, len(rs) // 25):
-            # A flip in the FIRST ResBlock (its BN statistics come from a different fp32 summation order than the
-            # oracle's: measured, swapping only the summation order of rua_col_stats moves the median error from 6e-6
-            # to 3e-3 with both orders within 4e-7 of the exact variance) reaches every tensor behind it through the
-            # 8-sample BatchNorms of the bottleneck.  The signature of that is a small median with a thin tail; a wrong
-            # kernel gives O(1) errors on whole tensors.  So: median and 90th percentile stay tight.
-            assert np.median(rs) < 5e-3 and np.quantile(rs, 0.9) < 5e-2, (float(np.median(rs)), float(np.quantile(rs, 0.9)), bad[:10])
+        raise AssertionError("check_step: gradient checks are anchored on the float64 oracle - pass exact=exact_grads(...)")
     eng.optimizer_step(1.0)
     torch.cuda.synchronize()
     w = eng.get_weights()
@@ -136,7 +117,8 @@ def test_tiny_multitask_fp32_two_steps(loss, opt):
     trainer, eng = make_pair(shape, C, True, 32, loss, opt, cw=cw)
     for step in range(2):
         x, y = make_batch(2, 64, 3, C, True, seed=11 + step, block=16)
-        check_step(trainer, eng, x, y, True, 1e-3, 1e-3, 5e-3, 2e-3, check_grads=(step == 0))
+        ex = exact_grads(trainer, x, y) if step == 0 else None
+        check_step(trainer, eng, x, y, True, 1e-3, 1e-3, 5e-3, 2e-3, check_grads=(step == 0), exact=ex)
         # the second step starts from the oracle's weights: after a ReLU flip (see check_step) Adam moves the affected
         # elements by +-lr the other way, and the 8-sample BatchNorms turn that into ~3e-3 on the logits
         eng.set_weights({k: v.detach().numpy() for k, v in trainer.params.items()})
@@ -157,7 +139,7 @@ def test_tiny_singletask_fp32_128():
     shape, C = (128, 128, 7), 2
     trainer, eng = make_pair(shape, C, False, 32, "tanimoto")
     x, y = make_batch(2, 128, 7, C, False, seed=5)
-    check_step(trainer, eng, x, y, False, 1e-3, 1e-3, 8e-3, 2e-3)
+    check_step(trainer, eng, x, y, False, 1e-3, 1e-3, 8e-3, 2e-3, exact=exact_grads(trainer, x, y))
 
 
 def test_full_width_block_bf16_close_to_oracle():
@@ -175,22 +157,110 @@ def test_full_width_block_bf16_close_to_oracle():
         assert rel(z, trainer.last_taps[h + "_logits"]) < 8e-2, h
 
 
+_ORACLE_CACHE = {}
+
+
+def oracle_step(name, shape, C, mt, loss, B, seed, cw=None):
+    """One oracle train step per full-size configuration, computed once per test session (20-60 s of host time each) and
+    shared by the tests that compare different HIP storage types against it."""
+    if name not in _ORACLE_CACHE:
+        lw = {"seg": 1.0, "bound": 1.0, "dist": 1.0, "color": 1.0}
+        rcfg = ref.RefConfig(input_shape=shape, num_classes=C, multitasking=mt)
+        params, order = ref.init_params(rcfg, 3)
+        tr = ref.RefTrainer(rcfg, {k: v.clone() for k, v in params.items()}, order,
+                            ref.CompileSpec(loss=loss, class_weights=cw, loss_weights=lw, optimizer="adam", lr=1e-3))
+        x, y = make_batch(B, shape[0], shape[2], C, mt, seed=seed)
+        exp = tr.train_on_batch(x, y)
+        taps = {k: v for k, v in tr.last_taps.items() if k.endswith("logits")}
+        _ORACLE_CACHE[name] = dict(params={k: v.numpy().copy() for k, v in params.items()}, x=x, y=y, exp=exp, taps=taps)
+    return _ORACLE_CACHE[name]
+
+
+def hip_engine(shape, C, mt, loss, dtype, weights, cw=None):
+    eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=mt), dtype=dtype, seed=0, split_k=True)
+    heads = ref.HEADS if mt else ["seg"]
+    if loss == "tanimoto":
+        kind = {h: L.LOSS_TANIMOTO for h in heads}
+    else:
+        kind = {"seg": L.LOSS_WCE, "bound": L.LOSS_BCE_LOGITS, "dist": L.LOSS_MSE, "color": L.LOSS_MSE}
+    eng.compile(LossSpec(kind={h: kind[h] for h in heads}, weight={h: 1.0 for h in heads}, class_weights=cw, optimizer="adam", lr=1e-3))
+    eng.set_weights(weights)
+    return eng
+
+
+def compare_full_size(o, eng, mt, tol_loss, tol_logit):
+    g = eng.forward_backward(o["x"], o["y"])
+    torch.cuda.synchronize()
+    got, exp = eng._results(g), o["exp"]
+    worst = {}
+    for i in range(5 if mt else 1):
+        worst["loss%d" % i] = abs(got[i] - exp[i]) / max(1.0, abs(exp[i]))
+        assert worst["loss%d" % i] <= tol_loss, (i, got[i], exp[i])
+    for h, z in eng.logits(True, o["x"].shape[0]).items():
+        worst[h] = rel(z, o["taps"][(h + "_logits") if mt else "logits"])
+        assert worst[h] < tol_logit, (h, worst[h])
+    print("full-size parity (%s):" % eng.dtype, {k: float("%.3g" % v) for k, v in worst.items()})
+    return got
+
+
+CFG3 = ("cfg3", (256, 256, 6), 6, True, "tanimoto", 2, 1234)
+
+
 def test_cfg3_full_size_fp32_loss_and_logits():
     """BASELINE config 3 at full size (256x256x6, 6 classes, multitask Tanimoto, reference width), batch 2:
     loss and per-head logits within the north-star 1e-3 relative tolerance of the CPU oracle."""
-    shape, C = (256, 256, 6), 6
-    lw = {"seg": 1.0, "bound": 1.0, "dist": 1.0, "color": 1.0}
-    trainer, eng = make_pair(shape, C, True, 32, "tanimoto", lw=lw, split_k=True)
-    x, y = make_batch(2, 256, 6, C, True, seed=1234)
-    exp = trainer.train_on_batch(x, y)
-    g = eng.forward_backward(x, y)
-    torch.cuda.synchronize()
-    got = eng._results(g)
-    for i in range(5):
-        assert abs(got[i] - exp[i]) <= 1e-3 * max(1.0, abs(exp[i])), (i, got[i], exp[i])
-    for h, z in eng.logits(True, 2).items():
-        assert rel(z, trainer.last_taps[h + "_logits"]) < 1e-3, h
+    o = oracle_step(*CFG3)
+    eng = hip_engine((256, 256, 6), 6, True, "tanimoto", "f32", o["params"])
+    compare_full_size(o, eng, True, 1e-3, 1e-3)
     assert eng.count_params() == 42736869
+
+
+def test_cfg3_full_size_bf16_bound_and_trajectory():
+    """The BENCHMARKED storage type at the benchmarked size.  (a) bf16 activations / bf16 weight copies
+    (fp32 master weights, statistics, losses) against the oracle on the same batch-2 step as the fp32 test: loss within
+    2e-2, per-head logits within 6e-2 of their scale.  (b) batch 8 (the bench's), ten Adam steps from the same weights,
+    bf16 against fp32 storage on the HIP path: the loss trajectories stay within 3e-2 of each other at every step and both
+    fall."""
+    o = oracle_step(*CFG3)
+    eng = hip_engine((256, 256, 6), 6, True, "tanimoto", "bf16", o["params"])
+    compare_full_size(o, eng, True, 2e-2, 6e-2)
+    x, y = make_batch(8, 256, 6, 6, True, seed=1234)
+    traj = {}
+    for dtype in ("f32", "bf16"):
+        e = hip_engine((256, 256, 6), 6, True, "tanimoto", dtype, o["params"])
+        traj[dtype] = np.array([e.train_step(x, y)[:5] for _ in range(10)])
+        del e
+        torch.cuda.empty_cache()
+    a, b = traj["f32"], traj["bf16"]
+    dev = np.abs(a - b) / np.maximum(1.0, np.abs(a))
+    print("cfg3 B=8 ten-step trajectory, total loss f32:", np.round(a[:, 0], 4), "bf16:", np.round(b[:, 0], 4), "max dev", float(dev.max()))
+    assert np.all(np.isfinite(b)) and dev.max() < 3e-2, (a[:, 0], b[:, 0])
+    assert a[-1, 0] < a[0, 0] and b[-1, 0] < b[0, 0]
+
+
+def test_cfg2_full_size_single_task_fp32_and_bf16():
+    """BASELINE config 2: ResUnet-a d6 single-task segmentation head (model2.py:144-147), 256x256x6, 6 classes: loss and
+    logits within 1e-3 of the oracle in fp32 storage, within the bf16 bounds of the cfg3 test in bf16 (the configuration's
+    own dtype)."""
+    o = oracle_step("cfg2", (256, 256, 6), 6, False, "tanimoto", 2, 4321)
+    eng = hip_engine((256, 256, 6), 6, False, "tanimoto", "f32", o["params"])
+    compare_full_size(o, eng, False, 1e-3, 1e-3)
+    assert eng.count_params() == 42690134
+    del eng
+    compare_full_size(o, hip_engine((256, 256, 6), 6, False, "tanimoto", "bf16", o["params"]), False, 2e-2, 6e-2)
+
+
+def test_cfg1_hip_fp32_vs_the_cpu_baseline_step():
+    """BASELINE config 1 (256x256x3, 6 classes, single task, bs 4, weighted CE with unit weights, Adam 1e-3) - the very
+    step bench.py's cpu_baseline leg times on the host cores ("parity check on the same run") - on the HIP fp32
+    path: loss and logits within 1e-3, and the metrics the reference prints (train_ISPRS.py:458-461)."""
+    o = oracle_step("cfg1", (256, 256, 3), 6, False, "weighted_cross_entropy", 4, 1234, cw=[1.0] * 6)
+    eng = hip_engine((256, 256, 3), 6, False, "weighted_cross_entropy", "f32", o["params"], cw=[1.0] * 6)
+    got = compare_full_size(o, eng, False, 1e-3, 1e-3)
+    exp = o["exp"]
+    assert abs(got[1] - exp[1]) < 2e-3                                  # accuracy
+    assert sum(got[2:]) == sum(exp[2:]) == 4 * 256 * 256 * 6            # TP+FP+TN+FN = every one-hot element
+    assert all(abs(a - b) <= 1e-3 * sum(exp[2:]) for a, b in zip(got[2:], exp[2:]))
 
 
 def test_graph_replay_equals_eager_launches():
@@ -261,7 +331,7 @@ def test_odd_batch_partial_tiles_fp32():
     shape, C = (64, 64, 3), 4
     trainer, eng = make_pair(shape, C, True, 32, "weighted_cross_entropy", "sgd", cw=[1.0, 2.0, 0.5, 1.5])
     x, y = make_batch(3, 64, 3, C, True, seed=23, block=16)
-    check_step(trainer, eng, x, y, True, 1e-3, 1e-3, 5e-3, 2e-3)
+    check_step(trainer, eng, x, y, True, 1e-3, 1e-3, 5e-3, 2e-3, exact=exact_grads(trainer, x, y))
 
 
 def test_odd_batch_bf16_graph_steps():

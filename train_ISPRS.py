@@ -110,8 +110,24 @@ class ScalarLog:
 
 
 
+def agree_from_rank0(value, world):
+    """Rank 0's value on every rank.  The metrics are already replica-aggregated inside train_on_batch / test_on_batch
+    (identical on all ranks); the stop / save decision still goes through one broadcast per epoch, so that no rank can
+    ever leave the epoch loop while the others wait in the next gradient all-reduce (reference :280-292 takes ONE
+    decision for all replicas)."""
+    if world <= 1:
+        return float(value)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, 0)
+    return float(t.item())
+
+
 def train_model(args, net, x_tr, y_tr, x_va, y_va, batch_size, epochs, x_shape, n_classes, patience=10, delta=0.001,
-                metrics_names=None, rank=0):
+                metrics_names=None, rank=0, world=1):
     say = print if rank == 0 else (lambda *a, **k: None)
     say("Start training...\n" + "=" * 60)
     say(f"Training on {len(x_tr)} images\nValidating on {len(x_va)} images\n" + "=" * 60 + f"\nTotal Epochs: {epochs}")
@@ -120,8 +136,10 @@ def train_model(args, net, x_tr, y_tr, x_va, y_va, batch_size, epochs, x_shape, 
     from resunet_a_mltsk_keras_amd.loader import PrefetchLoader
     # the reference loads 5*B .npy files serially before every step (train_ISPRS.py:115-141); here worker threads read
     # two batches ahead into pinned buffers
-    ld_tr = PrefetchLoader(x_tr, y_tr, batch_size)
-    ld_va = PrefetchLoader(x_va, y_va, batch_size)
+    # under data parallel `batch_size` is the global batch and every rank reads only its own shard of it
+    ld_tr = PrefetchLoader(x_tr, y_tr, batch_size, rank=rank, world=world)
+    ld_va = PrefetchLoader(x_va, y_va, batch_size, rank=rank, world=world)
+    shard = dict(local_shard=True) if world > 1 else {}
     min_loss, cont = float("inf"), 0
     rng = np.random.default_rng(args.seed)
     say(net.output_names)
@@ -130,10 +148,10 @@ def train_model(args, net, x_tr, y_tr, x_va, y_va, batch_size, epochs, x_shape, 
         ld_tr.set_order(rng.permutation(len(x_tr)))
         n_tr, n_va = len(ld_tr), len(ld_va)
         for xb, yb in ld_tr:
-            acc_tr += np.asarray(net.train_on_batch(x=xb, y=yb if args.multitasking else yb["seg"], return_dict=False))
+            acc_tr += np.asarray(net.train_on_batch(x=xb, y=yb if args.multitasking else yb["seg"], return_dict=False, **shard))
         acc_tr /= max(n_tr, 1)
         for xb, yb in ld_va:
-            acc_va += np.asarray(net.test_on_batch(x=xb, y=yb if args.multitasking else yb["seg"]))
+            acc_va += np.asarray(net.test_on_batch(x=xb, y=yb if args.multitasking else yb["seg"], **shard))
         acc_va /= max(n_va, 1)
         tm, vm = dict(zip(metrics_names, acc_tr)), dict(zip(metrics_names, acc_va))
         pre = "seg_" if args.multitasking else ""
@@ -154,7 +172,7 @@ def train_model(args, net, x_tr, y_tr, x_va, y_va, batch_size, epochs, x_shape, 
                 vw.scalar("Segmentation/MCC", mcc, epoch)
                 print(f"| {'Total':8s}{tm['loss']:13.5f}{vm['loss']:13.5f}{0:13d}{0:13d} |\n+{'-' * 62}+")
                 tw.scalar("Total/Loss", tm["loss"], epoch); vw.scalar("Total/Loss", vm["loss"], epoch)
-        val_loss = vm["loss"]
+        val_loss = agree_from_rank0(vm["loss"], world)
         if val_loss >= min_loss + delta:
             cont += 1
             say(f"EarlyStopping counter: {cont} out of {patience}")
@@ -233,13 +251,17 @@ def main(argv=None):
 
     if rank == 0:
         os.makedirs(args.results_path, exist_ok=True)
-    local_bs = args.batch_size // world if world > 1 else args.batch_size
+    if world > 1 and args.batch_size % world:
+        sys.exit(f"-bs {args.batch_size} is the GLOBAL batch and must divide by the {world} replicas")
     x_shape = (args.batch_size, rows, cols, channels)
     t0 = time.time()
     train_model(args, model, x_tr, y_tr, x_va, y_va, args.batch_size, args.epochs, x_shape, args.num_classes,
-                metrics_names=model.metrics_names, rank=rank)
+                metrics_names=model.metrics_names, rank=rank, world=world)
     say(f"\nTraining took: {(time.time() - t0) / 3600} \n")
-    del local_bs
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
