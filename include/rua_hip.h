@@ -75,6 +75,12 @@ typedef struct rua_conv_desc {
                                   the finalize kernels sum the replicas */
   const float* bias_more[3];   /* further [Cout] bias vectors (or NULL) added after `bias`, in this order: the branch-final convs
                                   of a ResBlock run as ONE concatenated conv whose bias is the sum of the branches' biases */
+  /* Normalise on load (model2.py:17-24: BatchNormalization -> ReLU -> Conv2D): segment 0 is read as
+   * [relu](in_scale[c] * x + in_shift[c]) - applied as the tile lands in LDS, zero padding stays zero - so the normalised
+   * copy of the conv input never exists in HBM.  NULL: plain read.  Only where rua_conv_fused_input_ok() says 1. */
+  const float* in_scale;
+  const float* in_shift;
+  int32_t in_relu;
 } rua_conv_desc;
 int rua_conv_fwd(const rua_conv_desc* d, void* stream);
 int rua_conv_smem_bytes(const rua_conv_desc* d);
@@ -90,7 +96,9 @@ int rua_profile_mid_event_fired(void);          /* 1 if the call made since the 
 int rua_conv_last_ksplit(void);                  /* K slices of the calling thread's latest rua_conv_fwd (1: single pass, no finisher) */
 int rua_conv_tile_bn(const rua_conv_desc* d);   /* 32 / 64 / 128 and */
 int rua_conv_kernel_id(const rua_conv_desc* d); /* 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA, bf16), 2: conv_dmap (LDS-DMA, pipelined across the stage barrier),
-                                                   3: conv_halo (input + halo resident in LDS), 4: conv_pw (narrow 1x1, per-wave streaming) */
+                                                   3: conv_halo (input + halo resident in LDS), 4: conv_pw (narrow 1x1, per-wave streaming),
+                                                   5: conv_strip (row-streaming 3x3 at C = Cout = 32, BatchNorm + ReLU applied on load) */
+int rua_conv_fused_input_ok(const rua_conv_desc* d);   /* 1: this shape runs on a kernel that honours in_scale / in_shift / in_relu */
 int rua_conv_tile_bm(const rua_conv_desc* d);   /* 128 / 256: which conv_igemm<T,BM,BN> instantiation a descriptor launches */
 
 /* ---- weight gradient (MFMA, split over pixels, fp32 atomic accumulation) ----------------
@@ -108,6 +116,11 @@ typedef struct rua_wgrad_desc {
                                                (taps 1, C * Cout <= 4096, bf16), whose replica accumulators and ticket counters are the
                                                LAST 264 KiB (16 * 16 KiB + 8 KiB): zero them once before the first call, every call
                                                leaves them zero.  One workspace per concurrently running stream. */
+  /* Normalise on load, as in rua_conv_desc: a is read as [relu](in_scale[c] * a + in_shift[c]), zero padding stays zero.
+   * Only the all-taps kernel honours it (rua_wgrad_kind() == 1); other shapes reject a non-NULL in_scale. */
+  const float* in_scale;
+  const float* in_shift;
+  int32_t in_relu;
 } rua_wgrad_desc;
 int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream);
 int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d);
@@ -165,7 +178,10 @@ int rua_bn_bwd_apply(int nb, const void* const* g, const float* const* coefA, co
 typedef struct rua_bn_branch {
   const float* gamma; const float* beta; float* moving_mean; float* moving_var;   /* [C] */
   float* scale; float* shift; float* mean; float* rstd;                           /* [C] published coefficients */
-  void* out;                                                                      /* [M][C] */
+  void* out;                                                                      /* [M][C]; NULL in EVERY branch: coefficients only
+                                                                                     (one block, nothing applied: the consumer
+                                                                                     normalises on load, rua_conv_desc.in_scale) */
+  const double* stats; int32_t replicas, pad;                                     /* this branch's own statistics (else the shared ones) */
 } rua_bn_branch;
 typedef struct rua_bn_fwd_desc {
   const void* x; int64_t M; int32_t C, dtype, nb, relu, training, replicas;

@@ -25,17 +25,18 @@ class ConvDesc(C.Structure):
                 ("stride", i32), ("dtype", i32), ("bias", vp), ("aux", vp), ("aux_mode", i32), ("mscale", vp),
                 ("mshift", vp), ("out_relu", i32), ("accumulate", i32), ("y", vp), ("out_stride", i32), ("OH", i32),
                 ("OW", i32), ("stats", vp), ("stats_mode", i32), ("workspace", vp), ("workspace_bytes", i64), ("stats_replicas", i32),
-                ("bias_more", vp * 3)]
+                ("bias_more", vp * 3), ("in_scale", vp), ("in_shift", vp), ("in_relu", i32)]
 
 
 class WgradDesc(C.Structure):
     _fields_ = [("a", vp), ("C", i32), ("Hs", i32), ("Ws", i32), ("dy", vp), ("Cout", i32), ("H", i32), ("W", i32),
-                ("N", i32), ("stride", i32), ("dil", i32), ("taps", i32), ("dtype", i32), ("dw", vp), ("workspace", vp), ("workspace_bytes", i64)]
+                ("N", i32), ("stride", i32), ("dil", i32), ("taps", i32), ("dtype", i32), ("dw", vp), ("workspace", vp), ("workspace_bytes", i64),
+                ("in_scale", vp), ("in_shift", vp), ("in_relu", i32)]
 
 
 class BnBranch(C.Structure):
     _fields_ = [("gamma", vp), ("beta", vp), ("moving_mean", vp), ("moving_var", vp), ("scale", vp), ("shift", vp),
-                ("mean", vp), ("rstd", vp), ("out", vp)]
+                ("mean", vp), ("rstd", vp), ("out", vp), ("stats", vp), ("replicas", i32), ("pad", i32)]
 
 
 class BnFwdDesc(C.Structure):
@@ -67,6 +68,7 @@ _SIGS = {
     "rua_conv_tile_bn": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_tile_bm": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_kernel_id": ([C.POINTER(ConvDesc)], i32),
+    "rua_conv_fused_input_ok": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_last_ksplit": ([], i32),
     "rua_profile_mid_event": ([vp], None),
     "rua_profile_mid_event_fired": ([], i32),

@@ -74,9 +74,27 @@ struct RuaTuning {
   int conv_pw_blocks = 0, conv_halo = 1, halo64_maxd = 1, conv_dmap = 1, dmap_target = 0, dmap_fused_finish = 0, dmap_rowb = 64, dmap_bm64 = 1;
   int wgrad_pw = 1, wgpw_blocks = 0, wgpw_r = 0, wgd_blocks = 0, wgrad_dmap = 1, wgd_mintiles = 9, wgrad_blocks = 0;
   int bn_grid = 0, tani_vec = 1, metrics_blocks = 0, stem_blocks = 0, head_blocks = 0;
-  int halo_fuse_bn = 1, halo_group = 1;
+  int conv_strip = 1;
 };
 extern RuaTuning g_tune;
 int rua_cu_count();          // compute units of the current device (queried once per device, cached)
+
+// ---- kernel-side view of a rua_conv_desc (filled by rua_conv_fwd, shared by the conv kernels of conv_mfma.hip / conv_strip.hip)
+struct SegK { const unsigned char* x; const unsigned char* w; int C, Hs, Ws, up, dil, taps, nchunk, ubegin; unsigned xbytes, wbytes; };
+struct ConvK {
+  SegK seg[RUA_MAX_SEG];
+  int nseg, nunits;
+  int N, H, W, Cout, stride;
+  long long M;
+  const float* bias; const float* bias_more[3]; const unsigned char* aux; int aux_mode; const float* mscale; const float* mshift;
+  int out_relu, accumulate; unsigned char* y; int out_stride, OH, OW; double* stats; int stats_mode; int stats_R;
+  int nbn, nbm, ksplit, stages_per_split; float* ws;
+  int* cnt;      // per-tile ticket counters (all zero between launches) for the in-launch split-K reduction, or null
+  const float* in_scale; const float* in_shift; int in_relu;     // per-input-channel affine (+ ReLU) applied to segment 0 on load (conv_strip)
+};
+typedef __attribute__((address_space(3))) void* lds_void_p;
+// conv_strip.hip
+bool rua_pick_strip(const rua_conv_desc* d);
+int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st);
 
 static inline int rua_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

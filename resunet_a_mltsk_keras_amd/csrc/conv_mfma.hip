@@ -10,17 +10,6 @@
 // ReLU-mask from `aux`, per-channel statistics (fp32 partials, fp64 atomics), 16-byte stores.
 #include "common.h"
 
-struct SegK { const unsigned char* x; const unsigned char* w; int C, Hs, Ws, up, dil, taps, nchunk, ubegin; unsigned xbytes, wbytes; };
-struct ConvK {
-  SegK seg[RUA_MAX_SEG];
-  int nseg, nunits;
-  int N, H, W, Cout, stride;
-  long long M;
-  const float* bias; const float* bias_more[3]; const unsigned char* aux; int aux_mode; const float* mscale; const float* mshift;
-  int out_relu, accumulate; unsigned char* y; int out_stride, OH, OW; double* stats; int stats_mode; int stats_R;
-  int nbn, nbm, ksplit, stages_per_split; float* ws;
-  int* cnt;      // per-tile ticket counters (all zero between launches) for the in-launch split-K reduction, or null
-};
 
 template <typename T> __device__ __forceinline__ void load8(const unsigned char* base, size_t elem_off, float* f) {
   if constexpr (sizeof(T) == 2) {
@@ -485,7 +474,6 @@ template <typename T> static void launch_splitk_finish(const ConvK& k, hipStream
 // (destination = wave-uniform base + lane*16); bank conflicts of the ds_read_b128 fragment reads are removed by an
 // XOR swizzle of the 16-byte piece index, slot = piece ^ ((row >> 2) & 3), applied to the per-lane SOURCE address
 // and to the fragment read address (never to the DMA destination).
-typedef __attribute__((address_space(3))) void* lds_void_p;
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_dma(const ConvK p) {
@@ -1604,7 +1592,15 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.stats = d->stats; k.stats_mode = d->stats_mode;
   k.stats_R = d->stats_replicas < 1 ? 1 : d->stats_replicas;
   RUA_CHECK_ARG((k.stats_R & (k.stats_R - 1)) == 0, "rua_conv_fwd: stats_replicas must be a power of two");
+  k.in_scale = d->in_scale; k.in_shift = d->in_shift; k.in_relu = d->in_relu;
   hipStream_t st = (hipStream_t)stream;
+  if (rua_pick_strip(d)) {
+    k.nbn = 1; k.nbm = 1; k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr; k.cnt = nullptr;
+    g_last_ksplit = 1;
+    return rua_launch_conv_strip(k, d, st);
+  }
+  RUA_CHECK_ARG(d->in_scale == nullptr, "rua_conv_fwd: in_scale / in_shift (normalise on load) is not available for this shape: ask "
+                                        "rua_conv_fused_input_ok() first");
   if (pick_halo(d)) {
     k.nbn = 1; k.nbm = 1; k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr; k.cnt = nullptr;
     g_last_ksplit = 1;
@@ -2010,6 +2006,7 @@ struct WgtK {
   int strips, spc, seglen, nchains;        // 64-pixel column strips per row, segments per chain, lattice rows per segment
   int njobs, nworkers, jpw;                // (chain, segment) jobs, pixel groups in the grid, jobs per group
   unsigned abytes, dybytes;
+  const float* in_scale; const float* in_shift; int in_relu;      // a is read as [relu](in_scale * a + in_shift) (zero padding stays zero)
 };
 
 template <int CC>
@@ -2048,6 +2045,14 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
     prel[k] = ((j - d) * CC + q * 8) * 2;
     plds[k] = (i < total) ? j * AROWB + swz(j, q) * 16 : -1;
     pneed[k] = (j < d ? 4 : 0) | (j >= 64 + d ? 8 : 0) | (i < total ? 0 : 16);
+  }
+  // normalise on load: GT is a multiple of PP, so every halo-row piece of this thread holds the same 8 input channels
+  const bool bn = p.in_scale != nullptr;
+  float sc8[8], sh8[8];
+  {
+    const int q = gt % PP;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc8[j] = bn ? p.in_scale[q * 8 + j] : 1.f; sh8[j] = (bn && p.in_shift) ? p.in_shift[q * 8 + j] : 0.f; }
   }
   int drel[DP], dlds[DP];
 #pragma unroll
@@ -2092,13 +2097,18 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
   // lattice row j (relative to i0; j = -1 .. nit) of the conv input -> registers; dy of stage jd (0 .. nit-1) -> registers.
   // TWO register sets: a load has two stages to land (one block per CU: the only latency hiding is this depth)
   uint4 va0[MAXP], vd0[DP], va1[MAXP], vd1[DP];
-  auto load_rows = [&](uint4* va, uint4* vd, int j, int jd) {
+  int vm0 = 0, vm1 = 0;                                  // which pieces of a register set are real pixels (not zero padding)
+  auto load_rows = [&](uint4* va, uint4* vd, int& vm, int j, int jd) {
     const int h = r_ + (i0 + j) * d;
     const bool rowok = nit > 0 && j <= nit && h >= 0 && h < H;
     const int segb = ((n_ * H + h) * W + x0) * CC * 2;
+    vm = 0;
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k)
-      va[k] = bufload16(ra_, (rowok && (pneed[k] & bad_lr) == 0) ? (unsigned)(segb + prel[k]) : RUA_OOB);
+    for (int k = 0; k < MAXP; ++k) {
+      const bool ok = rowok && (pneed[k] & bad_lr) == 0;
+      vm |= ok ? (1 << k) : 0;
+      va[k] = bufload16(ra_, ok ? (unsigned)(segb + prel[k]) : RUA_OOB);
+    }
     const int hd = r_ + (i0 + jd) * d;
     const bool dok = jd >= 0 && jd < nit;
     const int dyb = ((n_ * H + hd) * W + x0) * CC * 2;
@@ -2106,11 +2116,21 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
     for (int k = 0; k < DP; ++k)
       vd[k] = bufload16(rd_, (dok && dlds[k] >= 0) ? (unsigned)(dyb + drel[k]) : RUA_OOB);
   };
-  auto write_rows = [&](const uint4* va, const uint4* vd, int slot, bool with_dy) {
+  auto write_rows = [&](const uint4* va, const uint4* vd, int vm, int slot, bool with_dy) {
     unsigned char* dst = sA + slot * slot_bytes;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k)
-      if (plds[k] >= 0) *reinterpret_cast<uint4*>(dst + plds[k]) = va[k];
+      if (plds[k] >= 0) {
+        uint4 v = va[k];
+        if (bn && ((vm >> k) & 1)) {                     // BatchNorm (+ ReLU) of the conv input as it enters LDS (model2.py:17-24)
+          float f[8];
+          ET<bf16_t>::unpack(v, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { f[j] = fmaf(sc8[j], f[j], sh8[j]); if (p.in_relu) f[j] = fmaxf(f[j], 0.f); }
+          v = ET<bf16_t>::pack(f);
+        }
+        *reinterpret_cast<uint4*>(dst + plds[k]) = v;
+      }
     if (with_dy) {
 #pragma unroll
       for (int k = 0; k < DP; ++k)
@@ -2145,20 +2165,20 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
     __syncthreads();                                     // the previous job's last stage is done with the ring
     // window fill: rows -1 and 0 into slots 0 and 1 (row j lives in slot (j + 1) % 3), both loads in flight together;
     // then set 0 <- (row 1, dy 0), set 1 <- (row 2, dy 1)
-    load_rows(va0, vd0, -1, -1); load_rows(va1, vd1, 0, -1);
-    write_rows(va0, vd0, 0, false); write_rows(va1, vd1, 1, false);
-    load_rows(va0, vd0, 1, 0); load_rows(va1, vd1, 2, 1);
+    load_rows(va0, vd0, vm0, -1, -1); load_rows(va1, vd1, vm1, 0, -1);
+    write_rows(va0, vd0, vm0, 0, false); write_rows(va1, vd1, vm1, 1, false);
+    load_rows(va0, vd0, vm0, 1, 0); load_rows(va1, vd1, vm1, 2, 1);
     for (int it = 0; it < p.seglen; it += 2) {
       __syncthreads();                                   // everyone is done reading slot (it + 2) % 3 (row it - 1) and sD
-      write_rows(va0, vd0, (it + 2) % 3, true);          // row it + 1, dy of stage it
+      write_rows(va0, vd0, vm0, (it + 2) % 3, true);     // row it + 1, dy of stage it
       __syncthreads();
-      load_rows(va0, vd0, it + 3, it + 2);
+      load_rows(va0, vd0, vm0, it + 3, it + 2);
       compute(acc, it);
       if (it + 1 < p.seglen) {
         __syncthreads();
-        write_rows(va1, vd1, (it + 3) % 3, true);        // row it + 2, dy of stage it + 1
+        write_rows(va1, vd1, vm1, (it + 3) % 3, true);   // row it + 2, dy of stage it + 1
         __syncthreads();
-        load_rows(va1, vd1, it + 4, it + 3);
+        load_rows(va1, vd1, vm1, it + 4, it + 3);
         compute(acc, it + 1);
       }
     }
@@ -2234,6 +2254,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   WgtK k;
   k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.scratch = (float*)d->workspace; k.dw = d->dw;
   k.H = d->H; k.W = d->W; k.N = d->N; k.dil = d->dil;
+  k.in_scale = d->in_scale; k.in_shift = d->in_shift; k.in_relu = d->in_relu;
   const long long M = (long long)d->N * d->H * d->W;
   k.halo = 64 + 2 * d->dil;
   k.halo4 = (k.halo + 3) / 4 * 4;
@@ -2619,6 +2640,7 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   RUA_CHECK_ARG(d->C % vec == 0 && d->Cout % vec == 0, "rua_conv_wgrad: C=%d Cout=%d must be multiples of %d", d->C, d->Cout, vec);
   RUA_CHECK_ARG(d->taps == 1 || d->taps == 9, "rua_conv_wgrad: taps must be 1 or 9");
   if (rua_wgrad_kind(d) == 1) return launch_wgrad_taps(d, (hipStream_t)stream);
+  RUA_CHECK_ARG(d->in_scale == nullptr, "rua_conv_wgrad: in_scale / in_shift (normalise on load) needs the all-taps kernel (rua_wgrad_kind() == 1)");
   if (rua_wgrad_kind(d) == 2) return launch_wgrad_dmap(d, (hipStream_t)stream);
   if (rua_wgrad_kind(d) == 3) return launch_wgrad_pw(d, (hipStream_t)stream);
   RUA_CHECK_ARG((long long)(d->H - 1) * d->stride < d->Hs && (long long)(d->W - 1) * d->stride < d->Ws,
@@ -2741,8 +2763,11 @@ extern "C" int rua_conv_tile_bn(const rua_conv_desc* d) {
 }
 // 0: conv_igemm (register-staged), 1: conv_dma (LDS-DMA), 2: conv_dmap (LDS-DMA, pipelined across the stage barrier),
 // 3: conv_halo (input + halo resident in LDS, lattice tiles)
+extern "C" int rua_conv_fused_input_ok(const rua_conv_desc* d) { return (d && rua_pick_strip(d)) ? 1 : 0; }
+
 extern "C" int rua_conv_kernel_id(const rua_conv_desc* d) {
   if (!d) return RUA_ERR_ARG;
+  if (rua_pick_strip(d)) return 5;
   if (pick_halo(d)) return 3;
   if (pick_pw(d)) return 4;
   if (pick_dmap(d)) return 2;

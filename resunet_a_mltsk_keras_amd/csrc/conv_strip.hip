@@ -1,0 +1,344 @@
+// conv_strip<NW>: streaming 3x3 dilated convolution for the top level of the network (C = Cout = 32, bf16): the d6 residual
+// atrous block of the north star (ResBlock(32,[1,3,15,31]) at full resolution, model2.py:102) and its data gradients.
+//
+// Those convolutions move 67-100 MB for 9.7 GFLOP: their floor is the HBM time of ONE read of the input and ONE write of the
+// output.  conv_halo (conv_mfma.hip) reaches the minimum byte count but runs tile by tile - load, wait, compute, transpose,
+// store are serial inside a block - at 2-3 TB/s.  Here a block STREAMS: it owns a strip of SW = 32 * NW pixels of one image
+// and walks down the rows h = r, r + d, r + 2d, ... of one residue class mod d (for those rows the dilated conv is a plain
+// 3x3 conv over a sliding window of three rows), so that
+//   * every input row enters LDS once, by LDS-DMA (HBM -> LDS, no registers), into a ring of R row slots; the DMA of row
+//     i + R - 2 is issued at stage i and waited for with a COUNTED vmcnt at stage i + R - 3: R - 3 rows (40-60 KB per CU)
+//     are in flight all the time, across the one barrier per stage;
+//   * the BatchNorm + ReLU that precedes the conv in the reference graph (model2.py:17-24) is applied as the row lands: the
+//     wave that issued a DMA rewrites its own 16-byte pieces in place (scale * x + shift, ReLU; zero padding stays zero)
+//     before the barrier - the normalised copy of the input is never written to HBM;
+//   * the MFMA runs the TRANSPOSED product D^T[co][px] = W[co][k] * X^T[k][px] (weights = a-operand, in registers for the
+//     whole kernel; pixels = b-operand, one ds_read_b128 per tap and k-step), so an accumulator holds 4-channel groups of ONE
+//     pixel per lane and one 32-lane exchange per register pair gives 8-channel pieces: bias, mask / residual / accumulate,
+//     ReLU, statistics and the 16-byte stores happen in registers, no LDS round trip and no second barrier;
+//   * the tensor the epilogue needs per pixel (ReLU-mask source of a data gradient, residual, or the old output when
+//     accumulating) streams through a second LDS ring the same way.
+// Every vector-memory operation of the loop is either an LDS-DMA or a store, issued unconditionally by every wave, so the
+// counted waits are exact (loads, stores and LDS-DMA retire in issue order on one counter: MI355X_MICROARCH.md).
+#include "common.h"
+
+struct StripK {
+  ConvK c;
+  const unsigned char* ep;                // epilogue stream: aux (aux_mode 1 / 2) or the old output (accumulate); null: none
+  unsigned epbytes;
+  int d, strips, spc, seglen, njobs, nchains;
+  int slot_bytes, SWH;                    // bytes of one x-ring slot (multiple of 1024), pixels per slot row (SW + 2 d)
+};
+
+template <int NW, bool HAS_EP, int R>
+__global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) {
+  typedef bf16_t T;
+  constexpr int C = 32, NT = NW * 64, SW = NW * 32;
+  constexpr int NPX = 3, NPA = HAS_EP ? 2 : 0, RA = 3, NST = 2;
+  constexpr int PER = NPX + NPA + NST;
+  // ops issued after the youngest DMA a stage needs: x(i+1) was issued at stage i - (R - 3), ep(i) at stage i - (RA - 2)
+  constexpr int NWX = NPA + NST + (R - 4) * PER, NWE = NST + (RA - 2) * PER;
+  constexpr int NWAIT = HAS_EP ? (NWX < NWE ? NWX : NWE) : NWX;
+  constexpr int EP_SLOT = SW * 64;
+  constexpr unsigned OOB = 0x80000000u;
+  const ConvK& p = q.c;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sEP = smem + R * q.slot_bytes;
+  unsigned char* sDump = sEP + (HAS_EP ? RA * EP_SLOT : 0);
+  float* tab = reinterpret_cast<float*>(sDump + NW * 1024);         // [3][32]: bias sum, mask scale, mask shift
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int pl = lane & 31, kh = lane >> 5;
+  const int H = p.H, W = p.W, d = q.d;
+
+  // ---- job: (image, strip, residue class, segment of the chain) ------------------------------------------------------
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int job = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);     // neighbours in a chain share an XCD's L2
+  const int chain = job / q.spc, seg = job - chain * q.spc;
+  const int r_ = chain % d, tq = chain / d;
+  const int x0 = (tq % q.strips) * SW, n_ = tq / q.strips;
+  const int ny = (H - r_ + d - 1) / d;
+  const int i0 = seg * q.seglen;
+  int nit = ny - i0; if (nit > q.seglen) nit = q.seglen; if (nit < 0) nit = 0;
+
+  // ---- per-thread constants --------------------------------------------------------------------------------------------
+  if (tid < 32) {
+    float b = 0.f, ms = 1.f, mt = 0.f;
+    if (p.bias) { b = p.bias[tid]; for (int r = 0; r < 3; ++r) if (p.bias_more[r]) b += p.bias_more[r][tid]; }
+    if (p.aux_mode == 2) { if (p.mscale) ms = p.mscale[tid]; if (p.mshift) mt = p.mshift[tid]; }
+    tab[tid] = b; tab[32 + tid] = ms; tab[64 + tid] = mt;
+  }
+  // weights: a-operand row = output channel pl, k-slice = input channels ks * 16 + kh * 8 .. + 8, all nine taps
+  bf16x8 wf[9][2];
+  {
+    const unsigned char* wl = p.seg[0].w + ((size_t)pl * C + kh * 8) * 2;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const bf16x8*>(wl + ((size_t)t * C * C + ks * 16) * 2);
+  }
+  // the 16-byte piece this lane moves in every DMA instruction holds input channels psrc * 8 .. + 8 (slot = piece ^ ((pixel >> 1) & 3):
+  // conflict-free ds_read_b128 of the b-operand; the permutation is applied on the SOURCE side, the LDS image is lane-linear)
+  const int psrc = (lane & 3) ^ ((lane >> 3) & 3);
+  const bool bn = p.in_scale != nullptr;
+  float sc8[8], sh8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc8[j] = bn ? p.in_scale[psrc * 8 + j] : 1.f; sh8[j] = (bn && p.in_shift) ? p.in_shift[psrc * 8 + j] : 0.f; }
+  // all ordinary loads are consumed HERE, before the first LDS-DMA is issued (hipcc waits vmcnt(0) at the first use of a
+  // pending load: inside the loop that would drain the DMA ring)
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(wf[t][ks]));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(sc8[j]), "+v"(sh8[j]));
+  __syncthreads();                                      // tab
+
+  unsigned xrel[NPX]; int xdst[NPX]; bool xok[NPX];
+#pragma unroll
+  for (int k = 0; k < NPX; ++k) {
+    const int inst = k * NW + wv;                       // wave-instruction index inside the slot: 1 KiB = 16 pixels each
+    const int j = inst * 16 + (lane >> 2);              // pixel of the slot row (0 .. SWH-1), image column x0 - d + j
+    const int x = x0 - d + j;
+    const bool in_slot = inst * 1024 < q.slot_bytes;    // wave-uniform
+    xdst[k] = in_slot ? inst * 1024 : -1;               // -1: the instruction still issues (uniform op counts) into the wave's dump KiB
+    xok[k] = in_slot && j < q.SWH && x >= 0 && x < W;
+    xrel[k] = (unsigned)((x * C + psrc * 8) * 2);
+  }
+  unsigned erel[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) erel[k] = (unsigned)(((x0 + (k * NW + wv) * 16 + (lane >> 2)) * C + psrc * 8) * 2);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.seg[0].x, p.seg[0].xbytes);
+  const __amdgpu_buffer_rsrc_t re = make_rsrc(HAS_EP ? q.ep : p.seg[0].x, HAS_EP ? q.epbytes : 0u);
+
+  auto row_ok = [&](int rho) { const int h = r_ + (i0 + rho) * d; return rho <= nit && h >= 0 && h < H; };
+  auto x_slot = [&](int rho) { return smem + ((rho + 1 + R) % R) * q.slot_bytes; };        // rho >= -1
+  auto issue_x = [&](int rho) {
+    const bool ok = row_ok(rho);
+    const unsigned base = (unsigned)(((n_ * H + r_ + (i0 + rho) * d) * W) * C * 2);
+    unsigned char* slot = x_slot(rho);
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      unsigned char* dst = xdst[k] >= 0 ? slot + xdst[k] : sDump + wv * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)dst, 16, (unsigned)((ok && xok[k]) ? base + xrel[k] : OOB), 0, 0, 0);
+    }
+  };
+  auto issue_ep = [&](int e) {
+    if constexpr (HAS_EP) {
+      const bool ok = e < nit;
+      const unsigned base = (unsigned)(((n_ * H + r_ + (i0 + e) * d) * W) * C * 2);
+      unsigned char* slot = sEP + (e % RA) * EP_SLOT;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (lds_void_p)(slot + (k * NW + wv) * 1024), 16, (unsigned)(ok ? base + erel[k] : OOB), 0, 0, 0);
+    }
+  };
+  // BatchNorm (+ ReLU) of a landed row, in place, on the pieces this thread's own DMA instructions wrote (padding stays zero)
+  auto transform = [&](int rho) {
+    if (!row_ok(rho)) return;
+    unsigned char* slot = x_slot(rho);
+#pragma unroll
+    for (int k = 0; k < NPX; ++k)
+      if (xok[k]) {
+        uint4* ptr = reinterpret_cast<uint4*>(slot + xdst[k] + lane * 16);
+        float f[8];
+        ET<T>::unpack(*ptr, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { f[j] = fmaf(sc8[j], f[j], sh8[j]); if (p.in_relu) f[j] = fmaxf(f[j], 0.f); }
+        // raw write: hipcc orders a C++ LDS store behind every LDS-DMA in flight (s_waitcnt vmcnt(0): the ring would drain at
+        // every stage); this piece's own DMA has landed (counted wait above) and nobody else touches it before the barrier
+        const uint4 pk = ET<T>::pack(f);
+        const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
+        const unsigned la = (unsigned)(size_t)(lds_void_p)reinterpret_cast<unsigned char*>(ptr);
+        asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(pv) : "memory");
+      }
+  };
+
+  // b-operand fragment offsets inside a slot row: output pixel o = wv * 32 + pl, tap column tx reads slot pixel o + tx * d
+  const int o = wv * 32 + pl;
+  int boff[3][2];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) {
+    const int j = o + tx * d;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) boff[tx][ks] = j * 64 + (((ks * 2 + kh) ^ ((j >> 1) & 3)) * 16);
+  }
+  int eoff[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) eoff[g] = o * 64 + (((2 * g + kh) ^ ((o >> 1) & 3)) * 16);
+
+  float s1[2][8], s2[2][8];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[g][j] = 0.f; s2[g][j] = 0.f; }
+
+  // ---- prologue: rows -1 .. R-3 and the first RA-1 epilogue rows in flight, then everything landed ------------------------
+#pragma unroll
+  for (int rho = -1; rho <= R - 3; ++rho) issue_x(rho);
+#pragma unroll
+  for (int e = 0; e < RA - 1; ++e) issue_ep(e);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (bn) { transform(-1); transform(0); }
+
+  for (int i = 0; i < nit; ++i) {
+    if (i > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");       // row i + 1 and epilogue row i have landed (mine)
+    if (bn) transform(i + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // everyone's; and every wave is done with stage i - 1
+    issue_x(i + R - 2);                                  // into the slot of row i - 2
+    issue_ep(i + RA - 1);                                // into the slot of epilogue row i - 1
+
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    // the six fragments of window row ty + 1 are read while the six MFMAs of row ty execute (left alone, hipcc reads one
+    // fragment, waits for it, issues one MFMA: the LDS latency 18 times per stage)
+    bf16x8 fx[2][3][2];
+    auto read_row = [&](int ty, bf16x8 (*f)[2]) {
+      const unsigned char* row = x_slot(i - 1 + ty);
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) f[tx][ks] = *reinterpret_cast<const bf16x8*>(row + boff[tx][ks]);
+    };
+    read_row(0, fx[0]);
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      if (ty < 2) read_row(ty + 1, fx[(ty + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ty * 3 + tx][ks], fx[ty & 1][tx][ks], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // acc[r]: channel (r & 3) + 8 * (r >> 2) + 4 * kh of pixel pl; one half-wave exchange per register pair -> this lane holds
+    // channels 16 g + 8 kh .. + 7 of its pixel (see conv_pw)
+    float v[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = acc[(2 * g) * 4 + j], b = acc[(2 * g + 1) * 4 + j];
+        if (g == 0 && j == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        else asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v[g][j] = a;
+        v[g][4 + j] = b;
+      }
+    const int h = r_ + (i0 + i) * d;
+    unsigned char* yrow = p.y + ((size_t)((n_ * H + h) * W + x0 + o) * C) * 2;
+    const unsigned char* erow = sEP + (i % RA) * EP_SLOT;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int co = 16 * g + 8 * kh;
+      float a8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[g][j] += tab[co + j];
+      if constexpr (HAS_EP) {
+        ET<T>::unpack(*reinterpret_cast<const uint4*>(erow + eoff[g]), a8);
+        if (p.aux_mode == 0) {                            // the stream is the old output: accumulate
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[g][j] += a8[j];
+        } else if (p.aux_mode == 1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[g][j] += a8[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[g][j] = (fmaf(tab[32 + co + j], a8[j], tab[64 + co + j]) > 0.f) ? v[g][j] : 0.f;
+        }
+      }
+      if (p.out_relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[g][j] = fmaxf(v[g][j], 0.f);
+      }
+      const uint4 packed = ET<T>::pack(v[g]);
+      if (p.stats_mode == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], v[g][j], s2[g][j]); }
+      } else if (p.stats_mode == 2) {
+        if constexpr (HAS_EP) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], a8[j], s2[g][j]); }
+        }
+      }
+      stg16(yrow + co * 2, packed);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");       // the over-issued DMAs of the last stages
+  if (p.stats_mode != 0) {
+    __syncthreads();
+    float* sred = reinterpret_cast<float*>(smem);       // the ring is dead: [wave][channel][2]
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        for (int of = 1; of < 32; of <<= 1) { s1[g][j] += __shfl_xor(s1[g][j], of, 64); s2[g][j] += __shfl_xor(s2[g][j], of, 64); }
+    if (pl == 0) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sred[wv * 64 + (16 * g + 8 * kh + j) * 2] = s1[g][j]; sred[wv * 64 + (16 * g + 8 * kh + j) * 2 + 1] = s2[g][j]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int c = tid >> 1, k = tid & 1;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += sred[w * 64 + tid];
+      unsafeAtomicAdd(&p.stats[(size_t)(job & (p.stats_R - 1)) * 2 * C + k * C + c], (double)t);
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+static int strip_width(const rua_conv_desc* d) { return d->W % 256 == 0 ? 256 : (d->W % 128 == 0 ? 128 : 0); }
+
+bool rua_pick_strip(const rua_conv_desc* d) {
+  if (!g_tune.conv_strip || d->dtype != RUA_BF16 || d->nseg != 1) return false;
+  const rua_conv_seg& g = d->seg[0];
+  const int sw = strip_width(d);
+  if (!(g.taps == 9 && g.up_shift == 0 && g.C == 32 && d->Cout == 32 && d->stride == 1 && d->out_stride == 1 && d->OH == d->H &&
+        d->OW == d->W && g.Hs == d->H && g.Ws == d->W && sw != 0 && g.dil >= 1 && g.dil <= 31 && g.dil < d->H)) return false;
+  if ((long long)d->N * d->H * d->W < 65536) return false;
+  if (d->aux_mode == 3 || (d->aux_mode != 0 && d->accumulate)) return false;      // one epilogue stream
+  if (d->stats_mode == 2 && d->aux_mode == 0) return false;
+  return true;
+}
+
+template <int NW, bool HAS_EP, int R> static int launch_strip(const StripK& q, int smem, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32<NW, HAS_EP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((conv_strip32<NW, HAS_EP, R>), dim3(q.njobs), dim3(NW * 64), smem, st, q);
+  RUA_LAUNCH_CHECK("conv_strip32");
+  return RUA_OK;
+}
+
+int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st) {
+  StripK q;
+  q.c = k;
+  const int sw = strip_width(d), nw = sw / 32, dil = d->seg[0].dil;
+  const bool has_ep = d->aux_mode != 0 || d->accumulate;
+  q.ep = has_ep ? (d->aux_mode != 0 ? (const unsigned char*)d->aux : (const unsigned char*)d->y) : nullptr;
+  q.epbytes = (unsigned)((size_t)k.M * 32 * 2);
+  q.d = dil;
+  q.strips = d->W / sw;
+  q.SWH = sw + 2 * dil;
+  q.slot_bytes = (q.SWH * 64 + 1023) / 1024 * 1024;
+  RUA_CHECK_ARG(q.slot_bytes <= 3 * nw * 1024, "conv_strip: dilation %d too large for a %d-pixel strip", dil, sw);
+  q.nchains = d->N * q.strips * dil;
+  const int ny = (d->H + dil - 1) / dil;               // lattice rows of the longest chain
+  int spc = rua_cu_count() / q.nchains;                // one round of blocks where the chains allow it
+  if (spc < 1) spc = 1;
+  if (spc > (ny + 3) / 4) spc = (ny + 3) / 4;          // >= 4 rows per segment (a segment re-reads two window rows)
+  if (spc < 1) spc = 1;
+  q.seglen = (ny + spc - 1) / spc;
+  q.spc = (ny + q.seglen - 1) / q.seglen;
+  q.njobs = q.nchains * q.spc;
+  const int R = has_ep ? 5 : 7;
+  const int smem = R * q.slot_bytes + (has_ep ? 3 * sw * 64 : 0) + nw * 1024 + 3 * 32 * 4;
+  RUA_CHECK_ARG(smem <= 160 * 1024, "conv_strip: %d bytes of LDS", smem);
+  if (nw == 8) return has_ep ? launch_strip<8, true, 5>(q, smem, st) : launch_strip<8, false, 7>(q, smem, st);
+  return has_ep ? launch_strip<4, true, 5>(q, smem, st) : launch_strip<4, false, 7>(q, smem, st);
+}

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, lo
   float* mr = tab + p.nb * 2 * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     double mean, var;
-    if (p.training) {
+    if (p.training && p.stats) {
       double s1, s2;
       replica_sum(p.stats, p.replicas, C, c, s1, s2);
       mean = s1 / p.count;
@@ -398,6 +398,13 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, lo
     for (int b = 0; b < p.nb; ++b) {
       const rua_bn_branch& br = p.br[b];
       double m = mean, v = var;
+      if (p.training && br.stats) {                    // this branch normalises its own tensor (coefficient-only launches)
+        double s1, s2;
+        replica_sum(br.stats, br.replicas, C, c, s1, s2);
+        m = s1 / p.count;
+        v = s2 / p.count - m * m;
+        if (v < 0) v = 0;
+      }
       if (!p.training) { m = br.moving_mean[c]; v = br.moving_var[c]; }
       const double r = 1.0 / sqrt(v + (double)p.eps);
       const double sc = (double)br.gamma[c] * r;
@@ -417,6 +424,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, lo
     (void)mr;
   }
   __syncthreads();
+  if (p.br[0].out == nullptr) return;                  // coefficients only
   const unsigned char* x = (const unsigned char*)p.x;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += stride) {
@@ -436,14 +444,18 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, lo
 }
 
 extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream) {
-  RUA_CHECK_ARG(d && d->x && d->nb >= 1 && d->nb <= RUA_MAX_BRANCH && d->M > 0 && d->C > 0, "rua_bn_fwd: bad arguments");
+  RUA_CHECK_ARG(d && d->nb >= 1 && d->nb <= RUA_MAX_BRANCH && d->M > 0 && d->C > 0, "rua_bn_fwd: bad arguments");
+  const bool coef_only = d->br[0].out == nullptr;
+  RUA_CHECK_ARG(coef_only || d->x, "rua_bn_fwd: null input");
   RUA_CHECK_ARG(d->dtype == RUA_F32 || d->dtype == RUA_BF16, "rua_bn_fwd: bad dtype");
   const int vec = d->dtype == RUA_BF16 ? 8 : 4;
   RUA_CHECK_ARG(d->C % vec == 0, "rua_bn_fwd: C=%d not a multiple of %d", d->C, vec);
-  RUA_CHECK_ARG(!d->training || (d->stats && d->count > 0 && d->replicas >= 1), "rua_bn_fwd: training needs statistics");
+  RUA_CHECK_ARG(!d->training || d->count > 0, "rua_bn_fwd: training needs the element count");
   for (int b = 0; b < d->nb; ++b) {
     const rua_bn_branch& br = d->br[b];
-    RUA_CHECK_ARG(br.gamma && br.beta && br.scale && br.shift && br.out, "rua_bn_fwd: null branch pointer");
+    RUA_CHECK_ARG(br.gamma && br.beta && br.scale && br.shift, "rua_bn_fwd: null branch pointer");
+    RUA_CHECK_ARG((br.out == nullptr) == coef_only, "rua_bn_fwd: either every branch has an output or none (coefficients only)");
+    RUA_CHECK_ARG(!d->training || (br.stats ? br.replicas >= 1 : (d->stats && d->replicas >= 1)), "rua_bn_fwd: training needs statistics");
     RUA_CHECK_ARG(d->training || (br.moving_mean && br.moving_var), "rua_bn_fwd: inference needs moving statistics");
   }
   const size_t smem = (size_t)(d->nb * 2 + 2) * d->C * 4;
@@ -453,6 +465,7 @@ extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream) {
   int g = grid_for(pieces);
   const int cap = g_tune.bn_grid > 0 ? g_tune.bn_grid : 2 * rua_cu_count();      // 512 on MI355X
   if ((long long)d->replicas * d->C >= 512 && g > cap) g = cap;      // the prologue re-reads replicas*C*2 doubles per block
+  if (coef_only) g = 1;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == RUA_BF16) hipLaunchKernelGGL((bn_fwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, *d, pieces, CG);
   else hipLaunchKernelGGL((bn_fwd_kernel<float>), dim3(g), dim3(256), smem, st, *d, pieces, CG);

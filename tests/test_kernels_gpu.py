@@ -732,12 +732,138 @@ def test_conv_halo_lattice_tiles(H, W, dil, Cs, mode):
         exp = (conv + rnd(dt, y0).double().numpy()) * ((a * sc + sh) > 0)
         s2 = (exp * a).sum(axis=(0, 1, 2))
     # (C = 64 takes conv_halo only at d = 1 by default, where it wins; RUA_HALO64_MAXD=31 routes the other dilations through it)
+    # C = 32 with a row that splits into 128 / 256-pixel strips and one epilogue stream goes to conv_strip (its own test below)
+    strip = Cs == 32 and W % 128 == 0 and mode == "residual_stats"
     if Cs == 32 or dil == 1:
+        assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == (5 if strip else 3)
+    if strip:
+        lib.set_tuning(conv_strip=0)                             # this test is about conv_halo: route the shape back to it
         assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 3
-    lib.call("rua_conv_fwd", C.byref(d), stream())
+    try:
+        lib.call("rua_conv_fwd", C.byref(d), stream())
+    finally:
+        lib.set_tuning(conv_strip=1)
     torch.cuda.synchronize()
     got = y.float().cpu().numpy()
     assert rel_err(got, exp) < tol(dt)
     st = stats.cpu().numpy().reshape(R, 2 * Cout).sum(0)
     assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
     assert rel_err(st[Cout:], s2) < 5 * tol(dt) + 1e-4
+
+
+STRIP_CASES = [
+    # N, H, W, dil  (C = Cout = 32; W % 256 == 0: 8-wave blocks; W % 128 == 0: 4-wave blocks; ragged H: residue classes of unequal size)
+    (1, 256, 256, 1), (1, 256, 256, 3), (1, 256, 256, 15), (1, 256, 256, 31), (4, 128, 128, 3), (4, 128, 128, 31),
+    (1, 200, 512, 15), (2, 190, 384, 1), (1, 257, 256, 3),
+]
+
+
+@pytest.mark.parametrize("mode", ["bn_plain_stats", "bn_residual", "mask_stats2", "bn_accumulate_relu", "plain"])
+@pytest.mark.parametrize("N,H,W,dil", STRIP_CASES)
+def test_conv_strip_streaming_kernel(N, H, W, dil, mode):
+    """conv_strip (C = Cout = 32, bf16): rows streamed through an LDS ring by LDS-DMA with counted waits, BatchNorm + ReLU of
+    the input applied as a row lands (zero padding must stay zero: model2.py:17-24 pads AFTER the activation), transposed
+    MFMA product with the epilogue in registers, the epilogue's per-pixel tensor (residual / ReLU-mask source / old output)
+    through a second ring.  Every dilation of the reference's ResBlocks, one- and two-strip rows, ragged heights, chains cut
+    into segments, and every epilogue family, against a float64 convolution of the bf16-rounded operands."""
+    dt = L.RUA_BF16
+    rng = np.random.default_rng(1000 * dil + H + len(mode))
+    lib = L.lib()
+    Cs = Cout = 32
+    x = rng.standard_normal((N, H, W, Cs)).astype(np.float32)
+    w = (rng.standard_normal((9, Cout, Cs)) / np.sqrt(9 * Cs)).astype(np.float32)
+    aux = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    y0 = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    isc = (0.5 + rng.random(Cs)).astype(np.float32); ish = (0.4 * rng.standard_normal(Cs)).astype(np.float32)
+    msc = (0.5 + rng.random(Cout)).astype(np.float32); msh = (0.3 * rng.standard_normal(Cout)).astype(np.float32)
+    xd, wd, ad, bd = to_dev(x, dt), to_dev(w, dt), to_dev(aux, dt), torch.from_numpy(bias).to(dev())
+    iscd, ishd, mscd, mshd = (torch.from_numpy(a).to(dev()) for a in (isc, ish, msc, msh))
+    y = to_dev(y0, dt)
+    R = 8
+    stats = torch.zeros(R * 2 * Cout, dtype=torch.float64, device=dev())
+    d = L.ConvDesc()
+    d.nseg = 1
+    s = d.seg[0]
+    s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = xd.data_ptr(), wd.data_ptr(), Cs, H, W, 0, dil, 9
+    d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cout, 1, dt
+    d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+    d.stats, d.stats_replicas = stats.data_ptr(), R
+    xin = rnd(dt, x)
+    if mode.startswith("bn"):
+        d.in_scale, d.in_shift, d.in_relu = iscd.data_ptr(), ishd.data_ptr(), 1
+        xin = torch.relu(xin * torch.from_numpy(isc) + torch.from_numpy(ish)).to(torch.bfloat16).float()       # what lands in LDS
+    conv = ref_conv_nhwc(xin, rnd(dt, w), None, dil, 9).numpy()
+    a = rnd(dt, aux).double().numpy()
+    s2 = None
+    if mode == "bn_plain_stats":
+        d.bias, d.stats_mode = bd.data_ptr(), 1
+        exp = conv + bias.astype(np.float64)
+        s2 = (exp ** 2).sum(axis=(0, 1, 2))
+    elif mode == "bn_residual":
+        d.bias, d.aux, d.aux_mode, d.stats_mode = bd.data_ptr(), ad.data_ptr(), 1, 1
+        exp = conv + bias.astype(np.float64) + a
+        s2 = (exp ** 2).sum(axis=(0, 1, 2))
+    elif mode == "mask_stats2":
+        d.aux, d.aux_mode, d.mscale, d.mshift, d.stats_mode = ad.data_ptr(), 2, mscd.data_ptr(), mshd.data_ptr(), 2
+        exp = conv * ((a * msc + msh) > 0)
+        s2 = (exp * a).sum(axis=(0, 1, 2))
+    elif mode == "bn_accumulate_relu":
+        d.bias, d.accumulate, d.out_relu = bd.data_ptr(), 1, 1
+        exp = np.maximum(conv + bias.astype(np.float64) + rnd(dt, y0).double().numpy(), 0.0)
+    else:
+        exp = conv
+    assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 5 and lib.raw("rua_conv_fused_input_ok")(C.byref(d)) == 1
+    lib.call("rua_conv_fwd", C.byref(d), stream())
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy()
+    assert rel_err(got, exp) < tol(dt), rel_err(got, exp)
+    if s2 is not None:
+        st = stats.cpu().numpy().reshape(R, 2 * Cout).sum(0)
+        assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
+        assert rel_err(st[Cout:], s2) < 5 * tol(dt) + 1e-4
+    # a shape no fused-input kernel serves must refuse the request instead of ignoring it
+    d.Cout = 64
+    assert lib.raw("rua_conv_fused_input_ok")(C.byref(d)) == 0
+
+
+@pytest.mark.parametrize("Cs,H,W,dil", [(32, 256, 256, 1), (32, 256, 256, 31), (64, 128, 128, 3), (32, 136, 192, 15)])
+def test_wgrad_all_taps_normalise_on_load(Cs, H, W, dil):
+    """rua_conv_wgrad with in_scale / in_shift / in_relu (all-taps kernel of the two top levels): the conv input is
+    BatchNorm'ed + ReLU'ed as it enters LDS, so the weight gradient equals the one taken against the materialised
+    activation relu(scale * a + shift) - with the zero padding left at zero."""
+    dt = L.RUA_BF16
+    rng = np.random.default_rng(Cs + dil)
+    lib = L.lib()
+    N = 2
+    a = rng.standard_normal((N, H, W, Cs)).astype(np.float32)
+    dy = rng.standard_normal((N, H, W, Cs)).astype(np.float32)
+    sc = (0.5 + rng.random(Cs)).astype(np.float32); sh = (0.4 * rng.standard_normal(Cs)).astype(np.float32)
+    ad, dyd = to_dev(a, dt), to_dev(dy, dt)
+    scd, shd = torch.from_numpy(sc).to(dev()), torch.from_numpy(sh).to(dev())
+    act = torch.relu(rnd(dt, a) * torch.from_numpy(sc) + torch.from_numpy(sh)).to(torch.bfloat16).float()
+    actd = act.to(dev()).to(torch.bfloat16).contiguous()
+    d = L.WgradDesc()
+    d.C, d.Hs, d.Ws, d.dy, d.Cout, d.H, d.W = Cs, H, W, dyd.data_ptr(), Cs, H, W
+    d.N, d.stride, d.dil, d.taps, d.dtype = N, 1, dil, 9, dt
+    nb = lib.raw("rua_wgrad_workspace_bytes")(C.byref(d))
+    ws = torch.zeros(max(nb // 4, 16) + (264 << 8), dtype=torch.float32, device=dev())
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    assert lib.raw("rua_wgrad_kind")(C.byref(d)) == 1
+    outs = []
+    for fused in (True, False):
+        dw = torch.zeros(9 * Cs * Cs, dtype=torch.float32, device=dev())
+        d.dw = dw.data_ptr()
+        if fused:
+            d.a, d.in_scale, d.in_shift, d.in_relu = ad.data_ptr(), scd.data_ptr(), shd.data_ptr(), 1
+        else:
+            d.a, d.in_scale, d.in_shift, d.in_relu = actd.data_ptr(), None, None, 0
+        lib.call("rua_conv_wgrad", C.byref(d), stream())
+        torch.cuda.synchronize()
+        outs.append(dw.cpu().numpy())
+    # the same operands up to the rounding of one fused multiply-add (kernel) vs multiply then add (host) before the bf16 cast
+    assert rel_err(outs[0], outs[1]) < 2e-3
+    at = act.permute(0, 3, 1, 2).double()
+    g = torch.nn.grad.conv2d_weight(at, (Cs, Cs, 3, 3), rnd(dt, dy).permute(0, 3, 1, 2).double(), padding=dil, dilation=dil)
+    exp = g.permute(2, 3, 0, 1).reshape(9, Cs, Cs).numpy()
+    assert rel_err(outs[0].reshape(9, Cs, Cs), exp) < tol(dt)
