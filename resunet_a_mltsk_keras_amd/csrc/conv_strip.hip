@@ -78,9 +78,10 @@ __global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const bf16x8*>(wl + ((size_t)t * C * C + ks * 16) * 2);
   }
-  // the 16-byte piece this lane moves in every DMA instruction holds input channels psrc * 8 .. + 8 (slot = piece ^ ((pixel >> 1) & 3):
-  // conflict-free ds_read_b128 of the b-operand; the permutation is applied on the SOURCE side, the LDS image is lane-linear)
-  const int psrc = (lane & 3) ^ ((lane >> 3) & 3);
+  // the 16-byte piece this lane moves in every DMA instruction holds input channels psrc * 8 .. + 8 (slot = piece ^ ((pixel >> 2) & 3):
+  // conflict-free ds_read_b128 of the b-operand - the four pixels of one residue mod 4 in a 16-lane read group get four
+  // different slots, at every tap shift; the permutation is applied on the SOURCE side, the LDS image is lane-linear)
+  const int psrc = (lane & 3) ^ ((lane >> 4) & 3);
   const bool bn = p.in_scale != nullptr;
   float sc8[8], sh8[8];
 #pragma unroll
@@ -162,11 +163,11 @@ __global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) {
   for (int tx = 0; tx < 3; ++tx) {
     const int j = o + tx * d;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) boff[tx][ks] = j * 64 + (((ks * 2 + kh) ^ ((j >> 1) & 3)) * 16);
+    for (int ks = 0; ks < 2; ++ks) boff[tx][ks] = j * 64 + (((ks * 2 + kh) ^ ((j >> 2) & 3)) * 16);
   }
   int eoff[2];
 #pragma unroll
-  for (int g = 0; g < 2; ++g) eoff[g] = o * 64 + (((2 * g + kh) ^ ((o >> 1) & 3)) * 16);
+  for (int g = 0; g < 2; ++g) eoff[g] = o * 64 + (((2 * g + kh) ^ ((o >> 2) & 3)) * 16);
 
   float s1[2][8], s2[2][8];
 #pragma unroll

@@ -450,6 +450,24 @@ class Graph:
         plan.add("rua_bn_fwd", C.byref(d))
         return outs, coefs
 
+    def bn_coefs(self, plan: Plan, like: Ten, bns: List[dict], stats: List[Optional[Stat]], count, bessel=None) -> List[Coef]:
+        """Coefficients (scale, shift, mean, rstd; moving statistics updated in training) of several BatchNorms in ONE
+        one-block launch, nothing applied: the consumers normalise on load.  stats[i]: branch i's own statistics."""
+        coefs = [Coef(self, bn["C"]) for bn in bns]
+        d = L.BnFwdDesc()
+        d.x, d.M, d.C, d.dtype, d.nb, d.relu = None, like.M, like.C, self.dt, len(bns), 1
+        d.training = 1 if self.training else 0
+        d.count, d.bessel_n, d.momentum, d.eps = float(count), float(bessel or count), BN_MOMENTUM, BN_EPS
+        for i, (bn, c, st) in enumerate(zip(bns, coefs, stats)):
+            b = d.br[i]
+            b.gamma, b.beta, b.moving_mean, b.moving_var = self.P(bn["gamma"]), self.P(bn["beta"]), self.S(bn["mm"]), self.S(bn["mv"])
+            b.scale, b.shift, b.mean, b.rstd, b.out = c.scale, c.shift, c.mean, c.rstd, None
+            if self.training:
+                b.stats, b.replicas = st.ptr, st.R
+        plan.keep += [d] + coefs
+        plan.add("rua_bn_fwd", C.byref(d))
+        return coefs
+
     def bn_bwd(self, plan: Plan, gs: List[Ten], coefs: List[Coef], bns: List[dict], stats2: List[Stat], x: Ten, out: Ten,
                accumulate: int, count, dskip: Optional[Ten] = None, masked=False):
         """dx (=|+=) [dskip] + sum_b BN-backward_b(g_b) in ONE launch; dgamma/dbeta added by block 0."""
@@ -466,8 +484,15 @@ class Graph:
         plan.add("rua_bn_bwd", C.byref(d))
 
     def conv(self, plan: Plan, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual: Optional[Ten] = None,
-             out_relu=False, stats=None, bias_more=()):
-        """segs: [(Ten, up_shift, dil, taps)], layer_segs: [param seg dict] (same order)."""
+             out_relu=False, stats=None, bias_more=(), in_bn: Optional["Coef"] = None, accumulate: int = 0):
+        """segs: [(Ten, up_shift, dil, taps)], layer_segs: [param seg dict] (same order).  in_bn: the (single) source is
+        read as relu(scale * x + shift) - BatchNorm + ReLU applied by the kernel as the tile lands (normalise on load)."""
+        d = self.conv_desc(segs, layer_segs, cout, bias_ptr, out, stride, residual, out_relu, stats, bias_more, in_bn, accumulate)
+        plan.keep.append(d)
+        plan.add("rua_conv_fwd", C.byref(d))
+
+    def conv_desc(self, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual=None, out_relu=False, stats=None, bias_more=(),
+                  in_bn=None, accumulate=0):
         d = L.ConvDesc()
         d.nseg = len(segs)
         for i, ((t, up, dil, taps), ps) in enumerate(zip(segs, layer_segs)):
@@ -484,9 +509,30 @@ class Graph:
         d.y, d.out_stride, d.OH, d.OW = out.ptr, 1, out.H, out.W
         if stats is not None:
             d.stats, d.stats_mode, d.stats_replicas = stats.ptr, 1, stats.R
+        d.accumulate = accumulate
+        if in_bn is not None:
+            d.in_scale, d.in_shift, d.in_relu = in_bn.scale, in_bn.shift, 1
         self._ws(d)
-        plan.keep.append(d)
-        plan.add("rua_conv_fwd", C.byref(d))
+        return d
+
+    def fused_input_ok(self, x: Ten, nf: int, dil: int) -> bool:
+        """Does a 3x3 conv x -> nf channels at this dilation run on a kernel that normalises on load (and its weight
+        gradient on the all-taps kernel, which does too)?  Asked of the library, not guessed (rua_conv_fused_input_ok)."""
+        if self.dry or self.dt != L.RUA_BF16 or not self.e.fuse_bn:
+            return False
+        d = L.ConvDesc()
+        d.nseg = 1
+        sg = d.seg[0]
+        sg.x, sg.w, sg.C, sg.Hs, sg.Ws, sg.up_shift, sg.dil, sg.taps = x.ptr, x.ptr, x.C, x.H, x.W, 0, dil, 9
+        d.N, d.H, d.W, d.Cout, d.stride, d.dtype = x.N, x.H, x.W, nf, 1, self.dt
+        d.y, d.out_stride, d.OH, d.OW = x.ptr, 1, x.H, x.W
+        w = L.WgradDesc()
+        w.a, w.C, w.Hs, w.Ws, w.dy, w.Cout, w.H, w.W = x.ptr, x.C, x.H, x.W, x.ptr, nf, x.H, x.W
+        w.N, w.stride, w.dil, w.taps, w.dtype = x.N, 1, dil, 9, self.dt
+        sc = self.e.scratches[0]
+        w.workspace, w.workspace_bytes = sc.data_ptr(), sc.numel() * 4
+        lib = L.lib()
+        return lib.raw("rua_conv_fused_input_ok")(C.byref(d)) == 1 and lib.raw("rua_wgrad_kind")(C.byref(w)) == 1
 
     def _ws(self, d):
         """Shared split-K scratch (launches are serialised on one stream, so one buffer serves every conv)."""
@@ -515,9 +561,11 @@ class Graph:
         plan.keep.append(d)
         plan.add("rua_conv_fwd", C.byref(d))
 
-    def wgrad(self, plan: Plan, a: Ten, dy: Ten, dw_off: int, stride: int, dil: int, taps: int):
+    def wgrad(self, plan: Plan, a: Ten, dy: Ten, dw_off: int, stride: int, dil: int, taps: int, in_bn: Optional["Coef"] = None):
         d = L.WgradDesc()
         d.a, d.C, d.Hs, d.Ws = a.ptr, a.C, a.H, a.W
+        if in_bn is not None:                               # a is read as relu(scale * a + shift) (normalise on load)
+            d.in_scale, d.in_shift, d.in_relu = in_bn.scale, in_bn.shift, 1
         d.dy, d.Cout, d.H, d.W = dy.ptr, dy.C, dy.H, dy.W
         d.N, d.stride, d.dil, d.taps, d.dtype = dy.N, stride, dil, taps, self.dt
         d.dw = self.G(dw_off)
@@ -563,6 +611,8 @@ class Graph:
         cnt = x.M
         if tr and x.stats is None:
             x.stats = self.col_stats(F, x)
+        if all(self.fused_input_ok(x, nf, d) for d in dils):
+            return self.resblock_fused(x, nf, dils, lay, scope)
         a1, coef1 = self.bn_fwd(F, x, [l[0] for l in lay], True, x.stats, cnt)
         y1, coef2, a2 = [], [], []
         F.fork(len(dils))                                   # the branches are independent until the final sum
@@ -606,6 +656,56 @@ class Graph:
                 self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
                 g1s.append(g1); s1s.append(s1)
             Bp.join(len(dils)); self.cur_lane = 0
+            gx, acc = self.gacc(x)
+            self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None)
+            Bp.scope = None
+        self.back_steps.append(back)
+        return out
+
+    def resblock_fused(self, x: Ten, nf: int, dils: List[int], lay, scope: str) -> Ten:
+        """The same ResBlock (model2.py:15-34) with every BatchNorm + ReLU applied ON LOAD by the consuming kernel: no
+        normalised copy of x or of a first-conv output is ever written.  Forward per branch: conv(relu(BN1_b(x))) -> y1_b
+        (statistics in the epilogue) ; one coefficient launch for all BN2_b ; out = x + sum_b conv(relu(BN2_b(y1_b))) as one
+        residual launch and accumulating launches (each reads its y1_b once).  Backward: the weight gradients read x / y1_b
+        and normalise on load too; masks and BN-backward sums come out of the data-gradient epilogues as before."""
+        tr, F = self.training, self.fwd
+        v2 = self.cfg.variant == "model2"
+        cnt = x.M
+        nb = len(dils)
+        coef1 = self.bn_coefs(F, x, [l[0] for l in lay], [x.stats] * nb, cnt)
+        y1, st1 = [], []
+        for d, l, c1 in zip(dils, lay, coef1):
+            y = self.like(x)
+            st = self.stat(nf, (cnt + 127) // 128) if tr else None
+            self.conv(F, [(x, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st, in_bn=c1)
+            y1.append(y); st1.append(st)
+        coef2 = self.bn_coefs(F, x, [l[2] for l in lay], st1, cnt)
+        out = self.like(x)
+        for bi, (d, l, y, c2) in enumerate(zip(dils, lay, y1, coef2)):
+            self.conv(F, [(y, 0, d, 9)], [l[3]["segs"][0]], nf, self.P(l[3]["bias"]), out, in_bn=c2,
+                      residual=x if (v2 and bi == 0) else None, accumulate=1 if bi > 0 else 0)
+        F.scope = None
+        if not tr:
+            return out
+
+        def back():
+            Bp = self.bwd
+            Bp.scope = scope
+            dO = out.grad
+            self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
+            g1s, s1s = [], []
+            for d, l, y, c2, c1 in zip(dils, lay, y1, coef2, coef1):
+                self.wgrad(Bp, y, dO, l[3]["segs"][0]["off"], 1, d, 9, in_bn=c2)
+                g2 = self.like(x)
+                s2 = self.stat(nf, (cnt + 127) // 128)
+                self.dgrad(Bp, dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
+                dy1 = self.like(x)
+                self.bn_bwd(Bp, [g2], [c2], [l[2]], [s2], y, dy1, 0, cnt)
+                self.wgrad(Bp, x, dy1, l[1]["segs"][0]["off"], 1, d, 9, in_bn=c1)
+                g1 = g2
+                s1 = self.stat(nf, (cnt + 127) // 128)
+                self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
+                g1s.append(g1); s1s.append(s1)
             gx, acc = self.gacc(x)
             self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None)
             Bp.scope = None
@@ -990,6 +1090,7 @@ class Engine:
             raise ValueError(f"width={cfg.width}: the first-stage width must be a multiple of 32 (PSP branches are width/4 "
                              "channels and the MFMA epilogue stores 8-channel pieces)")
         self.dev = None
+        self.fuse_bn = os.environ.get("RUA_FUSE_BN", "1") != "0"     # normalise-on-load ResBlocks where the library offers it
         self.split_k = split_k       # False: bit-reproducible convolutions (no fp32-atomic K slices); parity tests on tiny
                                      # inputs use it because a BatchNorm over 2 samples amplifies atomic-order noise ~1e4x
         self.params = ParamStore()

@@ -82,7 +82,7 @@ def test_tuning_switches_are_the_only_global_state_and_no_environment_reads():
     keys = []
     while lib.dll.rua_tuning_key(len(keys)):
         keys.append(lib.dll.rua_tuning_key(len(keys)).decode())
-    assert {"conv_halo", "conv_dmap", "wgrad_dmap", "dmap_target", "bn_grid", "halo_fuse_bn"} <= set(keys)
+    assert {"conv_halo", "conv_dmap", "wgrad_dmap", "dmap_target", "bn_grid", "conv_strip"} <= set(keys)
     assert lib.get_tuning("conv_halo") == 1 and lib.get_tuning("dmap_target") == 0          # 0 = derived from the CU count
     lib.set_tuning(conv_halo=0, conv_pw_minm=1 << 40)
     assert lib.get_tuning("conv_halo") == 0 and lib.get_tuning("conv_pw_minm") == 1 << 40

@@ -362,3 +362,32 @@ def test_odd_batch_bf16_graph_steps():
         got = eng.train_step(x, y)
         assert np.all(np.isfinite(got))
         assert abs(got[0] - exp[0]) <= 5e-2 * max(1.0, abs(exp[0])), (step, got[0], exp[0])
+
+
+def test_normalise_on_load_resblocks_match_materialised_batchnorm():
+    """The top-level ResBlocks run with BatchNorm + ReLU applied on load by the conv / weight-gradient kernels (conv_strip,
+    wgrad_taps: no normalised copy of the conv input in HBM, model2.py:17-24) - against the same engine with the copies
+    materialised by rua_bn_fwd.  Same bf16 operands up to one rounding (fused multiply-add before the bf16 cast), so the two
+    must agree far inside the bf16-vs-oracle bounds: losses 2e-3, logits 1e-2 of their scale, gradients 2e-2 per tensor."""
+    shape, C = (256, 256, 6), 6
+    x, y = make_batch(1, 256, 6, C, True, seed=99)
+    res = []
+    for fuse in (True, False):
+        eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=True), dtype="bf16", seed=4, split_k=True)
+        eng.fuse_bn = fuse
+        eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in ref.HEADS}, weight={h: 1.0 for h in ref.HEADS}))
+        g = eng.forward_backward(x, y)
+        torch.cuda.synchronize()
+        names = [c[1] for c in g.fwd.calls]
+        res.append((eng._results(g), eng.logits(True, 1), eng.grads_keras(), names.count("rua_bn_fwd"), len(names)))
+        del eng, g
+        torch.cuda.empty_cache()
+    (la, za, ga, bna, na), (lb, zb, gb, bnb, nb) = res
+    assert bna < bnb and na <= nb                              # coefficient-only launches replace the apply passes
+    for i in range(5):
+        assert abs(la[i] - lb[i]) <= 2e-3 * max(1.0, abs(lb[i])), (i, la[i], lb[i])
+    for h in za:
+        assert rel(za[h], zb[h]) < 1e-2, (h, rel(za[h], zb[h]))
+    gmax = max(float(np.abs(v).max()) for v in gb.values())
+    worst = max((float(np.abs(ga[k] - gb[k]).max() / np.abs(gb[k]).max()), k) for k in gb if np.abs(gb[k]).max() > 1e-5 * gmax)
+    assert worst[0] < 2e-2, worst

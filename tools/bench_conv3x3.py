@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the top-level 3x3 convolutions through the C ABI: conv_strip (row streaming) against conv_halo
+(tile by tile) on the shapes of the d6 residual atrous block (8 x 256 x 256 x 32, dilations 1 / 3 / 15 / 31), forward
+(BatchNorm + ReLU on load, statistics) and data gradient (ReLU mask from aux, statistics).  Usage: python tools/bench_conv3x3.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from resunet_a_mltsk_keras_amd import _lib as L  # noqa: E402
+
+
+def main():
+    lib = L.lib()
+    dev = torch.device("cuda", 0)
+    N, H, W, Cc = 8, 256, 256, 32
+    only_mode = os.environ.get("B3_MODE")                      # restrict to one epilogue family / one kernel (profiling passes)
+    only_strip = os.environ.get("B3_STRIP")
+    dils = [int(v) for v in os.environ.get("B3_DILS", "1,3,15,31").split(",")]
+    reps = int(os.environ.get("B3_REPS", "50"))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn((N, H, W, Cc), generator=g).to(dev).to(torch.bfloat16)
+    aux = torch.randn((N, H, W, Cc), generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn((9, Cc, Cc), generator=g) / 17).to(dev).to(torch.bfloat16)
+    y = torch.zeros((N, H, W, Cc), device=dev, dtype=torch.bfloat16)
+    sc = torch.rand(Cc, device=dev) + 0.5
+    sh = torch.randn(Cc, device=dev) * 0.3
+    bias = torch.randn(Cc, device=dev)
+    stats = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    flops = 2.0 * N * H * W * Cc * Cc * 9
+    print(f"{N}x{H}x{W}x{Cc}: {flops / 1e9:.2f} GFLOP, {x.numel() * 2 / 1e6:.1f} MB per tensor")
+    for dil in dils:
+        for mode in ("fwd_bn_stats", "fwd_plain", "dgrad_mask_stats2", "fwd_bn_accumulate"):
+            if only_mode and mode != only_mode:
+                continue
+            row = []
+            for strip in (0, 1):
+                if only_strip is not None and int(only_strip) != strip:
+                    continue
+                d = L.ConvDesc()
+                d.nseg = 1
+                sg = d.seg[0]
+                sg.x, sg.w, sg.C, sg.Hs, sg.Ws, sg.up_shift, sg.dil, sg.taps = x.data_ptr(), w.data_ptr(), Cc, H, W, 0, dil, 9
+                d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cc, 1, L.RUA_BF16
+                d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+                d.stats, d.stats_replicas = stats.data_ptr(), 4
+                d.bias = bias.data_ptr()
+                if mode == "fwd_bn_stats":
+                    d.stats_mode = 1
+                    if strip:
+                        d.in_scale, d.in_shift, d.in_relu = sc.data_ptr(), sh.data_ptr(), 1
+                elif mode == "dgrad_mask_stats2":
+                    d.aux, d.aux_mode, d.mscale, d.mshift, d.stats_mode = aux.data_ptr(), 2, sc.data_ptr(), sh.data_ptr(), 2
+                elif mode == "fwd_bn_accumulate":
+                    d.accumulate = 1
+                    if strip:
+                        d.in_scale, d.in_shift, d.in_relu = sc.data_ptr(), sh.data_ptr(), 1
+                lib.set_tuning(conv_strip=strip)
+                kid = lib.raw("rua_conv_kernel_id")(C.byref(d))
+                for _ in range(5):
+                    lib.call("rua_conv_fwd", C.byref(d), s)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    lib.call("rua_conv_fwd", C.byref(d), s)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / reps
+                row.append(f"kernel {kid}: {us:6.1f} us {flops / us / 1e6:6.0f} TF/s")
+            print(f"d={dil:2d} {mode:20s} | " + " | ".join(row), flush=True)
+    lib.set_tuning(conv_strip=1)
+
+
+if __name__ == "__main__":
+    main()
