@@ -20,6 +20,11 @@
 //     accumulating) streams through a second LDS ring the same way.
 // Every vector-memory operation of the loop is either an LDS-DMA or a store, issued unconditionally by every wave, so the
 // counted waits are exact (loads, stores and LDS-DMA retire in issue order on one counter: MI355X_MICROARCH.md).
+// Measured (tools/bench_conv3x3.py, 8 x 256 x 256 x 32): 23-24 us plain, 31-33 us with BatchNorm on load + statistics or with
+// a ReLU mask, at every dilation (conv_halo: 25-30 / 31-38 without the BatchNorm) - in-kernel s_memtime stamps put the
+// streaming part within ~25 % of the HBM time of its bytes (a block reads 8 rows + 2 window-fill rows).  A ping-pong variant
+// (waves w / w + 4 of a SIMD alternate MFMA phase and epilogue, exact per-interval wait counts) overlapped the two phases as
+// designed and was no faster (24.4 us plain, step 9.88 vs 9.78 ms): the rows arrive no sooner.
 #include "common.h"
 
 struct StripK {
@@ -145,8 +150,13 @@ __global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) {
         uint4* ptr = reinterpret_cast<uint4*>(slot + xdst[k] + lane * 16);
         float f[8];
         ET<T>::unpack(*ptr, f);
+        if (p.in_relu) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { f[j] = fmaf(sc8[j], f[j], sh8[j]); if (p.in_relu) f[j] = fmaxf(f[j], 0.f); }
+          for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(sc8[j], f[j], sh8[j]), 0.f);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fmaf(sc8[j], f[j], sh8[j]);
+        }
         // raw write: hipcc orders a C++ LDS store behind every LDS-DMA in flight (s_waitcnt vmcnt(0): the ring would drain at
         // every stage); this piece's own DMA has landed (counted wait above) and nobody else touches it before the barrier
         const uint4 pk = ET<T>::pack(f);
