@@ -1,0 +1,498 @@
+"""Minimal HDF5 reader / writer for Keras weight files (train_ISPRS.py:292,474-480, test_ISPRS.py:278).
+
+h5py is not part of the runtime image, and the only HDF5 features a Keras `.h5` uses are the oldest ones, so this module
+implements exactly those from the HDF5 File Format Specification (version 0 structures, what libhdf5 writes with its
+default `libver='earliest'`):
+
+  superblock v0 . symbol-table groups (B-tree v1 + local heap + SNOD) . object headers v1 with continuation blocks .
+  datasets: contiguous / compact / unfiltered single-level chunked layouts . datatypes: IEEE floats, integers, fixed-length
+  strings, variable-length strings (global heap, attributes only) . attribute messages v1-v3.
+
+A file is exchanged as a `Group` tree: `Group.attrs` (dict), `Group.children` (name -> Group | numpy array).  Anything else
+(new-style groups with link messages, filters / compression, references, compound types) raises `H5Error` naming the
+feature.  Verified against libhdf5 itself where it exists: tests/golden/keras_tiny.h5 was written by h5py (script
+tests/golden/make_keras_h5.py) and is read here; files written here are read back by h5py in tests/test_h5lite.py when an
+interpreter with h5py is present (the build container has one under /opt/conda).
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+
+UNDEF = 0xFFFFFFFFFFFFFFFF
+SIG = b"\x89HDF\r\n\x1a\n"
+
+
+class H5Error(ValueError):
+    pass
+
+
+class Group:
+    def __init__(self, attrs: Optional[dict] = None, children: Optional[dict] = None):
+        self.attrs: Dict[str, object] = dict(attrs or {})
+        self.children: Dict[str, Union["Group", np.ndarray]] = dict(children or {})
+
+    def __getitem__(self, path: str):
+        node = self
+        for part in [p for p in path.split("/") if p]:
+            if not isinstance(node, Group) or part not in node.children:
+                raise KeyError(path)
+            node = node.children[part]
+        return node
+
+    def __contains__(self, path: str) -> bool:
+        try:
+            self[path]
+            return True
+        except KeyError:
+            return False
+
+    def require_group(self, path: str) -> "Group":
+        node = self
+        for part in [p for p in path.split("/") if p]:
+            nxt = node.children.get(part)
+            if nxt is None:
+                nxt = node.children[part] = Group()
+            if not isinstance(nxt, Group):
+                raise H5Error(f"{part} is a dataset, not a group")
+            node = nxt
+        return node
+
+    def set(self, path: str, value: np.ndarray) -> None:
+        parts = [p for p in path.split("/") if p]
+        self.require_group("/".join(parts[:-1])).children[parts[-1]] = np.asarray(value)
+
+
+# =========================================================================================================================
+# writer
+# =========================================================================================================================
+LEAF_K, INTERNAL_K = 64, 16              # superblock fields: a SNOD holds 2 * LEAF_K entries, a B-tree node 2 * INTERNAL_K children
+
+
+def _pad8(b: bytes) -> bytes:
+    return b + b"\0" * (-len(b) % 8)
+
+
+def _dtype_msg(dt: np.dtype) -> bytes:
+    dt = np.dtype(dt)
+    if dt.kind == "f" and dt.itemsize in (4, 8):
+        sign, eloc, esz, msz, bias = (31, 23, 8, 23, 127) if dt.itemsize == 4 else (63, 52, 11, 52, 1023)
+        return struct.pack("<BBBBI", 0x11, 0x20, sign, 0, dt.itemsize) + struct.pack("<HHBBBBI", 0, dt.itemsize * 8, eloc, esz, 0, msz, bias)
+    if dt.kind in "iu" and dt.itemsize in (1, 2, 4, 8):
+        return struct.pack("<BBBBI", 0x10, 0x08 if dt.kind == "i" else 0x00, 0, 0, dt.itemsize) + struct.pack("<HH", 0, dt.itemsize * 8)
+    if dt.kind == "S":
+        return struct.pack("<BBBBI", 0x13, 0x01, 0, 0, max(dt.itemsize, 1))          # null-padded ASCII, like h5py's numpy 'S' mapping
+    raise H5Error(f"cannot write dtype {dt}")
+
+
+def _space_msg(shape: Tuple[int, ...]) -> bytes:
+    return struct.pack("<BBBBI", 1, len(shape), 0, 0, 0) + b"".join(struct.pack("<Q", int(s)) for s in shape)
+
+
+def _as_array(v) -> np.ndarray:
+    if isinstance(v, str):
+        v = v.encode("utf8")
+    if isinstance(v, bytes):
+        return np.array(v, dtype=f"S{max(len(v), 1)}")
+    a = np.asarray(v)
+    if a.dtype.kind == "U":
+        a = np.char.encode(a, "utf8")
+    if a.dtype.kind == "O":
+        a = np.array([x if isinstance(x, bytes) else str(x).encode("utf8") for x in a.reshape(-1)]).reshape(a.shape)
+    if a.dtype == np.bool_:
+        a = a.astype(np.int8)
+    return a
+
+
+def _attr_msg(name: str, value) -> bytes:
+    a = _as_array(value)
+    nm = name.encode("utf8") + b"\0"
+    dt, sp = _dtype_msg(a.dtype), _space_msg(a.shape)
+    body = struct.pack("<BBHHH", 1, 0, len(nm), len(dt), len(sp)) + _pad8(nm) + _pad8(dt) + _pad8(sp) + np.ascontiguousarray(a).tobytes()
+    if len(body) > 65000:
+        raise H5Error(f"attribute {name} is {len(body)} bytes: over the 64 KiB object-header message limit (split it like Keras does)")
+    return body
+
+
+class _Writer:
+    def __init__(self):
+        self.buf = bytearray(96)                       # superblock, filled in at the end
+
+    def alloc(self, data: bytes) -> int:
+        self.buf += b"\0" * (-len(self.buf) % 8)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    def header(self, msgs: List[Tuple[int, bytes]]) -> int:
+        body = b"".join(struct.pack("<HHBBH", t, len(_pad8(d)), 0, 0, 0) + _pad8(d) for t, d in msgs)
+        return self.alloc(struct.pack("<BBHII", 1, 0, len(msgs), 1, len(body)) + b"\0" * 4 + body)
+
+    def dataset(self, a: np.ndarray) -> int:
+        a = _as_array(a)
+        raw = np.ascontiguousarray(a).tobytes()
+        addr = self.alloc(raw) if raw else UNDEF
+        msgs = [(0x0001, _space_msg(a.shape)), (0x0003, _dtype_msg(a.dtype)), (0x0005, struct.pack("<BBBB", 2, 2, 2, 0)),
+                (0x0008, struct.pack("<BBQQ", 3, 1, addr, len(raw)))]
+        return self.header(msgs)
+
+    def group(self, g: Group) -> Tuple[int, int, int]:
+        """-> (object header address, B-tree address, local heap address)"""
+        names = sorted(g.children, key=lambda s: s.encode("utf8"))
+        if len(names) > 2 * LEAF_K * 2 * INTERNAL_K:
+            raise H5Error("too many links in one group")
+        child_addr = {}
+        for n in names:
+            c = g.children[n]
+            child_addr[n] = self.group(c) if isinstance(c, Group) else (self.dataset(c), None, None)
+        heap = bytearray(b"\0" * 8)                    # offset 0: the empty string
+        off = {}
+        for n in names:
+            off[n] = len(heap)
+            heap += _pad8(n.encode("utf8") + b"\0")
+        heap_data = self.alloc(bytes(heap))
+        heap_addr = self.alloc(b"HEAP" + struct.pack("<BBBBQQQ", 0, 0, 0, 0, len(heap), 1, heap_data))      # free list: 1 = none
+        snods, keys = [], [0]
+        for i in range(0, len(names), 2 * LEAF_K):
+            chunk = names[i:i + 2 * LEAF_K]
+            ent = b""
+            for n in chunk:
+                oh, bt, hp = child_addr[n]
+                if bt is None:
+                    ent += struct.pack("<QQII", off[n], oh, 0, 0) + b"\0" * 16
+                else:
+                    ent += struct.pack("<QQIIQQ", off[n], oh, 1, 0, bt, hp)
+            ent += b"\0" * (40 * (2 * LEAF_K - len(chunk)))
+            snods.append(self.alloc(b"SNOD" + struct.pack("<BBH", 1, 0, len(chunk)) + ent))
+            keys.append(off[chunk[-1]])
+        node = b"TREE" + struct.pack("<BBHQQ", 0, 0, len(snods), UNDEF, UNDEF)
+        body = b""
+        for i in range(2 * INTERNAL_K):
+            body += struct.pack("<Q", keys[i] if i < len(keys) else 0)
+            body += struct.pack("<Q", snods[i] if i < len(snods) else 0)
+        body += struct.pack("<Q", keys[2 * INTERNAL_K] if len(keys) > 2 * INTERNAL_K else 0)
+        btree = self.alloc(node + body)
+        msgs = [(0x0011, struct.pack("<QQ", btree, heap_addr))] + [(0x000C, _attr_msg(k, v)) for k, v in g.attrs.items()]
+        return self.header(msgs), btree, heap_addr
+
+    def finish(self, root: Group) -> bytes:
+        oh, bt, hp = self.group(root)
+        self.buf += b"\0" * (-len(self.buf) % 8)
+        sb = SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, LEAF_K, INTERNAL_K, 0)
+        sb += struct.pack("<QQQQ", 0, UNDEF, len(self.buf), UNDEF)
+        sb += struct.pack("<QQIIQQ", 0, oh, 1, 0, bt, hp)
+        assert len(sb) == 96
+        self.buf[0:96] = sb
+        return bytes(self.buf)
+
+
+def write_h5(path: str, root: Group) -> None:
+    data = _Writer().finish(root)
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+# =========================================================================================================================
+# reader
+# =========================================================================================================================
+class _Reader:
+    def __init__(self, data: bytes):
+        self.d = data
+        if data[:8] != SIG:
+            raise H5Error("not an HDF5 file (no signature at offset 0)")
+        ver = data[8]
+        if ver not in (0, 1):
+            raise H5Error(f"superblock version {ver}: only the version-0/1 layout (libver='earliest', what Keras / h5py write by default) is supported")
+        so, sl = data[13], data[14]
+        if (so, sl) != (8, 8):
+            raise H5Error(f"offsets of {so} bytes / lengths of {sl} bytes are not supported")
+        p = 24 + (4 if ver == 1 else 0)
+        self.base = struct.unpack_from("<Q", data, p)[0]
+        self.root_entry = p + 32
+
+    def u(self, fmt: str, off: int):
+        return struct.unpack_from("<" + fmt, self.d, off)
+
+    # -- object headers ---------------------------------------------------------------------------------------------------
+    def messages(self, addr: int) -> List[Tuple[int, int, int, int]]:
+        """[(type, offset of data, size, flags)] of the (version 1) object header at addr, continuation blocks followed."""
+        if self.d[addr:addr + 4] == b"OHDR":
+            raise H5Error("version-2 object headers (new-style groups, libver='latest') are not supported")
+        ver, _, nmsg, _, size = self.u("BBHII", addr)
+        if ver != 1:
+            raise H5Error(f"object header version {ver}")
+        out, blocks = [], [(addr + 16, size)]
+        while blocks and len(out) < nmsg:
+            p, left = blocks.pop(0)
+            end = p + left
+            while p + 8 <= end and len(out) < nmsg:
+                t, sz, fl = self.u("HHB", p)
+                p += 8
+                if t == 0x0010:
+                    o, ln = self.u("QQ", p)
+                    blocks.append((o + self.base, ln))
+                out.append((t, p, sz, fl))
+                p += sz
+        return out
+
+    # -- datatypes ------------------------------------------------------------------------------------------------------
+    def dtype(self, p: int):
+        """-> ('num', numpy dtype) | ('str', size) | ('vstr',)"""
+        cv, b0, b1, b2, size = self.u("BBBBI", p)
+        cls, ver = cv & 0x0F, cv >> 4
+        if ver not in (1, 2, 3):
+            raise H5Error(f"datatype version {ver}")
+        order = ">" if (b0 & 1) else "<"
+        if cls == 0:
+            return ("num", np.dtype(f"{order}{'i' if b0 & 8 else 'u'}{size}"))
+        if cls == 1:
+            if size not in (2, 4, 8):
+                raise H5Error(f"{size}-byte floats")
+            return ("num", np.dtype(f"{order}f{size}"))
+        if cls == 3:
+            return ("str", size)
+        if cls == 9:
+            if (b0 & 0x0F) == 1:
+                return ("vstr",)
+            raise H5Error("variable-length sequences")
+        raise H5Error(f"datatype class {cls} (only integers, floats and strings occur in Keras weight files)")
+
+    def space(self, p: int) -> Tuple[int, ...]:
+        ver = self.d[p]
+        if ver == 1:
+            rank = self.d[p + 1]
+            return tuple(self.u(f"{rank}Q", p + 8)) if rank else ()
+        if ver == 2:
+            rank, _, typ = self.d[p + 1], self.d[p + 2], self.d[p + 3]
+            if typ == 2:
+                return (0,)
+            return tuple(self.u(f"{rank}Q", p + 4)) if rank else ()
+        raise H5Error(f"dataspace version {ver}")
+
+    def gheap(self, addr: int, index: int) -> bytes:
+        addr += self.base
+        if self.d[addr:addr + 4] != b"GCOL":
+            raise H5Error("bad global heap collection")
+        size = self.u("Q", addr + 8)[0]
+        p, end = addr + 16, addr + size
+        while p + 16 <= end:
+            idx, _, _, osz = self.u("HHIQ", p)
+            if idx == index:
+                return self.d[p + 16:p + 16 + osz]
+            if idx == 0:
+                break
+            p += 16 + osz + (-osz % 8)
+        raise H5Error("global heap object not found")
+
+    def decode(self, dt, shape, raw: bytes):
+        n = int(np.prod(shape)) if shape else 1
+        if dt[0] == "num":
+            return np.frombuffer(raw, dtype=dt[1], count=n).astype(dt[1].newbyteorder("=")).reshape(shape)
+        if dt[0] == "str":
+            a = np.frombuffer(raw, dtype=f"S{dt[1]}", count=n).reshape(shape)
+            return a if shape else a.reshape(()).item()
+        vals = []
+        for i in range(n):
+            ln, addr, idx = struct.unpack_from("<IQI", raw, i * 16)
+            vals.append(self.gheap(addr, idx)[:ln] if ln else b"")
+        if not shape:
+            return vals[0].decode("utf8", "replace")
+        return np.array(vals, dtype=object).reshape(shape)
+
+    def attribute(self, p: int):
+        ver = self.d[p]
+        if ver == 1:
+            nsz, dsz, ssz = self.u("HHH", p + 2)
+            q = p + 8
+            name = self.d[q:q + nsz].split(b"\0")[0].decode("utf8"); q += nsz + (-nsz % 8)
+            dt = self.dtype(q); q += dsz + (-dsz % 8)
+            shape = self.space(q); q += ssz + (-ssz % 8)
+        elif ver in (2, 3):
+            nsz, dsz, ssz = self.u("HHH", p + 2)
+            q = p + 8 + (1 if ver == 3 else 0)
+            name = self.d[q:q + nsz].split(b"\0")[0].decode("utf8"); q += nsz
+            dt = self.dtype(q); q += dsz
+            shape = self.space(q); q += ssz
+        else:
+            raise H5Error(f"attribute message version {ver}")
+        return name, self.decode(dt, shape, self.d[q:])
+
+    # -- groups -----------------------------------------------------------------------------------------------------------
+    def heap_name(self, heap_addr: int, off: int) -> str:
+        if self.d[heap_addr:heap_addr + 4] != b"HEAP":
+            raise H5Error("bad local heap")
+        data = self.u("Q", heap_addr + 24)[0] + self.base
+        end = self.d.index(b"\0", data + off)
+        return self.d[data + off:end].decode("utf8")
+
+    def btree_entries(self, addr: int, heap: int) -> List[Tuple[str, int]]:
+        if self.d[addr:addr + 4] == b"SNOD":
+            n = self.u("H", addr + 6)[0]
+            out = []
+            for i in range(n):
+                no, oh = self.u("QQ", addr + 8 + 40 * i)
+                out.append((self.heap_name(heap, no), oh + self.base))
+            return out
+        if self.d[addr:addr + 4] != b"TREE":
+            raise H5Error("bad group B-tree node")
+        ntype, _, used = self.u("BBH", addr + 4)
+        if ntype != 0:
+            raise H5Error("not a group B-tree")
+        out = []
+        for i in range(used):
+            child = self.u("Q", addr + 24 + 8 + 16 * i)[0] + self.base
+            out += self.btree_entries(child, heap)
+        return out
+
+    def chunked(self, p: int, dt, shape):
+        rank = self.d[p + 2]
+        bt = self.u("Q", p + 3)[0]
+        cdims = self.u(f"{rank}I", p + 11)
+        if dt[0] != "num":
+            raise H5Error("chunked string datasets")
+        out = np.zeros(shape, dtype=dt[1].newbyteorder("="))
+        if bt == UNDEF:
+            return out
+
+        def walk(addr):
+            if self.d[addr:addr + 4] != b"TREE" or self.d[addr + 4] != 1:
+                raise H5Error("bad chunk B-tree node")
+            level, used = self.u("BH", addr + 5)
+            ksz = 8 + 8 * rank
+            for i in range(used):
+                k = addr + 24 + i * (ksz + 8)
+                csize, mask = self.u("II", k)
+                offs = self.u(f"{rank}Q", k + 8)
+                child = self.u("Q", k + ksz)[0] + self.base
+                if level > 0:
+                    walk(child)
+                    continue
+                if mask != 0:
+                    raise H5Error("filtered (compressed) chunks")
+                chunk = np.frombuffer(self.d, dtype=dt[1], count=int(np.prod(cdims[:-1])), offset=child).reshape(cdims[:-1])
+                sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs[:-1], cdims[:-1], shape))
+                out[sl] = chunk[tuple(slice(0, s.stop - s.start) for s in sl)]
+        walk(bt + self.base)
+        return out
+
+    def obj(self, addr: int):
+        msgs = self.messages(addr)
+        attrs = {}
+        for t, p, sz, fl in msgs:
+            if t == 0x000C:
+                if fl & 2:
+                    raise H5Error("shared attribute messages")
+                k, v = self.attribute(p)
+                attrs[k] = v
+        kinds = {t for t, *_ in msgs}
+        if 0x0011 in kinds:
+            p = next(p for t, p, *_ in msgs if t == 0x0011)
+            bt, hp = self.u("QQ", p)
+            g = Group(attrs)
+            for name, oh in self.btree_entries(bt + self.base, hp + self.base):
+                g.children[name] = self.obj(oh)
+            return g
+        if 0x0008 in kinds:
+            if 0x000B in kinds:
+                raise H5Error("filter pipelines (compression) are not supported")
+            dt = self.dtype(next(p for t, p, *_ in msgs if t == 0x0003))
+            shape = self.space(next(p for t, p, *_ in msgs if t == 0x0001))
+            p = next(p for t, p, *_ in msgs if t == 0x0008)
+            ver, cls = self.d[p], self.d[p + 1]
+            if ver != 3:
+                raise H5Error(f"data layout message version {ver}")
+            if cls == 1:
+                a, ln = self.u("QQ", p + 2)
+                raw = b"" if a == UNDEF else self.d[a + self.base:a + self.base + ln]
+                if a == UNDEF and (int(np.prod(shape)) if shape else 1):
+                    return np.zeros(shape, dtype=dt[1]) if dt[0] == "num" else self.decode(dt, shape, b"\0" * 16 * 1024)
+                return self.decode(dt, shape, raw)
+            if cls == 0:
+                ln = self.u("H", p + 2)[0]
+                return self.decode(dt, shape, self.d[p + 4:p + 4 + ln])
+            if cls == 2:
+                return self.chunked(p, dt, shape)
+            raise H5Error(f"data layout class {cls}")
+        if 0x0002 in kinds or 0x0006 in kinds:
+            raise H5Error("new-style groups (link messages) are not supported: save with libver='earliest'")
+        return Group(attrs)
+
+    def root(self) -> Group:
+        oh = self.u("Q", self.root_entry + 8)[0] + self.base
+        return self.obj(oh)
+
+
+def read_h5(path: str) -> Group:
+    with open(path, "rb") as f:
+        data = f.read()
+    try:
+        return _Reader(data).root()
+    except (struct.error, IndexError) as exc:
+        raise H5Error(f"{path}: truncated or malformed HDF5 file ({exc})") from None
+
+
+def is_hdf5(path: str) -> bool:
+    try:
+        with open(path, "rb") as f:
+            return f.read(8) == SIG
+    except OSError:
+        return False
+
+
+# =========================================================================================================================
+# Keras layout: f.attrs['layer_names'], f[layer].attrs['weight_names'], f[layer][weight_name]  (keras/saving/hdf5_format.py)
+# =========================================================================================================================
+def _names(v) -> List[str]:
+    if isinstance(v, (bytes, str)):
+        v = [v]
+    return [x.decode("utf8") if isinstance(x, bytes) else str(x) for x in np.asarray(v).reshape(-1)]
+
+
+def keras_weights_from_group(g: Group) -> Dict[str, np.ndarray]:
+    """{variable name ('conv2d_3/kernel:0'): array} from a Keras weight group (the file root of save_weights(), or
+    f['model_weights'] of model.save()).  Attributes Keras split into layer_names0, layer_names1, .. are joined."""
+    if "layer_names" not in g.attrs and "model_weights" in g.children:
+        g = g.children["model_weights"]
+
+    def attr_list(node, key):
+        if key in node.attrs:
+            return _names(node.attrs[key])
+        out, i = [], 0
+        while f"{key}{i}" in node.attrs:
+            out += _names(node.attrs[f"{key}{i}"]); i += 1
+        return out
+    layers = attr_list(g, "layer_names")
+    if not layers:
+        raise H5Error("no 'layer_names' attribute: not a Keras weight file")
+    out = {}
+    for ln in layers:
+        lg = g.children.get(ln)
+        if not isinstance(lg, Group):
+            raise H5Error(f"layer group '{ln}' missing")
+        for wn in attr_list(lg, "weight_names"):
+            a = lg[wn]
+            if isinstance(a, Group):
+                raise H5Error(f"{ln}/{wn} is not a dataset")
+            out[wn] = np.asarray(a)
+    return out
+
+
+def keras_group_from_weights(weights: Dict[str, np.ndarray]) -> Group:
+    """The inverse: variables 'layer/var:0' (a ':0' is appended when missing) -> a group in the layout Keras' load_weights reads."""
+    g = Group()
+    order: Dict[str, List[str]] = {}
+    for name, a in weights.items():
+        name = name if ":" in name else name + ":0"
+        layer = name.split("/")[0]
+        order.setdefault(layer, []).append(name)
+        g.require_group(layer).set(name, np.asarray(a, dtype=np.float32))
+    width = max(len(n) for n in order)
+    g.attrs["layer_names"] = np.array([n.encode("utf8") for n in order], dtype=f"S{width}")
+    g.attrs["backend"] = b"tensorflow"
+    g.attrs["keras_version"] = b"2.4.0"
+    for layer, names in order.items():
+        w = max(len(n) for n in names)
+        g.children[layer].attrs["weight_names"] = np.array([n.encode("utf8") for n in names], dtype=f"S{w}")
+    return g

@@ -298,18 +298,31 @@ class Model:
             return {h: np.concatenate([o[h] for o in outs], axis=0) for h in HEADS}
         return np.concatenate(outs, axis=0)
 
-    # -- checkpoints (train_ISPRS.py:292,474-480; own container: h5py is not available) -----------------
+    # -- checkpoints (train_ISPRS.py:292,474-480): real HDF5 in the Keras layout, written / read by h5lite (no h5py needed) --
     def save(self, path):
+        """`model.save('best_model.h5')` (train_ISPRS.py:292): an HDF5 file whose `model_weights` group is exactly what Keras'
+        save_weights writes (layer_names / weight_names attributes, HWIO kernels, BN gamma, beta, moving_mean,
+        moving_variance) - so Keras' `load_weights` reads it - plus this package's own metadata (root attribute
+        `rua_checkpoint`: graph configuration, compile arguments, step count) and optimizer moments (`optimizer_weights`)."""
+        from . import h5lite
         e = self.engine
-        meta = dict(cfg=dict(input_shape=list(self.cfg.input_shape), num_classes=self.cfg.num_classes,
-                             multitasking=self.cfg.multitasking, variant=self.cfg.variant, width=self.cfg.width, depth=self.cfg.depth),
-                    dtype=e.dtype, t=e.t)
+        meta = dict(format="rua-checkpoint-2", cfg=dict(input_shape=list(self.cfg.input_shape), num_classes=self.cfg.num_classes,
+                                                        multitasking=self.cfg.multitasking, variant=self.cfg.variant, width=self.cfg.width,
+                                                        depth=self.cfg.depth), dtype=e.dtype, t=e.t)
+        root = h5lite.Group()
         if e.loss is not None:
             sp = e.loss
             meta["loss"] = dict(kind=sp.kind, weight=sp.weight, class_weights=sp.class_weights, optimizer=sp.optimizer, lr=sp.lr,
                                 beta_1=sp.beta_1, beta_2=sp.beta_2, momentum=sp.momentum)
-        torch.save({"format": "rua-checkpoint-1", "meta": json.dumps(meta), "weights": e.get_weights(),
-                    "opt_m": e.M1.cpu(), "opt_v": e.V1.cpu()}, path)
+            og = root.require_group("optimizer_weights")
+            og.set("rua/m:0", e.M1.cpu().numpy()); og.set("rua/v:0", e.V1.cpu().numpy())
+            og.set("rua/iterations:0", np.array(e.t, np.int64))
+            og.attrs["weight_names"] = np.array([b"rua/iterations:0", b"rua/m:0", b"rua/v:0"])
+        root.attrs["keras_version"] = b"2.4.0"
+        root.attrs["backend"] = b"tensorflow"
+        root.attrs["rua_checkpoint"] = json.dumps(meta).encode("utf8")
+        root.children["model_weights"] = h5lite.keras_group_from_weights(e.get_weights())
+        h5lite.write_h5(path, root)
 
     def get_weights_dict(self) -> Dict[str, np.ndarray]:
         return self.engine.get_weights()
@@ -317,15 +330,25 @@ class Model:
     def set_weights_dict(self, w: Dict[str, np.ndarray]):
         self.engine.set_weights(w)
 
-    # -- weight exchange with the reference.  h5py is not in this image, so the carrier is an .npz of
-    #    Keras variable names -> arrays in Keras layout (kernel HWIO, BN gamma/beta/moving_mean/moving_variance); on the
-    #    TensorFlow side that is `np.savez(path, **{w.name: w.numpy() for w in model.weights})`.
+    # -- weight exchange with the reference: Keras' own HDF5 layout (`model.save_weights('w.h5')` on the
+    #    TensorFlow side, or the `model_weights` group of a full `model.save`), kernels HWIO, BN gamma / beta / moving_mean /
+    #    moving_variance, layers matched by order within a type (canonical_keras_names).  `.npz` (Keras variable name ->
+    #    array) stays as a second carrier.
     def save_weights(self, path):
-        np.savez(path, **{k + ":0": v for k, v in self.engine.get_weights().items()})
+        if str(path).endswith(".npz"):
+            np.savez(path, **{k + ":0": v for k, v in self.engine.get_weights().items()})
+            return
+        from . import h5lite
+        h5lite.write_h5(path, h5lite.keras_group_from_weights(self.engine.get_weights()))
 
     def load_weights(self, path):
-        with np.load(path) as z:
-            self.engine.set_weights(canonical_keras_names({k: z[k] for k in z.files}, self.engine.get_weights()))
+        if str(path).endswith(".npz"):
+            with np.load(path) as z:
+                given = {k: z[k] for k in z.files}
+        else:
+            from . import h5lite
+            given = h5lite.keras_weights_from_group(h5lite.read_h5(path))
+        self.engine.set_weights(canonical_keras_names(given, self.engine.get_weights()))
 
 
 def canonical_keras_names(given: Dict[str, np.ndarray], want: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
@@ -361,22 +384,71 @@ def canonical_keras_names(given: Dict[str, np.ndarray], want: Dict[str, np.ndarr
     return out
 
 
-def load_model(path, compile=True, custom_objects=None, dtype=None, **_):
-    blob = torch.load(path, map_location="cpu", weights_only=False)
-    if blob.get("format") != "rua-checkpoint-1":
-        raise ValueError(f"{path} is not a checkpoint written by this package (Keras .h5 import is not supported)")
-    meta = json.loads(blob["meta"])
+def _cfg_from_keras_file(root, weights, input_shape):
+    """Graph configuration of a file Keras itself wrote (no `rua_checkpoint` attribute): channels / width / classes / heads /
+    depth from the variable shapes (file order = Keras layer order), the graph variant (model2.py or model.py) by which
+    parameter layout the variables fit, the patch size from `model_config` (InputLayer batch_input_shape) or the caller."""
+    kernels = [(k, v) for k, v in weights.items() if k.split(":")[0].endswith("/kernel") and v.ndim == 4]
+    if not kernels:
+        raise ValueError("no convolution kernels in the file")
+    stem = kernels[0][1]
+    cin, width = int(stem.shape[2]), int(stem.shape[3])
+    names = {k.split(":")[0] for k in weights}
+    multitask = any(n.startswith(("seg3/", "color/")) for n in names)
+    ncls = int(next(v for k, v in kernels if k.startswith("seg3/")).shape[-1]) if multitask else int(kernels[-1][1].shape[-1])
+    depth = 7 if max(int(v.shape[-1]) for _, v in kernels) >= width * 64 else 6
+    if input_shape is None:
+        cfgs = root.attrs.get("model_config")
+        try:
+            mc = json.loads(cfgs.decode("utf8") if isinstance(cfgs, bytes) else cfgs)
+            shp = next(l["config"]["batch_input_shape"] for l in mc["config"]["layers"] if l["class_name"] == "InputLayer")
+            input_shape = (int(shp[1]), int(shp[2]), cin)
+        except Exception:
+            raise ValueError("this Keras file does not say the patch size (no usable model_config): pass load_model(path, input_shape=(H, W, C))") from None
+    err = None
+    for variant in ("model2", "model"):
+        cfg = ModelConfig(tuple(input_shape), ncls, multitask, variant, width, depth)
+        ps = Engine.param_layout(cfg)
+        want = ps.to_keras(np.zeros(ps.n, np.float32), np.zeros(ps.ns, np.float32))
+        try:
+            canonical_keras_names(weights, want)
+            return cfg
+        except ValueError as exc:
+            err = exc
+    raise ValueError(f"the variables fit neither ResUnet_a/model2.py nor ResUnet_a/model.py ({err})")
+
+
+def load_model(path, compile=True, custom_objects=None, dtype=None, input_shape=None, **_):
+    """`load_model('best_model.h5')` (train_ISPRS.py:474, test_ISPRS.py:278).  Reads HDF5 only - nothing is unpickled, so a
+    checkpoint cannot run code.  A file written by Model.save() restores graph, compile arguments and optimizer state; a file
+    written by Keras itself (`model.save` / `save_weights` of the reference) is loaded as weights into a model whose
+    configuration is read off the variable shapes (compile it yourself afterwards)."""
+    from . import h5lite
+    if not h5lite.is_hdf5(path):
+        raise ValueError(f"{path} is not an HDF5 file (checkpoints of this package and of Keras are HDF5; nothing else is read)")
+    root = h5lite.read_h5(path)
+    weights = h5lite.keras_weights_from_group(root)
+    meta_raw = root.attrs.get("rua_checkpoint")
+    if meta_raw is None:
+        m = Model(_cfg_from_keras_file(root, weights, input_shape), dtype=dtype or "bf16")
+        m.engine.set_weights(canonical_keras_names(weights, m.engine.get_weights()))
+        return m
+    meta = json.loads(meta_raw.decode("utf8") if isinstance(meta_raw, bytes) else meta_raw)
+    if meta.get("format") != "rua-checkpoint-2":
+        raise ValueError(f"{path}: unknown checkpoint format {meta.get('format')!r}")
     c = meta["cfg"]
     cfg = ModelConfig(tuple(c["input_shape"]), c["num_classes"], c["multitasking"], c["variant"], c["width"], c["depth"])
     m = Model(cfg, dtype=dtype or meta["dtype"])
-    m.engine.set_weights(blob["weights"])
+    m.engine.set_weights(canonical_keras_names(weights, m.engine.get_weights()))
     if compile and "loss" in meta:
         lo = meta["loss"]
         opt = Adam(lr=lo["lr"], beta_1=lo["beta_1"], beta_2=lo["beta_2"]) if lo["optimizer"] == "adam" else SGD(lr=lo["lr"], momentum=lo["momentum"])
         m.optimizer = opt
         m.engine.compile(LossSpec(kind={k: int(v) for k, v in lo["kind"].items()}, weight=lo["weight"], class_weights=lo["class_weights"],
                                   optimizer=lo["optimizer"], lr=lo["lr"], beta_1=lo["beta_1"], beta_2=lo["beta_2"], momentum=lo["momentum"]))
-        m.engine.M1.copy_(blob["opt_m"]); m.engine.V1.copy_(blob["opt_v"]); m.engine.t = meta["t"]
+        og = root["optimizer_weights"]
+        m.engine.M1.copy_(torch.from_numpy(np.ascontiguousarray(og["rua/m:0"]))); m.engine.V1.copy_(torch.from_numpy(np.ascontiguousarray(og["rua/v:0"])))
+        m.engine.t = int(og["rua/iterations:0"])
         m._finish_compile(restored_optimizer_state=True)
     return m
 

@@ -179,6 +179,25 @@ def test_keras_style_model_roundtrip(tmp_path):
     net4.model.save_weights(str(tmp_path / "to_keras.npz"))
     with np.load(str(tmp_path / "to_keras.npz")) as z:
         assert set(z.files) == {k + ":0" for k in w} and all(np.array_equal(z[k + ":0"], w[k]) for k in w)
+    # the same exchange through real HDF5 in Keras' own layout (h5lite, no h5py): a file "Keras wrote" (shifted layer
+    # numbers, no metadata of ours) -> load_model reads the configuration off the variables; save_weights -> Keras layout
+    from resunet_a_mltsk_keras_amd import h5lite
+    root = h5lite.Group({"keras_version": b"2.4.0", "backend": b"tensorflow"})
+    root.children["model_weights"] = h5lite.keras_group_from_weights(shifted)
+    h5lite.write_h5(str(tmp_path / "from_keras.h5"), root)
+    m5 = load_model(str(tmp_path / "from_keras.h5"), compile=False, input_shape=(64, 64, 3), dtype="f32")
+    assert (m5.cfg.num_classes, m5.cfg.multitasking, m5.cfg.variant) == (4, True, "model2")
+    assert np.abs(m5.predict(x)["seg"] - m3.predict(x)["seg"]).max() < 1e-6
+    net4.model.save_weights(str(tmp_path / "to_keras.h5"))
+    back = h5lite.keras_weights_from_group(h5lite.read_h5(str(tmp_path / "to_keras.h5")))
+    assert set(back) == {k + ":0" for k in w} and all(np.array_equal(back[k + ":0"], w[k]) for k in w)
+    ck = h5lite.read_h5(path)                                  # model.save(): Keras weight layout + our metadata + optimizer moments
+    assert "rua_checkpoint" in ck.attrs and "model_weights" in ck and ck["optimizer_weights/rua/m:0"].dtype == np.float32
+    import pickle
+    bad = str(tmp_path / "pickled.h5")
+    pickle.dump({"weights": 1}, open(bad, "wb"))
+    with pytest.raises(ValueError, match="not an HDF5 file"):  # nothing is ever unpickled
+        load_model(bad)
 
 
 def test_cli_end_to_end_on_synthetic_dataset(tmp_path):

@@ -10,7 +10,8 @@ Deviations, all additive or forced by the reference's hard-coded values (SURVEY.
   * the default weighted-CE class weights are the reference's five values (reference :424) only when
     --num_classes is 5; otherwise uniform weights.
   * scalars go to `<results_path>/logs/{train,val}/scalars.jsonl` with the reference's TensorBoard tag names
-    (tensorboard is not available); the best model is `<results_path>/best_model.h5` in this package's format.
+    (tensorboard is not available); the best model is `<results_path>/best_model.h5`: real HDF5 whose `model_weights` group is
+    Keras' own weight layout (plus this package's metadata and optimizer state, written without h5py by h5lite).
   * `--dtype {bf16,f32}`, `--seed`: engine options.  Launch with torch.distributed.run for multi-GPU data
     parallel (`-bs` is then the GLOBAL batch, as under MirroredStrategy).
 """
