@@ -8,7 +8,7 @@ import re
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CXXFILT = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+CXXFILT = next((c for c in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "/usr/bin/llvm-cxxfilt", "/usr/bin/c++filt") if os.path.exists(c)), "c++filt")
 
 
 def short(nm):

@@ -394,8 +394,8 @@ def _cfg_from_keras_file(root, weights, input_shape):
     stem = kernels[0][1]
     cin, width = int(stem.shape[2]), int(stem.shape[3])
     names = {k.split(":")[0] for k in weights}
-    multitask = any(n.startswith(("seg3/", "color/")) for n in names)
-    ncls = int(next(v for k, v in kernels if k.startswith("seg3/")).shape[-1]) if multitask else int(kernels[-1][1].shape[-1])
+    multitask = any(n.startswith(("seg3", "color")) for n in names)             # the multitask heads carry explicit layer names (model2.py:153-188)
+    ncls = int(next(v for k, v in kernels if k.startswith("seg3")).shape[-1]) if multitask else int(kernels[-1][1].shape[-1])
     depth = 7 if max(int(v.shape[-1]) for _, v in kernels) >= width * 64 else 6
     if input_shape is None:
         cfgs = root.attrs.get("model_config")
