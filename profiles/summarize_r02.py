@@ -21,7 +21,7 @@ def short(nm):
 raw = json.load(open(os.path.join(HERE, "r02", "counters_raw.json")))
 bench = json.loads(open(os.path.join(HERE, "r02", "bench.json")).read().strip().splitlines()[-1])
 rows = list(csv.DictReader(open(os.path.join(HERE, "r02", "kernel_stats.csv"))))
-steps = bench["steps"] * bench.get("timed_blocks", 1) + bench["warmup"] + 4 + 1          # + keep-busy steps + the instrumented step
+steps = bench["steps"] * bench.get("timed_blocks", 1) + bench["warmup"] + 4 + 2          # + keep-busy steps + the two instrumented steps
 stat = {short(r["Name"]): (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6) for r in rows}
 tot_ms = sum(v[2] for v in stat.values())
 out = {"source": "rocprofv3 --pmc (tools/pmc_kernel.sh: three SQ passes, FETCH_SIZE, WRITE_SIZE; kernel trace only) over `bench.py --steps 2 --warmup 1`, "
