@@ -144,7 +144,7 @@ def profile_kernels(eng, g, dtype):
                 else:
                     wk = lib.raw("rua_wgrad_kind")(C.byref(d)); kn = (f"wgrad_kernel<{tname}>", f"wgrad_taps_kernel<{d.C}>", "wgrad_dmap", "wgrad_pw")[wk]
                     two = fired
-                    fl, tag, second = wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, ""), "wgrad_taps_reduce"
+                    fl, tag, second = wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, ""), ("wgrad_taps_reduce" if wk == 1 else "wgrad_slab_reduce")
                 if two:                                     # per-kernel rows, as rocprofv3 names them
                     rec.append((kn, e0, em, fl, tag)); rec.append((second, em, e1, 0.0, tag))
                 else:

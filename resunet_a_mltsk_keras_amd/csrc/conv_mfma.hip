@@ -1684,6 +1684,8 @@ struct WgK {
   int C, Hs, Ws, Cout, H, W, N, stride, dil, taps;
   long long M; int pix_per_block, ntc, nti, ksplit;
   int wshift, hshift;      // log2(W), log2(H) when both are powers of two, else -1 (generic division path)
+  float* slabs;            // K split: slice ks stores its partial dW into slabs[ks * taps * Cout * C ..] (plain stores; summed in a
+                           // fixed order by wgrad_slab_reduce: bit-reproducible); null: fp32 atomics into dw
 };
 
 template <typename T>
@@ -1805,12 +1807,51 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
           float* dst = &p.dw[((size_t)tap * p.Cout + co) * p.C + ci];
           // one K slice = one writer per element: a plain read-modify-write (float atomics run at ~1.3 TB/s chip-wide,
           // plain traffic at ~6; the 8x8 level writes its whole 37.7 MB gradient this way)
-          if (p.ksplit == 1) *dst += acc[i]; else unsafeAtomicAdd(dst, acc[i]);
+          if (p.ksplit == 1) *dst += acc[i];
+          else if (p.slabs) p.slabs[(size_t)ks * p.taps * p.Cout * p.C + ((size_t)tap * p.Cout + co) * p.C + ci] = acc[i];
+          else unsafeAtomicAdd(dst, acc[i]);
         }
       }
     }
   }
 }
+
+// dw += sum of the K slices' slabs, in a FIXED order (bit-reproducible).  256 threads = 16 float4 columns x 16 slice lanes: lane sl
+// adds slices sl, sl + 16, .. (all its loads independent), the 16 lanes are folded through LDS in lane order.
+__global__ __launch_bounds__(256) void wgrad_slab_reduce(const float* __restrict__ slabs, float* __restrict__ dw, long long n4, int ksplit) {
+  __shared__ float4 sh[256];
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + el;
+  float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+  if (i < n4) {
+    const float4* s = reinterpret_cast<const float4*>(slabs) + i;
+    int k = sl;
+    for (; k + 16 < ksplit; k += 32) {
+      const float4 v0 = s[(size_t)k * n4], v1 = s[(size_t)(k + 16) * n4];
+      t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w; t1.x += v1.x; t1.y += v1.y; t1.z += v1.z; t1.w += v1.w;
+    }
+    if (k < ksplit) { const float4 v0 = s[(size_t)k * n4]; t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w; }
+  }
+  sh[threadIdx.x] = make_float4(t0.x + t1.x, t0.y + t1.y, t0.z + t1.z, t0.w + t1.w);
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const float4 v = sh[k * 16 + el]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    float4* d = reinterpret_cast<float4*>(dw) + i;
+    float4 o = *d;
+    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+    *d = o;
+  }
+}
+static int launch_slab_reduce(const float* slabs, float* dw, long long n, int ksplit, hipStream_t st) {
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(wgrad_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, slabs, dw, n4, ksplit);
+  RUA_LAUNCH_CHECK("wgrad_slab_reduce");
+  return RUA_OK;
+}
+// K slices that fit the caller's workspace as fp32 slabs (the last WG_PW_TAIL bytes belong to wgrad_pw); 1: no room
+static int slab_capacity(const rua_wgrad_desc* d, long long ndw);
 
 // =========================================================================================
 // wgrad_dmap: the weight gradient of the wide levels (C, Cout multiples of 128, bf16, stride 1, power-of-two maps) on the
@@ -1827,6 +1868,7 @@ struct WgdK {
   long long M;
   int ntc, nti, ksplit, stages_per_split;
   unsigned abytes, dybytes;
+  float* slabs;            // as in WgK
 };
 
 // Transposing LDS read that hipcc's wait insertion cannot see (it puts s_waitcnt vmcnt(0) in front of a ds_read_b64_tr_b16
@@ -1985,7 +2027,9 @@ __global__ __launch_bounds__(256) void wgrad_dmap(const WgdK p) {
         float* dst = &p.dw[((size_t)tap * p.Cout + co) * p.C + ci];
         // K slices add with float atomics: per-slice partial tiles in a workspace + a reduce launch were measured and are no
         // faster (64x64x128 level 32.8 vs 35.6 us, still behind wgrad_kernel's 33.7; 32x32x256 level 27.9 vs 27.0)
-        if (p.ksplit == 1) *dst += acc[a][b][i]; else unsafeAtomicAdd(dst, acc[a][b][i]);
+        if (p.ksplit == 1) *dst += acc[a][b][i];
+        else if (p.slabs) p.slabs[(size_t)ks_i * p.taps * p.Cout * p.C + ((size_t)tap * p.Cout + co) * p.C + ci] = acc[a][b][i];
+        else unsafeAtomicAdd(dst, acc[a][b][i]);
       }
 }
 
@@ -2584,6 +2628,12 @@ extern "C" int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d) {
   return wg_taps_bytes(d) + WG_PW_TAIL;                 // all-taps block partials + wgrad_pw's replicas and ticket (the tail)
 }
 
+static int slab_capacity(const rua_wgrad_desc* d, long long ndw) {
+  if (!d->workspace || d->workspace_bytes <= WG_PW_TAIL) return 1;
+  const long long n = (d->workspace_bytes - WG_PW_TAIL) / (ndw * 4);
+  return n > 64 ? 64 : (int)n;
+}
+
 // which kernel a descriptor launches: 1 = all-taps (top levels), 0 = generic tiled
 static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
   WgdK k;
@@ -2599,13 +2649,18 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
   long long want = target / tiles; if (want < 1) want = 1;
   if (want > stages / 4) want = stages / 4;             // >= 4 stages per K slice
   if (want < 1) want = 1;
+  const long long ndw = (long long)d->taps * d->Cout * d->C;
+  const int cap = g_tune.wgrad_slabs ? slab_capacity(d, ndw) : 0;
+  if (cap >= 2 && want > cap) want = cap;               // deterministic K split: one fp32 slab per slice must fit the workspace
   k.stages_per_split = (int)((stages + want - 1) / want);
   k.ksplit = (stages + k.stages_per_split - 1) / k.stages_per_split;
+  k.slabs = (cap >= 2 && k.ksplit > 1) ? (float*)d->workspace : nullptr;
   k.abytes = (unsigned)((size_t)k.M * d->C * 2); k.dybytes = (unsigned)((size_t)k.M * d->Cout * 2);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
   hipLaunchKernelGGL(wgrad_dmap, dim3((unsigned)(tiles * k.ksplit)), dim3(256), 96 * 1024, st, k);
   RUA_LAUNCH_CHECK("wgrad_dmap");
+  if (k.slabs) { record_mid_event(st); return launch_slab_reduce(k.slabs, d->dw, ndw, k.ksplit, st); }
   return RUA_OK;
 }
 
@@ -2663,15 +2718,20 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   long long want = target / tiles; if (want < 1) want = 1;
   long long stages = (k.M + 63) / 64;
   if (want > stages) want = stages;
+  const long long ndw = (long long)d->taps * d->Cout * d->C;
+  const int cap = (g_tune.wgrad_slabs && ndw % 4 == 0) ? slab_capacity(d, ndw) : 0;
+  if (cap >= 2 && want > cap) want = cap;              // deterministic K split: one fp32 slab per slice must fit the workspace
   long long spb = (stages + want - 1) / want;          // stages per block
   k.pix_per_block = (int)(spb * 64);
   k.ksplit = (int)((k.M + k.pix_per_block - 1) / k.pix_per_block);
+  k.slabs = (cap >= 2 && k.ksplit > 1) ? (float*)d->workspace : nullptr;
   const long long grid = tiles * k.ksplit;
   RUA_CHECK_ARG(grid < (1ll << 31), "rua_conv_wgrad: grid too large");
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == RUA_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, k);
   else hipLaunchKernelGGL((wgrad_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, k);
   RUA_LAUNCH_CHECK("wgrad_kernel");
+  if (k.slabs) { record_mid_event(st); return launch_slab_reduce(k.slabs, d->dw, ndw, k.ksplit, st); }
   return RUA_OK;
 }
 

@@ -52,20 +52,28 @@ def canny_u8(img: np.ndarray, low: float, high: float) -> np.ndarray:
     return np.where(keep[lab], 255, 0).astype(np.uint8)
 
 
+def dilate_cross(img: np.ndarray, ksize=(3, 3)) -> np.ndarray:
+    """cv2.dilate(img, getStructuringElement(MORPH_CROSS, ksize), iterations=1): ksize = (width, height); the element is the
+    centre row plus the centre column (anchor at the centre), the outside of the image is ignored (max over the inside)."""
+    kw, kh = int(ksize[0]), int(ksize[1])
+    ax, ay = kw // 2, kh // 2
+    H, W = img.shape
+    p = np.pad(img, ((ay, kh - 1 - ay), (ax, kw - 1 - ax)), mode="constant", constant_values=0)
+    views = [p[ay:ay + H, j:j + W] for j in range(kw)] + [p[i:i + H, ax:ax + W] for i in range(kh)]
+    return np.maximum.reduce(views)
+
+
 def dilate_cross3(img: np.ndarray) -> np.ndarray:
-    """cv2.dilate(img, getStructuringElement(MORPH_CROSS, (3, 3)), iterations=1): max over the 3x3 cross, the outside ignored."""
-    p = np.pad(img, 1, mode="constant", constant_values=0)
-    return np.maximum.reduce([p[1:-1, 1:-1], p[:-2, 1:-1], p[2:, 1:-1], p[1:-1, :-2], p[1:-1, 2:]])
+    return dilate_cross(img, (3, 3))
 
 
 def get_boundary_label(label: np.ndarray, kernel_size=(3, 3)) -> np.ndarray:
-    """multitasking_utils.py:6-23: per class channel Canny(0, 1) of the {0,1} mask, dilated by a 3x3 cross, scaled to [0, 1]."""
-    if tuple(kernel_size) != (3, 3):
-        raise NotImplementedError("the reference only ever uses the 3x3 cross")
+    """multitasking_utils.py:6-23: per class channel Canny(0, 1) of the {0,1} mask, dilated by a `kernel_size` cross (the
+    reference's callers use the default 3x3), scaled to [0, 1]."""
     tl = label.astype(np.uint8)
     out = np.empty(label.shape, np.float32)
     for c in range(label.shape[2]):
-        out[:, :, c] = dilate_cross3(canny_u8(tl[:, :, c], 0, 1)).astype(np.float32) / 255.0
+        out[:, :, c] = dilate_cross(canny_u8(tl[:, :, c], 0, 1), kernel_size).astype(np.float32) / 255.0
     return out
 
 

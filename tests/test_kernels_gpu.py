@@ -264,6 +264,20 @@ def test_conv_wgrad(case, dt):
     y = ref_conv_nhwc(rnd(dt, a).double(), w, None, dil, taps, stride)
     y.backward(rnd(dt, dy).double())
     assert rel_err(dw.cpu().numpy(), w.grad.numpy()) < tol(dt)
+    # with a workspace the K slices go through fp32 slabs summed in a fixed order: the same gradient, bit-reproducible and
+    # ADDED to what dW holds (the atomic K split was order-dependent)
+    ws = torch.empty((32 << 20) // 4, dtype=torch.float32, device=dev())
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if L.lib().raw("rua_wgrad_kind")(C.byref(d)) in (0, 2):
+        outs = []
+        for rep in range(2):
+            dw.fill_(1.0)
+            ws.uniform_(-1e3, 1e3)                               # slabs need no initialisation
+            L.lib().call("rua_conv_wgrad", C.byref(d), stream())
+            torch.cuda.synchronize()
+            outs.append(dw.cpu().numpy().copy())
+        assert np.array_equal(outs[0], outs[1])
+        assert rel_err(outs[0] - 1.0, w.grad.numpy()) < tol(dt)
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 32, 1), (1, 128, 64, 32, 3), (2, 64, 128, 32, 15), (1, 64, 64, 32, 31),

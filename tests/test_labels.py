@@ -65,3 +65,21 @@ def test_multitask_labels_shapes():
     assert set(out) == {"seg", "bound", "dist", "color"}
     assert all(v.dtype == np.float32 for v in out.values())
     assert out["bound"].shape == out["dist"].shape == (16, 16, 2) and out["color"].shape == (16, 16, 3)
+
+
+def test_cross_dilation_of_any_size_matches_a_direct_loop():
+    """cv2.getStructuringElement(MORPH_CROSS, (kw, kh)) = centre row + centre column; dilate = max over it, outside ignored."""
+    from resunet_a_mltsk_keras_amd.labels import dilate_cross, get_boundary_label
+    rng = np.random.default_rng(2)
+    img = (rng.random((13, 17)) > 0.85).astype(np.uint8) * 255
+    for kw, kh in ((3, 3), (5, 5), (5, 3), (1, 7)):
+        exp = np.zeros_like(img)
+        for y in range(img.shape[0]):
+            for x in range(img.shape[1]):
+                vals = [img[y, xx] for xx in range(x - kw // 2, x - kw // 2 + kw) if 0 <= xx < img.shape[1]]
+                vals += [img[yy, x] for yy in range(y - kh // 2, y - kh // 2 + kh) if 0 <= yy < img.shape[0]]
+                exp[y, x] = max(vals)
+        assert np.array_equal(dilate_cross(img, (kw, kh)), exp), (kw, kh)
+    seg = np.zeros((16, 16, 2), np.float32); seg[4:12, 4:12, 0] = 1; seg[..., 1] = 1 - seg[..., 0]
+    b3, b5 = get_boundary_label(seg), get_boundary_label(seg, (5, 5))
+    assert b5.sum() > b3.sum() and np.all(b5 >= b3)            # a wider cross only adds boundary pixels
