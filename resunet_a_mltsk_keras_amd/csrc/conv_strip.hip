@@ -144,24 +144,32 @@ __global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) {
   auto transform = [&](int rho) {
     if (!row_ok(rho)) return;
     unsigned char* slot = x_slot(rho);
+    // all pieces are read first (one LDS round trip for the row instead of one per piece: piece by piece the dependent
+    // read -> arithmetic -> write chains cost ~1000 cycles per row and wave), then normalised, then written back
+    uint4 raw[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; ++k)
+      raw[k] = *reinterpret_cast<const uint4*>(xok[k] ? slot + xdst[k] + lane * 16 : sDump + wv * 1024 + lane * 16);
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      float f[8];
+      ET<T>::unpack(raw[k], f);
+      if (p.in_relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(sc8[j], f[j], sh8[j]), 0.f);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaf(sc8[j], f[j], sh8[j]);
+      }
+      raw[k] = ET<T>::pack(f);
+    }
 #pragma unroll
     for (int k = 0; k < NPX; ++k)
       if (xok[k]) {
-        uint4* ptr = reinterpret_cast<uint4*>(slot + xdst[k] + lane * 16);
-        float f[8];
-        ET<T>::unpack(*ptr, f);
-        if (p.in_relu) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(sc8[j], f[j], sh8[j]), 0.f);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = fmaf(sc8[j], f[j], sh8[j]);
-        }
         // raw write: hipcc orders a C++ LDS store behind every LDS-DMA in flight (s_waitcnt vmcnt(0): the ring would drain at
         // every stage); this piece's own DMA has landed (counted wait above) and nobody else touches it before the barrier
-        const uint4 pk = ET<T>::pack(f);
-        const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
-        const unsigned la = (unsigned)(size_t)(lds_void_p)reinterpret_cast<unsigned char*>(ptr);
+        const u32x4_t pv = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+        const unsigned la = (unsigned)(size_t)(lds_void_p)(slot + xdst[k] + lane * 16);
         asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(pv) : "memory");
       }
   };
@@ -304,7 +312,12 @@ __global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
-static int strip_width(const rua_conv_desc* d) { return d->W % 256 == 0 ? 256 : (d->W % 128 == 0 ? 128 : 0); }
+// strip width: 256 pixels (8 waves) where the row allows it; tuning key strip_narrow_maxd: dilations up to it take 128-pixel
+// strips instead (twice the chains, half the window-fill overhead, four waves per block)
+static int strip_width(const rua_conv_desc* d) {
+  if (d->W % 256 == 0 && d->seg[0].dil > g_tune.strip_narrow_maxd) return 256;
+  return d->W % 128 == 0 ? 128 : 0;
+}
 
 bool rua_pick_strip(const rua_conv_desc* d) {
   if (!g_tune.conv_strip || d->dtype != RUA_BF16 || d->nseg != 1) return false;

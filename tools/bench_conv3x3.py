@@ -34,7 +34,7 @@ def main():
     flops = 2.0 * N * H * W * Cc * Cc * 9
     print(f"{N}x{H}x{W}x{Cc}: {flops / 1e9:.2f} GFLOP, {x.numel() * 2 / 1e6:.1f} MB per tensor")
     for dil in dils:
-        for mode in ("fwd_bn_stats", "fwd_plain", "dgrad_mask_stats2", "fwd_bn_accumulate"):
+        for mode in ("fwd_plain", "fwd_bn", "fwd_bn_stats", "dgrad_mask_stats2", "fwd_bn_accumulate"):
             if only_mode and mode != only_mode:
                 continue
             row = []
@@ -47,10 +47,10 @@ def main():
                 sg.x, sg.w, sg.C, sg.Hs, sg.Ws, sg.up_shift, sg.dil, sg.taps = x.data_ptr(), w.data_ptr(), Cc, H, W, 0, dil, 9
                 d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cc, 1, L.RUA_BF16
                 d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
-                d.stats, d.stats_replicas = stats.data_ptr(), 4
+                d.stats, d.stats_replicas = stats.data_ptr(), 32        # what the engine passes for 4096 row tiles
                 d.bias = bias.data_ptr()
-                if mode == "fwd_bn_stats":
-                    d.stats_mode = 1
+                if mode in ("fwd_bn_stats", "fwd_bn"):
+                    d.stats_mode = 1 if mode == "fwd_bn_stats" else 0
                     if strip:
                         d.in_scale, d.in_shift, d.in_relu = sc.data_ptr(), sh.data_ptr(), 1
                 elif mode == "dgrad_mask_stats2":
@@ -59,7 +59,7 @@ def main():
                     d.accumulate = 1
                     if strip:
                         d.in_scale, d.in_shift, d.in_relu = sc.data_ptr(), sh.data_ptr(), 1
-                lib.set_tuning(conv_strip=strip)
+                lib.set_tuning(conv_strip=strip, strip_narrow_maxd=int(os.environ.get("B3_NARROW", "0")))
                 kid = lib.raw("rua_conv_kernel_id")(C.byref(d))
                 for _ in range(5):
                     lib.call("rua_conv_fwd", C.byref(d), s)
