@@ -390,5 +390,7 @@ def test_normalise_on_load_resblocks_match_materialised_batchnorm():
     for h in za:
         assert rel(za[h], zb[h]) < 5e-2, (h, rel(za[h], zb[h]))
     gmax = max(float(np.abs(v).max()) for v in gb.values())
-    worst = max((float(np.abs(ga[k] - gb[k]).max() / np.abs(gb[k]).max()), k) for k in gb if np.abs(gb[k]).max() > 1e-5 * gmax)
+    # per tensor, relative to its own scale - but not below 1e-3 of the largest gradient: biases that feed a training-mode
+    # BatchNorm have a true gradient of exactly zero and hold bf16 rounding noise on both sides
+    worst = max((float(np.abs(ga[k] - gb[k]).max() / max(np.abs(gb[k]).max(), 1e-3 * gmax)), k) for k in gb)
     assert worst[0] < 1e-1, worst
