@@ -198,6 +198,8 @@ typedef struct rua_bn_bwd_branch {
 typedef struct rua_bn_bwd_desc {
   const void* x; const void* dskip; void* dx; int64_t M; int32_t C, dtype, nb, masked, accumulate, pad; double count;
   rua_bn_bwd_branch br[RUA_MAX_BRANCH];
+  double* skip_stats;          /* optional [skip_replicas][2][C]: per-channel sum of dskip added into slot 0 (the bias gradient of */
+  int32_t skip_replicas, pad2; /* the convs whose output the skip tensor is the gradient of: model2.py:27-31) - saves a pass over dskip */
 } rua_bn_bwd_desc;
 int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream);
 

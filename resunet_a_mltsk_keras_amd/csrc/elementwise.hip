@@ -505,6 +505,10 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, lo
   const unsigned char* dskip = (const unsigned char*)p.dskip;
   unsigned char* dx = (unsigned char*)p.dx;
   const long long stride = (long long)gridDim.x * 256;
+  // per-channel sum of dskip (256 is a multiple of CG, so a thread stays on one channel group for the whole sweep)
+  float sk[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sk[j] = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += stride) {
     const int c = (int)(i % CG) * VEC;
     float xv[VEC], acc[VEC];
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, lo
       float dd[VEC];
       ET<T>::unpack(ldg16(dskip + i * 16), dd);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] += dd[j];
+      for (int j = 0; j < VEC; ++j) { acc[j] += dd[j]; sk[j] += dd[j]; }
     }
     if (p.accumulate) {
       float dd[VEC];
@@ -534,6 +538,20 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, lo
     }
     stg16(dx + i * 16, ET<T>::pack(acc));
   }
+  if (p.skip_stats && dskip) {                           // uniform: fold the block's partial sums through LDS, one fp64 add per channel
+    __syncthreads();                                     // the coefficient table is dead
+    float* red = tab;                                    // [256][VEC] (the launcher sized the dynamic LDS for it)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = sk[j];
+    __syncthreads();
+    const int per = 256 / CG;                            // threads per channel group
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+      const int cg = ch / VEC, j = ch - cg * VEC;
+      float t = 0.f;
+      for (int k = 0; k < per; ++k) t += red[(k * CG + cg) * VEC + j];
+      unsafeAtomicAdd(&p.skip_stats[(size_t)(blockIdx.x & (p.skip_replicas - 1)) * 2 * C + ch], (double)t);
+    }
+  }
 }
 
 extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
@@ -547,9 +565,14 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
     RUA_CHECK_ARG(br.g && br.stats2 && br.replicas >= 1 && br.gamma && br.mean && br.rstd, "rua_bn_bwd: null branch pointer");
     if (br.replicas > rmax) rmax = br.replicas;
   }
-  const size_t smem = (size_t)(d->nb * 3 + 2) * d->C * 4;
+  size_t smem = (size_t)(d->nb * 3 + 2) * d->C * 4;
   RUA_CHECK_ARG(smem <= 64 * 1024, "rua_bn_bwd: coefficient table too large");
   const int CG = d->C / vec;
+  if (d->skip_stats) {
+    RUA_CHECK_ARG(d->dskip && d->skip_replicas >= 1 && (d->skip_replicas & (d->skip_replicas - 1)) == 0 && CG <= 256 && 256 % CG == 0,
+                  "rua_bn_bwd: skip_stats needs dskip, a power-of-two replica count and C / %d dividing 256", vec);
+    if (smem < (size_t)256 * vec * 4) smem = (size_t)256 * vec * 4;
+  }
   const long long pieces = d->M * CG;
   int g = grid_for(pieces);
   // measured (4 branches): 256x256x32 53 -> 46 us, 128x128x64 35 -> 31 us with 1024 blocks; smaller tensors prefer 512

@@ -469,8 +469,10 @@ class Graph:
         return coefs
 
     def bn_bwd(self, plan: Plan, gs: List[Ten], coefs: List[Coef], bns: List[dict], stats2: List[Stat], x: Ten, out: Ten,
-               accumulate: int, count, dskip: Optional[Ten] = None, masked=False):
-        """dx (=|+=) [dskip] + sum_b BN-backward_b(g_b) in ONE launch; dgamma/dbeta added by block 0."""
+               accumulate: int, count, dskip: Optional[Ten] = None, masked=False, skip_bias: Optional[List[int]] = None):
+        """dx (=|+=) [dskip] + sum_b BN-backward_b(g_b) in ONE launch; dgamma/dbeta added by block 0.
+        skip_bias: bias offsets whose gradient is the per-channel sum of dskip - accumulated by this launch while it reads
+        dskip anyway (instead of a col_stats pass over the same tensor), converted by one rua_stats_to_f32."""
         d = L.BnBwdDesc()
         d.x, d.dx, d.M, d.C, d.dtype, d.nb = x.ptr, out.ptr, x.M, x.C, self.dt, len(gs)
         d.dskip = dskip.ptr if dskip is not None else None
@@ -480,8 +482,21 @@ class Graph:
             b.g, b.stats2, b.replicas = g.ptr, s2.ptr, s2.R
             b.gamma, b.mean, b.rstd, b.scale, b.shift = self.P(bn["gamma"]), c.mean, c.rstd, c.scale, c.shift
             b.dgamma, b.dbeta = self.G(bn["gamma"]), self.G(bn["beta"])
+        st = None
+        cg = x.C // self.vec
+        if skip_bias and dskip is not None and not (cg <= 256 and 256 % cg == 0):
+            self.bias_grad(plan, dskip, skip_bias)            # (d7 in fp32: 2048 channels = 512 pieces per pixel: its own pass)
+            skip_bias = None
+        if skip_bias and dskip is not None:
+            blocks = max(1, min(1024, x.M * (x.C // self.vec) // 256))
+            st = self.stat(x.C, blocks, burst=True)
+            d.skip_stats, d.skip_replicas = st.ptr, st.R
         plan.keep.append(d)
         plan.add("rua_bn_bwd", C.byref(d))
+        if st is not None:
+            dst = L.ptr_array([self.G(o) for o in skip_bias])
+            plan.keep.append(dst)
+            plan.add("rua_stats_to_f32", st.ptr, st.R, x.C, dst, len(skip_bias))
 
     def conv(self, plan: Plan, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual: Optional[Ten] = None,
              out_relu=False, stats=None, bias_more=(), in_bn: Optional["Coef"] = None, accumulate: int = 0):
@@ -638,7 +653,8 @@ class Graph:
             Bp = self.bwd
             Bp.scope = scope
             dO = out.grad
-            self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
+            if not v2:
+                self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])      # (model2: summed by the final bn_bwd, which reads dO as the skip gradient)
             g1s, s1s = [], []
             Bp.fork(len(dils))
             for bi, (d, l, a_1, y, c2, a_2, c1) in enumerate(zip(dils, lay, a1, y1, coef2, a2, coef1)):
@@ -657,7 +673,8 @@ class Graph:
                 g1s.append(g1); s1s.append(s1)
             Bp.join(len(dils)); self.cur_lane = 0
             gx, acc = self.gacc(x)
-            self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None)
+            self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None,
+                        skip_bias=[l[3]["bias"] for l in lay] if v2 else None)
             Bp.scope = None
         self.back_steps.append(back)
         return out
@@ -692,7 +709,8 @@ class Graph:
             Bp = self.bwd
             Bp.scope = scope
             dO = out.grad
-            self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
+            if not v2:
+                self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
             g1s, s1s = [], []
             for d, l, y, c2, c1 in zip(dils, lay, y1, coef2, coef1):
                 self.wgrad(Bp, y, dO, l[3]["segs"][0]["off"], 1, d, 9, in_bn=c2)
@@ -707,7 +725,8 @@ class Graph:
                 self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
                 g1s.append(g1); s1s.append(s1)
             gx, acc = self.gacc(x)
-            self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None)
+            self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None,
+                        skip_bias=[l[3]["bias"] for l in lay] if v2 else None)
             Bp.scope = None
         self.back_steps.append(back)
         return out
