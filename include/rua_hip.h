@@ -121,7 +121,26 @@ typedef struct rua_wgrad_desc {
   const float* in_scale;
   const float* in_shift;
   int32_t in_relu;
+  /* Deferred reduction: with defer != 0 a call whose kernel leaves partial sums (the all-taps block partials, the K slices'
+   * slabs) does NOT launch its reduction; `workspace` must then stay untouched until rua_wgrad_reduce_batch has consumed the
+   * record rua_wgrad_plan() returns for this descriptor (one workspace per deferred call; size: rua_wgrad_workspace_bytes). */
+  int32_t defer;
 } rua_wgrad_desc;
+typedef struct rua_wgrad_pending {
+  int32_t kind;                /* 0: nothing to reduce (single writer / wgrad_pw), 1: all-taps partials, 2: K-slice slabs */
+  int32_t parts;               /* partial buffers to sum (blocks of the all-taps kernel per output-channel half / K slices) */
+  int64_t n;                   /* elements of dW */
+  const float* partials;
+  float* dw;
+  int32_t CC;                  /* kind 1: channels */
+  int32_t blocks;              /* 256-thread blocks the reduction of this record takes */
+  int32_t block_begin, pad;    /* filled by the caller: first block of this record in the batched launch (prefix sum of `blocks`) */
+} rua_wgrad_pending;
+/* the record a deferred rua_conv_wgrad(d) leaves behind - computed without launching anything */
+int rua_wgrad_plan(const rua_wgrad_desc* d, rua_wgrad_pending* out);
+/* dw += partial sums for every record, in ONE launch, each in its fixed order (bit-reproducible): items in device memory, sorted by
+ * block_begin, total_blocks = sum of their `blocks` */
+int rua_wgrad_reduce_batch(const rua_wgrad_pending* items_dev, int n_items, int total_blocks, void* stream);
 int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream);
 int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d);
 int rua_wgrad_kind(const rua_wgrad_desc* d);   /* 0: generic tiled kernel, 1: all-taps kernel + deterministic partial reduce,

@@ -31,7 +31,12 @@ class ConvDesc(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [("a", vp), ("C", i32), ("Hs", i32), ("Ws", i32), ("dy", vp), ("Cout", i32), ("H", i32), ("W", i32),
                 ("N", i32), ("stride", i32), ("dil", i32), ("taps", i32), ("dtype", i32), ("dw", vp), ("workspace", vp), ("workspace_bytes", i64),
-                ("in_scale", vp), ("in_shift", vp), ("in_relu", i32)]
+                ("in_scale", vp), ("in_shift", vp), ("in_relu", i32), ("defer", i32)]
+
+
+class WgradPending(C.Structure):
+    _fields_ = [("kind", i32), ("parts", i32), ("n", i64), ("partials", vp), ("dw", vp), ("CC", i32), ("blocks", i32),
+                ("block_begin", i32), ("pad", i32)]
 
 
 class BnBranch(C.Structure):
@@ -81,6 +86,8 @@ _SIGS = {
     "rua_conv_wgrad": ([C.POINTER(WgradDesc), vp], i32),
     "rua_wgrad_workspace_bytes": ([C.POINTER(WgradDesc)], i64),
     "rua_wgrad_kind": ([C.POINTER(WgradDesc)], i32),
+    "rua_wgrad_plan": ([C.POINTER(WgradDesc), C.POINTER(WgradPending)], i32),
+    "rua_wgrad_reduce_batch": ([vp, i32, i32, vp], i32),
     "rua_weight_prep": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "rua_stem_fwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "rua_stem_bwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),

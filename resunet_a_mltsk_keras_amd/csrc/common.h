@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include "../../include/rua_hip.h"
 
 typedef __bf16 bf16_t;

@@ -455,6 +455,15 @@ static thread_local hipEvent_t g_mid_event = nullptr;
 static thread_local int g_mid_fired = 0;
 extern "C" void rua_profile_mid_event(void* ev) { g_mid_event = (hipEvent_t)ev; if (ev) g_mid_fired = 0; }
 extern "C" int rua_profile_mid_event_fired(void) { return g_mid_fired; }     // 1: the call since the last arm had a second launch
+// rua_wgrad_plan(): the launchers below run with g_wgrad_dry set - every geometry decision is taken, nothing is launched - and
+// report the reduction they would leave pending through g_wgrad_pending (also filled by real deferred calls).
+static thread_local bool g_wgrad_dry = false;
+static thread_local rua_wgrad_pending* g_wgrad_pending = nullptr;
+static inline void note_pending(int kind, int parts, long long n, const float* partials, float* dw, int CC, int blocks) {
+  if (!g_wgrad_pending) return;
+  g_wgrad_pending->kind = kind; g_wgrad_pending->parts = parts; g_wgrad_pending->n = n; g_wgrad_pending->partials = partials;
+  g_wgrad_pending->dw = dw; g_wgrad_pending->CC = CC; g_wgrad_pending->blocks = blocks;
+}
 static inline void record_mid_event(hipStream_t st) {
   if (g_mid_event) { (void)hipEventRecord(g_mid_event, st); g_mid_event = nullptr; g_mid_fired = 1; }
 }
@@ -1818,10 +1827,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
 
 // dw += sum of the K slices' slabs, in a FIXED order (bit-reproducible).  256 threads = 16 float4 columns x 16 slice lanes: lane sl
 // adds slices sl, sl + 16, .. (all its loads independent), the 16 lanes are folded through LDS in lane order.
-__global__ __launch_bounds__(256) void wgrad_slab_reduce(const float* __restrict__ slabs, float* __restrict__ dw, long long n4, int ksplit) {
+__device__ __forceinline__ void wgrad_slab_reduce_body(const float* __restrict__ slabs, float* __restrict__ dw, long long n4, int ksplit, int vblock) {
   __shared__ float4 sh[256];
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long long i = (long long)blockIdx.x * 16 + el;
+  const long long i = (long long)vblock * 16 + el;
   float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
   if (i < n4) {
     const float4* s = reinterpret_cast<const float4*>(slabs) + i;
@@ -1843,6 +1852,9 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce(const float* __restrict
     o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
     *d = o;
   }
+}
+__global__ __launch_bounds__(256) void wgrad_slab_reduce(const float* __restrict__ slabs, float* __restrict__ dw, long long n4, int ksplit) {
+  wgrad_slab_reduce_body(slabs, dw, n4, ksplit, (int)blockIdx.x);
 }
 static int launch_slab_reduce(const float* slabs, float* dw, long long n, int ksplit, hipStream_t st) {
   const long long n4 = n / 4;
@@ -2253,13 +2265,13 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
 
 // dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 16 elements x 16 slices:
 // every thread has all its loads in flight at once, slices are folded through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_taps_reduce(const float* __restrict__ scratch, float* __restrict__ dw, int CC, int gx) {
+__device__ __forceinline__ void wgrad_taps_reduce_body(const float* __restrict__ scratch, float* __restrict__ dw, int CC, int gx, int vblock) {
   // 16 float4 columns x 16 partial slices per block: a 16-lane group reads 256 contiguous bytes of one partial (the scalar
   // version read 64-byte runs: 6.7 us per launch, 37 launches per step), four loads in flight, slices folded in a fixed order
   __shared__ float4 sh[256];
   const int total4 = 9 * CC * CC / 4;
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int e4 = blockIdx.x * 16 + el;
+  const int e4 = vblock * 16 + el;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e4 < total4) {
     const int e = e4 * 4;
@@ -2291,6 +2303,10 @@ __global__ __launch_bounds__(256) void wgrad_taps_reduce(const float* __restrict
     o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
     *d = o;
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_taps_reduce(const float* __restrict__ scratch, float* __restrict__ dw, int CC, int gx) {
+  wgrad_taps_reduce_body(scratch, dw, CC, gx, (int)blockIdx.x);
 }
 
 static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
@@ -2325,6 +2341,9 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   size_t smem = (size_t)k.group_bytes * k.NPG;
   const size_t red = (size_t)(k.NPG - 1) * 3 * (CC / 32) * 3 * 16 * 64 * 4;
   if (red > smem) smem = red;
+  const int rblocks = rua_div_up(9 * CC * CC / 4, 16);
+  note_pending(1, gx, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks);
+  if (g_wgrad_dry) return RUA_OK;
   static bool attr32 = false, attr64 = false;
   if (CC == 32) {
     if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr32 = true; }
@@ -2334,8 +2353,9 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_taps_kernel<64>), dim3(gx, gy), dim3(768), smem, st, k);
   }
   RUA_LAUNCH_CHECK("wgrad_taps_kernel");
+  if (d->defer) return RUA_OK;                         // the caller sums the block partials later (rua_wgrad_reduce_batch)
   record_mid_event(st);
-  hipLaunchKernelGGL(wgrad_taps_reduce, dim3(rua_div_up(9 * CC * CC / 4, 16)), dim3(256), 0, st, (const float*)k.scratch, d->dw, CC, gx);
+  hipLaunchKernelGGL(wgrad_taps_reduce, dim3(rblocks), dim3(256), 0, st, (const float*)k.scratch, d->dw, CC, gx);
   RUA_LAUNCH_CHECK("wgrad_taps_reduce");
   return RUA_OK;
 }
@@ -2582,6 +2602,7 @@ static bool pick_wgrad_pw(const rua_wgrad_desc* d) {
 }
 
 static int launch_wgrad_pw(const rua_wgrad_desc* d, hipStream_t st) {
+  if (g_wgrad_dry) return RUA_OK;                       // reduces inside its own launch: nothing pending
   WgpK k;
   k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.dw = d->dw;
   char* tail = (char*)d->workspace + d->workspace_bytes - WG_PW_TAIL;
@@ -2625,7 +2646,12 @@ static int launch_wgrad_pw(const rua_wgrad_desc* d, hipStream_t st) {
 
 extern "C" int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d) {
   if (!d) return 0;
-  return wg_taps_bytes(d) + WG_PW_TAIL;                 // all-taps block partials + wgrad_pw's replicas and ticket (the tail)
+  // all-taps block partials, or 64 K-slice slabs of dW (capped at 64 MiB: the launchers split K no further than the slabs that
+  // fit), + wgrad_pw's replicas and ticket (the tail)
+  int64_t slabs = (int64_t)64 * d->taps * d->Cout * d->C * 4;
+  if (slabs > (64ll << 20)) slabs = 64ll << 20;
+  const int64_t taps = wg_taps_bytes(d);
+  return (taps > slabs ? taps : slabs) + WG_PW_TAIL;
 }
 
 static int slab_capacity(const rua_wgrad_desc* d, long long ndw) {
@@ -2656,11 +2682,13 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
   k.ksplit = (stages + k.stages_per_split - 1) / k.stages_per_split;
   k.slabs = (cap >= 2 && k.ksplit > 1) ? (float*)d->workspace : nullptr;
   k.abytes = (unsigned)((size_t)k.M * d->C * 2); k.dybytes = (unsigned)((size_t)k.M * d->Cout * 2);
+  if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + 15) / 16));
+  if (g_wgrad_dry) return RUA_OK;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
   hipLaunchKernelGGL(wgrad_dmap, dim3((unsigned)(tiles * k.ksplit)), dim3(256), 96 * 1024, st, k);
   RUA_LAUNCH_CHECK("wgrad_dmap");
-  if (k.slabs) { record_mid_event(st); return launch_slab_reduce(k.slabs, d->dw, ndw, k.ksplit, st); }
+  if (k.slabs && !d->defer) { record_mid_event(st); return launch_slab_reduce(k.slabs, d->dw, ndw, k.ksplit, st); }
   return RUA_OK;
 }
 
@@ -2728,10 +2756,39 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   const long long grid = tiles * k.ksplit;
   RUA_CHECK_ARG(grid < (1ll << 31), "rua_conv_wgrad: grid too large");
   hipStream_t st = (hipStream_t)stream;
+  if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + 15) / 16));
+  if (g_wgrad_dry) return RUA_OK;
   if (d->dtype == RUA_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, k);
   else hipLaunchKernelGGL((wgrad_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, k);
   RUA_LAUNCH_CHECK("wgrad_kernel");
-  if (k.slabs) { record_mid_event(st); return launch_slab_reduce(k.slabs, d->dw, ndw, k.ksplit, st); }
+  if (k.slabs && !d->defer) { record_mid_event(st); return launch_slab_reduce(k.slabs, d->dw, ndw, k.ksplit, st); }
+  return RUA_OK;
+}
+
+extern "C" int rua_wgrad_plan(const rua_wgrad_desc* d, rua_wgrad_pending* out) {
+  RUA_CHECK_ARG(d && out, "rua_wgrad_plan: null pointer");
+  memset(out, 0, sizeof(*out));
+  g_wgrad_pending = out; g_wgrad_dry = true;
+  const int rc = rua_conv_wgrad(d, nullptr);
+  g_wgrad_pending = nullptr; g_wgrad_dry = false;
+  return rc;
+}
+
+// One launch for any number of pending weight-gradient reductions: block -> record by binary search over block_begin, then the
+// record's own reduction (same arithmetic and order as wgrad_taps_reduce / wgrad_slab_reduce: bit-reproducible).
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const rua_wgrad_pending* __restrict__ items, int n_items) {
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+  const rua_wgrad_pending it = items[lo];
+  const int vb = (int)blockIdx.x - it.block_begin;
+  if (vb >= it.blocks) return;
+  if (it.kind == 1) wgrad_taps_reduce_body(it.partials, it.dw, it.CC, it.parts, vb);
+  else if (it.kind == 2) wgrad_slab_reduce_body(it.partials, it.dw, it.n / 4, it.parts, vb);
+}
+extern "C" int rua_wgrad_reduce_batch(const rua_wgrad_pending* items_dev, int n_items, int total_blocks, void* stream) {
+  RUA_CHECK_ARG(items_dev && n_items >= 1 && total_blocks >= 1, "rua_wgrad_reduce_batch: bad arguments");
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+  RUA_LAUNCH_CHECK("rua_wgrad_reduce_batch");
   return RUA_OK;
 }
 

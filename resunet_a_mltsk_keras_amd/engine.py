@@ -341,6 +341,8 @@ class Graph:
         self.grad_touch: Dict[int, int] = {}
         self.cur_lane = 0
         self.block_tag = ""
+        self.pending: List[tuple] = []          # deferred weight-gradient reductions (record, dW offset)
+        self.pending_bucket = 0
         self.allocs: List[torch.Tensor] = []
         self.stats_used = 16                 # the first 16 doubles of the arena are the loss / metric scalars
         self.act_bytes = 0
@@ -587,8 +589,49 @@ class Graph:
         if not self.dry:
             sc = self.e.scratches[self.cur_lane]
             d.workspace, d.workspace_bytes = sc.data_ptr(), sc.numel() * 4
+            if self.e.defer_reduce and plan is self.bwd:
+                self._defer_wgrad(plan, d, dw_off)
         plan.keep.append(d)
         plan.add("rua_conv_wgrad", C.byref(d))
+
+    # -- deferred weight-gradient reductions: the partial sums of many weight gradients (all-taps block partials, K-slice slabs)
+    #    are added into dW by ONE batched launch instead of one small launch each (80 of them per cfg3 step).  Under data
+    #    parallel the batch is flushed whenever the next weight gradient belongs to another all-reduce bucket, so a bucket's
+    #    gradients are final - and its all-reduce starts - as early as before.
+    def _defer_wgrad(self, plan: Plan, d, dw_off: int):
+        lib = L.lib()
+        bucket = self.e.dist.bucket_of(dw_off) if self.e.dist is not None else 0
+        if self.pending and bucket != self.pending_bucket:
+            self.flush_wgrad(plan)
+        self.pending_bucket = bucket
+        rec = L.WgradPending()
+        d.defer = 1
+        lib.call("rua_wgrad_plan", C.byref(d), C.byref(rec))           # with the shared scratch: which kind of partials, if any
+        if rec.kind == 0:
+            d.defer = 0
+            return
+        # exactly the partials this call writes (all-taps: one per CU and output-channel half; slabs: one dW per K slice) + the tail
+        nbytes = (self.e.cu_count * 9 * 32 * rec.CC * 4 if rec.kind == 1 else rec.parts * rec.n * 4) + (264 << 10)
+        ws = self.alloc(((nbytes + 3) // 4,), torch.float32, zero=True)   # private until the flush (zeroed: the tail convention)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        lib.call("rua_wgrad_plan", C.byref(d), C.byref(rec))           # the record for the private workspace
+        assert rec.kind != 0
+        self.pending.append((rec, dw_off))
+
+    def flush_wgrad(self, plan: Plan):
+        if not self.pending:
+            return
+        recs = (L.WgradPending * len(self.pending))()
+        blocks = 0
+        for i, (r, off) in enumerate(self.pending):
+            r.block_begin = blocks
+            blocks += r.blocks
+            C.memmove(C.byref(recs, i * C.sizeof(L.WgradPending)), C.byref(r), C.sizeof(L.WgradPending))
+            self.grad_touch[off] = len(plan.calls)                     # this launch makes the gradient final
+        table = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8).to(self.dev)
+        self.allocs.append(table)
+        plan.add("rua_wgrad_reduce_batch", table.data_ptr(), len(self.pending), blocks)
+        self.pending = []
 
     def bias_grad(self, plan: Plan, dy: Ten, bias_offs: List[int]):
         s = self.col_stats(plan, dy)
@@ -1092,6 +1135,7 @@ class Graph:
             for step in reversed(self.back_steps):
                 step()
             self.back_steps = []
+            self.flush_wgrad(self.bwd)
 
 
 # ---------------------------------------------------------------------------------------
@@ -1110,6 +1154,8 @@ class Engine:
                              "channels and the MFMA epilogue stores 8-channel pieces)")
         self.dev = None
         self.fuse_bn = os.environ.get("RUA_FUSE_BN", "1") != "0"     # normalise-on-load ResBlocks where the library offers it
+        self.defer_reduce = os.environ.get("RUA_DEFER_REDUCE", "1") != "0"     # weight-gradient partials summed by batched launches
+        self.cu_count = 256
         self.split_k = split_k       # False: bit-reproducible convolutions (no fp32-atomic K slices); parity tests on tiny
                                      # inputs use it because a BatchNorm over 2 samples amplifies atomic-order noise ~1e4x
         self.params = ParamStore()
@@ -1129,6 +1175,9 @@ class Engine:
         if not torch.cuda.is_available():
             raise L.RuaError("no HIP device visible: the ResUnet-a training path runs on MI355X only (there is no CPU fallback)")
         self.dev = device or torch.device("cuda", torch.cuda.current_device())
+        cu = C.c_int32(0)
+        if L.lib().raw("rua_device_info")(C.byref(cu), None, None, 0) == 0 and cu.value > 0:
+            self.cu_count = cu.value
         z = lambda n, dt=torch.float32: torch.zeros(max(n, 16), dtype=dt, device=self.dev)
         self.P, self.G, self.M1, self.V1, self.S = z(ps.n), z(ps.n), z(ps.n), z(ps.n), z(ps.ns)
         tdt = torch.bfloat16 if dtype == "bf16" else torch.float32

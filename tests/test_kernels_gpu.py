@@ -881,3 +881,53 @@ def test_wgrad_all_taps_normalise_on_load(Cs, H, W, dil):
     g = torch.nn.grad.conv2d_weight(at, (Cs, Cs, 3, 3), rnd(dt, dy).permute(0, 3, 1, 2).double(), padding=dil, dilation=dil)
     exp = g.permute(2, 3, 0, 1).reshape(9, Cs, Cs).numpy()
     assert rel_err(outs[0].reshape(9, Cs, Cs), exp) < tol(dt)
+
+
+def test_wgrad_deferred_batched_reduction_is_bit_identical():
+    """rua_conv_wgrad(defer=1) leaves its partial sums (all-taps block partials / K-slice slabs) in a private workspace;
+    rua_wgrad_reduce_batch adds the partials of SEVERAL weight gradients into their dW in one launch - same arithmetic, same
+    order as the per-call reductions, so bit-identical to them."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(77)
+    cases = [(2, 64, 64, 32, 32, 1, 3, 9), (1, 128, 64, 64, 64, 1, 15, 9), (4, 32, 32, 256, 256, 1, 3, 9), (2, 16, 16, 128, 256, 1, 1, 1),
+             (2, 64, 64, 32, 8, 1, 1, 1)]                                    # all-taps x2, wgrad_dmap, generic with K split, wgrad_pw (nothing pending)
+    descs, keep, imm = [], [], []
+    for (N, H, W, Cs, Cout, stride, dil, taps) in cases:
+        a = to_dev(rng.standard_normal((N, H, W, Cs)).astype(np.float32), dt)
+        dy = to_dev(rng.standard_normal((N, H, W, Cout)).astype(np.float32), dt)
+        base = torch.from_numpy(rng.standard_normal((taps, Cout, Cs)).astype(np.float32)).to(dev())
+        d = L.WgradDesc()
+        d.a, d.C, d.Hs, d.Ws, d.dy, d.Cout, d.H, d.W = a.data_ptr(), Cs, H, W, dy.data_ptr(), Cout, H, W
+        d.N, d.stride, d.dil, d.taps, d.dtype = N, stride, dil, taps, dt
+        ws = torch.zeros(lib.raw("rua_wgrad_workspace_bytes")(C.byref(d)) // 4 + 16, dtype=torch.float32, device=dev())
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        dw = base.clone()
+        d.dw = dw.data_ptr()
+        lib.call("rua_conv_wgrad", C.byref(d), stream())                      # immediate
+        torch.cuda.synchronize()
+        imm.append(dw.cpu().numpy().copy())
+        dw.copy_(base)
+        descs.append(d); keep += [a, dy, ws, dw, base]
+    recs, kinds = [], []
+    for d in descs:                                                           # deferred
+        d.defer = 1
+        r = L.WgradPending()
+        lib.call("rua_wgrad_plan", C.byref(d), C.byref(r))
+        kinds.append(r.kind)
+        lib.call("rua_conv_wgrad", C.byref(d), stream())
+        if r.kind:
+            recs.append(r)
+    assert kinds == [1, 1, 2, 2, 0]
+    table = (L.WgradPending * len(recs))()
+    blocks = 0
+    for i, r in enumerate(recs):
+        r.block_begin = blocks
+        blocks += r.blocks
+        C.memmove(C.byref(table, i * C.sizeof(L.WgradPending)), C.byref(r), C.sizeof(L.WgradPending))
+    tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev())
+    lib.call("rua_wgrad_reduce_batch", tdev.data_ptr(), len(recs), blocks, stream())
+    torch.cuda.synchronize()
+    for i, d in enumerate(descs):
+        got = keep[5 * i + 3].cpu().numpy()
+        assert np.array_equal(got, imm[i]), i
