@@ -127,7 +127,9 @@ typedef struct rua_wgrad_desc {
   int32_t defer;
 } rua_wgrad_desc;
 typedef struct rua_wgrad_pending {
-  int32_t kind;                /* 0: nothing to reduce (single writer / wgrad_pw), 1: all-taps partials, 2: K-slice slabs */
+  int32_t kind;                /* 0: nothing to reduce (single writer / wgrad_pw), 1: all-taps partials, 2: K-slice slabs,
+                                  3 (built by the caller): partials = replicated fp64 statistics [parts][2][n], dw[c] += sum of slot 0
+                                  (what rua_stats_to_f32 does: bias gradients), blocks = ceil(n / 256) */
   int32_t parts;               /* partial buffers to sum (blocks of the all-taps kernel per output-channel half / K slices) */
   int64_t n;                   /* elements of dW */
   const float* partials;

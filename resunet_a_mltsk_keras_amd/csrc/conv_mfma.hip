@@ -2784,6 +2784,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const rua_wgrad
   if (vb >= it.blocks) return;
   if (it.kind == 1) wgrad_taps_reduce_body(it.partials, it.dw, it.CC, it.parts, vb);
   else if (it.kind == 2) wgrad_slab_reduce_body(it.partials, it.dw, it.n / 4, it.parts, vb);
+  else if (it.kind == 3) {                             // per-channel fp64 sums (replicated statistics) -> += an fp32 vector (bias gradients)
+    const int c = vb * 256 + (int)threadIdx.x;
+    if (c < (int)it.n) {
+      double a, unused;
+      replica_sum(reinterpret_cast<const double*>(it.partials), it.parts, (int)it.n, c, a, unused);
+      it.dw[c] += (float)a;
+    }
+  }
 }
 extern "C" int rua_wgrad_reduce_batch(const rua_wgrad_pending* items_dev, int n_items, int total_blocks, void* stream) {
   RUA_CHECK_ARG(items_dev && n_items >= 1 && total_blocks >= 1, "rua_wgrad_reduce_batch: bad arguments");

@@ -146,28 +146,6 @@ extern "C" int rua_col_stats2(const void* g, const void* x, const float* mscale,
 }
 
 // ---------------------------------------------------------------------------------------
-// Sum of the R replicas of stats[.][2][C] for channel c: the R loads are issued together (independent
-// addresses, unrolled) instead of a dependent chain, so a finalize launch costs one memory round trip.
-__device__ __forceinline__ void replica_sum(const double* __restrict__ stats, int R, int C, int c, double& s1, double& s2) {
-  double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
-  int r = 0;
-  for (; r + 8 <= R; r += 8) {                           // 16 independent loads in flight: one round trip per 8 replicas
-    double x[8], y[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { x[u] = stats[(size_t)(r + u) * 2 * C + c]; y[u] = stats[(size_t)(r + u) * 2 * C + C + c]; }
-    a1 += (x[0] + x[1]) + (x[2] + x[3]); b1 += (x[4] + x[5]) + (x[6] + x[7]);
-    a2 += (y[0] + y[1]) + (y[2] + y[3]); b2 += (y[4] + y[5]) + (y[6] + y[7]);
-  }
-  for (; r + 4 <= R; r += 4) {
-    const double x0 = stats[(size_t)(r + 0) * 2 * C + c], y0 = stats[(size_t)(r + 0) * 2 * C + C + c];
-    const double x1 = stats[(size_t)(r + 1) * 2 * C + c], y1 = stats[(size_t)(r + 1) * 2 * C + C + c];
-    const double x2 = stats[(size_t)(r + 2) * 2 * C + c], y2 = stats[(size_t)(r + 2) * 2 * C + C + c];
-    const double x3 = stats[(size_t)(r + 3) * 2 * C + c], y3 = stats[(size_t)(r + 3) * 2 * C + C + c];
-    a1 += x0 + x1; b1 += x2 + x3; a2 += y0 + y1; b2 += y2 + y3;
-  }
-  for (; r < R; ++r) { a1 += stats[(size_t)r * 2 * C + c]; a2 += stats[(size_t)r * 2 * C + C + c]; }
-  s1 = a1 + b1; s2 = a2 + b2;
-}
 
 __global__ void bn_finalize_kernel(const double* stats, int R, double count, double bessel_n, const float* gamma, const float* beta,
                                    float* mmean, float* mvar, float momentum, float eps, int training,

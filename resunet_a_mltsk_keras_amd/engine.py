@@ -496,9 +496,7 @@ class Graph:
         plan.keep.append(d)
         plan.add("rua_bn_bwd", C.byref(d))
         if st is not None:
-            dst = L.ptr_array([self.G(o) for o in skip_bias])
-            plan.keep.append(dst)
-            plan.add("rua_stats_to_f32", st.ptr, st.R, x.C, dst, len(skip_bias))
+            self.stats_to_grads(plan, st, x.C, skip_bias)
 
     def conv(self, plan: Plan, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual: Optional[Ten] = None,
              out_relu=False, stats=None, bias_more=(), in_bn: Optional["Coef"] = None, accumulate: int = 0):
@@ -635,9 +633,24 @@ class Graph:
 
     def bias_grad(self, plan: Plan, dy: Ten, bias_offs: List[int]):
         s = self.col_stats(plan, dy)
-        dst = L.ptr_array([self.G(o) for o in bias_offs])
-        plan.keep.append(dst)
-        plan.add("rua_stats_to_f32", s.ptr, s.R, dy.C, dst, len(bias_offs))
+        self.stats_to_grads(plan, s, dy.C, bias_offs)
+
+    def stats_to_grads(self, plan: Plan, s: Stat, Cc: int, offs: List[int]):
+        """G[off .. off + C) += per-channel sums of `s` for every offset: its own small launch, or - deferred - records of the next
+        batched reduction launch (see _defer_wgrad)."""
+        if self.dry or not (self.e.defer_reduce and plan is self.bwd):
+            dst = L.ptr_array([self.G(o) for o in offs])
+            plan.keep.append(dst)
+            plan.add("rua_stats_to_f32", s.ptr, s.R, Cc, dst, len(offs))
+            return
+        for o in offs:
+            bucket = self.e.dist.bucket_of(o) if self.e.dist is not None else 0
+            if self.pending and bucket != self.pending_bucket:
+                self.flush_wgrad(plan)
+            self.pending_bucket = bucket
+            rec = L.WgradPending()
+            rec.kind, rec.parts, rec.n, rec.partials, rec.dw, rec.blocks = 3, s.R, Cc, s.ptr, self.G(o), (Cc + 255) // 256
+            self.pending.append((rec, o))
 
     def bn_bwd_finalize(self, plan: Plan, stats2, count, bn, coef: Coef):
         plan.add("rua_bn_bwd_finalize", stats2.ptr, stats2.R, float(count), self.P(bn["gamma"]), coef.mean, coef.rstd,
