@@ -367,34 +367,35 @@ def test_odd_batch_bf16_graph_steps():
 def test_normalise_on_load_resblocks_match_materialised_batchnorm():
     """The top-level ResBlocks run with BatchNorm + ReLU applied on load by the conv / weight-gradient kernels (conv_strip,
     wgrad_taps: no normalised copy of the conv input in HBM, model2.py:17-24) - against the same engine with the copies
-    materialised by rua_bn_fwd.  Same bf16 operands up to one rounding (fused multiply-add before the bf16 cast), so the two
-    must agree like any two bf16 evaluations of this graph do: losses 2e-3, logits 5e-2 of their scale (each is ~2.5e-2 from the
-    oracle), gradients 1e-1 per tensor."""
+    materialised by rua_bn_fwd, and both against fp32 storage on the HIP path.  Losses and logits of the two bf16 variants agree
+    like any two bf16 evaluations of this graph (2e-3 / 5e-2 of the logit scale: each is ~2.5e-2 from the oracle).  Gradients
+    at batch 1 are noisy in bf16 (median distance to the fp32 gradient ~0.17 of a tensor's scale for EITHER variant: the
+    bottleneck BatchNorms see 64 samples): the bar is that normalising on load is no further from the fp32 gradient than
+    materialising is."""
     shape, C = (256, 256, 6), 6
     x, y = make_batch(1, 256, 6, C, True, seed=99)
-    res = []
-    for fuse in (True, False):
-        eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=True), dtype="bf16", seed=4, split_k=True)
+    res = {}
+    for tag, fuse, dtype in (("fused", True, "bf16"), ("copies", False, "bf16"), ("f32", False, "f32")):
+        eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=True), dtype=dtype, seed=4, split_k=True)
         eng.fuse_bn = fuse
         eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in ref.HEADS}, weight={h: 1.0 for h in ref.HEADS}))
         g = eng.forward_backward(x, y)
         torch.cuda.synchronize()
         names = [c[1] for c in g.fwd.calls]
-        res.append((eng._results(g), eng.logits(True, 1), eng.grads_keras(), names.count("rua_bn_fwd"), len(names)))
+        res[tag] = (eng._results(g), eng.logits(True, 1), eng.grads_keras(), names.count("rua_bn_fwd"), len(names))
         del eng, g
         torch.cuda.empty_cache()
-    (la, za, ga, bna, na), (lb, zb, gb, bnb, nb) = res
+    (la, za, ga, bna, na), (lb, zb, gb, bnb, nb), (lf, zf, gf, _, _) = res["fused"], res["copies"], res["f32"]
     assert bna < bnb and na <= nb                              # coefficient-only launches replace the apply passes
     for i in range(5):
         assert abs(la[i] - lb[i]) <= 2e-3 * max(1.0, abs(lb[i])), (i, la[i], lb[i])
+        assert abs(la[i] - lf[i]) <= 2e-3 * max(1.0, abs(lf[i])), (i, la[i], lf[i])
     for h in za:
-        assert rel(za[h], zb[h]) < 5e-2, (h, rel(za[h], zb[h]))
-    gmax = max(float(np.abs(v).max()) for v in gb.values())
-    # per tensor, relative to its own scale (not below 1e-3 of the largest gradient).  Kernels and BN scales are sums of like-
-    # signed products and compare tightly; biases / betas are sums over every pixel that cancel to (almost) nothing - exactly
-    # nothing where the bias feeds a training-mode BatchNorm - so two bf16 evaluations agree on them only in order of magnitude
-    r = {k: float(np.abs(ga[k] - gb[k]).max() / max(np.abs(gb[k]).max(), 1e-3 * gmax)) for k in gb}
-    tight = {k: v for k, v in r.items() if k.endswith(("/kernel", "/gamma"))}
-    worst = max((v, k) for k, v in tight.items())
-    assert worst[0] < 1e-1 and np.median(list(tight.values())) < 3e-2, (worst, float(np.median(list(tight.values()))))
-    assert all(np.isfinite(ga[k]).all() for k in ga) and np.median(list(r.values())) < 5e-2
+        assert rel(za[h], zb[h]) < 5e-2 and rel(za[h], zf[h]) < 5e-2, (h, rel(za[h], zb[h]), rel(za[h], zf[h]))
+    gmax = max(float(np.abs(v).max()) for v in gf.values())
+    keys = [k for k in gf if k.endswith(("/kernel", "/gamma"))]          # well-conditioned sums (biases / betas cancel to ~0)
+    dist = lambda g: np.array([float(np.abs(g[k] - gf[k]).max() / max(np.abs(gf[k]).max(), 1e-3 * gmax)) for k in keys])
+    da, db = dist(ga), dist(gb)
+    print("bf16 gradient distance to the fp32 gradient (median / max): on load %.3f / %.3f, copies %.3f / %.3f" % (np.median(da), da.max(), np.median(db), db.max()))
+    assert np.median(da) <= 1.25 * np.median(db) + 1e-2 and da.max() <= 1.25 * db.max() + 5e-2, (np.median(da), np.median(db), da.max(), db.max())
+    assert all(np.isfinite(ga[k]).all() for k in ga)
