@@ -58,8 +58,12 @@ def measured_traffic(kernel, args):
     k = t["kernels"].get(name)
     if k:
         return k["bytes_per_launch"]
-    # template instantiations the bench name folds together (conv_halo<32> = conv_halo<32,2> + conv_halo<32,3>, ...)
-    fam = [v for kk, v in t["kernels"].items() if kk.startswith(name[:-1] + ",")]
+    # template instantiations the bench name folds together (conv_halo<32> = conv_halo<32,2> + conv_halo<32,3>, ...;
+    # conv_strip<32> = conv_strip32<8,true,5> + conv_strip32<8,false,7>)
+    pref = name[:-1] + ","
+    if name.startswith("conv_strip<"):
+        pref = "conv_strip" + name[len("conv_strip<"):-1] + "<"
+    fam = [v for kk, v in t["kernels"].items() if kk.startswith(pref)]
     n = sum(v["launches_seen"] for v in fam)
     return round(sum(v["bytes_per_launch"] * v["launches_seen"] for v in fam) / n) if n else None
 
