@@ -399,3 +399,34 @@ def test_normalise_on_load_resblocks_match_materialised_batchnorm():
     print("bf16 gradient distance to the fp32 gradient (median / max): on load %.3f / %.3f, copies %.3f / %.3f" % (np.median(da), da.max(), np.median(db), db.max()))
     assert np.median(da) <= 1.25 * np.median(db) + 1e-2 and da.max() <= 1.25 * db.max() + 5e-2, (np.median(da), np.median(db), da.max(), db.max())
     assert all(np.isfinite(ga[k]).all() for k in ga)
+
+
+def test_inference_with_normalise_on_load_matches_materialised_and_oracle():
+    """Evaluation mode (moving statistics, test_ISPRS.py:28 / test_on_batch) through the normalise-on-load ResBlocks: the
+    coefficient-only BatchNorm launch takes the moving statistics, conv_strip applies them on load.  bf16 predictions with and
+    without the fused blocks, and the oracle's, agree within the bf16 bounds; batch 1 is what `predict(batch_size=1)` uses."""
+    shape, C = (256, 256, 6), 6
+    rcfg = ref.RefConfig(input_shape=shape, num_classes=C, multitasking=True)
+    params, order = ref.init_params(rcfg, 9)
+    rng = np.random.default_rng(1)
+    for k in params:                                           # non-trivial moving statistics
+        if k.endswith("moving_mean"):
+            params[k] = torch.from_numpy(rng.normal(0, 0.2, params[k].shape).astype(np.float32))
+        if k.endswith("moving_variance"):
+            params[k] = torch.from_numpy(rng.uniform(0.5, 1.5, params[k].shape).astype(np.float32))
+    x, _ = make_batch(1, 256, 6, C, True, seed=5)
+    exp = ref.forward(rcfg, params, x, training=False)
+    outs = []
+    for fuse in (True, False):
+        eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=True), dtype="bf16", seed=0)
+        eng.fuse_bn = fuse
+        eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in ref.HEADS}, weight={h: 1.0 for h in ref.HEADS}))
+        eng.set_weights({k: v.numpy() for k, v in params.items()})
+        outs.append(eng.predict(x))
+        names = [c[1] for c in eng.graph(1, False).fwd.calls]
+        assert ("rua_bn_apply" not in names)
+        del eng
+        torch.cuda.empty_cache()
+    for h in outs[0]:
+        assert np.abs(outs[0][h] - outs[1][h]).max() < 3e-2, h            # probabilities in [0, 1]
+        assert np.abs(outs[0][h] - np.asarray(exp[h])).max() < 3e-2, h
