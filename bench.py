@@ -129,7 +129,18 @@ def profile_kernels(eng, g, dtype):
                 empty.append((mark(), mark()))
             if fn is None:
                 continue                                    # fork / join markers: this pass runs everything on one stream
-            if name in ("rua_conv_fwd", "rua_conv_wgrad"):
+            if name == "rua_conv_fwd_group":               # the dilation branches of a ResBlock in one grid: one row, N x the FLOPs
+                arr, n = args
+                e0 = mark()
+                rc = fn(*args, sp)
+                e1 = mark()
+                d0 = arr[0]
+                kid = lib.raw("rua_conv_kernel_id")(C.byref(d0))
+                bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d0)), lib.raw('rua_conv_tile_bn')(C.byref(d0))
+                kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap<{bm_},{bn_}>", f"conv_halo<{d0.Cout}>", "conv_pw", f"conv_strip<{d0.Cout}>")[kid]
+                fl = sum(conv_flops(arr[i]) for i in range(n))
+                rec.append((kn + f" x{n} (grouped)", e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.seg[0].taps * d0.seg[0].C, 0, f"group of {n}")))
+            elif name in ("rua_conv_fwd", "rua_conv_wgrad"):
                 em = mark(False)                            # recorded by the library between the main kernel and the
                 mid(em)                                     # second launch of a two-launch call
                 e0 = mark()
@@ -178,6 +189,8 @@ def profile_kernels(eng, g, dtype):
                 continue
             if sc is not None and name in ("rua_conv_fwd", "rua_conv_wgrad"):
                 scopes[(pname, sc)][2] += conv_flops(args[0]._obj) if name == "rua_conv_fwd" else wgrad_flops(args[0]._obj)
+            elif sc is not None and name == "rua_conv_fwd_group":
+                scopes[(pname, sc)][2] += sum(conv_flops(args[0][i]) for i in range(args[1]))
             rc = fn(*args, sp)
             if rc != 0:
                 lib.check(rc, name)

@@ -83,6 +83,9 @@ typedef struct rua_conv_desc {
   int32_t in_relu;
 } rua_conv_desc;
 int rua_conv_fwd(const rua_conv_desc* d, void* stream);
+/* n (<= RUA_MAX_BRANCH) INDEPENDENT convolutions - the dilation branches of a ResBlock (model2.py:26-31) - with the results of n
+ * rua_conv_fwd calls; members that land on the same kernel are issued as ONE grid (no drain / launch gap between the branches) */
+int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream);
 int rua_conv_smem_bytes(const rua_conv_desc* d);
 int64_t rua_conv_workspace_bytes(const rua_conv_desc* d);   /* bytes of ONE slab (N*H*W*Cout fp32); split-K uses up to 32 */
 /* profiling only (bench.py): timing events without the system-scope release a default event performs when recorded */

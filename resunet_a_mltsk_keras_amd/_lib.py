@@ -70,6 +70,7 @@ _SIGS = {
     "rua_version": ([], i32),
     "rua_device_info": ([C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32], i32),
     "rua_conv_fwd": ([C.POINTER(ConvDesc), vp], i32),
+    "rua_conv_fwd_group": ([C.POINTER(ConvDesc), i32, vp], i32),
     "rua_conv_smem_bytes": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_tile_bn": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_tile_bm": ([C.POINTER(ConvDesc)], i32),

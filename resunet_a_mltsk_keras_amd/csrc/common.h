@@ -75,7 +75,7 @@ struct RuaTuning {
   int conv_pw_blocks = 0, conv_halo = 1, halo64_maxd = 1, conv_dmap = 1, dmap_target = 0, dmap_fused_finish = 0, dmap_rowb = 64, dmap_bm64 = 1;
   int wgrad_pw = 1, wgpw_blocks = 0, wgpw_r = 0, wgd_blocks = 0, wgrad_dmap = 1, wgd_mintiles = 9, wgrad_blocks = 0;
   int bn_grid = 0, tani_vec = 1, metrics_blocks = 0, stem_blocks = 0, head_blocks = 0;
-  int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0;
+  int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0, conv_group = 1;
 };
 extern RuaTuning g_tune;
 int rua_cu_count();          // compute units of the current device (queried once per device, cached)
@@ -117,6 +117,18 @@ struct ConvK {
   const float* in_scale; const float* in_shift; int in_relu;     // per-input-channel affine (+ ReLU) applied to segment 0 on load (conv_strip)
 };
 typedef __attribute__((address_space(3))) void* lds_void_p;
+struct ConvKG { ConvK k[RUA_MAX_BRANCH]; };           // members of a grouped launch: blockIdx.y picks one
+// capture mode of the launchers (rua_conv_fwd_group): a groupable launch is recorded instead of issued
+struct ConvGroupCapture {
+  int n; int kind[RUA_MAX_BRANCH]; unsigned grid[RUA_MAX_BRANCH]; int smem[RUA_MAX_BRANCH]; ConvK k[RUA_MAX_BRANCH];
+  bool add(int kd, unsigned g, int sm, const ConvK& kk) {
+    if (n >= RUA_MAX_BRANCH) return false;
+    kind[n] = kd; grid[n] = g; smem[n] = sm; k[n] = kk; ++n;
+    return true;
+  }
+};
+extern thread_local ConvGroupCapture* g_conv_group;
+int rua_strip_group_flush(hipStream_t st);             // conv_strip.hip: issues the conv_strip members captured since the group began
 // conv_strip.hip
 bool rua_pick_strip(const rua_conv_desc* d);
 int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st);

@@ -190,7 +190,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
 }
 
 template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
+__device__ __forceinline__ void conv_igemm_body(const ConvK& p) {
   constexpr int KU = 2;
   constexpr int VEC = ET<T>::VEC, ES = sizeof(T);
   constexpr int PPR = 32 / VEC;
@@ -440,6 +440,11 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) {
 
 // split-K finisher: the shared epilogue over the sum of the K slices' fp32 slabs (one block per FM x 64 output tile;
 // FM = 32 where 128-row tiles would leave most of the chip idle: the 8x8 level has 4 x 16 of them)
+template <typename T, int BM, int BN> __global__ __launch_bounds__(256) void conv_igemm(const ConvK p) { conv_igemm_body<T, BM, BN>(p); }
+// grouped launch (rua_conv_fwd_group): independent convolutions of one shape class - the dilation branches of a ResBlock - in ONE
+// grid, blockIdx.y picks the member (no drain / launch gap between the branches, their tails overlap)
+template <typename T, int BM, int BN> __global__ __launch_bounds__(256) void conv_igemm_g(const ConvKG g) { conv_igemm_body<T, BM, BN>(g.k[blockIdx.y]); }
+
 template <typename T, int FM>
 __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK p) {
   __shared__ float sred[4 * 8 * 16];
@@ -693,7 +698,7 @@ __global__ __launch_bounds__(256) void conv_dma(const ConvK p) {
 //   k-step 3                  : vmcnt(PER_STAGE) [stage s+1 landed] ; lgkmcnt(0) [my reads of stage s done] ; s_barrier ;
 //                               DMA stage s+3 into the buffer of stage s ; read fragments (s+1, 0) ; MFMA k-step 3
 template <int BM, int BN, int ROWB>
-__global__ __launch_bounds__(256) void conv_dmap(const ConvK p) {
+__device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
   typedef bf16_t T;
   // a stage = 64 channels, 4 k-steps of 16.  ROWB = 128: one LDS image [rows][128 B], every DMA row a full line;
   // ROWB = 64: two sub-images [2][rows][64 B] (32 channels each)
@@ -933,6 +938,9 @@ __global__ __launch_bounds__(256) void conv_dmap(const ConvK p) {
 
 
 
+template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap(const ConvK p) { conv_dmap_body<BM, BN, ROWB>(p); }
+template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap_g(const ConvKG g) { conv_dmap_body<BM, BN, ROWB>(g.k[blockIdx.y]); }
+
 template <int BM, int BN> static constexpr int conv_dmap_smem() {
   constexpr int STAGE = 2 * (BM + BN) * 64;
   constexpr int EPI = BM * (BN + 4) * 4 + 4 * (BN / 8) * 16 * 4;
@@ -1130,6 +1138,10 @@ template <typename T, int BM, int BN> static int launch_conv(const ConvK& k, int
   // split-K invariant: the workspace is all zeros on entry (caller zero-fills it once) and the finisher writes the
   // zeros back after consuming the sums, so no memset is launched per convolution.
   const int smem_now = conv_smem_base<T, BM, BN>() + ((k.nunits * 16 + 255) / 256) * 256;     // unit table sized to this launch
+  if (g_conv_group && k.ksplit == 1 && sizeof(T) == 2 && BM == 256 && BN == 64) {           // the C = 64 level's 3x3 convs
+    if (!g_conv_group->add(3, (unsigned)(nbm * k.nbn), smem_now, k)) return RUA_ERR_ARG;
+    return RUA_OK;
+  }
   hipLaunchKernelGGL((conv_igemm<T, BM, BN>), dim3(nbm * k.nbn * k.ksplit), dim3(256), smem_now, st, k);
   RUA_LAUNCH_CHECK("conv_igemm");
   if (k.ksplit > 1) {
@@ -1215,6 +1227,10 @@ template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, 
     attr_set = true;
   }
   constexpr int smem = conv_dmap_smem<BM, BN>();
+  if (g_conv_group && k.ksplit == 1 && ROWB == 64) {
+    if (!g_conv_group->add(BM == 128 ? 1 : 2, (unsigned)(k.nbm * k.nbn), smem, k)) return RUA_ERR_ARG;
+    return RUA_OK;
+  }
   hipLaunchKernelGGL((conv_dmap<BM, BN, ROWB>), dim3(k.nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
   RUA_LAUNCH_CHECK("conv_dmap");
   if (k.ksplit > 1 && k.cnt == nullptr) {
@@ -1681,6 +1697,58 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   if (pick_dma(d, bn)) return dispatch_conv_dma(k, bm, bn, nbm, st);
   if (d->dtype == RUA_BF16) return dispatch_conv<bf16_t>(k, bm, bn, nbm, st);
   return dispatch_conv<float>(k, bm, bn, nbm, st);
+}
+
+// ---- grouped launch --------------------------------------------------------------------------------------------------
+// rua_conv_fwd_group: n INDEPENDENT convolutions (the dilation branches of a ResBlock: model2.py:26-31).  Every member goes
+// through rua_conv_fwd's own dispatch with the launchers in capture mode; members that land on the same kernel with the same
+// grid are then issued as ONE grid (blockIdx.y = member), the rest one by one.  Results are those of n separate calls.
+thread_local ConvGroupCapture* g_conv_group = nullptr;
+
+template <typename KG, typename F1, typename FG>
+static int issue_group(const ConvGroupCapture& c, const int* idx, int m, F1 single, FG grouped, int smem_attr, hipStream_t st, const char* what) {
+  if (m == 1) {
+    hipLaunchKernelGGL(single, dim3(c.grid[idx[0]]), dim3(256), c.smem[idx[0]], st, c.k[idx[0]]);
+  } else {
+    static thread_local bool attr[8] = {false};
+    const int slot = c.kind[idx[0]];
+    if (!attr[slot]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grouped), hipFuncAttributeMaxDynamicSharedMemorySize, smem_attr); attr[slot] = true; }
+    KG g;
+    for (int i = 0; i < m; ++i) g.k[i] = c.k[idx[i]];
+    hipLaunchKernelGGL(grouped, dim3(c.grid[idx[0]], m), dim3(256), c.smem[idx[0]], st, g);
+  }
+  RUA_LAUNCH_CHECK(what);
+  return RUA_OK;
+}
+
+extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
+  RUA_CHECK_ARG(d && n >= 1 && n <= RUA_MAX_BRANCH, "rua_conv_fwd_group: 1..%d members", RUA_MAX_BRANCH);
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 1 || !g_tune.conv_group) {
+    for (int i = 0; i < n; ++i) { const int rc = rua_conv_fwd(d + i, stream); if (rc != RUA_OK) return rc; }
+    return RUA_OK;
+  }
+  ConvGroupCapture cap;
+  cap.n = 0;
+  g_conv_group = &cap;
+  int rc = RUA_OK;
+  for (int i = 0; i < n && rc == RUA_OK; ++i) rc = rua_conv_fwd(d + i, stream);      // non-groupable members launch right here
+  g_conv_group = nullptr;
+  if (rc != RUA_OK) return rc;
+  rc = rua_strip_group_flush(st);
+  if (rc != RUA_OK) return rc;
+  bool done[RUA_MAX_BRANCH] = {false};
+  for (int i = 0; i < cap.n; ++i) {
+    if (done[i]) continue;
+    int idx[RUA_MAX_BRANCH], m = 0;
+    for (int j = i; j < cap.n; ++j)
+      if (!done[j] && cap.kind[j] == cap.kind[i] && cap.grid[j] == cap.grid[i] && cap.smem[j] == cap.smem[i]) { idx[m++] = j; done[j] = true; }
+    if (cap.kind[i] == 1) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap<128, 128, 64>, conv_dmap_g<128, 128, 64>, conv_dmap_smem<128, 128>(), st, "conv_dmap (group)");
+    else if (cap.kind[i] == 2) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap<64, 128, 64>, conv_dmap_g<64, 128, 64>, conv_dmap_smem<64, 128>(), st, "conv_dmap (group)");
+    else rc = issue_group<ConvKG>(cap, idx, m, conv_igemm<bf16_t, 256, 64>, conv_igemm_g<bf16_t, 256, 64>, conv_smem<bf16_t, 256, 64>(), st, "conv_igemm (group)");
+    if (rc != RUA_OK) return rc;
+  }
+  return RUA_OK;
 }
 
 // =========================================================================================

@@ -36,7 +36,7 @@ struct StripK {
 };
 
 template <int NW, bool HAS_EP, int R>
-__global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) {
+__device__ __forceinline__ void conv_strip32_body(const StripK& q) {
   typedef bf16_t T;
   constexpr int C = 32, NT = NW * 64, SW = NW * 32;
   constexpr int NPX = 3, NPA = HAS_EP ? 2 : 0, RA = 3, NST = 2;
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int job = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);     // neighbours in a chain share an XCD's L2
+  if (job >= q.njobs) return;                           // (grouped launch: the grid is the largest member's)
   const int chain = job / q.spc, seg = job - chain * q.spc;
   const int r_ = chain % d, tq = chain / d;
   const int x0 = (tq % q.strips) * SW, n_ = tq / q.strips;
@@ -311,6 +312,11 @@ __global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) {
   }
 }
 
+struct StripKG { StripK k[RUA_MAX_BRANCH]; };
+template <int NW, bool HAS_EP, int R> __global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) { conv_strip32_body<NW, HAS_EP, R>(q); }
+// grouped launch (rua_conv_fwd_group): the four dilation branches of the d6 block in one grid, blockIdx.y = branch
+template <int NW, bool HAS_EP, int R> __global__ __launch_bounds__(NW * 64) void conv_strip32_g(const StripKG g) { conv_strip32_body<NW, HAS_EP, R>(g.k[blockIdx.y]); }
+
 // ---- host side ---------------------------------------------------------------------------------------------------------
 // strip width: 256 pixels (8 waves) where the row allows it; tuning key strip_narrow_maxd: dilations up to it take 128-pixel
 // strips instead (twice the chains, half the window-fill overhead, four waves per block)
@@ -331,12 +337,46 @@ bool rua_pick_strip(const rua_conv_desc* d) {
   return true;
 }
 
-template <int NW, bool HAS_EP, int R> static int launch_strip(const StripK& q, int smem, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32<NW, HAS_EP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL((conv_strip32<NW, HAS_EP, R>), dim3(q.njobs), dim3(NW * 64), smem, st, q);
+// members captured while rua_conv_fwd_group runs its members' dispatch (see conv_mfma.hip)
+struct StripCapture { int n; int variant[RUA_MAX_BRANCH]; int smem[RUA_MAX_BRANCH]; StripK k[RUA_MAX_BRANCH]; };
+static thread_local StripCapture g_strip_cap = {0, {0}, {0}, {}};
+
+template <int NW, bool HAS_EP, int R> static int launch_strip_members(const StripK* ks, const int* smems, int m, hipStream_t st) {
+  static bool attr = false, attr_g = false;
+  if (m == 1) {
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32<NW, HAS_EP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((conv_strip32<NW, HAS_EP, R>), dim3(ks[0].njobs), dim3(NW * 64), smems[0], st, ks[0]);
+  } else {
+    if (!attr_g) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32_g<NW, HAS_EP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_g = true; }
+    StripKG g;
+    int grid = 0, smem = 0;
+    for (int i = 0; i < m; ++i) { g.k[i] = ks[i]; if (ks[i].njobs > grid) grid = ks[i].njobs; if (smems[i] > smem) smem = smems[i]; }
+    hipLaunchKernelGGL((conv_strip32_g<NW, HAS_EP, R>), dim3(grid, m), dim3(NW * 64), smem, st, g);
+  }
   RUA_LAUNCH_CHECK("conv_strip32");
   return RUA_OK;
+}
+static int launch_strip_variant(int variant, const StripK* ks, const int* smems, int m, hipStream_t st) {
+  switch (variant) {
+    case 0: return launch_strip_members<8, true, 5>(ks, smems, m, st);
+    case 1: return launch_strip_members<8, false, 7>(ks, smems, m, st);
+    case 2: return launch_strip_members<4, true, 5>(ks, smems, m, st);
+    default: return launch_strip_members<4, false, 7>(ks, smems, m, st);
+  }
+}
+int rua_strip_group_flush(hipStream_t st) {
+  StripCapture& c = g_strip_cap;
+  bool done[RUA_MAX_BRANCH] = {false};
+  int rc = RUA_OK;
+  for (int i = 0; i < c.n && rc == RUA_OK; ++i) {
+    if (done[i]) continue;
+    StripK ks[RUA_MAX_BRANCH]; int sm[RUA_MAX_BRANCH], m = 0;
+    for (int j = i; j < c.n; ++j)
+      if (!done[j] && c.variant[j] == c.variant[i]) { ks[m] = c.k[j]; sm[m] = c.smem[j]; ++m; done[j] = true; }
+    rc = launch_strip_variant(c.variant[i], ks, sm, m, st);
+  }
+  c.n = 0;
+  return rc;
 }
 
 int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st) {
@@ -363,6 +403,12 @@ int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st
   const int R = has_ep ? 5 : 7;
   const int smem = R * q.slot_bytes + (has_ep ? 3 * sw * 64 : 0) + nw * 1024 + 3 * 32 * 4;
   RUA_CHECK_ARG(smem <= 160 * 1024, "conv_strip: %d bytes of LDS", smem);
-  if (nw == 8) return has_ep ? launch_strip<8, true, 5>(q, smem, st) : launch_strip<8, false, 7>(q, smem, st);
-  return has_ep ? launch_strip<4, true, 5>(q, smem, st) : launch_strip<4, false, 7>(q, smem, st);
+  const int variant = (nw == 8 ? 0 : 2) + (has_ep ? 0 : 1);
+  if (g_conv_group) {                                   // capture mode: issued by rua_strip_group_flush, grouped with its siblings
+    StripCapture& c = g_strip_cap;
+    RUA_CHECK_ARG(c.n < RUA_MAX_BRANCH, "conv_strip: group capture overflow");
+    c.variant[c.n] = variant; c.smem[c.n] = smem; c.k[c.n] = q; ++c.n;
+    return RUA_OK;
+  }
+  return launch_strip_variant(variant, &q, &smem, 1, st);
 }

@@ -559,6 +559,24 @@ class Graph:
               mask: Optional[Tuple[Ten, Optional[int], Optional[int]]] = None, stats2: Optional[int] = None,
               stat_aux: Optional[Ten] = None, out_stride: int = 1):
         """out (=|+=) conv(dy, W^T flipped) [* relu-mask(aux)], optional sum g / sum g*aux statistics."""
+        d = self.dgrad_desc(dy, wd_ptr, cin, dil, taps, out, accumulate, mask, stats2, stat_aux, out_stride)
+        plan.keep.append(d)
+        plan.add("rua_conv_fwd", C.byref(d))
+
+    def conv_group(self, plan: Plan, descs: List):
+        """Independent convolutions (the dilation branches of a ResBlock) in one call: members on the same kernel share ONE grid."""
+        if len(descs) == 1:
+            plan.keep.append(descs[0])
+            plan.add("rua_conv_fwd", C.byref(descs[0]))
+            return
+        arr = (L.ConvDesc * len(descs))()
+        for i, dsc in enumerate(descs):
+            C.memmove(C.byref(arr, i * C.sizeof(L.ConvDesc)), C.byref(dsc), C.sizeof(L.ConvDesc))
+        plan.keep.append(arr)
+        plan.add("rua_conv_fwd_group", arr, len(descs))
+
+    def dgrad_desc(self, dy: Ten, wd_ptr, cin: int, dil: int, taps: int, out: Ten, accumulate: int, mask=None, stats2=None,
+                   stat_aux=None, out_stride: int = 1):
         d = L.ConvDesc()
         d.nseg = 1
         s = d.seg[0]
@@ -573,8 +591,7 @@ class Graph:
         if stats2 is not None:
             d.stats, d.stats_mode, d.stats_replicas = stats2.ptr, 2, stats2.R
         self._ws(d)
-        plan.keep.append(d)
-        plan.add("rua_conv_fwd", C.byref(d))
+        return d
 
     def wgrad(self, plan: Plan, a: Ten, dy: Ten, dw_off: int, stride: int, dil: int, taps: int, in_bn: Optional["Coef"] = None):
         d = L.WgradDesc()
@@ -685,18 +702,15 @@ class Graph:
         if all(self.fused_input_ok(x, nf, d) for d in dils):
             return self.resblock_fused(x, nf, dils, lay, scope)
         a1, coef1 = self.bn_fwd(F, x, [l[0] for l in lay], True, x.stats, cnt)
-        y1, coef2, a2 = [], [], []
-        F.fork(len(dils))                                   # the branches are independent until the final sum
-        for bi, (d, l, a) in enumerate(zip(dils, lay, a1)):
-            F.set_lane(bi); self.cur_lane = bi
-            y = self.like(x)
-            st = self.stat(nf, (cnt + 127) // 128) if tr else None
-            self.conv(F, [(a, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st)
+        y1 = [self.like(x) for _ in dils]
+        st1 = [self.stat(nf, (cnt + 127) // 128) if tr else None for _ in dils]
+        # the branches are independent until the final sum: their first convs go out as one grouped call
+        self.conv_group(F, [self.conv_desc([(a, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st)
+                            for d, l, a, y, st in zip(dils, lay, a1, y1, st1)])
+        coef2, a2 = [], []
+        for l, y, st in zip(lay, y1, st1):
             o2, c2l = self.bn_fwd(F, y, [l[2]], True, st, cnt)
-            c2 = c2l[0]
-            y1.append(y); coef2.append(c2)
-            a2.append(o2[0])
-        F.join(len(dils)); self.cur_lane = 0
+            coef2.append(c2l[0]); a2.append(o2[0])
         out = self.like(x)
         biases = [self.P(l[3]["bias"]) for l in lay]        # the concatenated conv's bias = sum of the branches' biases
         self.conv(F, [(a, 0, d, 9) for a, d in zip(a2, dils)], [l[3]["segs"][0] for l in lay], nf, biases[0], out,
@@ -711,23 +725,22 @@ class Graph:
             dO = out.grad
             if not v2:
                 self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])      # (model2: summed by the final bn_bwd, which reads dO as the skip gradient)
-            g1s, s1s = [], []
-            Bp.fork(len(dils))
-            for bi, (d, l, a_1, y, c2, a_2, c1) in enumerate(zip(dils, lay, a1, y1, coef2, a2, coef1)):
-                Bp.set_lane(bi); self.cur_lane = bi
+            for d, l, a_2 in zip(dils, lay, a2):
                 self.wgrad(Bp, a_2, dO, l[3]["segs"][0]["off"], 1, d, 9)
-                g2 = self.like(x)
-                s2 = self.stat(nf, (cnt + 127) // 128)
-                self.dgrad(Bp, dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
-                dy1 = self.like(x)
+            g2s = [self.like(x) for _ in dils]
+            s2s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
+            self.conv_group(Bp, [self.dgrad_desc(dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
+                                 for d, l, y, c2, g2, s2 in zip(dils, lay, y1, coef2, g2s, s2s)])
+            dy1s = [self.like(x) for _ in dils]
+            for l, y, c2, g2, s2, dy1 in zip(lay, y1, coef2, g2s, s2s, dy1s):
                 self.bn_bwd(Bp, [g2], [c2], [l[2]], [s2], y, dy1, 0, cnt)
-                # no bias gradient launch: the output of a BN backward sums to zero per channel, so d b1 == 0 exactly
+            # no bias gradient launch: the output of a BN backward sums to zero per channel, so d b1 == 0 exactly
+            for d, l, a_1, dy1 in zip(dils, lay, a1, dy1s):
                 self.wgrad(Bp, a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9)
-                g1 = g2                                    # g2 is dead after bn_bwd_apply: reuse its storage
-                s1 = self.stat(nf, (cnt + 127) // 128)
-                self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
-                g1s.append(g1); s1s.append(s1)
-            Bp.join(len(dils)); self.cur_lane = 0
+            g1s = g2s                                          # g2 is dead after its bn_bwd: reuse the storage
+            s1s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
+            self.conv_group(Bp, [self.dgrad_desc(dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
+                                 for d, l, dy1, c1, g1, s1 in zip(dils, lay, dy1s, coef1, g1s, s1s)])
             gx, acc = self.gacc(x)
             self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None,
                         skip_bias=[l[3]["bias"] for l in lay] if v2 else None)
@@ -746,12 +759,10 @@ class Graph:
         cnt = x.M
         nb = len(dils)
         coef1 = self.bn_coefs(F, x, [l[0] for l in lay], [x.stats] * nb, cnt)
-        y1, st1 = [], []
-        for d, l, c1 in zip(dils, lay, coef1):
-            y = self.like(x)
-            st = self.stat(nf, (cnt + 127) // 128) if tr else None
-            self.conv(F, [(x, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st, in_bn=c1)
-            y1.append(y); st1.append(st)
+        y1 = [self.like(x) for _ in dils]
+        st1 = [self.stat(nf, (cnt + 127) // 128) if tr else None for _ in dils]
+        self.conv_group(F, [self.conv_desc([(x, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st, in_bn=c1)
+                            for d, l, c1, y, st in zip(dils, lay, coef1, y1, st1)])       # all four dilations: ONE grid
         coef2 = self.bn_coefs(F, x, [l[2] for l in lay], st1, cnt)
         out = self.like(x)
         for bi, (d, l, y, c2) in enumerate(zip(dils, lay, y1, coef2)):
@@ -767,19 +778,21 @@ class Graph:
             dO = out.grad
             if not v2:
                 self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
-            g1s, s1s = [], []
-            for d, l, y, c2, c1 in zip(dils, lay, y1, coef2, coef1):
+            for d, l, y, c2 in zip(dils, lay, y1, coef2):
                 self.wgrad(Bp, y, dO, l[3]["segs"][0]["off"], 1, d, 9, in_bn=c2)
-                g2 = self.like(x)
-                s2 = self.stat(nf, (cnt + 127) // 128)
-                self.dgrad(Bp, dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
-                dy1 = self.like(x)
+            g2s = [self.like(x) for _ in dils]
+            s2s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
+            self.conv_group(Bp, [self.dgrad_desc(dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
+                                 for d, l, y, c2, g2, s2 in zip(dils, lay, y1, coef2, g2s, s2s)])
+            dy1s = [self.like(x) for _ in dils]
+            for l, y, c2, g2, s2, dy1 in zip(lay, y1, coef2, g2s, s2s, dy1s):
                 self.bn_bwd(Bp, [g2], [c2], [l[2]], [s2], y, dy1, 0, cnt)
+            for d, l, c1, dy1 in zip(dils, lay, coef1, dy1s):
                 self.wgrad(Bp, x, dy1, l[1]["segs"][0]["off"], 1, d, 9, in_bn=c1)
-                g1 = g2
-                s1 = self.stat(nf, (cnt + 127) // 128)
-                self.dgrad(Bp, dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
-                g1s.append(g1); s1s.append(s1)
+            g1s = g2s
+            s1s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
+            self.conv_group(Bp, [self.dgrad_desc(dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
+                                 for d, l, dy1, c1, g1, s1 in zip(dils, lay, dy1s, coef1, g1s, s1s)])
             gx, acc = self.gacc(x)
             self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None,
                         skip_bias=[l[3]["bias"] for l in lay] if v2 else None)

@@ -934,3 +934,52 @@ def test_wgrad_deferred_batched_reduction_is_bit_identical():
             assert np.array_equal(got, imm[i]), i
         else:                                                                 # wgrad_pw adds through replica atomics: equal up to their order
             assert np.allclose(got, imm[i], rtol=1e-5, atol=1e-4), i
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 64, 128, [1, 3, 15]), (2, 256, 256, 32, [1, 3, 15, 31]), (4, 128, 128, 64, [3, 15, 31]), (8, 16, 16, 512, [1, 3])])
+def test_conv_group_equals_separate_launches(shape):
+    """rua_conv_fwd_group: the dilation branches of a ResBlock in one call.  Members on the same kernel (conv_dmap at the
+    64x64x128 level, conv_strip at 256x256x32, conv_igemm at 128x128x64) share ONE grid; members the launcher cannot group
+    (split-K at 16x16x512) run one by one.  Either way the results are bit-identical to separate rua_conv_fwd calls."""
+    N, H, W, Cs, dils = shape
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(Cs)
+    x = to_dev(rng.standard_normal((N, H, W, Cs)).astype(np.float32), dt)
+    aux = to_dev(rng.standard_normal((N, H, W, Cs)).astype(np.float32), dt)
+    sc = torch.from_numpy((0.5 + rng.random(Cs)).astype(np.float32)).to(dev()); sh = torch.from_numpy((0.3 * rng.standard_normal(Cs)).astype(np.float32)).to(dev())
+    ws = torch.zeros(8 << 20, dtype=torch.float32, device=dev())
+    ws2 = torch.zeros(8 << 20, dtype=torch.float32, device=dev())
+    keep, descs = [], []
+    for dil in dils:
+        w = to_dev((rng.standard_normal((9, Cs, Cs)) / np.sqrt(9 * Cs)).astype(np.float32), dt)
+        bias = torch.from_numpy(rng.standard_normal(Cs).astype(np.float32)).to(dev())
+        y = torch.zeros((N, H, W, Cs), dtype=torch.bfloat16, device=dev())
+        stats = torch.zeros(32 * 2 * Cs, dtype=torch.float64, device=dev())
+        d = L.ConvDesc()
+        d.nseg = 1
+        s = d.seg[0]
+        s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = x.data_ptr(), w.data_ptr(), Cs, H, W, 0, dil, 9
+        d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cs, 1, dt
+        d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+        d.bias = bias.data_ptr()
+        d.aux, d.aux_mode, d.mscale, d.mshift = aux.data_ptr(), 2, sc.data_ptr(), sh.data_ptr()
+        d.stats, d.stats_mode, d.stats_replicas = stats.data_ptr(), 2, 32
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        keep += [w, bias, y, stats]
+        descs.append(d)
+    sep = []
+    for d in descs:
+        lib.call("rua_conv_fwd", C.byref(d), stream())
+    torch.cuda.synchronize()
+    for i in range(len(dils)):
+        sep.append((keep[4 * i + 2].clone(), keep[4 * i + 3].clone()))
+        keep[4 * i + 2].zero_(); keep[4 * i + 3].zero_()
+    arr = (L.ConvDesc * len(descs))()
+    for i, d in enumerate(descs):
+        C.memmove(C.byref(arr, i * C.sizeof(L.ConvDesc)), C.byref(d), C.sizeof(L.ConvDesc))
+    lib.call("rua_conv_fwd_group", arr, len(descs), stream())
+    torch.cuda.synchronize()
+    for i in range(len(dils)):
+        assert torch.equal(keep[4 * i + 2], sep[i][0]), (i, dils[i])
+        assert np.allclose(keep[4 * i + 3].cpu().numpy().reshape(32, -1).sum(0), sep[i][1].cpu().numpy().reshape(32, -1).sum(0), rtol=1e-9)
