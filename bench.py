@@ -63,6 +63,8 @@ def measured_traffic(kernel, args):
     pref = name[:-1] + ","
     if name.startswith("conv_strip<"):
         pref = "conv_strip" + name[len("conv_strip<"):-1] + "<"
+    elif name.startswith("conv_strip_g<"):
+        pref = "conv_strip" + name[len("conv_strip_g<"):-1] + "_g<"
     fam = [v for kk, v in t["kernels"].items() if kk.startswith(pref)]
     n = sum(v["launches_seen"] for v in fam)
     return round(sum(v["bytes_per_launch"] * v["launches_seen"] for v in fam) / n) if n else None
@@ -137,9 +139,13 @@ def profile_kernels(eng, g, dtype):
                 d0 = arr[0]
                 kid = lib.raw("rua_conv_kernel_id")(C.byref(d0))
                 bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d0)), lib.raw('rua_conv_tile_bn')(C.byref(d0))
-                kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap<{bm_},{bn_}>", f"conv_halo<{d0.Cout}>", "conv_pw", f"conv_strip<{d0.Cout}>")[kid]
+                # rocprofv3 names the grouped grids conv_igemm_g<...>, conv_dmap_g<...>, conv_strip32_g<...>
+                kn = (f"conv_igemm_g<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap_g<{bm_},{bn_}>", f"conv_halo<{d0.Cout}>", "conv_pw", f"conv_strip_g<{d0.Cout}>")[kid]
+                grids = lib.raw("rua_conv_group_last_grids")()
+                if grids != 1:                              # members the launchers could not put into one grid
+                    kn = f"{kn.replace('_g<', '<')} ({n} members in {grids} launches)"
                 fl = sum(conv_flops(arr[i]) for i in range(n))
-                rec.append((kn + f" x{n} (grouped)", e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.seg[0].taps * d0.seg[0].C, 0, f"group of {n}")))
+                rec.append((kn, e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.seg[0].taps * d0.seg[0].C, 0, f"group of {n}")))
             elif name in ("rua_conv_fwd", "rua_conv_wgrad"):
                 em = mark(False)                            # recorded by the library between the main kernel and the
                 mid(em)                                     # second launch of a two-launch call

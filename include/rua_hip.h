@@ -86,6 +86,7 @@ int rua_conv_fwd(const rua_conv_desc* d, void* stream);
 /* n (<= RUA_MAX_BRANCH) INDEPENDENT convolutions - the dilation branches of a ResBlock (model2.py:26-31) - with the results of n
  * rua_conv_fwd calls; members that land on the same kernel are issued as ONE grid (no drain / launch gap between the branches) */
 int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream);
+int rua_conv_group_last_grids(void);             /* grids the calling thread's latest rua_conv_fwd_group issued (1: all members in one) */
 int rua_conv_smem_bytes(const rua_conv_desc* d);
 int64_t rua_conv_workspace_bytes(const rua_conv_desc* d);   /* bytes of ONE slab (N*H*W*Cout fp32); split-K uses up to 32 */
 /* profiling only (bench.py): timing events without the system-scope release a default event performs when recorded */

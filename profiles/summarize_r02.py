@@ -72,6 +72,8 @@ names = bench["roofline"]["all_mfma_kernels"]
 
 def fam_avg(name):
     strip = "conv_strip" + name[len("conv_strip<"):-1] + "<" if name.startswith("conv_strip<") else None
+    if name.startswith("conv_strip_g<"):
+        strip = "conv_strip" + name[len("conv_strip_g<"):-1] + "_g<"
     fam = [(c, t) for nm, (c, _, t) in stat.items() if nm == name or nm.startswith(name[:-1] + ",") or (name in ("conv_pw", "wgrad_pw") and nm.startswith(name + "<"))
            or (strip and nm.startswith(strip))]
     return round(1e3 * sum(t for _, t in fam) / sum(c for c, _ in fam), 2) if fam else None

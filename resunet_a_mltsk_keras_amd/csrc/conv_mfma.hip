@@ -1704,6 +1704,8 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
 // through rua_conv_fwd's own dispatch with the launchers in capture mode; members that land on the same kernel with the same
 // grid are then issued as ONE grid (blockIdx.y = member), the rest one by one.  Results are those of n separate calls.
 thread_local ConvGroupCapture* g_conv_group = nullptr;
+static thread_local int g_group_last_grids = 0;
+extern "C" int rua_conv_group_last_grids(void) { return g_group_last_grids; }   // grids the calling thread's latest rua_conv_fwd_group issued (1: one grid for all members)
 
 template <typename KG, typename F1, typename FG>
 static int issue_group(const ConvGroupCapture& c, const int* idx, int m, F1 single, FG grouped, int smem_attr, hipStream_t st, const char* what) {
@@ -1724,6 +1726,7 @@ static int issue_group(const ConvGroupCapture& c, const int* idx, int m, F1 sing
 extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
   RUA_CHECK_ARG(d && n >= 1 && n <= RUA_MAX_BRANCH, "rua_conv_fwd_group: 1..%d members", RUA_MAX_BRANCH);
   hipStream_t st = (hipStream_t)stream;
+  g_group_last_grids = n;
   if (n == 1 || !g_tune.conv_group) {
     for (int i = 0; i < n; ++i) { const int rc = rua_conv_fwd(d + i, stream); if (rc != RUA_OK) return rc; }
     return RUA_OK;
@@ -1735,7 +1738,8 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
   for (int i = 0; i < n && rc == RUA_OK; ++i) rc = rua_conv_fwd(d + i, stream);      // non-groupable members launch right here
   g_conv_group = nullptr;
   if (rc != RUA_OK) return rc;
-  rc = rua_strip_group_flush(st);
+  int grids = n - cap.n - rua_strip_group_pending();        // members no launcher captured were launched one by one above
+  rc = rua_strip_group_flush(st, &grids);
   if (rc != RUA_OK) return rc;
   bool done[RUA_MAX_BRANCH] = {false};
   for (int i = 0; i < cap.n; ++i) {
@@ -1747,7 +1751,9 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
     else if (cap.kind[i] == 2) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap<64, 128, 64>, conv_dmap_g<64, 128, 64>, conv_dmap_smem<64, 128>(), st, "conv_dmap (group)");
     else rc = issue_group<ConvKG>(cap, idx, m, conv_igemm<bf16_t, 256, 64>, conv_igemm_g<bf16_t, 256, 64>, conv_smem<bf16_t, 256, 64>(), st, "conv_igemm (group)");
     if (rc != RUA_OK) return rc;
+    ++grids;
   }
+  g_group_last_grids = grids;
   return RUA_OK;
 }
 

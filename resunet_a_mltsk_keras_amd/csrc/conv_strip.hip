@@ -364,7 +364,8 @@ static int launch_strip_variant(int variant, const StripK* ks, const int* smems,
     default: return launch_strip_members<4, false, 7>(ks, smems, m, st);
   }
 }
-int rua_strip_group_flush(hipStream_t st) {
+int rua_strip_group_pending(void) { return g_strip_cap.n; }
+int rua_strip_group_flush(hipStream_t st, int* grids) {
   StripCapture& c = g_strip_cap;
   bool done[RUA_MAX_BRANCH] = {false};
   int rc = RUA_OK;
@@ -374,6 +375,7 @@ int rua_strip_group_flush(hipStream_t st) {
     for (int j = i; j < c.n; ++j)
       if (!done[j] && c.variant[j] == c.variant[i]) { ks[m] = c.k[j]; sm[m] = c.smem[j]; ++m; done[j] = true; }
     rc = launch_strip_variant(c.variant[i], ks, sm, m, st);
+    if (grids) ++*grids;
   }
   c.n = 0;
   return rc;

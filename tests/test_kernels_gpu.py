@@ -979,6 +979,7 @@ def test_conv_group_equals_separate_launches(shape):
     for i, d in enumerate(descs):
         C.memmove(C.byref(arr, i * C.sizeof(L.ConvDesc)), C.byref(d), C.sizeof(L.ConvDesc))
     lib.call("rua_conv_fwd_group", arr, len(descs), stream())
+    assert lib.raw("rua_conv_group_last_grids")() == (len(dils) if Cs == 512 else 1)
     torch.cuda.synchronize()
     for i in range(len(dils)):
         assert torch.equal(keep[4 * i + 2], sep[i][0]), (i, dils[i])
