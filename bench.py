@@ -146,6 +146,19 @@ def profile_kernels(eng, g, dtype):
                     kn = f"{kn.replace('_g<', '<')} ({n} members in {grids} launches)"
                 fl = sum(conv_flops(arr[i]) for i in range(n))
                 rec.append((kn, e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.seg[0].taps * d0.seg[0].C, 0, f"group of {n}")))
+            elif name == "rua_conv_wgrad_group":          # the branches' weight gradients in one grid (reductions deferred)
+                arr, n = args
+                e0 = mark()
+                rc = fn(*args, sp)
+                e1 = mark()
+                d0 = arr[0]
+                wk = lib.raw("rua_wgrad_kind")(C.byref(d0))
+                kn = (f"wgrad_kernel_g", f"wgrad_taps_kernel_g<{d0.C}>", "wgrad_dmap_g", "wgrad_pw")[wk]
+                grids = lib.raw("rua_wgrad_group_last_grids")()
+                if grids != 1:
+                    kn = f"{kn.replace('_g', '')} ({n} members in {grids} launches)"
+                fl = sum(wgrad_flops(arr[i]) for i in range(n))
+                rec.append((kn, e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.C * d0.taps, 0, f"group of {n}")))
             elif name in ("rua_conv_fwd", "rua_conv_wgrad"):
                 em = mark(False)                            # recorded by the library between the main kernel and the
                 mid(em)                                     # second launch of a two-launch call
@@ -197,6 +210,8 @@ def profile_kernels(eng, g, dtype):
                 scopes[(pname, sc)][2] += conv_flops(args[0]._obj) if name == "rua_conv_fwd" else wgrad_flops(args[0]._obj)
             elif sc is not None and name == "rua_conv_fwd_group":
                 scopes[(pname, sc)][2] += sum(conv_flops(args[0][i]) for i in range(args[1]))
+            elif sc is not None and name == "rua_conv_wgrad_group":
+                scopes[(pname, sc)][2] += sum(wgrad_flops(args[0][i]) for i in range(args[1]))
             rc = fn(*args, sp)
             if rc != 0:
                 lib.check(rc, name)

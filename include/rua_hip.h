@@ -148,6 +148,11 @@ int rua_wgrad_plan(const rua_wgrad_desc* d, rua_wgrad_pending* out);
  * block_begin, total_blocks = sum of their `blocks` */
 int rua_wgrad_reduce_batch(const rua_wgrad_pending* items_dev, int n_items, int total_blocks, void* stream);
 int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream);
+/* n (<= RUA_MAX_BRANCH) INDEPENDENT weight gradients - the dilation branches of a ResBlock (model2.py:26-31) - with the results of n
+ * rua_conv_wgrad calls; members on the same kernel run as ONE grid.  Members must not share dw or partial-sum workspace (a group
+ * that does runs member by member). */
+int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream);
+int rua_wgrad_group_last_grids(void);            /* grids the calling thread's latest rua_conv_wgrad_group issued */
 int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d);
 int rua_wgrad_kind(const rua_wgrad_desc* d);   /* 0: generic tiled kernel, 1: all-taps kernel + deterministic partial reduce,
                                                   2: wgrad_dmap (wide levels), 3: wgrad_pw (narrow 1x1) */

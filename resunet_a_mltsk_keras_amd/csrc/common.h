@@ -75,7 +75,7 @@ struct RuaTuning {
   int conv_pw_blocks = 0, conv_halo = 1, halo64_maxd = 1, conv_dmap = 1, dmap_target = 0, dmap_fused_finish = 0, dmap_rowb = 64, dmap_bm64 = 1;
   int wgrad_pw = 1, wgpw_blocks = 0, wgpw_r = 0, wgd_blocks = 0, wgrad_dmap = 1, wgd_mintiles = 9, wgrad_blocks = 0;
   int bn_grid = 0, tani_vec = 1, metrics_blocks = 0, stem_blocks = 0, head_blocks = 0;
-  int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0, conv_group = 1;
+  int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0, conv_group = 1, wgrad_group = 1;
 };
 extern RuaTuning g_tune;
 int rua_cu_count();          // compute units of the current device (queried once per device, cached)

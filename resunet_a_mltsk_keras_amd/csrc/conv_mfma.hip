@@ -1772,7 +1772,7 @@ struct WgK {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
+__device__ __forceinline__ void wgrad_kernel_body(const WgK& p) {
   constexpr int VEC = ET<T>::VEC, ES = sizeof(T);
   constexpr int TP = 64;                         // pixels per stage
   constexpr int PPR = 64 / VEC;                  // pieces per 64-channel row
@@ -1898,6 +1898,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
     }
   }
 }
+template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) { wgrad_kernel_body<T>(p); }
+// grouped launch (rua_conv_wgrad_group): the weight gradients of the dilation branches of a ResBlock in ONE grid; blockIdx.y picks
+// the member, blocks beyond a member's own grid leave at once
+struct WgKG { WgK k[RUA_MAX_BRANCH]; };
+__global__ __launch_bounds__(256) void wgrad_kernel_g(const WgKG g) {
+  const WgK& p = g.k[blockIdx.y];
+  if ((long long)blockIdx.x >= (long long)p.ntc * p.nti * p.taps * p.ksplit) return;
+  wgrad_kernel_body<bf16_t>(p);
+}
 
 // dw += sum of the K slices' slabs, in a FIXED order (bit-reproducible).  256 threads = 16 float4 columns x 16 slice lanes: lane sl
 // adds slices sl, sl + 16, .. (all its loads independent), the 16 lanes are folded through LDS in lane order.
@@ -1967,7 +1976,7 @@ __device__ __forceinline__ s16x4 lds_tr_raw(const unsigned char* p) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void wgrad_dmap(const WgdK p) {
+__device__ __forceinline__ void wgrad_dmap_body(const WgdK& p) {
   constexpr int NBUF = 3, PX = 64, ROWB = 256, KS = 4;
   constexpr int D_BYTES = PX * ROWB, STAGE = 2 * D_BYTES;
   constexpr int PER_STAGE = 8;                                      // DMA instructions per wave per stage (4 dy + 4 a)
@@ -2118,6 +2127,13 @@ __global__ __launch_bounds__(256) void wgrad_dmap(const WgdK p) {
         else unsafeAtomicAdd(dst, acc[a][b][i]);
       }
 }
+__global__ __launch_bounds__(256) void wgrad_dmap(const WgdK p) { wgrad_dmap_body(p); }
+struct WgdKG { WgdK k[RUA_MAX_BRANCH]; };
+__global__ __launch_bounds__(256) void wgrad_dmap_g(const WgdKG g) {
+  const WgdK& p = g.k[blockIdx.y];
+  if ((long long)blockIdx.x >= (long long)p.ntc * p.nti * p.taps * p.ksplit) return;
+  wgrad_dmap_body(p);
+}
 
 // =========================================================================================
 // All-taps weight gradient for the two top levels (Cin = Cout = CC in {32, 64}, 3x3, stride 1, W % 64 == 0; bf16).
@@ -2140,7 +2156,7 @@ struct WgtK {
 };
 
 template <int CC>
-__global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
+__device__ __forceinline__ void wgrad_taps_body(const WgtK& p) {
   constexpr int NH = CC / 32;             // 32-wide input-channel halves = waves per kernel row
   constexpr int GW = 3 * NH;              // waves per pixel group
   constexpr int GT = GW * 64;             // threads per pixel group
@@ -2336,6 +2352,13 @@ __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) {
       }
   }
 }
+template <int CC> __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) { wgrad_taps_body<CC>(p); }
+struct WgtKG { WgtK k[RUA_MAX_BRANCH]; };
+template <int CC> __global__ __launch_bounds__(768) void wgrad_taps_kernel_g(const WgtKG g) {      // blockIdx.z = member
+  const WgtK& p = g.k[blockIdx.z];
+  if ((int)blockIdx.x >= p.gx) return;
+  wgrad_taps_body<CC>(p);
+}
 
 // dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 16 elements x 16 slices:
 // every thread has all its loads in flight at once, slices are folded through LDS in a fixed order (deterministic).
@@ -2383,6 +2406,17 @@ __global__ __launch_bounds__(256) void wgrad_taps_reduce(const float* __restrict
   wgrad_taps_reduce_body(scratch, dw, CC, gx, (int)blockIdx.x);
 }
 
+// rua_conv_wgrad_group: the launchers below record instead of launching while g_wg_group is set
+struct WgGroupCapture {
+  int n;
+  int kind[RUA_MAX_BRANCH];                 // 0 wgrad_kernel<bf16>, 1 wgrad_taps<32>, 2 wgrad_taps<64>, 3 wgrad_dmap
+  unsigned gx[RUA_MAX_BRANCH]; int smem[RUA_MAX_BRANCH];
+  WgK g[RUA_MAX_BRANCH]; WgdK d[RUA_MAX_BRANCH]; WgtK t[RUA_MAX_BRANCH];
+  int post[RUA_MAX_BRANCH];                 // reduction the member wants right after its grid (not deferred): 0 none, 1 block partials, 2 slabs
+  const float* part[RUA_MAX_BRANCH]; float* dw[RUA_MAX_BRANCH]; long long ndw[RUA_MAX_BRANCH]; int parts[RUA_MAX_BRANCH], CC[RUA_MAX_BRANCH], rblocks[RUA_MAX_BRANCH];
+};
+static thread_local WgGroupCapture* g_wg_group = nullptr;
+
 static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   const int CC = d->C;
   WgtK k;
@@ -2418,6 +2452,12 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   const int rblocks = rua_div_up(9 * CC * CC / 4, 16);
   note_pending(1, gx, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks);
   if (g_wgrad_dry) return RUA_OK;
+  if (g_wg_group && g_wg_group->n < RUA_MAX_BRANCH) {
+    WgGroupCapture& c = *g_wg_group; const int i = c.n++;
+    c.kind[i] = CC == 32 ? 1 : 2; c.gx[i] = gx; c.smem[i] = (int)smem; c.t[i] = k;
+    c.post[i] = d->defer ? 0 : 1; c.part[i] = k.scratch; c.dw[i] = d->dw; c.CC[i] = CC; c.parts[i] = gx; c.rblocks[i] = rblocks; c.ndw[i] = 0;
+    return RUA_OK;
+  }
   static bool attr32 = false, attr64 = false;
   if (CC == 32) {
     if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr32 = true; }
@@ -2758,6 +2798,12 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
   k.abytes = (unsigned)((size_t)k.M * d->C * 2); k.dybytes = (unsigned)((size_t)k.M * d->Cout * 2);
   if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + 15) / 16));
   if (g_wgrad_dry) return RUA_OK;
+  if (g_wg_group && g_wg_group->n < RUA_MAX_BRANCH) {
+    WgGroupCapture& c = *g_wg_group; const int i = c.n++;
+    c.kind[i] = 3; c.gx[i] = (unsigned)(tiles * k.ksplit); c.smem[i] = 96 * 1024; c.d[i] = k;
+    c.post[i] = (k.slabs && !d->defer) ? 2 : 0; c.part[i] = k.slabs; c.dw[i] = d->dw; c.ndw[i] = ndw; c.parts[i] = k.ksplit; c.CC[i] = 0; c.rblocks[i] = 0;
+    return RUA_OK;
+  }
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
   hipLaunchKernelGGL(wgrad_dmap, dim3((unsigned)(tiles * k.ksplit)), dim3(256), 96 * 1024, st, k);
@@ -2832,10 +2878,89 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + 15) / 16));
   if (g_wgrad_dry) return RUA_OK;
+  if (g_wg_group && g_wg_group->n < RUA_MAX_BRANCH && d->dtype == RUA_BF16) {
+    WgGroupCapture& c = *g_wg_group; const int i = c.n++;
+    c.kind[i] = 0; c.gx[i] = (unsigned)grid; c.smem[i] = 0; c.g[i] = k;
+    c.post[i] = (k.slabs && !d->defer) ? 2 : 0; c.part[i] = k.slabs; c.dw[i] = d->dw; c.ndw[i] = ndw; c.parts[i] = k.ksplit; c.CC[i] = 0; c.rblocks[i] = 0;
+    return RUA_OK;
+  }
   if (d->dtype == RUA_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, k);
   else hipLaunchKernelGGL((wgrad_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, k);
   RUA_LAUNCH_CHECK("wgrad_kernel");
   if (k.slabs && !d->defer) { record_mid_event(st); return launch_slab_reduce(k.slabs, d->dw, ndw, k.ksplit, st); }
+  return RUA_OK;
+}
+
+// rua_conv_wgrad_group: n INDEPENDENT weight gradients (the dilation branches of a ResBlock) with the results of n rua_conv_wgrad
+// calls.  Members that land on the same kernel go out as ONE grid (blockIdx.y / .z = member; the grid is the largest member's,
+// the others' surplus blocks leave at once), the rest one by one.  Members that share partial-sum workspace cannot overlap:
+// such a group runs member by member.
+static thread_local int g_wg_group_last_grids = 0;
+extern "C" int rua_wgrad_group_last_grids(void) { return g_wg_group_last_grids; }
+extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream) {
+  RUA_CHECK_ARG(d && n >= 1 && n <= RUA_MAX_BRANCH, "rua_conv_wgrad_group: 1..%d members", RUA_MAX_BRANCH);
+  hipStream_t st = (hipStream_t)stream;
+  bool shared = false;
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      const char* a0 = (const char*)d[i].workspace; const char* b0 = (const char*)d[j].workspace;
+      if (a0 && b0 && a0 < b0 + d[j].workspace_bytes && b0 < a0 + d[i].workspace_bytes) shared = true;
+      if (d[i].dw == d[j].dw) shared = true;
+    }
+  g_wg_group_last_grids = n;
+  if (n == 1 || shared || !g_tune.wgrad_group) {
+    for (int i = 0; i < n; ++i) { const int rc = rua_conv_wgrad(d + i, stream); if (rc != RUA_OK) return rc; }
+    return RUA_OK;
+  }
+  WgGroupCapture cap;
+  cap.n = 0;
+  g_wg_group = &cap;
+  int rc = RUA_OK;
+  for (int i = 0; i < n && rc == RUA_OK; ++i) rc = rua_conv_wgrad(d + i, stream);      // members no launcher captures launch right here
+  g_wg_group = nullptr;
+  if (rc != RUA_OK) return rc;
+  int grids = n - cap.n;
+  bool done[RUA_MAX_BRANCH] = {false};
+  for (int i = 0; i < cap.n; ++i) {
+    if (done[i]) continue;
+    int idx[RUA_MAX_BRANCH], m = 0; unsigned gx = 0; int smem = 0;
+    for (int j = i; j < cap.n; ++j)
+      if (!done[j] && cap.kind[j] == cap.kind[i]) { idx[m++] = j; done[j] = true; if (cap.gx[j] > gx) gx = cap.gx[j]; if (cap.smem[j] > smem) smem = cap.smem[j]; }
+    static thread_local bool attr[4] = {false, false, false, false};
+    const int kd = cap.kind[i];
+    if (kd == 0) {
+      if (m == 1) hipLaunchKernelGGL((wgrad_kernel<bf16_t>), dim3(gx), dim3(256), 0, st, cap.g[idx[0]]);
+      else { WgKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.g[idx[q]]; hipLaunchKernelGGL(wgrad_kernel_g, dim3(gx, m), dim3(256), 0, st, g); }
+    } else if (kd == 3) {
+      if (!attr[3]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap_g), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr[3] = true;
+      }
+      if (m == 1) hipLaunchKernelGGL(wgrad_dmap, dim3(gx), dim3(256), smem, st, cap.d[idx[0]]);
+      else { WgdKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.d[idx[q]]; hipLaunchKernelGGL(wgrad_dmap_g, dim3(gx, m), dim3(256), smem, st, g); }
+    } else {
+      const int gy = kd == 1 ? 1 : 2;
+      if (!attr[kd]) {
+        if (kd == 1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel_g<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        else { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+               (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel_g<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        attr[kd] = true;
+      }
+      WgtKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.t[idx[q]];
+      if (m == 1) { if (kd == 1) hipLaunchKernelGGL((wgrad_taps_kernel<32>), dim3(gx, gy), dim3(768), smem, st, g.k[0]);
+                    else hipLaunchKernelGGL((wgrad_taps_kernel<64>), dim3(gx, gy), dim3(768), smem, st, g.k[0]); }
+      else if (kd == 1) hipLaunchKernelGGL((wgrad_taps_kernel_g<32>), dim3(gx, gy, m), dim3(768), smem, st, g);
+      else hipLaunchKernelGGL((wgrad_taps_kernel_g<64>), dim3(gx, gy, m), dim3(768), smem, st, g);
+    }
+    RUA_LAUNCH_CHECK("rua_conv_wgrad_group");
+    ++grids;
+  }
+  g_wg_group_last_grids = grids;
+  for (int i = 0; i < cap.n; ++i) {                      // members that did not defer their reduction
+    if (cap.post[i] == 1) { hipLaunchKernelGGL(wgrad_taps_reduce, dim3(cap.rblocks[i]), dim3(256), 0, st, cap.part[i], cap.dw[i], cap.CC[i], cap.parts[i]); RUA_LAUNCH_CHECK("wgrad_taps_reduce"); }
+    else if (cap.post[i] == 2) { rc = launch_slab_reduce(cap.part[i], cap.dw[i], cap.ndw[i], cap.parts[i], st); if (rc != RUA_OK) return rc; }
+  }
   return RUA_OK;
 }
 

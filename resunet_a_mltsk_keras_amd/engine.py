@@ -593,21 +593,47 @@ class Graph:
         self._ws(d)
         return d
 
-    def wgrad(self, plan: Plan, a: Ten, dy: Ten, dw_off: int, stride: int, dil: int, taps: int, in_bn: Optional["Coef"] = None):
+    def wgrad_desc(self, plan: Plan, a: Ten, dy: Ten, dw_off: int, stride: int, dil: int, taps: int, in_bn: Optional["Coef"] = None,
+                   may_flush: bool = True):
         d = L.WgradDesc()
         d.a, d.C, d.Hs, d.Ws = a.ptr, a.C, a.H, a.W
         if in_bn is not None:                               # a is read as relu(scale * a + shift) (normalise on load)
             d.in_scale, d.in_shift, d.in_relu = in_bn.scale, in_bn.shift, 1
         d.dy, d.Cout, d.H, d.W = dy.ptr, dy.C, dy.H, dy.W
         d.N, d.stride, d.dil, d.taps, d.dtype = dy.N, stride, dil, taps, self.dt
+        defer = (not self.dry) and self.e.defer_reduce and plan is self.bwd
+        if defer and may_flush:                             # before G(): a flush is a launch of its own and must not count as this one
+            bucket = self.e.dist.bucket_of(dw_off) if self.e.dist is not None else 0
+            if self.pending and bucket != self.pending_bucket:
+                self.flush_wgrad(plan)
+            self.pending_bucket = bucket
         d.dw = self.G(dw_off)
         if not self.dry:
             sc = self.e.scratches[self.cur_lane]
             d.workspace, d.workspace_bytes = sc.data_ptr(), sc.numel() * 4
-            if self.e.defer_reduce and plan is self.bwd:
+            if defer:
                 self._defer_wgrad(plan, d, dw_off)
+        return d
+
+    def wgrad(self, plan: Plan, a: Ten, dy: Ten, dw_off: int, stride: int, dil: int, taps: int, in_bn: Optional["Coef"] = None):
+        d = self.wgrad_desc(plan, a, dy, dw_off, stride, dil, taps, in_bn)
         plan.keep.append(d)
         plan.add("rua_conv_wgrad", C.byref(d))
+
+    def wgrad_group(self, plan: Plan, specs: List[tuple]):
+        """Independent weight gradients (the dilation branches of a ResBlock) in one call: members on the same kernel share ONE
+        grid.  specs: (a, dy, dw_off, stride, dil, taps, in_bn).  Under data parallel the group counts as one launch of the
+        bucket of its first member (a pending-reduction flush can only come in front of the whole group)."""
+        if len(specs) == 1 or self.dry:
+            for sp in specs:
+                self.wgrad(plan, *sp)
+            return
+        descs = [self.wgrad_desc(plan, *sp, may_flush=(i == 0)) for i, sp in enumerate(specs)]
+        arr = (L.WgradDesc * len(descs))()
+        for i, dsc in enumerate(descs):
+            C.memmove(C.byref(arr, i * C.sizeof(L.WgradDesc)), C.byref(dsc), C.sizeof(L.WgradDesc))
+        plan.keep.append(arr)
+        plan.add("rua_conv_wgrad_group", arr, len(descs))
 
     # -- deferred weight-gradient reductions: the partial sums of many weight gradients (all-taps block partials, K-slice slabs)
     #    are added into dW by ONE batched launch instead of one small launch each (80 of them per cfg3 step).  Under data
@@ -615,10 +641,6 @@ class Graph:
     #    gradients are final - and its all-reduce starts - as early as before.
     def _defer_wgrad(self, plan: Plan, d, dw_off: int):
         lib = L.lib()
-        bucket = self.e.dist.bucket_of(dw_off) if self.e.dist is not None else 0
-        if self.pending and bucket != self.pending_bucket:
-            self.flush_wgrad(plan)
-        self.pending_bucket = bucket
         rec = L.WgradPending()
         d.defer = 1
         lib.call("rua_wgrad_plan", C.byref(d), C.byref(rec))           # with the shared scratch: which kind of partials, if any
@@ -725,8 +747,7 @@ class Graph:
             dO = out.grad
             if not v2:
                 self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])      # (model2: summed by the final bn_bwd, which reads dO as the skip gradient)
-            for d, l, a_2 in zip(dils, lay, a2):
-                self.wgrad(Bp, a_2, dO, l[3]["segs"][0]["off"], 1, d, 9)
+            self.wgrad_group(Bp, [(a_2, dO, l[3]["segs"][0]["off"], 1, d, 9, None) for d, l, a_2 in zip(dils, lay, a2)])
             g2s = [self.like(x) for _ in dils]
             s2s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
             self.conv_group(Bp, [self.dgrad_desc(dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
@@ -735,8 +756,7 @@ class Graph:
             for l, y, c2, g2, s2, dy1 in zip(lay, y1, coef2, g2s, s2s, dy1s):
                 self.bn_bwd(Bp, [g2], [c2], [l[2]], [s2], y, dy1, 0, cnt)
             # no bias gradient launch: the output of a BN backward sums to zero per channel, so d b1 == 0 exactly
-            for d, l, a_1, dy1 in zip(dils, lay, a1, dy1s):
-                self.wgrad(Bp, a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9)
+            self.wgrad_group(Bp, [(a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9, None) for d, l, a_1, dy1 in zip(dils, lay, a1, dy1s)])
             g1s = g2s                                          # g2 is dead after its bn_bwd: reuse the storage
             s1s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
             self.conv_group(Bp, [self.dgrad_desc(dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
@@ -778,8 +798,7 @@ class Graph:
             dO = out.grad
             if not v2:
                 self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
-            for d, l, y, c2 in zip(dils, lay, y1, coef2):
-                self.wgrad(Bp, y, dO, l[3]["segs"][0]["off"], 1, d, 9, in_bn=c2)
+            self.wgrad_group(Bp, [(y, dO, l[3]["segs"][0]["off"], 1, d, 9, c2) for d, l, y, c2 in zip(dils, lay, y1, coef2)])
             g2s = [self.like(x) for _ in dils]
             s2s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
             self.conv_group(Bp, [self.dgrad_desc(dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
@@ -787,8 +806,7 @@ class Graph:
             dy1s = [self.like(x) for _ in dils]
             for l, y, c2, g2, s2, dy1 in zip(lay, y1, coef2, g2s, s2s, dy1s):
                 self.bn_bwd(Bp, [g2], [c2], [l[2]], [s2], y, dy1, 0, cnt)
-            for d, l, c1, dy1 in zip(dils, lay, coef1, dy1s):
-                self.wgrad(Bp, x, dy1, l[1]["segs"][0]["off"], 1, d, 9, in_bn=c1)
+            self.wgrad_group(Bp, [(x, dy1, l[1]["segs"][0]["off"], 1, d, 9, c1) for d, l, c1, dy1 in zip(dils, lay, coef1, dy1s)])
             g1s = g2s
             s1s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
             self.conv_group(Bp, [self.dgrad_desc(dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)

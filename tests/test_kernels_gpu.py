@@ -984,3 +984,79 @@ def test_conv_group_equals_separate_launches(shape):
     for i in range(len(dils)):
         assert torch.equal(keep[4 * i + 2], sep[i][0]), (i, dils[i])
         assert np.allclose(keep[4 * i + 3].cpu().numpy().reshape(32, -1).sum(0), sep[i][1].cpu().numpy().reshape(32, -1).sum(0), rtol=1e-9)
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 256, 32, [1, 3, 15, 31], True), (4, 128, 128, 64, [1, 3, 15, 31], False), (8, 32, 32, 256, [1, 3, 15], False),
+                                   (8, 64, 64, 128, [1, 3, 15], False), (4, 32, 32, 64, [1, 3, 15], False)])
+def test_wgrad_group_equals_separate_launches(shape):
+    """rua_conv_wgrad_group: the weight gradients of the dilation branches of a ResBlock in one call (wgrad_taps<32> with BatchNorm
+    on load, wgrad_taps<64>, wgrad_dmap, wgrad_kernel with K slabs): ONE grid, results bit-identical to separate calls - both with
+    the reductions run by the call itself and deferred to rua_wgrad_reduce_batch.  Members that share workspace run one by one."""
+    N, H, W, Cs, dils, bn = shape
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(Cs + 1)
+    a = to_dev(rng.standard_normal((N, H, W, Cs)).astype(np.float32), dt)
+    sc = torch.from_numpy((0.5 + rng.random(Cs)).astype(np.float32)).to(dev()); sh = torch.from_numpy((0.3 * rng.standard_normal(Cs)).astype(np.float32)).to(dev())
+    keep, descs = [], []
+    for dil in dils:
+        dy = to_dev(rng.standard_normal((N, H, W, Cs)).astype(np.float32), dt)
+        d = L.WgradDesc()
+        d.a, d.C, d.Hs, d.Ws, d.dy, d.Cout, d.H, d.W = a.data_ptr(), Cs, H, W, dy.data_ptr(), Cs, H, W
+        d.N, d.stride, d.dil, d.taps, d.dtype = N, 1, dil, 9, dt
+        if bn:
+            d.in_scale, d.in_shift, d.in_relu = sc.data_ptr(), sh.data_ptr(), 1
+        ws = torch.zeros(lib.raw("rua_wgrad_workspace_bytes")(C.byref(d)) // 4 + 16, dtype=torch.float32, device=dev())
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        dw = torch.zeros(9 * Cs * Cs, dtype=torch.float32, device=dev())
+        d.dw = dw.data_ptr()
+        keep += [dy, ws, dw]
+        descs.append(d)
+    sep = []
+    for i, d in enumerate(descs):
+        lib.call("rua_conv_wgrad", C.byref(d), stream())
+        torch.cuda.synchronize()
+        sep.append(keep[3 * i + 2].clone())
+        keep[3 * i + 2].zero_()
+
+    def as_array():
+        arr = (L.WgradDesc * len(descs))()
+        for i, d in enumerate(descs):
+            C.memmove(C.byref(arr, i * C.sizeof(L.WgradDesc)), C.byref(d), C.sizeof(L.WgradDesc))
+        return arr
+    lib.call("rua_conv_wgrad_group", as_array(), len(descs), stream())
+    assert lib.raw("rua_wgrad_group_last_grids")() == 1
+    torch.cuda.synchronize()
+    for i in range(len(dils)):
+        assert torch.equal(keep[3 * i + 2], sep[i]), (i, dils[i])
+        keep[3 * i + 2].zero_()
+    # deferred reductions: the group leaves the partial sums, one batched launch adds them
+    recs = []
+    for d in descs:
+        d.defer = 1
+        r = L.WgradPending()
+        lib.call("rua_wgrad_plan", C.byref(d), C.byref(r))
+        assert r.kind != 0
+        recs.append(r)
+    lib.call("rua_conv_wgrad_group", as_array(), len(descs), stream())
+    table = (L.WgradPending * len(recs))()
+    blocks = 0
+    for i, r in enumerate(recs):
+        r.block_begin = blocks
+        blocks += r.blocks
+        C.memmove(C.byref(table, i * C.sizeof(L.WgradPending)), C.byref(r), C.sizeof(L.WgradPending))
+    tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev())
+    lib.call("rua_wgrad_reduce_batch", tdev.data_ptr(), len(recs), blocks, stream())
+    torch.cuda.synchronize()
+    for i in range(len(dils)):
+        assert torch.equal(keep[3 * i + 2], sep[i]), ("deferred", i, dils[i])
+        keep[3 * i + 2].zero_()
+    # shared workspace: not groupable, still correct
+    for d in descs:
+        d.defer = 0
+        d.workspace, d.workspace_bytes = descs[0].workspace, descs[0].workspace_bytes
+    lib.call("rua_conv_wgrad_group", as_array(), len(descs), stream())
+    assert lib.raw("rua_wgrad_group_last_grids")() == len(descs)
+    torch.cuda.synchronize()
+    for i in range(len(dils)):
+        assert torch.equal(keep[3 * i + 2], sep[i]), ("shared", i, dils[i])
