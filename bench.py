@@ -413,7 +413,7 @@ def main():
         # its 8 convolutions + BatchNorm passes, forward; and the same for every ResBlock of the network (SURVEY 7 hard-part 2:
         # per-level fractions), forward and backward.  FLOPs: conv (fwd), data + weight gradient (bwd), nothing else counted.
         lv = []
-        for key in sorted(k for k in blocks if k.startswith("fwd:")):
+        for key in sorted(k for k in blocks if k.startswith("fwd:") and "ResBlock" in k):
             sec, fl = blocks[key]
             row = {"block": key[4:], "fwd_gflop": round(fl / 1e9, 2), "fwd_us": round(1e6 * sec, 1), "fwd_frac": round(fl / sec / 1e12 / peak, 4)}
             if "bwd:" + key[4:] in blocks:
@@ -425,6 +425,14 @@ def main():
             out["roofline"]["d6_block"] = {"block": top["block"], "gflop": top["fwd_gflop"], "us": top["fwd_us"], "frac": top["fwd_frac"],
                                            "target_frac": 0.40, "pass": "forward, batch %d, every launch of the block (BN + 8 convs)" % B}
         out["roofline"]["resblocks"] = lv
+        # every other composite of the step (stem, stride-2 convs, PSPPooling, upsample + combine, heads, losses): microseconds only
+        comp = {}
+        for key, (sec, fl) in blocks.items():
+            pn, sc = key.split(":", 1)
+            if "ResBlock" not in sc:
+                comp.setdefault(sc, {})[pn + "_us"] = round(1e6 * sec, 1)
+        out["roofline"]["other_composites"] = comp
+        out["roofline"]["composites_total_us"] = round(1e6 * sum(sec for sec, _ in blocks.values()), 1)
         if not args.no_cpu_baseline and world == 1:            # the CPU oracle is timed at N=1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

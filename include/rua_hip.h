@@ -47,6 +47,17 @@ typedef struct rua_conv_seg {
   int32_t taps;        /* 1 or 9 */
 } rua_conv_seg;
 
+/* model2.py:17-24 BatchNormalization in training mode, folded into the consuming convolution (rua_conv_desc.in_fold) */
+typedef struct rua_bn_fold {
+  const double* stats;          /* [replicas][2][C] fp64: sum x, sum x^2 of the conv input, complete when the conv starts */
+  int32_t replicas, pad;
+  double count, bessel_n;       /* elements per channel; count for the unbiased moving variance (count if no replication) */
+  float eps, momentum;
+  const float* gamma; const float* beta;
+  float* moving_mean; float* moving_var;         /* updated once per call (NULL: not) */
+  float* scale; float* shift; float* mean; float* rstd;   /* published by one workgroup for later kernels (NULL mean / rstd: not) */
+} rua_bn_fold;
+
 typedef struct rua_conv_desc {
   rua_conv_seg seg[RUA_MAX_SEG];
   int32_t nseg;
@@ -81,6 +92,12 @@ typedef struct rua_conv_desc {
   const float* in_scale;
   const float* in_shift;
   int32_t in_relu;
+  int32_t pad_fold;
+  /* Training-mode BatchNorm whose coefficients the CONSUMER derives itself (no coefficient launch between the producer of the
+   * statistics and this convolution): every workgroup sums the replicated fp64 statistics of the input in its prologue, one
+   * designated workgroup publishes scale / shift / mean / rstd (ReLU masks, backward) and updates the moving statistics.
+   * Non-NULL: in_scale / in_shift must be NULL; in_relu applies.  Same shapes as in_scale (rua_conv_fused_input_ok). */
+  const struct rua_bn_fold* in_fold;
 } rua_conv_desc;
 int rua_conv_fwd(const rua_conv_desc* d, void* stream);
 /* n (<= RUA_MAX_BRANCH) INDEPENDENT convolutions - the dilation branches of a ResBlock (model2.py:26-31) - with the results of n

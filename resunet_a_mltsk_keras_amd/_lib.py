@@ -25,7 +25,12 @@ class ConvDesc(C.Structure):
                 ("stride", i32), ("dtype", i32), ("bias", vp), ("aux", vp), ("aux_mode", i32), ("mscale", vp),
                 ("mshift", vp), ("out_relu", i32), ("accumulate", i32), ("y", vp), ("out_stride", i32), ("OH", i32),
                 ("OW", i32), ("stats", vp), ("stats_mode", i32), ("workspace", vp), ("workspace_bytes", i64), ("stats_replicas", i32),
-                ("bias_more", vp * 3), ("in_scale", vp), ("in_shift", vp), ("in_relu", i32)]
+                ("bias_more", vp * 3), ("in_scale", vp), ("in_shift", vp), ("in_relu", i32), ("pad_fold", i32), ("in_fold", vp)]
+
+
+class BnFold(C.Structure):
+    _fields_ = [("stats", vp), ("replicas", i32), ("pad", i32), ("count", f64), ("bessel_n", f64), ("eps", f32), ("momentum", f32),
+                ("gamma", vp), ("beta", vp), ("moving_mean", vp), ("moving_var", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("rstd", vp)]
 
 
 class WgradDesc(C.Structure):

@@ -1624,8 +1624,8 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     g_last_ksplit = 1;
     return rua_launch_conv_strip(k, d, st);
   }
-  RUA_CHECK_ARG(d->in_scale == nullptr, "rua_conv_fwd: in_scale / in_shift (normalise on load) is not available for this shape: ask "
-                                        "rua_conv_fused_input_ok() first");
+  RUA_CHECK_ARG(d->in_scale == nullptr && d->in_fold == nullptr, "rua_conv_fwd: in_scale / in_shift / in_fold (normalise on load) is not available for "
+                                        "this shape: ask rua_conv_fused_input_ok() first");
   if (pick_halo(d)) {
     k.nbn = 1; k.nbm = 1; k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr; k.cnt = nullptr;
     g_last_ksplit = 1;

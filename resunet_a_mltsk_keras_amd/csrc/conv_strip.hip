@@ -33,6 +33,7 @@ struct StripK {
   unsigned epbytes;
   int d, strips, spc, seglen, njobs, nchains;
   int slot_bytes, SWH;                    // bytes of one x-ring slot (multiple of 1024), pixels per slot row (SW + 2 d)
+  int has_fold; rua_bn_fold f;            // BatchNorm coefficients derived in the prologue from the input's statistics (in_fold)
 };
 
 template <int NW, bool HAS_EP, int R>
@@ -50,7 +51,7 @@ __device__ __forceinline__ void conv_strip32_body(const StripK& q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sEP = smem + R * q.slot_bytes;
   unsigned char* sDump = sEP + (HAS_EP ? RA * EP_SLOT : 0);
-  float* tab = reinterpret_cast<float*>(sDump + NW * 1024);         // [3][32]: bias sum, mask scale, mask shift
+  float* tab = reinterpret_cast<float*>(sDump + NW * 1024);         // [5][32]: bias sum, mask scale, mask shift, folded BN scale, shift
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pl = lane & 31, kh = lane >> 5;
@@ -88,10 +89,48 @@ __device__ __forceinline__ void conv_strip32_body(const StripK& q) {
   // conflict-free ds_read_b128 of the b-operand - the four pixels of one residue mod 4 in a 16-lane read group get four
   // different slots, at every tap shift; the permutation is applied on the SOURCE side, the LDS image is lane-linear)
   const int psrc = (lane & 3) ^ ((lane >> 4) & 3);
-  const bool bn = p.in_scale != nullptr;
+  const bool bn = p.in_scale != nullptr || q.has_fold;
   float sc8[8], sh8[8];
+  if (q.has_fold) {
+    // in_fold: the coefficient launch folded into this prologue.  NT / 32 thread groups each sum a share of the replicated fp64
+    // statistics (one or two loads deep), the first 32 threads add the shares in a fixed order and finish mean / variance ->
+    // scale / shift; job 0 publishes them and updates the moving statistics.  The x ring is still empty: it serves as scratch.
+    const rua_bn_fold& f = q.f;
+    constexpr int NG = NT / 32;
+    double* red = reinterpret_cast<double*>(smem);                   // [NG][2][32]
+    const int c = tid & 31, grp = tid >> 5;
+    double a1 = 0, a2 = 0;
+    for (int r = grp; r < f.replicas; r += NG) { a1 += f.stats[(size_t)r * 64 + c]; a2 += f.stats[(size_t)r * 64 + 32 + c]; }
+    red[(grp * 2) * 32 + c] = a1; red[(grp * 2 + 1) * 32 + c] = a2;
+    __syncthreads();
+    if (tid < 32) {
+      double s1 = 0, s2 = 0;
+      for (int g = 0; g < NG; ++g) { s1 += red[(g * 2) * 32 + tid]; s2 += red[(g * 2 + 1) * 32 + tid]; }
+      const double m = s1 / f.count;
+      double v = s2 / f.count - m * m;
+      if (v < 0) v = 0;
+      const double r = 1.0 / sqrt(v + (double)f.eps);
+      const double sc = (double)f.gamma[tid] * r;
+      const float scf = (float)sc, shf = (float)((double)f.beta[tid] - m * sc);
+      tab[96 + tid] = scf; tab[128 + tid] = shf;
+      if (job == 0) {
+        f.scale[tid] = scf; f.shift[tid] = shf;
+        if (f.mean) f.mean[tid] = (float)m;
+        if (f.rstd) f.rstd[tid] = (float)r;
+        if (f.moving_mean) {
+          const double unb = f.bessel_n > 1 ? v * (f.bessel_n / (f.bessel_n - 1)) : v;
+          f.moving_mean[tid] = (float)((double)f.moving_mean[tid] * f.momentum + m * (1.0 - f.momentum));
+          f.moving_var[tid] = (float)((double)f.moving_var[tid] * f.momentum + unb * (1.0 - f.momentum));
+        }
+      }
+    }
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sc8[j] = bn ? p.in_scale[psrc * 8 + j] : 1.f; sh8[j] = (bn && p.in_shift) ? p.in_shift[psrc * 8 + j] : 0.f; }
+    for (int j = 0; j < 8; ++j) { sc8[j] = tab[96 + psrc * 8 + j]; sh8[j] = tab[128 + psrc * 8 + j]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc8[j] = bn ? p.in_scale[psrc * 8 + j] : 1.f; sh8[j] = (bn && p.in_shift) ? p.in_shift[psrc * 8 + j] : 0.f; }
+  }
   // all ordinary loads are consumed HERE, before the first LDS-DMA is issued (hipcc waits vmcnt(0) at the first use of a
   // pending load: inside the loop that would drain the DMA ring)
 #pragma unroll
@@ -403,7 +442,15 @@ int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st
   q.spc = (ny + q.seglen - 1) / q.seglen;
   q.njobs = q.nchains * q.spc;
   const int R = has_ep ? 5 : 7;
-  const int smem = R * q.slot_bytes + (has_ep ? 3 * sw * 64 : 0) + nw * 1024 + 3 * 32 * 4;
+  const int smem = R * q.slot_bytes + (has_ep ? 3 * sw * 64 : 0) + nw * 1024 + 5 * 32 * 4;
+  q.has_fold = d->in_fold ? 1 : 0;
+  if (d->in_fold) {
+    q.f = *d->in_fold;
+    RUA_CHECK_ARG(!d->in_scale && !d->in_shift, "conv_strip: in_fold excludes in_scale / in_shift");
+    RUA_CHECK_ARG(q.f.stats && q.f.replicas >= 1 && q.f.count > 0 && q.f.gamma && q.f.beta && q.f.scale && q.f.shift, "conv_strip: incomplete in_fold");
+    RUA_CHECK_ARG((q.f.moving_mean == nullptr) == (q.f.moving_var == nullptr), "conv_strip: in_fold needs both moving statistics or neither");
+    RUA_CHECK_ARG(nw * 2 * 2 * 32 * 8 <= R * q.slot_bytes, "conv_strip: no room for the in_fold scratch");
+  } else memset(&q.f, 0, sizeof(q.f));
   RUA_CHECK_ARG(smem <= 160 * 1024, "conv_strip: %d bytes of LDS", smem);
   const int variant = (nw == 8 ? 0 : 2) + (has_ep ? 0 : 1);
   if (g_conv_group) {                                   // capture mode: issued by rua_strip_group_flush, grouped with its siblings

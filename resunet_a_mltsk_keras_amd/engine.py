@@ -321,6 +321,28 @@ class Coef:
         self.scale, self.shift, self.mean, self.rstd, self.A, self.B, self.Cc = [p + i * st for i in range(7)]
 
 
+class _BackSteps(list):
+    """The backward closures of a graph, in creation order.  A closure appended while a composite tag is set records its launches
+    under that tag (unless it names a scope itself, as the ResBlocks do)."""
+
+    def __init__(self, g):
+        super().__init__()
+        self.g = g
+
+    def append(self, fn):
+        tag = self.g.cur_tag
+        if tag is None:
+            return super().append(fn)
+
+        def run():
+            Bp = self.g.bwd
+            prev = Bp.scope
+            Bp.scope = tag
+            fn()
+            Bp.scope = prev
+        super().append(run)
+
+
 class Graph:
     """One recorded instance of the network for a fixed batch size and mode."""
 
@@ -337,7 +359,8 @@ class Graph:
         self.fwd = Plan(dry)
         self.bwd = Plan(dry)
         self.loss_plan = Plan(dry)
-        self.back_steps: List = []
+        self.back_steps: List = _BackSteps(self)
+        self.cur_tag: Optional[str] = None      # composite being recorded (stem, down, PSP, combine, heads): per-composite timing in bench.py
         self.grad_touch: Dict[int, int] = {}
         self.cur_lane = 0
         self.block_tag = ""
@@ -499,15 +522,27 @@ class Graph:
             self.stats_to_grads(plan, st, x.C, skip_bias)
 
     def conv(self, plan: Plan, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual: Optional[Ten] = None,
-             out_relu=False, stats=None, bias_more=(), in_bn: Optional["Coef"] = None, accumulate: int = 0):
+             out_relu=False, stats=None, bias_more=(), in_bn: Optional["Coef"] = None, accumulate: int = 0, in_fold=None):
         """segs: [(Ten, up_shift, dil, taps)], layer_segs: [param seg dict] (same order).  in_bn: the (single) source is
         read as relu(scale * x + shift) - BatchNorm + ReLU applied by the kernel as the tile lands (normalise on load)."""
-        d = self.conv_desc(segs, layer_segs, cout, bias_ptr, out, stride, residual, out_relu, stats, bias_more, in_bn, accumulate)
+        d = self.conv_desc(segs, layer_segs, cout, bias_ptr, out, stride, residual, out_relu, stats, bias_more, in_bn, accumulate, in_fold)
         plan.keep.append(d)
         plan.add("rua_conv_fwd", C.byref(d))
 
+    def bn_fold(self, plan: Plan, bn: dict, stats: Stat, count, bessel=None):
+        """(Coef, rua_bn_fold) of a training-mode BatchNorm whose coefficients the consuming convolution derives in its own
+        prologue from `stats` (no coefficient launch); the Coef buffers are filled by that convolution."""
+        c = Coef(self, bn["C"])
+        f = L.BnFold()
+        f.stats, f.replicas = stats.ptr, stats.R
+        f.count, f.bessel_n, f.eps, f.momentum = float(count), float(bessel or count), BN_EPS, BN_MOMENTUM
+        f.gamma, f.beta, f.moving_mean, f.moving_var = self.P(bn["gamma"]), self.P(bn["beta"]), self.S(bn["mm"]), self.S(bn["mv"])
+        f.scale, f.shift, f.mean, f.rstd = c.scale, c.shift, c.mean, c.rstd
+        plan.keep += [c, f]
+        return c, f
+
     def conv_desc(self, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual=None, out_relu=False, stats=None, bias_more=(),
-                  in_bn=None, accumulate=0):
+                  in_bn=None, accumulate=0, in_fold=None):
         d = L.ConvDesc()
         d.nseg = len(segs)
         for i, ((t, up, dil, taps), ps) in enumerate(zip(segs, layer_segs)):
@@ -525,7 +560,9 @@ class Graph:
         if stats is not None:
             d.stats, d.stats_mode, d.stats_replicas = stats.ptr, 1, stats.R
         d.accumulate = accumulate
-        if in_bn is not None:
+        if in_fold is not None:                             # the kernel derives (and publishes) the coefficients itself
+            d.in_fold, d.in_relu = C.addressof(in_fold), 1
+        elif in_bn is not None:
             d.in_scale, d.in_shift, d.in_relu = in_bn.scale, in_bn.shift, 1
         self._ws(d)
         return d
@@ -778,15 +815,24 @@ class Graph:
         v2 = self.cfg.variant == "model2"
         cnt = x.M
         nb = len(dils)
-        coef1 = self.bn_coefs(F, x, [l[0] for l in lay], [x.stats] * nb, cnt)
+        fold = tr and self.e.fold_bn
+        if fold:                                             # training: the convs derive the BN coefficients in their prologue
+            cf1 = [self.bn_fold(F, l[0], x.stats, cnt) for l in lay]
+            coef1, fold1 = [c for c, _ in cf1], [f for _, f in cf1]
+        else:
+            coef1, fold1 = self.bn_coefs(F, x, [l[0] for l in lay], [x.stats] * nb, cnt), [None] * nb
         y1 = [self.like(x) for _ in dils]
         st1 = [self.stat(nf, (cnt + 127) // 128) if tr else None for _ in dils]
-        self.conv_group(F, [self.conv_desc([(x, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st, in_bn=c1)
-                            for d, l, c1, y, st in zip(dils, lay, coef1, y1, st1)])       # all four dilations: ONE grid
-        coef2 = self.bn_coefs(F, x, [l[2] for l in lay], st1, cnt)
+        self.conv_group(F, [self.conv_desc([(x, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st, in_bn=c1, in_fold=f1)
+                            for d, l, c1, f1, y, st in zip(dils, lay, coef1, fold1, y1, st1)])       # all four dilations: ONE grid
+        if fold:
+            cf2 = [self.bn_fold(F, l[2], st, cnt) for l, st in zip(lay, st1)]
+            coef2, fold2 = [c for c, _ in cf2], [f for _, f in cf2]
+        else:
+            coef2, fold2 = self.bn_coefs(F, x, [l[2] for l in lay], st1, cnt), [None] * nb
         out = self.like(x)
-        for bi, (d, l, y, c2) in enumerate(zip(dils, lay, y1, coef2)):
-            self.conv(F, [(y, 0, d, 9)], [l[3]["segs"][0]], nf, self.P(l[3]["bias"]), out, in_bn=c2,
+        for bi, (d, l, y, c2, f2) in enumerate(zip(dils, lay, y1, coef2, fold2)):
+            self.conv(F, [(y, 0, d, 9)], [l[3]["segs"][0]], nf, self.P(l[3]["bias"]), out, in_bn=c2, in_fold=f2,
                       residual=x if (v2 and bi == 0) else None, accumulate=1 if bi > 0 else 0)
         F.scope = None
         if not tr:
@@ -1118,6 +1164,15 @@ class Graph:
         self.back_steps.append(back)
 
     # -- whole network ---------------------------------------------------------------------------------
+    def tagged(self, tag: str, fn, *args):
+        """Record fn(*args) - forward launches now, its backward closures later - under the composite name `tag`."""
+        self.cur_tag = tag
+        prev, self.fwd.scope = self.fwd.scope, tag
+        out = fn(*args)
+        self.fwd.scope = prev
+        self.cur_tag = None
+        return out
+
     def _build(self):
         cfg, F, tr = self.cfg, self.fwd, self.training
         if cfg.variant not in ("model2", "model"):
@@ -1130,41 +1185,47 @@ class Graph:
         self.x_in = self.new(self.B, H, W, Cin, f32=True)
         stem = self.Lconv([Cin], w0, 1, mfma=False)
         c1 = self.new(self.B, H, W, w0)
+        self.cur_tag, F.scope = "stem", "stem"
         F.add("rua_stem_fwd", self.x_in.ptr, self.P(stem["segs"][0]["off"]), self.P(stem["bias"]), c1.ptr, c1.M, Cin, w0, self.dt)
         if tr:
             def stem_back():
                 self.bwd.add("rua_stem_bwd", self.x_in.ptr, c1.grad.ptr, self.G(stem["segs"][0]["off"]), self.G(stem["bias"]),
                              c1.M, Cin, w0, self.dt)
             self.back_steps.append(stem_back)
+        self.cur_tag, F.scope = None, None
         x = c1
         skips = []
         for i, (nf, dils) in enumerate(lv):
             if i > 0:
-                x = self.down(x, nf)
+                x = self.tagged(f"down{i + 1}", self.down, x, nf)
             self.block_tag = f"enc{i + 1}"
             x = self.resblock(x, nf, dils)
             skips.append(x)
-        x = self.psp(x, lv[-1][0]) if v2 else self.psp_v1(x, lv[-1][0])
+        x = self.tagged("psp_mid", self.psp if v2 else self.psp_v1, x, lv[-1][0])
         for i in range(len(lv) - 2, -1, -1):
             nf, dils = lv[i]
-            x = self.up_combine(x, skips[i], nf) if v2 else self.up_combine_v1(x, skips[i], nf)
+            x = self.tagged(f"up{i + 1}", self.up_combine if v2 else self.up_combine_v1, x, skips[i], nf)
             self.block_tag = f"dec{i + 1}"
             x = self.resblock(x, nf, dils)
-        x_comb = self.final_combine(x, c1, w0) if v2 else self.relu_cat_conv_v1(x, 0, c1, w0, want_stats=False)
-        x_psp = self.psp(x_comb, w0) if v2 else self.psp_v1(x_comb, w0)
+        x_comb = self.tagged("combine_top", self.final_combine, x, c1, w0) if v2 else self.tagged("combine_top", self.relu_cat_conv_v1, x, 0, c1, w0, False)
+        x_psp = self.tagged("psp_top", self.psp if v2 else self.psp_v1, x_comb, w0)
         Cc = cfg.num_classes
         if not cfg.multitasking:
-            self.head(x_psp, Cc, L.ACT_SOFTMAX, "seg")
+            self.tagged("head_seg", self.head, x_psp, Cc, L.ACT_SOFTMAX, "seg")
         else:
-            s = self.conv3x3_relu(x_psp, w0, "seg1")
-            s = self.conv3x3_relu(s, w0, "seg2")
-            self.head(s, Cc, L.ACT_SOFTMAX, "seg", "seg3")
-            b = self.conv3x3_relu(x_psp, w0)
-            self.head(b, Cc, L.ACT_SIGMOID, "bound")
-            d = self.conv3x3_relu(x_comb, w0)
-            d = self.conv3x3_relu(d, w0)
-            self.head(d, Cc, L.ACT_SOFTMAX, "dist")
-            self.head(x_comb, 3, L.ACT_SIGMOID, "color", "color")
+            def seg_head():
+                s = self.conv3x3_relu(x_psp, w0, "seg1")
+                s = self.conv3x3_relu(s, w0, "seg2")
+                self.head(s, Cc, L.ACT_SOFTMAX, "seg", "seg3")
+
+            def dist_head():
+                d = self.conv3x3_relu(x_comb, w0)
+                d = self.conv3x3_relu(d, w0)
+                self.head(d, Cc, L.ACT_SOFTMAX, "dist")
+            self.tagged("head_seg", seg_head)
+            self.tagged("head_bound", lambda: self.head(self.conv3x3_relu(x_psp, w0), Cc, L.ACT_SIGMOID, "bound"))
+            self.tagged("head_dist", dist_head)
+            self.tagged("head_color", self.head, x_comb, 3, L.ACT_SIGMOID, "color", "color")
         self.outputs = {h["name"]: h for h in self.heads}
         if self.e.loss is not None and not self.dry:
             self._record_losses()
@@ -1172,7 +1233,9 @@ class Graph:
     def _record_losses(self):
         """Loss / metric launches and (training) the whole backward plan, in reverse creation order."""
         for h in self.heads:
+            self.cur_tag = self.loss_plan.scope = "loss_" + h["name"]
             self.head_loss(h)
+        self.cur_tag = self.loss_plan.scope = None
         seg = self.outputs["seg"]
         self.loss_plan.add("rua_seg_metrics", seg["p"].ptr, seg["y"].ptr, seg["x"].M, seg["C"], self.e.scalars_ptr + 8 * 8)
         if self.training:
@@ -1198,6 +1261,7 @@ class Engine:
                              "channels and the MFMA epilogue stores 8-channel pieces)")
         self.dev = None
         self.fuse_bn = os.environ.get("RUA_FUSE_BN", "1") != "0"     # normalise-on-load ResBlocks where the library offers it
+        self.fold_bn = os.environ.get("RUA_FOLD_BN", "1") != "0"     # ... and their coefficient launches folded into the convs' prologues
         self.defer_reduce = os.environ.get("RUA_DEFER_REDUCE", "1") != "0"     # weight-gradient partials summed by batched launches
         self.cu_count = 256
         self.split_k = split_k       # False: bit-reproducible convolutions (no fp32-atomic K slices); parity tests on tiny

@@ -1060,3 +1060,64 @@ def test_wgrad_group_equals_separate_launches(shape):
     torch.cuda.synchronize()
     for i in range(len(dils)):
         assert torch.equal(keep[3 * i + 2], sep[i]), ("shared", i, dils[i])
+
+
+@pytest.mark.parametrize("N,H,W,dil,R", [(2, 256, 256, 1, 32), (1, 256, 256, 31, 8), (4, 128, 128, 3, 1), (1, 200, 512, 15, 16)])
+def test_conv_strip_folded_batchnorm_coefficients(N, H, W, dil, R):
+    """rua_conv_desc.in_fold: the convolution derives the training-mode BatchNorm coefficients of its input from the replicated
+    fp64 statistics in its own prologue (no coefficient launch), publishes scale / shift / mean / rstd and updates the moving
+    statistics once.  Against rua_bn_fwd's coefficient launch + the in_scale path: published vectors and moving statistics agree
+    to fp32 rounding of a differently ordered fp64 sum, the conv output to bf16 rounding of those coefficients."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(H + dil)
+    Cs = 32
+    x = (1.5 * rng.standard_normal((N, H, W, Cs)) + 0.3).astype(np.float32)
+    xd = to_dev(x, dt)
+    w = to_dev((rng.standard_normal((9, Cs, Cs)) / np.sqrt(9 * Cs)).astype(np.float32), dt)
+    bias = torch.from_numpy(rng.standard_normal(Cs).astype(np.float32)).to(dev())
+    gamma = torch.from_numpy((0.5 + rng.random(Cs)).astype(np.float32)).to(dev())
+    beta = torch.from_numpy((0.3 * rng.standard_normal(Cs)).astype(np.float32)).to(dev())
+    M = N * H * W
+    stats = torch.zeros(R * 2 * Cs, dtype=torch.float64, device=dev())
+    lib.call("rua_col_stats", xd.data_ptr(), M, Cs, stats.data_ptr(), R, dt, stream())
+    res = []
+    for fold in (False, True):
+        mm = torch.full((Cs,), 0.25, dtype=torch.float32, device=dev()); mv = torch.full((Cs,), 2.0, dtype=torch.float32, device=dev())
+        co = torch.zeros(4, Cs, dtype=torch.float32, device=dev())
+        y = torch.zeros((N, H, W, Cs), dtype=torch.bfloat16, device=dev())
+        d = L.ConvDesc()
+        d.nseg = 1
+        s = d.seg[0]
+        s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = xd.data_ptr(), w.data_ptr(), Cs, H, W, 0, dil, 9
+        d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cs, 1, dt
+        d.y, d.out_stride, d.OH, d.OW, d.bias = y.data_ptr(), 1, H, W, bias.data_ptr()
+        f = L.BnFold()
+        if fold:
+            f.stats, f.replicas, f.count, f.bessel_n, f.eps, f.momentum = stats.data_ptr(), R, float(M), float(M), 1e-3, 0.99
+            f.gamma, f.beta, f.moving_mean, f.moving_var = gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr()
+            f.scale, f.shift, f.mean, f.rstd = (co[i].data_ptr() for i in range(4))
+            d.in_fold, d.in_relu = C.addressof(f), 1
+        else:
+            b = L.BnFwdDesc()
+            b.x, b.M, b.C, b.dtype, b.nb, b.relu, b.training = None, M, Cs, dt, 1, 1, 1
+            b.stats, b.replicas, b.count, b.bessel_n, b.momentum, b.eps = stats.data_ptr(), R, float(M), float(M), 0.99, 1e-3
+            br = b.br[0]
+            br.gamma, br.beta, br.moving_mean, br.moving_var = gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr()
+            br.scale, br.shift, br.mean, br.rstd, br.out = (co[0].data_ptr(), co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), None)
+            lib.call("rua_bn_fwd", C.byref(b), stream())
+            d.in_scale, d.in_shift, d.in_relu = co[0].data_ptr(), co[1].data_ptr(), 1
+        assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 5
+        lib.call("rua_conv_fwd", C.byref(d), stream())
+        torch.cuda.synchronize()
+        res.append((y.float().cpu().numpy(), co.cpu().numpy(), mm.cpu().numpy(), mv.cpu().numpy()))
+    (y0, c0, mm0, mv0), (y1, c1, mm1, mv1) = res
+    assert np.allclose(c1, c0, rtol=2e-6, atol=1e-7)
+    assert np.allclose(mm1, mm0, rtol=1e-6) and np.allclose(mv1, mv0, rtol=1e-6)
+    xr = rnd(dt, x).double().numpy()
+    assert np.allclose(c1[2], xr.mean(axis=(0, 1, 2)), rtol=1e-4, atol=1e-5)       # published mean = the batch mean of the bf16 input
+    assert np.allclose(mm1, 0.25 * 0.99 + 0.01 * xr.mean(axis=(0, 1, 2)), rtol=1e-4, atol=1e-6)
+    assert rel_err(y1, y0) < 2e-3                                                 # a last-bit coefficient difference moves a few bf16 roundings
+    # in_fold on a shape no normalise-on-load kernel serves is refused
+    d.Cout = 64
+    assert lib.raw("rua_conv_fwd")(C.byref(d), None) != 0
