@@ -75,7 +75,10 @@ struct RuaTuning {
   int conv_pw_blocks = 0, conv_halo = 1, halo64_maxd = 1, conv_dmap = 1, dmap_target = 0, dmap_fused_finish = 0, dmap_rowb = 64, dmap_bm64 = 1;
   int wgrad_pw = 1, wgpw_blocks = 0, wgpw_r = 0, wgd_blocks = 0, wgrad_dmap = 1, wgd_mintiles = 9, wgrad_blocks = 0;
   int bn_grid = 0, tani_vec = 1, metrics_blocks = 0, stem_blocks = 0, head_blocks = 0;
-  int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0, conv_group = 1, wgrad_group = 1;
+  int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0;
+  // grouped launches of a ResBlock's dilation branches, one bit per kernel family (0: every member launches on its own)
+  int conv_group = 15;                  // 1 conv_strip, 2 conv_igemm<bf16,256,64>, 4 conv_dmap<128,128>, 8 conv_dmap<64,128>
+  int wgrad_group = 7;                  // 1 wgrad_kernel, 2 wgrad_taps<32>, 4 wgrad_taps<64>, 8 wgrad_dmap (off: three members at once thrash the L2, 27.6 vs 24.6 us each)
 };
 extern RuaTuning g_tune;
 int rua_cu_count();          // compute units of the current device (queried once per device, cached)

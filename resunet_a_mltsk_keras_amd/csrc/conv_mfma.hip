@@ -1138,7 +1138,7 @@ template <typename T, int BM, int BN> static int launch_conv(const ConvK& k, int
   // split-K invariant: the workspace is all zeros on entry (caller zero-fills it once) and the finisher writes the
   // zeros back after consuming the sums, so no memset is launched per convolution.
   const int smem_now = conv_smem_base<T, BM, BN>() + ((k.nunits * 16 + 255) / 256) * 256;     // unit table sized to this launch
-  if (g_conv_group && k.ksplit == 1 && sizeof(T) == 2 && BM == 256 && BN == 64) {           // the C = 64 level's 3x3 convs
+  if (g_conv_group && (g_tune.conv_group & 2) && k.ksplit == 1 && sizeof(T) == 2 && BM == 256 && BN == 64) {           // the C = 64 level's 3x3 convs
     if (!g_conv_group->add(3, (unsigned)(nbm * k.nbn), smem_now, k)) return RUA_ERR_ARG;
     return RUA_OK;
   }
@@ -1227,7 +1227,7 @@ template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, 
     attr_set = true;
   }
   constexpr int smem = conv_dmap_smem<BM, BN>();
-  if (g_conv_group && k.ksplit == 1 && ROWB == 64) {
+  if (g_conv_group && (g_tune.conv_group & (BM == 128 ? 4 : 8)) && k.ksplit == 1 && ROWB == 64) {
     if (!g_conv_group->add(BM == 128 ? 1 : 2, (unsigned)(k.nbm * k.nbn), smem, k)) return RUA_ERR_ARG;
     return RUA_OK;
   }
@@ -2452,7 +2452,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   const int rblocks = rua_div_up(9 * CC * CC / 4, 16);
   note_pending(1, gx, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks);
   if (g_wgrad_dry) return RUA_OK;
-  if (g_wg_group && g_wg_group->n < RUA_MAX_BRANCH) {
+  if (g_wg_group && (g_tune.wgrad_group & (CC == 32 ? 2 : 4)) && g_wg_group->n < RUA_MAX_BRANCH) {
     WgGroupCapture& c = *g_wg_group; const int i = c.n++;
     c.kind[i] = CC == 32 ? 1 : 2; c.gx[i] = gx; c.smem[i] = (int)smem; c.t[i] = k;
     c.post[i] = d->defer ? 0 : 1; c.part[i] = k.scratch; c.dw[i] = d->dw; c.CC[i] = CC; c.parts[i] = gx; c.rblocks[i] = rblocks; c.ndw[i] = 0;
@@ -2798,7 +2798,7 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
   k.abytes = (unsigned)((size_t)k.M * d->C * 2); k.dybytes = (unsigned)((size_t)k.M * d->Cout * 2);
   if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + 15) / 16));
   if (g_wgrad_dry) return RUA_OK;
-  if (g_wg_group && g_wg_group->n < RUA_MAX_BRANCH) {
+  if (g_wg_group && (g_tune.wgrad_group & 8) && g_wg_group->n < RUA_MAX_BRANCH) {
     WgGroupCapture& c = *g_wg_group; const int i = c.n++;
     c.kind[i] = 3; c.gx[i] = (unsigned)(tiles * k.ksplit); c.smem[i] = 96 * 1024; c.d[i] = k;
     c.post[i] = (k.slabs && !d->defer) ? 2 : 0; c.part[i] = k.slabs; c.dw[i] = d->dw; c.ndw[i] = ndw; c.parts[i] = k.ksplit; c.CC[i] = 0; c.rblocks[i] = 0;
@@ -2878,7 +2878,7 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + 15) / 16));
   if (g_wgrad_dry) return RUA_OK;
-  if (g_wg_group && g_wg_group->n < RUA_MAX_BRANCH && d->dtype == RUA_BF16) {
+  if (g_wg_group && (g_tune.wgrad_group & 1) && g_wg_group->n < RUA_MAX_BRANCH && d->dtype == RUA_BF16) {
     WgGroupCapture& c = *g_wg_group; const int i = c.n++;
     c.kind[i] = 0; c.gx[i] = (unsigned)grid; c.smem[i] = 0; c.g[i] = k;
     c.post[i] = (k.slabs && !d->defer) ? 2 : 0; c.part[i] = k.slabs; c.dw[i] = d->dw; c.ndw[i] = ndw; c.parts[i] = k.ksplit; c.CC[i] = 0; c.rblocks[i] = 0;

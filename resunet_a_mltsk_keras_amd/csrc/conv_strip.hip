@@ -453,7 +453,7 @@ int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st
   } else memset(&q.f, 0, sizeof(q.f));
   RUA_CHECK_ARG(smem <= 160 * 1024, "conv_strip: %d bytes of LDS", smem);
   const int variant = (nw == 8 ? 0 : 2) + (has_ep ? 0 : 1);
-  if (g_conv_group) {                                   // capture mode: issued by rua_strip_group_flush, grouped with its siblings
+  if (g_conv_group && (g_tune.conv_group & 1)) {        // capture mode: issued by rua_strip_group_flush, grouped with its siblings
     StripCapture& c = g_strip_cap;
     RUA_CHECK_ARG(c.n < RUA_MAX_BRANCH, "conv_strip: group capture overflow");
     c.variant[c.n] = variant; c.smem[c.n] = smem; c.k[c.n] = q; ++c.n;

@@ -1024,12 +1024,22 @@ def test_wgrad_group_equals_separate_launches(shape):
         for i, d in enumerate(descs):
             C.memmove(C.byref(arr, i * C.sizeof(L.WgradDesc)), C.byref(d), C.sizeof(L.WgradDesc))
         return arr
+    old = lib.get_tuning("wgrad_group")
+    lib.set_tuning(wgrad_group=15)                          # every kernel family (wgrad_dmap is grouped only on request: slower in the step)
     lib.call("rua_conv_wgrad_group", as_array(), len(descs), stream())
     assert lib.raw("rua_wgrad_group_last_grids")() == 1
     torch.cuda.synchronize()
     for i in range(len(dils)):
         assert torch.equal(keep[3 * i + 2], sep[i]), (i, dils[i])
         keep[3 * i + 2].zero_()
+    lib.set_tuning(wgrad_group=0)                           # no grouping: one launch per member
+    lib.call("rua_conv_wgrad_group", as_array(), len(descs), stream())
+    assert lib.raw("rua_wgrad_group_last_grids")() == len(descs)
+    torch.cuda.synchronize()
+    for i in range(len(dils)):
+        assert torch.equal(keep[3 * i + 2], sep[i]), (i, dils[i])
+        keep[3 * i + 2].zero_()
+    lib.set_tuning(wgrad_group=old)
     # deferred reductions: the group leaves the partial sums, one batched launch adds them
     recs = []
     for d in descs:
