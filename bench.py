@@ -142,10 +142,13 @@ def profile_kernels(eng, g, dtype):
                 # rocprofv3 names the grouped grids conv_igemm_g<...>, conv_dmap_g<...>, conv_strip32_g<...>
                 kn = (f"conv_igemm_g<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap_g<{bm_},{bn_}>", f"conv_halo<{d0.Cout}>", "conv_pw", f"conv_strip_g<{d0.Cout}>")[kid]
                 grids = lib.raw("rua_conv_group_last_grids")()
-                if grids != 1:                              # members the launchers could not put into one grid
+                nl = 1
+                if grids == n and all(lib.raw("rua_conv_kernel_id")(C.byref(arr[i])) == kid for i in range(n)):
+                    kn, nl = kn.replace("_g<", "<"), n     # not grouped: n launches of the plain kernel
+                elif grids != 1:                            # members the launchers could not put into one grid
                     kn = f"{kn.replace('_g<', '<')} ({n} members in {grids} launches)"
                 fl = sum(conv_flops(arr[i]) for i in range(n))
-                rec.append((kn, e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.seg[0].taps * d0.seg[0].C, 0, f"group of {n}")))
+                rec.append((kn, e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.seg[0].taps * d0.seg[0].C, 0, f"group of {n}"), nl))
             elif name == "rua_conv_wgrad_group":          # the branches' weight gradients in one grid (reductions deferred)
                 arr, n = args
                 e0 = mark()
@@ -155,10 +158,13 @@ def profile_kernels(eng, g, dtype):
                 wk = lib.raw("rua_wgrad_kind")(C.byref(d0))
                 kn = (f"wgrad_kernel_g", f"wgrad_taps_kernel_g<{d0.C}>", "wgrad_dmap_g", "wgrad_pw")[wk]
                 grids = lib.raw("rua_wgrad_group_last_grids")()
-                if grids != 1:
+                nl = 1
+                if grids == n:                              # this kernel family is not grouped: n launches of the plain kernel
+                    kn, nl = kn.replace("_g", ""), n
+                elif grids != 1:
                     kn = f"{kn.replace('_g', '')} ({n} members in {grids} launches)"
                 fl = sum(wgrad_flops(arr[i]) for i in range(n))
-                rec.append((kn, e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.C * d0.taps, 0, f"group of {n}")))
+                rec.append((kn, e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.C * d0.taps, 0, f"group of {n}"), nl))
             elif name in ("rua_conv_fwd", "rua_conv_wgrad"):
                 em = mark(False)                            # recorded by the library between the main kernel and the
                 mid(em)                                     # second launch of a two-launch call
@@ -223,16 +229,16 @@ def profile_kernels(eng, g, dtype):
     t1, t2, empty_us = med(cal1), med(cal2), med(empty)
     ov = max(2 * t1 - t2, 0.0) * 1e-6                    # seconds the two markers add to a bracket with a kernel inside
     out = {}
-    for kn, e0, e1, fl, _ in rec:
+    for kn, e0, e1, fl, _, *nl in rec:
         t = out.setdefault(kn, [0, 0.0, 0.0])
-        t[0] += 1; t[1] += max(us(e0, e1) * 1e-6 - ov, 1e-7); t[2] += fl
+        t[0] += nl[0] if nl else 1; t[1] += max(us(e0, e1) * 1e-6 - ov, 1e-7); t[2] += fl
     out["_event_overhead_us"] = ov * 1e6
     # whole composites (every launch of a ResBlock: BN passes, convolutions, weight / data gradients), forward and backward
     out["_blocks"] = {f"{pn}:{sc}": (max(us(e0, e1) * 1e-6 - ov, 1e-7), fl) for (pn, sc), (e0, e1, fl) in scopes.items() if e1 is not None}
     log(f"event bracket calibration: one fill {t1:.2f} us, two fills {t2:.2f} us, empty pair {empty_us:.2f} us -> overhead {ov * 1e6:.2f} us")
     if os.environ.get("RUA_BENCH_DETAIL"):
         groups = {}
-        for kn, e0, e1, fl, tag in rec:
+        for kn, e0, e1, fl, tag, *_ in rec:
             gkey = (kn,) + tag
             t = groups.setdefault(gkey, [0, 0.0, 0.0])
             t[0] += 1; t[1] += us(e0, e1) * 1e-6; t[2] += fl

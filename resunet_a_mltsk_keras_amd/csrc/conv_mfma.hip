@@ -1964,6 +1964,7 @@ struct WgdK {
   int ntc, nti, ksplit, stages_per_split;
   unsigned abytes, dybytes;
   float* slabs;            // as in WgK
+  int ks_slow;             // block -> (K slice, tap, tile) order, see the kernel
 };
 
 // Transposing LDS read that hipcc's wait insertion cannot see (it puts s_waitcnt vmcnt(0) in front of a ds_read_b64_tr_b16
@@ -1986,7 +1987,12 @@ __device__ __forceinline__ void wgrad_dmap_body(const WgdK& p) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int ks_i = vid % p.ksplit; vid /= p.ksplit;
+  // K slice slowest: the taps x tiles blocks that read the SAME pixels of dy and of the input are neighbours in vid, i.e. run on one
+  // XCD and share its L2 (K slice fastest spread them over all eight: every XCD fetched every slice - 94 MB per launch for
+  // 8-17 MB of tensors)
+  const int ncombo = p.nti * p.ntc * p.taps;
+  const int ks_i = p.ks_slow ? vid / ncombo : vid % p.ksplit;
+  vid = p.ks_slow ? vid - ks_i * ncombo : vid / p.ksplit;
   const int ti = vid % p.nti; vid /= p.nti;
   const int tc = vid % p.ntc;
   const int tap = vid / p.ntc;
@@ -2796,6 +2802,7 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
   k.ksplit = (stages + k.stages_per_split - 1) / k.stages_per_split;
   k.slabs = (cap >= 2 && k.ksplit > 1) ? (float*)d->workspace : nullptr;
   k.abytes = (unsigned)((size_t)k.M * d->C * 2); k.dybytes = (unsigned)((size_t)k.M * d->Cout * 2);
+  k.ks_slow = g_tune.wgd_ks_slow;
   if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + 15) / 16));
   if (g_wgrad_dry) return RUA_OK;
   if (g_wg_group && (g_tune.wgrad_group & 8) && g_wg_group->n < RUA_MAX_BRANCH) {
