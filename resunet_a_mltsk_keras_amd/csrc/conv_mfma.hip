@@ -1977,14 +1977,14 @@ __device__ __forceinline__ s16x4 lds_tr_raw(const unsigned char* p) {
   return v;
 }
 
-__device__ __forceinline__ void wgrad_dmap_body(const WgdK& p) {
+__device__ __forceinline__ void wgrad_dmap_body(const WgdK& p, const int nwg) {
   constexpr int NBUF = 3, PX = 64, ROWB = 256, KS = 4;
   constexpr int D_BYTES = PX * ROWB, STAGE = 2 * D_BYTES;
   constexpr int PER_STAGE = 8;                                      // DMA instructions per wave per stage (4 dy + 4 a)
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int bid = blockIdx.x;                          // nwg: this weight gradient's own block count (a grouped grid is padded)
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   // K slice slowest: the taps x tiles blocks that read the SAME pixels of dy and of the input are neighbours in vid, i.e. run on one
@@ -2133,12 +2133,13 @@ __device__ __forceinline__ void wgrad_dmap_body(const WgdK& p) {
         else unsafeAtomicAdd(dst, acc[a][b][i]);
       }
 }
-__global__ __launch_bounds__(256) void wgrad_dmap(const WgdK p) { wgrad_dmap_body(p); }
+__global__ __launch_bounds__(256) void wgrad_dmap(const WgdK p) { wgrad_dmap_body(p, (int)gridDim.x); }
 struct WgdKG { WgdK k[RUA_MAX_BRANCH]; };
 __global__ __launch_bounds__(256) void wgrad_dmap_g(const WgdKG g) {
   const WgdK& p = g.k[blockIdx.y];
-  if ((long long)blockIdx.x >= (long long)p.ntc * p.nti * p.taps * p.ksplit) return;
-  wgrad_dmap_body(p);
+  const int nwg = p.ntc * p.nti * p.taps * p.ksplit;   // gridDim.x is a multiple of 8: member y's block x runs on XCD x & 7, as ungrouped
+  if ((int)blockIdx.x >= nwg) return;
+  wgrad_dmap_body(p, nwg);
 }
 
 // =========================================================================================
@@ -2944,7 +2945,7 @@ extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap_g), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr[3] = true;
       }
       if (m == 1) hipLaunchKernelGGL(wgrad_dmap, dim3(gx), dim3(256), smem, st, cap.d[idx[0]]);
-      else { WgdKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.d[idx[q]]; hipLaunchKernelGGL(wgrad_dmap_g, dim3(gx, m), dim3(256), smem, st, g); }
+      else { WgdKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.d[idx[q]]; hipLaunchKernelGGL(wgrad_dmap_g, dim3((gx + 7) / 8 * 8, m), dim3(256), smem, st, g); }
     } else {
       const int gy = kd == 1 ? 1 : 2;
       if (!attr[kd]) {
