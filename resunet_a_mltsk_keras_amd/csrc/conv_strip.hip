@@ -327,25 +327,35 @@ __device__ __forceinline__ void conv_strip32_body(const StripK& q) {
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");       // the over-issued DMAs of the last stages
   if (p.stats_mode != 0) {
+    // 32 partial sums per lane, to be folded over the 32 pixels of a half-wave: through LDS (the ring is dead) - every lane writes
+    // its values as a column of [wave][value row][33], thread (wave, row) adds the row.  (Butterfly shuffles: 320 ds_bpermute per
+    // wave, ~2 us at the end of every launch with statistics.)
     __syncthreads();
-    float* sred = reinterpret_cast<float*>(smem);       // the ring is dead: [wave][channel][2]
+    float* sred = reinterpret_cast<float*>(smem);       // [NW][64][33]
+    float* sw = sred + NW * 64 * 33;                    // [NW][64]
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        for (int of = 1; of < 32; of <<= 1) { s1[g][j] += __shfl_xor(s1[g][j], of, 64); s2[g][j] += __shfl_xor(s2[g][j], of, 64); }
-    if (pl == 0) {
+      for (int j = 0; j < 8; ++j) {
+        const int row = (kh * 16 + g * 8 + j) * 2;
+        sred[(wv * 64 + row) * 33 + pl] = s1[g][j];
+        sred[(wv * 64 + row + 1) * 33 + pl] = s2[g][j];
+      }
+    __syncthreads();
+    {
+      const float* rowp = sred + tid * 33;              // tid = wave * 64 + row
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { sred[wv * 64 + (16 * g + 8 * kh + j) * 2] = s1[g][j]; sred[wv * 64 + (16 * g + 8 * kh + j) * 2 + 1] = s2[g][j]; }
+      for (int k = 0; k < 32; k += 4) { t0 += rowp[k]; t1 += rowp[k + 1]; t2 += rowp[k + 2]; t3 += rowp[k + 3]; }
+      sw[tid] = (t0 + t1) + (t2 + t3);
     }
     __syncthreads();
     if (tid < 64) {
       const int c = tid >> 1, k = tid & 1;
+      const int row = (((c >> 3) & 1) * 16 + (c >> 4) * 8 + (c & 7)) * 2 + k;
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) t += sred[w * 64 + tid];
+      for (int w = 0; w < NW; ++w) t += sw[w * 64 + row];
       unsafeAtomicAdd(&p.stats[(size_t)(job & (p.stats_R - 1)) * 2 * C + k * C + c], (double)t);
     }
   }
@@ -443,6 +453,7 @@ int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st
   q.njobs = q.nchains * q.spc;
   const int R = has_ep ? 5 : 7;
   const int smem = R * q.slot_bytes + (has_ep ? 3 * sw * 64 : 0) + nw * 1024 + 5 * 32 * 4;
+  RUA_CHECK_ARG(smem >= nw * (64 * 33 + 64) * 4, "conv_strip: no room for the statistics fold");
   q.has_fold = d->in_fold ? 1 : 0;
   if (d->in_fold) {
     q.f = *d->in_fold;
