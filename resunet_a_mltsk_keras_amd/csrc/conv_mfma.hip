@@ -1258,7 +1258,7 @@ template <int KS, bool DENSE>
 __global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_pw(const PwK<KS> q) {      // >= 3 waves per SIMD for K <= 64
   const ConvK& p = q.c;
   __shared__ float tab[3 * 32];                       // bias sum, mask scale, mask shift per output channel
-  __shared__ float sred[4 * 64];
+  __shared__ float sred[4 * 64 * 33 + 4 * 64];        // statistics fold: [wave][value row][33] + [wave][64]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int pl = lane & 31, lh = lane >> 5;
   if (tid < 32) {
@@ -1390,22 +1390,30 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_pw(const PwK<KS> 
     load_tile(T0, t0 + 64); process(T1, t0 + 32);
   }
   if (p.stats_mode != 0) {
-    // fold the 32 pixel lanes of each half, then the four waves through LDS: sred[wave][channel 0..31][2]
+    // fold the 32 pixel lanes of each half through LDS (every lane writes its 32 partial sums as a column, thread (wave, row)
+    // adds the row; as butterfly shuffles this was 320 ds_bpermute per wave, ~2 us at the end of the launch), then the four waves
+    float* sw = sred + 4 * 64 * 33;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        for (int o = 1; o < 32; o <<= 1) { s1[g][j] += __shfl_xor(s1[g][j], o, 64); s2[g][j] += __shfl_xor(s2[g][j], o, 64); }
-    if (pl == 0) {
+      for (int j = 0; j < 8; ++j) {
+        const int row = (lh * 16 + g * 8 + j) * 2;
+        sred[(wid * 64 + row) * 33 + pl] = s1[g][j];
+        sred[(wid * 64 + row + 1) * 33 + pl] = s2[g][j];
+      }
+    __syncthreads();
+    {
+      const float* rowp = sred + tid * 33;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { sred[wid * 64 + (16 * g + 8 * lh + j) * 2] = s1[g][j]; sred[wid * 64 + (16 * g + 8 * lh + j) * 2 + 1] = s2[g][j]; }
+      for (int k = 0; k < 32; k += 4) { t0 += rowp[k]; t1 += rowp[k + 1]; t2 += rowp[k + 2]; t3 += rowp[k + 3]; }
+      sw[tid] = (t0 + t1) + (t2 + t3);
     }
     __syncthreads();
     if (tid < 64) {
       const int c = tid >> 1, k = tid & 1;
-      const float t = sred[tid] + sred[64 + tid] + sred[128 + tid] + sred[192 + tid];
+      const int row = (((c >> 3) & 1) * 16 + (c >> 4) * 8 + (c & 7)) * 2 + k;
+      const float t = sw[row] + sw[64 + row] + sw[128 + row] + sw[192 + row];
       if (c < p.Cout) unsafeAtomicAdd(&p.stats[(size_t)(blockIdx.x & (p.stats_R - 1)) * 2 * p.Cout + k * p.Cout + c], (double)t);
     }
   }
