@@ -1916,40 +1916,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel_g(const WgKG g) {
   wgrad_kernel_body<bf16_t>(p);
 }
 
-// dw += sum of the K slices' slabs, in a FIXED order (bit-reproducible).  256 threads = 16 float4 columns x 16 slice lanes: lane sl
-// adds slices sl, sl + 16, .. (all its loads independent), the 16 lanes are folded through LDS in lane order.
+// dw += sum of the K slices' slabs, in a FIXED order (bit-reproducible).  A thread owns one float4 column and walks the slices
+// eight loads at a time: a wave reads 1 KiB runs of every slab, nothing is exchanged.  (Before: 16 columns x 16 slice lanes per
+// block folded through LDS - 256-byte runs and 40x the blocks; the batched reduction of a step took 287 us for 1.04 GB.)
+constexpr int SLAB_RED_COLS = 256;                      // float4 columns per block
 __device__ __forceinline__ void wgrad_slab_reduce_body(const float* __restrict__ slabs, float* __restrict__ dw, long long n4, int ksplit, int vblock) {
-  __shared__ float4 sh[256];
-  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long long i = (long long)vblock * 16 + el;
-  float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
-  if (i < n4) {
-    const float4* s = reinterpret_cast<const float4*>(slabs) + i;
-    int k = sl;
-    for (; k + 16 < ksplit; k += 32) {
-      const float4 v0 = s[(size_t)k * n4], v1 = s[(size_t)(k + 16) * n4];
-      t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w; t1.x += v1.x; t1.y += v1.y; t1.z += v1.z; t1.w += v1.w;
-    }
-    if (k < ksplit) { const float4 v0 = s[(size_t)k * n4]; t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w; }
-  }
-  sh[threadIdx.x] = make_float4(t0.x + t1.x, t0.y + t1.y, t0.z + t1.z, t0.w + t1.w);
-  __syncthreads();
-  if (sl == 0 && i < n4) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long i = (long long)vblock * SLAB_RED_COLS + threadIdx.x;
+  if (i >= n4) return;
+  const float4* s = reinterpret_cast<const float4*>(slabs) + i;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+  int k = 0;
+  for (; k + 8 <= ksplit; k += 8) {
+    float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { const float4 v = sh[k * 16 + el]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-    float4* d = reinterpret_cast<float4*>(dw) + i;
-    float4 o = *d;
-    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
-    *d = o;
+    for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(k + u) * n4];
+    float4 a = v[0], b = v[4];
+    add4(a, v[1]); add4(b, v[5]); add4(a, v[2]); add4(b, v[6]); add4(a, v[3]); add4(b, v[7]);
+    add4(a, b); add4(t, a);
   }
+  for (; k < ksplit; ++k) add4(t, s[(size_t)k * n4]);
+  float4* d = reinterpret_cast<float4*>(dw) + i;
+  float4 o = *d;
+  add4(o, t);
+  *d = o;
 }
 __global__ __launch_bounds__(256) void wgrad_slab_reduce(const float* __restrict__ slabs, float* __restrict__ dw, long long n4, int ksplit) {
   wgrad_slab_reduce_body(slabs, dw, n4, ksplit, (int)blockIdx.x);
 }
 static int launch_slab_reduce(const float* slabs, float* dw, long long n, int ksplit, hipStream_t st) {
   const long long n4 = n / 4;
-  hipLaunchKernelGGL(wgrad_slab_reduce, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, slabs, dw, n4, ksplit);
+  hipLaunchKernelGGL(wgrad_slab_reduce, dim3((unsigned)((n4 + SLAB_RED_COLS - 1) / SLAB_RED_COLS)), dim3(256), 0, st, slabs, dw, n4, ksplit);
   RUA_LAUNCH_CHECK("wgrad_slab_reduce");
   return RUA_OK;
 }
@@ -2375,44 +2372,41 @@ template <int CC> __global__ __launch_bounds__(768) void wgrad_taps_kernel_g(con
   wgrad_taps_body<CC>(p);
 }
 
-// dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 16 elements x 16 slices:
-// every thread has all its loads in flight at once, slices are folded through LDS in a fixed order (deterministic).
+// dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 64 float4 columns x 4 slice lanes: a wave
+// reads 1 KiB runs of a partial, eight loads in flight per thread, the four lanes are folded through LDS in a fixed order
+// (deterministic).  (Before: 16 columns x 16 lanes - 256-byte runs, four loads in flight, 4x the blocks.)
+constexpr int TAPS_RED_COLS = 64;
 __device__ __forceinline__ void wgrad_taps_reduce_body(const float* __restrict__ scratch, float* __restrict__ dw, int CC, int gx, int vblock) {
-  // 16 float4 columns x 16 partial slices per block: a 16-lane group reads 256 contiguous bytes of one partial (the scalar
-  // version read 64-byte runs: 6.7 us per launch, 37 launches per step), four loads in flight, slices folded in a fixed order
   __shared__ float4 sh[256];
   const int total4 = 9 * CC * CC / 4;
-  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int e4 = vblock * 16 + el;
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int e4 = vblock * TAPS_RED_COLS + el;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
   if (e4 < total4) {
     const int e = e4 * 4;
     const int tap = e / (CC * CC), r = e - tap * CC * CC, co = r / CC, ci = r - co * CC;
     const float* src = scratch + ((size_t)(co >> 5) * gx * 9 + tap) * 32 * CC + (co & 31) * CC + ci;
     const size_t pstride = (size_t)9 * 32 * CC;
-    float4 t0 = s, t1 = s, t2 = s, t3 = s;
-    auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
     int b = sl;
-    for (; b + 48 < gx; b += 64) {
-      const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)b * pstride);
-      const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(b + 16) * pstride);
-      const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(b + 32) * pstride);
-      const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(b + 48) * pstride);
-      add4(t0, v0); add4(t1, v1); add4(t2, v2); add4(t3, v3);
+    for (; b + 28 < gx; b += 32) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(b + 4 * u) * pstride);
+      float4 a = v[0], c = v[4];
+      add4(a, v[1]); add4(c, v[5]); add4(a, v[2]); add4(c, v[6]); add4(a, v[3]); add4(c, v[7]);
+      add4(a, c); add4(s, a);
     }
-    for (; b < gx; b += 16) add4(t0, *reinterpret_cast<const float4*>(src + (size_t)b * pstride));
-    s.x = (t0.x + t1.x) + (t2.x + t3.x); s.y = (t0.y + t1.y) + (t2.y + t3.y);
-    s.z = (t0.z + t1.z) + (t2.z + t3.z); s.w = (t0.w + t1.w) + (t2.w + t3.w);
+    for (; b < gx; b += 4) add4(s, *reinterpret_cast<const float4*>(src + (size_t)b * pstride));
   }
   sh[threadIdx.x] = s;
   __syncthreads();
   if (sl == 0 && e4 < total4) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { const float4 v = sh[k * 16 + el]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    float4 t = sh[el];
+    add4(t, sh[64 + el]); add4(t, sh[128 + el]); add4(t, sh[192 + el]);
     float4* d = reinterpret_cast<float4*>(dw + (size_t)e4 * 4);
     float4 o = *d;
-    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+    add4(o, t);
     *d = o;
   }
 }
@@ -2464,7 +2458,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   size_t smem = (size_t)k.group_bytes * k.NPG;
   const size_t red = (size_t)(k.NPG - 1) * 3 * (CC / 32) * 3 * 16 * 64 * 4;
   if (red > smem) smem = red;
-  const int rblocks = rua_div_up(9 * CC * CC / 4, 16);
+  const int rblocks = rua_div_up(9 * CC * CC / 4, TAPS_RED_COLS);
   note_pending(1, gx, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks);
   if (g_wgrad_dry) return RUA_OK;
   if (g_wg_group && (g_tune.wgrad_group & (CC == 32 ? 2 : 4)) && g_wg_group->n < RUA_MAX_BRANCH) {
@@ -2812,7 +2806,7 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
   k.slabs = (cap >= 2 && k.ksplit > 1) ? (float*)d->workspace : nullptr;
   k.abytes = (unsigned)((size_t)k.M * d->C * 2); k.dybytes = (unsigned)((size_t)k.M * d->Cout * 2);
   k.ks_slow = g_tune.wgd_ks_slow;
-  if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + 15) / 16));
+  if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + SLAB_RED_COLS - 1) / SLAB_RED_COLS));
   if (g_wgrad_dry) return RUA_OK;
   if (g_wg_group && (g_tune.wgrad_group & 8) && g_wg_group->n < RUA_MAX_BRANCH) {
     WgGroupCapture& c = *g_wg_group; const int i = c.n++;
@@ -2892,7 +2886,7 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   const long long grid = tiles * k.ksplit;
   RUA_CHECK_ARG(grid < (1ll << 31), "rua_conv_wgrad: grid too large");
   hipStream_t st = (hipStream_t)stream;
-  if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + 15) / 16));
+  if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + SLAB_RED_COLS - 1) / SLAB_RED_COLS));
   if (g_wgrad_dry) return RUA_OK;
   if (g_wg_group && (g_tune.wgrad_group & 1) && g_wg_group->n < RUA_MAX_BRANCH && d->dtype == RUA_BF16) {
     WgGroupCapture& c = *g_wg_group; const int i = c.n++;
