@@ -122,6 +122,7 @@ struct ConvK {
 };
 typedef __attribute__((address_space(3))) void* lds_void_p;
 struct ConvKG { ConvK k[RUA_MAX_BRANCH]; };           // members of a grouped launch: blockIdx.y picks one
+static_assert(sizeof(ConvKG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 // capture mode of the launchers (rua_conv_fwd_group): a groupable launch is recorded instead of issued
 struct ConvGroupCapture {
   int n; int kind[RUA_MAX_BRANCH]; unsigned grid[RUA_MAX_BRANCH]; int smem[RUA_MAX_BRANCH]; ConvK k[RUA_MAX_BRANCH];

@@ -1910,6 +1910,7 @@ template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const 
 // grouped launch (rua_conv_wgrad_group): the weight gradients of the dilation branches of a ResBlock in ONE grid; blockIdx.y picks
 // the member, blocks beyond a member's own grid leave at once
 struct WgKG { WgK k[RUA_MAX_BRANCH]; };
+static_assert(sizeof(WgKG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 __global__ __launch_bounds__(256) void wgrad_kernel_g(const WgKG g) {
   const WgK& p = g.k[blockIdx.y];
   if ((long long)blockIdx.x >= (long long)p.ntc * p.nti * p.taps * p.ksplit) return;
@@ -2140,6 +2141,7 @@ __device__ __forceinline__ void wgrad_dmap_body(const WgdK& p, const int nwg) {
 }
 __global__ __launch_bounds__(256) void wgrad_dmap(const WgdK p) { wgrad_dmap_body(p, (int)gridDim.x); }
 struct WgdKG { WgdK k[RUA_MAX_BRANCH]; };
+static_assert(sizeof(WgdKG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 __global__ __launch_bounds__(256) void wgrad_dmap_g(const WgdKG g) {
   const WgdK& p = g.k[blockIdx.y];
   const int nwg = p.ntc * p.nti * p.taps * p.ksplit;   // gridDim.x is a multiple of 8: member y's block x runs on XCD x & 7, as ungrouped
@@ -2366,6 +2368,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgtK& p) {
 }
 template <int CC> __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) { wgrad_taps_body<CC>(p); }
 struct WgtKG { WgtK k[RUA_MAX_BRANCH]; };
+static_assert(sizeof(WgtKG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 template <int CC> __global__ __launch_bounds__(768) void wgrad_taps_kernel_g(const WgtKG g) {      // blockIdx.z = member
   const WgtK& p = g.k[blockIdx.z];
   if ((int)blockIdx.x >= p.gx) return;

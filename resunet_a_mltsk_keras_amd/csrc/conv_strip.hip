@@ -362,6 +362,7 @@ __device__ __forceinline__ void conv_strip32_body(const StripK& q) {
 }
 
 struct StripKG { StripK k[RUA_MAX_BRANCH]; };
+static_assert(sizeof(StripKG) <= 4096, "a grouped launch passes its members by value: HIP kernel arguments are limited to 4 KiB");
 template <int NW, bool HAS_EP, int R> __global__ __launch_bounds__(NW * 64) void conv_strip32(const StripK q) { conv_strip32_body<NW, HAS_EP, R>(q); }
 // grouped launch (rua_conv_fwd_group): the four dilation branches of the d6 block in one grid, blockIdx.y = branch
 template <int NW, bool HAS_EP, int R> __global__ __launch_bounds__(NW * 64) void conv_strip32_g(const StripKG g) { conv_strip32_body<NW, HAS_EP, R>(g.k[blockIdx.y]); }
