@@ -83,3 +83,85 @@ def test_cross_dilation_of_any_size_matches_a_direct_loop():
     seg = np.zeros((16, 16, 2), np.float32); seg[4:12, 4:12, 0] = 1; seg[..., 1] = 1 - seg[..., 0]
     b3, b5 = get_boundary_label(seg), get_boundary_label(seg, (5, 5))
     assert b5.sum() > b3.sum() and np.all(b5 >= b3)            # a wider cross only adds boundary pixels
+
+
+def _shapes():
+    """Class masks of the kind ISPRS patches hold: blobs, thin structures, shapes cut by the patch border, a checkerboard."""
+    rng = np.random.default_rng(5)
+    H, W = 40, 48
+    yy, xx = np.mgrid[0:H, 0:W]
+    out = []
+    out.append((((yy - 18) ** 2 / 90.0 + (xx - 20) ** 2 / 200.0) < 1).astype(np.uint8))            # ellipse
+    out.append(((np.abs(yy - xx * 0.6 - 3) < 2.5) | ((yy > 28) & (xx < 9))).astype(np.uint8))       # oblique band + a block on the border
+    m = np.zeros((H, W), np.uint8); m[5:30, 10] = 1; m[12, 4:40] = 1; m[20:23, 20:45] = 1            # one-pixel lines and a bar
+    out.append(m)
+    out.append((((yy // 3) + (xx // 3)) % 2).astype(np.uint8))                                       # 3x3 checkerboard
+    from scipy import ndimage
+    out.append((ndimage.gaussian_filter(rng.standard_normal((H, W)), 2.5) > 0.02).astype(np.uint8))  # random blobs
+    m = np.ones((H, W), np.uint8); m[0:3, :] = 0; m[10:14, 30:48] = 0                                # mostly full, holes at the border
+    out.append(m)
+    return out
+
+
+def test_canny_agrees_with_the_pixel_loop_restatement_on_non_trivial_shapes():
+    """labels.canny_u8 (vectorised) against oracle/cv_naive.canny_loops (cv::Canny's scalar loop structure, written
+    independently): thresholds of the reference's call (0, 1) on {0,1} masks and a grey-level case with real hysteresis."""
+    from oracle import cv_naive
+    for i, m in enumerate(_shapes()):
+        assert np.array_equal(lb.canny_u8(m, 0, 1), cv_naive.canny_loops(m, 0, 1)), i
+    rng = np.random.default_rng(9)
+    from scipy import ndimage
+    g = np.clip(ndimage.gaussian_filter(rng.standard_normal((36, 44)) * 400, 2.0) + 128, 0, 255).astype(np.uint8)
+    for lo, hi in ((20, 60), (60, 20), (5, 200), (0, 0)):
+        e = lb.canny_u8(g, lo, hi)
+        assert np.array_equal(e, cv_naive.canny_loops(g, lo, hi)), (lo, hi)
+    assert 0 < (lb.canny_u8(g, 20, 60) > 0).mean() < 0.5
+
+
+def test_canny_hand_computed_cases():
+    """Answers worked out by hand from the algorithm.  A vertical step edge between columns 3 | 4 of a {0,1} image: Sobel dx = 4 on
+    both columns next to the step (3 and 4), dy = 0 -> horizontal gradient, non-maximum suppression keeps the LEFT one of two
+    equal neighbours (m > left, m >= right) -> exactly column 3, every row (replicated borders keep dx = 4 in the first / last row)."""
+    img = np.zeros((6, 8), np.uint8); img[:, 4:] = 1
+    e = lb.canny_u8(img, 0, 1)
+    exp = np.zeros_like(e); exp[:, 3] = 255
+    assert np.array_equal(e, exp)
+    # horizontal step between rows 2 | 3: dy = 4 on rows 2 and 3, vertical gradient, (m > up, m >= down) keeps row 2
+    img = np.zeros((7, 5), np.uint8); img[3:, :] = 1
+    exp = np.zeros((7, 5), np.uint8); exp[2, :] = 255
+    assert np.array_equal(lb.canny_u8(img, 0, 1), exp)
+    # an isolated pixel: the 8 neighbours carry magnitude 2 (corners: |dx| = |dy| = 1) or 2 (sides: 2 + 0), the centre 0.  Corners
+    # are diagonal-gradient pixels whose diagonal neighbours along the gradient are the centre (0) and outside (0): maxima; sides
+    # compare with the centre (0) and the outside (0): maxima.  All eight exceed high = 1: a ring.
+    img = np.zeros((5, 5), np.uint8); img[2, 2] = 1
+    exp = np.zeros((5, 5), np.uint8); exp[1:4, 1:4] = 255; exp[2, 2] = 0
+    assert np.array_equal(lb.canny_u8(img, 0, 1), exp)
+
+
+def test_distance_and_boundary_labels_on_non_trivial_shapes():
+    from oracle import cv_naive
+    ms = _shapes()
+    lab = np.stack(ms, axis=-1).astype(np.float32)
+    d = lb.get_distance_label(lab)
+    b = lb.get_boundary_label(lab)
+    for c, m in enumerate(ms):
+        brute = cv_naive.edt_brute(m)
+        exp = (brute - brute.min()) / (brute.max() - brute.min()) if brute.max() > brute.min() else np.zeros_like(brute)
+        assert np.allclose(d[:, :, c], exp, atol=1e-6), c
+        edges = cv_naive.canny_loops(m, 0, 1)
+        assert np.array_equal(b[:, :, c] > 0, lb.dilate_cross3(edges) > 0), c
+    # hand-computed: a 5x5 block inside zeros -> distances 1,2,3 rings -> normalised 1/3, 2/3, 1
+    m = np.zeros((9, 9), np.float32); m[2:7, 2:7] = 1
+    dd = lb.get_distance_label(m[:, :, None])[:, :, 0]
+    assert np.allclose(dd[2, 2:7], 1 / 3) and np.allclose(dd[3, 3:6], 2 / 3) and dd[4, 4] == 1.0 and dd[0, 0] == 0.0
+
+
+def test_hsv_fixed_point_tables_stay_within_one_unit_of_the_real_formula():
+    from oracle import cv_naive
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, size=(64, 64, 3)).astype(np.uint8)
+    rgb[0, :8] = [[0, 0, 0], [255, 255, 255], [10, 10, 10], [255, 0, 0], [0, 255, 0], [0, 0, 255], [1, 0, 0], [254, 255, 253]]
+    got = lb.rgb_to_hsv_u8(rgb).astype(np.float64)
+    ref = cv_naive.hsv_float(rgb)
+    dh = np.abs(got[..., 0] - ref[..., 0]); dh = np.minimum(dh, 180 - dh)              # hue wraps at 180
+    assert dh.max() <= 1.0 and np.abs(got[..., 1] - ref[..., 1]).max() <= 1.0 and np.array_equal(got[..., 2], ref[..., 2])
