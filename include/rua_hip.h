@@ -255,6 +255,15 @@ int rua_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, i
 int rua_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int accumulate, int N, int H, int W, int C, int k, int dtype, void* stream);
 /* y[n,h,w,c] = sum over the k x k block (adjoint of nearest upsampling) */
 int rua_sumpool(const void* x, void* y, int N, int H, int W, int C, int k, int dtype, void* stream);
+/* The 2 / 4 / 8 pyramid of one PSPPooling: the max-pool with window 2k from the max-pool with window k and its argmax bytes
+ * (values and argmax bytes of a direct rua_maxpool_fwd with 2k; y_half is [N][H_half][W_half][C]: x is read once, by the k = 2
+ * pass), the scatter of up to three pooled gradients into dx (one read-modify-write of dx), and the three window sums in one pass
+ * (fp32 partial sums carried up the pyramid). */
+int rua_maxpool_derive(const void* y_half, const uint8_t* idx_half, void* y, uint8_t* idx, int N, int H_half, int W_half, int C,
+                       int k_half, int dtype, void* stream);
+int rua_maxpool_bwd_multi(int n, const void* const* dy, const uint8_t* const* idx, const int* ks, void* dx, int accumulate,
+                          int N, int H, int W, int C, int dtype, void* stream);
+int rua_sumpool_pyramid(const void* x, void* y2, void* y4, void* y8, int N, int H, int W, int C, int dtype, void* stream);
 int rua_upsample_nearest(const void* x, void* y, int N, int H, int W, int C, int k, int dtype, void* stream);
 
 /* ---- elementwise ------------------------------------------------------------------------- */

@@ -115,6 +115,9 @@ _SIGS = {
     "rua_maxpool_fwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "rua_maxpool_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "rua_sumpool": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "rua_maxpool_derive": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "rua_maxpool_bwd_multi": ([i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "rua_sumpool_pyramid": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "rua_upsample_nearest": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "rua_add_n": ([i32, PP, vp, i32, i64, i32, vp], i32),
     "rua_relu_mask": ([vp, vp, i64, i32, vp], i32),

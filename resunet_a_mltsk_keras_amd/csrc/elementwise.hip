@@ -566,6 +566,22 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
   return RUA_OK;
 }
 
+// argmax bytes of one piece (VEC = 8: one 8-byte access, VEC = 4: one 4-byte access) instead of VEC byte accesses
+template <int VEC> __device__ __forceinline__ void idx_load(const uint8_t* p, int* out) {
+  if constexpr (VEC == 8) { const uint2 q = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { out[j] = (q.x >> (8 * j)) & 255; out[4 + j] = (q.y >> (8 * j)) & 255; } }
+  else { const unsigned q = *reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = (q >> (8 * j)) & 255; }
+}
+template <int VEC> __device__ __forceinline__ void idx_store(uint8_t* p, const int* v) {
+  if constexpr (VEC == 8) { uint2 q; q.x = (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24);
+    q.y = (unsigned)v[4] | ((unsigned)v[5] << 8) | ((unsigned)v[6] << 16) | ((unsigned)v[7] << 24);
+    *reinterpret_cast<uint2*>(p) = q; }
+  else *reinterpret_cast<unsigned*>(p) = (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24);
+}
+
 // ---------------------------------------------------------------------------------------
 // pooling / resampling: one thread per output (or input) piece
 // K > 0: window size known at compile time - the K loads of a window row are issued together (the runtime-k loop did
@@ -606,8 +622,7 @@ __global__ void maxpool_fwd_kernel(const unsigned char* x, unsigned char* y, uin
         }
     }
     stg16(y + i * 16, ET<T>::pack(best));
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) idx[i * VEC + j] = (uint8_t)bi[j];
+    idx_store<VEC>(idx + i * VEC, bi);
   }
 }
 
@@ -630,8 +645,10 @@ __global__ void maxpool_bwd_kernel(const unsigned char* dy, const uint8_t* idx, 
       float g[VEC];
       ET<T>::unpack(ldg16(dy + pi * 16), g);
       const int pos = (h % k) * k + (w % k);
+      int ib[VEC];
+      idx_load<VEC>(idx + pi * VEC, ib);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) if (idx[pi * VEC + j] == pos) o[j] += g[j];
+      for (int j = 0; j < VEC; ++j) if (ib[j] == pos) o[j] += g[j];
     }
     stg16(dx + i * 16, ET<T>::pack(o));
   }
@@ -688,6 +705,143 @@ __global__ void upsample_kernel(const unsigned char* x, unsigned char* y, int N,
   }
 }
 
+// ---- the 2 / 4 / 8 pooling pyramid of a PSPPooling (model2.py:47-60) ------------------------------------------------------------
+// Max-pool with window 2k from the max-pool with window k of the same tensor and its argmax bytes: a thread compares the four
+// k x k winners of its 2k x 2k window; on equal values the smaller row-major position inside the 2k x 2k window wins, which is
+// what a direct scan of the window (first maximum wins) finds.  The 4- and 8-windows of the pyramid come from the 2-windows this
+// way: x is read once, by the k = 2 pass (a thread per 8x8 window doing all three levels in one pass was tried: 31 us against 21
+// for three separate passes - 1/64 of the threads, 64 dependent compare rounds each).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_derive_kernel(const unsigned char* yp, const uint8_t* ip, unsigned char* y, uint8_t* idx,
+                                                             int N, int Hp, int Wp, int CG, int kp) {
+  constexpr int VEC = ET<T>::VEC;
+  const int Ho = Hp / 2, Wo = Wp / 2, k = 2 * kp;
+  const long long total = (long long)N * Ho * Wo * CG;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cp = (int)(i % CG); long long r = i / CG;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); const int n = (int)(r / Ho);
+    uint4 q[4]; size_t o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      o[u] = (((size_t)n * Hp + ho * 2 + (u >> 1)) * Wp + wo * 2 + (u & 1)) * CG + cp;
+      q[u] = ldg16(yp + o[u] * 16);
+    }
+    float best[VEC]; int bi[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = k * k; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[VEC];
+      ET<T>::unpack(q[u], v);
+      int ib[VEC];
+      idx_load<VEC>(ip + o[u] * VEC, ib);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int pp = ib[j];
+        const int pos = ((u >> 1) * kp + pp / kp) * k + (u & 1) * kp + pp % kp;
+        if (v[j] > best[j] || (v[j] == best[j] && pos < bi[j])) { best[j] = v[j]; bi[j] = pos; }
+      }
+    }
+    stg16(y + i * 16, ET<T>::pack(best));
+    idx_store<VEC>(idx + i * VEC, bi);
+  }
+}
+
+// dx (=|+=) the scatter of up to three pooled gradients (k = ks[0..n)) through their argmax bytes: ONE read-modify-write of dx
+// instead of one per pooling size (45 -> 16 us at 256x256x32).
+struct PoolPyr { const unsigned char* dy[3]; const uint8_t* idx[3]; int k[3]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_multi_kernel(const PoolPyr q, unsigned char* dx, int accumulate, int N, int H, int W, int CG) {
+  constexpr int VEC = ET<T>::VEC;
+  const long long total = (long long)N * H * W * CG;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cp = (int)(i % CG); long long r = i / CG;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H); const int n = (int)(r / H);
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+    if (accumulate) ET<T>::unpack(ldg16(dx + i * 16), o);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (u >= q.n) break;
+      const int k = q.k[u], Ho = H / k, Wo = W / k;
+      const size_t pi = (((size_t)n * Ho + h / k) * Wo + w / k) * CG + cp;
+      float g[VEC];
+      ET<T>::unpack(ldg16(q.dy[u] + pi * 16), g);
+      const int pos = (h % k) * k + (w % k);
+      int ib[VEC];
+      idx_load<VEC>(q.idx[u] + pi * VEC, ib);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) if (ib[j] == pos) o[j] += g[j];
+    }
+    stg16(dx + i * 16, ET<T>::pack(o));
+  }
+}
+
+// sums over the 2x2, 4x4 and 8x8 windows of x in one pass (the adjoint of the folded nearest upsampling of the three pooled
+// PSPPooling branches): fp32 partial sums carried up the pyramid, each level rounded once
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool_pyramid_kernel(const unsigned char* x, unsigned char* y2, unsigned char* y4, unsigned char* y8,
+                                                              int N, int H, int W, int CG) {
+  constexpr int VEC = ET<T>::VEC;
+  const int H8 = H / 8, W8 = W / 8;
+  const long long total = (long long)N * H8 * W8 * CG;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cp = (int)(i % CG); long long r = i / CG;
+    const int w8 = (int)(r % W8); r /= W8;
+    const int h8 = (int)(r % H8); const int n = (int)(r / H8);
+    float s8[VEC], s4[2][VEC], s2[4][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s8[j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      uint4 q[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) q[b] = ldg16(x + ((((size_t)n * H + h8 * 8 + a) * W + w8 * 8 + b) * CG + cp) * 16);
+      if ((a & 1) == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) s2[u][j] = 0.f;
+      }
+      if ((a & 3) == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) s4[u][j] = 0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        float v[VEC];
+        ET<T>::unpack(q[b], v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s2[b >> 1][j] += v[j];
+      }
+      if (a & 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t o = (((size_t)n * (H / 2) + h8 * 4 + (a >> 1)) * (W / 2) + w8 * 4 + u) * CG + cp;
+          stg16(y2 + o * 16, ET<T>::pack(s2[u]));
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) s4[u >> 1][j] += s2[u][j];
+        }
+      }
+      if ((a & 3) == 3) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const size_t o = (((size_t)n * (H / 4) + h8 * 2 + (a >> 2)) * (W / 4) + w8 * 2 + u) * CG + cp;
+          stg16(y4 + o * 16, ET<T>::pack(s4[u]));
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) s8[j] += s4[u][j];
+        }
+      }
+    }
+    stg16(y8 + i * 16, ET<T>::pack(s8));
+  }
+}
+
 #define POOL_ARGS_CHECK(name) \
   RUA_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && k >= 1, name ": bad arguments"); \
   RUA_CHECK_ARG(dtype == RUA_F32 || dtype == RUA_BF16, name ": bad dtype"); \
@@ -698,6 +852,7 @@ __global__ void upsample_kernel(const unsigned char* x, unsigned char* y, int N,
 extern "C" int rua_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int k, int dtype, void* stream) {
   POOL_ARGS_CHECK("rua_maxpool_fwd");
   RUA_CHECK_ARG(idx && H % k == 0 && W % k == 0 && k * k <= 256, "rua_maxpool_fwd: H,W must be divisible by k");
+  RUA_CHECK_ARG(((size_t)idx & 7) == 0, "rua_maxpool_fwd: idx must be 8-byte aligned");
   const int g = grid_for((int64_t)N * (H / k) * (W / k) * CG);
 #define RUA_MAXPOOL(TT, KK) hipLaunchKernelGGL((maxpool_fwd_kernel<TT, KK>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y, idx, N, H, W, CG, k)
   if (dtype == RUA_BF16) { if (k == 2) RUA_MAXPOOL(bf16_t, 2); else if (k == 4) RUA_MAXPOOL(bf16_t, 4); else if (k == 8) RUA_MAXPOOL(bf16_t, 8); else RUA_MAXPOOL(bf16_t, 0); }
@@ -709,6 +864,7 @@ extern "C" int rua_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int 
 extern "C" int rua_maxpool_bwd(const void* x, const uint8_t* idx, void* y, int accumulate, int N, int H, int W, int C, int k, int dtype, void* stream) {
   POOL_ARGS_CHECK("rua_maxpool_bwd");
   RUA_CHECK_ARG(idx && H % k == 0 && W % k == 0, "rua_maxpool_bwd: H,W must be divisible by k");
+  RUA_CHECK_ARG(((size_t)idx & 7) == 0, "rua_maxpool_bwd: idx must be 8-byte aligned");
   const int g = grid_for((int64_t)N * H * W * CG);
   if (dtype == RUA_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, idx, (unsigned char*)y, accumulate, N, H, W, CG, k);
   else hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, idx, (unsigned char*)y, accumulate, N, H, W, CG, k);
@@ -724,6 +880,48 @@ extern "C" int rua_sumpool(const void* x, void* y, int N, int H, int W, int C, i
   else { if (k == 2) RUA_SUMPOOL(float, 2); else if (k == 4) RUA_SUMPOOL(float, 4); else if (k == 8) RUA_SUMPOOL(float, 8); else RUA_SUMPOOL(float, 0); }
 #undef RUA_SUMPOOL
   RUA_LAUNCH_CHECK("rua_sumpool");
+  return RUA_OK;
+}
+
+extern "C" int rua_maxpool_derive(const void* y_half, const uint8_t* idx_half, void* y, uint8_t* idx, int N, int H_half, int W_half, int C,
+                                  int k_half, int dtype, void* stream) {
+  const void* x = y_half; const int H = H_half, W = W_half, k = k_half;
+  POOL_ARGS_CHECK("rua_maxpool_derive");
+  RUA_CHECK_ARG(idx_half && idx && H % 2 == 0 && W % 2 == 0 && 4 * k * k <= 256, "rua_maxpool_derive: even input grid, window 2k with 4 k^2 <= 256");
+  RUA_CHECK_ARG((((size_t)idx | (size_t)idx_half) & 7) == 0, "rua_maxpool_derive: idx buffers must be 8-byte aligned");
+  const int g = grid_for((long long)N * (H / 2) * (W / 2) * CG);
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((maxpool_derive_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const unsigned char*)y_half, idx_half, (unsigned char*)y, idx, N, H, W, CG, k);
+  else hipLaunchKernelGGL((maxpool_derive_kernel<float>), dim3(g), dim3(256), 0, st, (const unsigned char*)y_half, idx_half, (unsigned char*)y, idx, N, H, W, CG, k);
+  RUA_LAUNCH_CHECK("rua_maxpool_derive");
+  return RUA_OK;
+}
+
+extern "C" int rua_maxpool_bwd_multi(int n, const void* const* dy, const uint8_t* const* idx, const int* ks, void* dx, int accumulate,
+                                     int N, int H, int W, int C, int dtype, void* stream) {
+  const void* x = dx; const void* y = dx; const int k = 1;
+  POOL_ARGS_CHECK("rua_maxpool_bwd_multi");
+  RUA_CHECK_ARG(n >= 1 && n <= 3 && dy && idx && ks, "rua_maxpool_bwd_multi: 1..3 pooled gradients");
+  PoolPyr q;
+  q.n = n;
+  for (int u = 0; u < 3; ++u) {
+    q.dy[u] = u < n ? (const unsigned char*)dy[u] : nullptr; q.idx[u] = u < n ? idx[u] : nullptr; q.k[u] = u < n ? ks[u] : 1;
+    if (u < n) RUA_CHECK_ARG(dy[u] && idx[u] && ((size_t)idx[u] & 7) == 0 && ks[u] >= 1 && H % ks[u] == 0 && W % ks[u] == 0, "rua_maxpool_bwd_multi: member %d: H, W must be divisible by k, idx 8-byte aligned", u);
+  }
+  const int g = grid_for((long long)N * H * W * CG);
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((maxpool_bwd_multi_kernel<bf16_t>), dim3(g), dim3(256), 0, st, q, (unsigned char*)dx, accumulate, N, H, W, CG);
+  else hipLaunchKernelGGL((maxpool_bwd_multi_kernel<float>), dim3(g), dim3(256), 0, st, q, (unsigned char*)dx, accumulate, N, H, W, CG);
+  RUA_LAUNCH_CHECK("rua_maxpool_bwd_multi");
+  return RUA_OK;
+}
+
+extern "C" int rua_sumpool_pyramid(const void* x, void* y2, void* y4, void* y8, int N, int H, int W, int C, int dtype, void* stream) {
+  const void* y = y2; const int k = 8;
+  POOL_ARGS_CHECK("rua_sumpool_pyramid");
+  RUA_CHECK_ARG(y4 && y8 && H % 8 == 0 && W % 8 == 0, "rua_sumpool_pyramid: H, W must be multiples of 8, every output given");
+  const int g = grid_for((long long)N * (H / 8) * (W / 8) * CG);
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((sumpool_pyramid_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y2, (unsigned char*)y4, (unsigned char*)y8, N, H, W, CG);
+  else hipLaunchKernelGGL((sumpool_pyramid_kernel<float>), dim3(g), dim3(256), 0, st, (const unsigned char*)x, (unsigned char*)y2, (unsigned char*)y4, (unsigned char*)y8, N, H, W, CG);
+  RUA_LAUNCH_CHECK("rua_sumpool_pyramid");
   return RUA_OK;
 }
 extern "C" int rua_upsample_nearest(const void* x, void* y, int N, int H, int W, int C, int k, int dtype, void* stream) {

@@ -935,6 +935,11 @@ class Graph:
         if bias:
             self.bias_grad(Bp, dy, [lay["bias"]])
         pooled = {0: dy}
+        ups = sorted({up for _, up in segs})
+        if ups == [0, 1, 2, 3] and dy.H % 8 == 0 and dy.W % 8 == 0 and self.e.pool_pyramid:      # the PSP fuse conv: 2 / 4 / 8 in one pass over dy
+            for up in (1, 2, 3):
+                pooled[up] = self.new(dy.N, dy.H >> up, dy.W >> up, dy.C)
+            Bp.add("rua_sumpool_pyramid", dy.ptr, pooled[1].ptr, pooled[2].ptr, pooled[3].ptr, dy.N, dy.H, dy.W, dy.C, self.dt)
         for (t, up), seg, tg in zip(segs, lay["segs"], targets):
             if up not in pooled:
                 k = 1 << up
@@ -959,6 +964,7 @@ class Graph:
         w_in = self.cfg.input_shape[1]
         ks = [1, 2] + ([4] if w_in >= 128 else []) + ([8] if w_in >= 256 else [])
         pooled, idxs = [], []
+        pyramid = ks == [1, 2, 4, 8] and x.H % 8 == 0 and x.W % 8 == 0 and self.e.pool_pyramid     # one pass for the three poolings
         for k in ks:
             if k == 1:
                 pooled.append(x); idxs.append(None)
@@ -967,8 +973,13 @@ class Graph:
                 p = self.new(x.N, x.H // k, x.W // k, x.C)
                 idx = self.alloc((p.t.numel(),), torch.uint8)
                 F.keep.append(idx)
-                F.add("rua_maxpool_fwd", x.ptr, p.ptr, idx.data_ptr(), x.N, x.H, x.W, x.C, k, self.dt)
+                if not pyramid:
+                    F.add("rua_maxpool_fwd", x.ptr, p.ptr, idx.data_ptr(), x.N, x.H, x.W, x.C, k, self.dt)
                 pooled.append(p); idxs.append(idx)
+        if pyramid:                                            # x is read once (k = 2); the 4- and 8-windows come from the level below
+            F.add("rua_maxpool_fwd", x.ptr, pooled[1].ptr, idxs[1].data_ptr(), x.N, x.H, x.W, x.C, 2, self.dt)
+            F.add("rua_maxpool_derive", pooled[1].ptr, idxs[1].data_ptr(), pooled[2].ptr, idxs[2].data_ptr(), x.N, x.H // 2, x.W // 2, x.C, 2, self.dt)
+            F.add("rua_maxpool_derive", pooled[2].ptr, idxs[2].data_ptr(), pooled[3].ptr, idxs[3].data_ptr(), x.N, x.H // 4, x.W // 4, x.C, 4, self.dt)
         # Keras creates the branch Conv2DN layers (conv, bn) in order, then the fuse Conv2DN
         br = []
         for k, p in zip(ks, pooled):
@@ -989,9 +1000,15 @@ class Graph:
                 for (k, p, z, lay, zb, node), idx in zip(br, idxs):
                     node["back"]()                                 # zb.grad -> z.grad
                     self.conv1x1_multi_back(Bp, [(p, 0)], lay, z, [None])   # -> p.grad (p is x for k == 1)
-                    if k > 1:
+                    if k > 1 and not pyramid:
                         gx, acc = self.gacc(x)
                         Bp.add("rua_maxpool_bwd", p.grad.ptr, idx.data_ptr(), gx.ptr, acc, x.N, x.H, x.W, x.C, k, self.dt)
+                if pyramid:                                        # the three pooled gradients scattered in ONE pass over x.grad
+                    gx, acc = self.gacc(x)
+                    dys = L.ptr_array([b_[1].grad.ptr for b_ in br[1:]]); ixs = L.ptr_array([i.data_ptr() for i in idxs[1:]])
+                    kk = (C.c_int32 * 3)(2, 4, 8)
+                    Bp.keep += [dys, ixs, kk]
+                    Bp.add("rua_maxpool_bwd_multi", 3, dys, ixs, kk, gx.ptr, acc, x.N, x.H, x.W, x.C, self.dt)
             self.back_steps.append(back)
         return out
 
@@ -1261,6 +1278,7 @@ class Engine:
                              "channels and the MFMA epilogue stores 8-channel pieces)")
         self.dev = None
         self.fuse_bn = os.environ.get("RUA_FUSE_BN", "1") != "0"     # normalise-on-load ResBlocks where the library offers it
+        self.pool_pyramid = os.environ.get("RUA_POOL_PYRAMID", "1") != "0"   # PSPPooling: the 2 / 4 / 8 poolings (and their adjoints) in single passes
         self.fold_bn = os.environ.get("RUA_FOLD_BN", "1") != "0"     # ... and their coefficient launches folded into the convs' prologues
         self.defer_reduce = os.environ.get("RUA_DEFER_REDUCE", "1") != "0"     # weight-gradient partials summed by batched launches
         self.cu_count = 256

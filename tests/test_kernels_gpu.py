@@ -1131,3 +1131,51 @@ def test_conv_strip_folded_batchnorm_coefficients(N, H, W, dil, R):
     # in_fold on a shape no normalise-on-load kernel serves is refused
     d.Cout = 64
     assert lib.raw("rua_conv_fwd")(C.byref(d), None) != 0
+
+
+@pytest.mark.parametrize("dt", [L.RUA_BF16, L.RUA_F32])
+def test_pooling_pyramid_passes_equal_the_separate_launches(dt):
+    """PSPPooling's 2 / 4 / 8 pyramid (model2.py:47-60): rua_maxpool_derive gives the values AND the argmax bytes of a direct
+    rua_maxpool_fwd with twice the window from the level below (many ties: the input is quantised, the first maximum in row-major
+    order must win),
+    rua_maxpool_bwd_multi the sum of three rua_maxpool_bwd scatters (plain and accumulating), rua_sumpool_pyramid the three
+    window sums."""
+    rng = np.random.default_rng(21)
+    lib = L.lib()
+    N, H, W, Cc = 2, 40, 56, 16
+    x = np.round(rng.standard_normal((N, H, W, Cc)) * 2).astype(np.float32) / 2          # ties
+    xd = to_dev(x, dt)
+    ys, ids, gs = {}, {}, {}
+    for k in (2, 4, 8):
+        ys[k] = torch.empty((N, H // k, W // k, Cc), dtype=tdt(dt), device=dev())
+        ids[k] = torch.empty(ys[k].numel(), dtype=torch.uint8, device=dev())
+        lib.call("rua_maxpool_fwd", xd.data_ptr(), ys[k].data_ptr(), ids[k].data_ptr(), N, H, W, Cc, k, dt, stream())
+        gs[k] = to_dev(rng.standard_normal((N, H // k, W // k, Cc)).astype(np.float32), dt)
+    py = {k: torch.zeros_like(ys[k]) for k in ys}
+    pi = {k: torch.full_like(ids[k], 255) for k in ids}
+    lib.call("rua_maxpool_derive", ys[2].data_ptr(), ids[2].data_ptr(), py[4].data_ptr(), pi[4].data_ptr(), N, H // 2, W // 2, Cc, 2, dt, stream())
+    lib.call("rua_maxpool_derive", py[4].data_ptr(), pi[4].data_ptr(), py[8].data_ptr(), pi[8].data_ptr(), N, H // 4, W // 4, Cc, 4, dt, stream())
+    torch.cuda.synchronize()
+    for k in (4, 8):
+        assert torch.equal(py[k], ys[k]) and torch.equal(pi[k], ids[k]), k
+    for acc in (0, 1):
+        base = to_dev(rng.standard_normal((N, H, W, Cc)).astype(np.float32), dt)
+        ref = base.clone()
+        for j, k in enumerate((2, 4, 8)):
+            lib.call("rua_maxpool_bwd", gs[k].data_ptr(), ids[k].data_ptr(), ref.data_ptr(), 1 if (acc or j) else 0, N, H, W, Cc, k, dt, stream())
+        got = base.clone()
+        dys = L.ptr_array([gs[k].data_ptr() for k in (2, 4, 8)]); ixs = L.ptr_array([ids[k].data_ptr() for k in (2, 4, 8)])
+        kk = (C.c_int32 * 3)(2, 4, 8)
+        lib.call("rua_maxpool_bwd_multi", 3, dys, ixs, kk, got.data_ptr(), acc, N, H, W, Cc, dt, stream())
+        torch.cuda.synchronize()
+        # one rounding after the three additions here, one per launch there
+        assert rel_err(got.float().cpu().numpy(), ref.float().cpu().numpy()) < (1e-2 if dt == L.RUA_BF16 else 1e-6)
+    sp = {k: torch.empty_like(ys[k]) for k in ys}
+    lib.call("rua_sumpool_pyramid", xd.data_ptr(), sp[2].data_ptr(), sp[4].data_ptr(), sp[8].data_ptr(), N, H, W, Cc, dt, stream())
+    torch.cuda.synchronize()
+    xr = rnd(dt, x)
+    for k in (2, 4, 8):
+        exp = F.avg_pool2d(xr.permute(0, 3, 1, 2).double(), k, k).permute(0, 2, 3, 1).numpy() * k * k
+        assert rel_err(sp[k].float().cpu().numpy(), exp) < tol(dt), k
+    # shapes the pyramid cannot serve are refused
+    assert lib.raw("rua_sumpool_pyramid")(xd.data_ptr(), sp[2].data_ptr(), sp[4].data_ptr(), sp[8].data_ptr(), N, 36, W, Cc, dt, None) != 0
