@@ -187,6 +187,11 @@ int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db, int64_t M
 /* heads: Conv2D(num_classes,(1,1)) + softmax / sigmoid (model2.py:145-146,160-162,169-171,181-183,186-188).
  * act: 0 none, 1 softmax over channels, 2 sigmoid.  z (logits) and p are fp32 [M][Cout<=8]. */
 int rua_head_fwd(const void* x, const float* w, const float* b, float* z, float* p, int64_t M, int Cin, int Cout, int act, int dtype, void* stream);
+/* rua_head_fwd with the loss moments of its output in the epilogue (the probabilities are in registers): tanimoto_sums
+ * [B][Cout][6] fp64 as rua_tanimoto_sums accumulates them against the labels y [B*HW][Cout] (NULL: not), metrics[5] fp64 as
+ * rua_seg_metrics (NULL: not); both zeroed by the caller.  Replaces those passes over p (train_ISPRS.py:456-461). */
+int rua_head_fwd_loss(const void* x, const float* w, const float* b, float* z, float* p, const float* y, double* tanimoto_sums,
+                      double* metrics, int B, int64_t HW, int Cin, int Cout, int act, int dtype, void* stream);
 /* scratch (optional, >= 1024*(Cout*Cin+Cout)*4 bytes): per-block partials + fixed-order reduce instead of fp32 atomics.
  * mask_dx: x is the output of a fused ReLU (the heads' 3x3 conv + relu, model2.py:153-158): dx *= (x > 0), i.e. the ReLU's
  * backward is applied here instead of in a pass of its own */

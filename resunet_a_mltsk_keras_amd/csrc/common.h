@@ -78,6 +78,7 @@ struct RuaTuning {
   int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0;
   // grouped launches of a ResBlock's dilation branches, one bit per kernel family (0: every member launches on its own)
   int conv_group = 15;                  // 1 conv_strip, 2 conv_igemm<bf16,256,64>, 4 conv_dmap<128,128>, 8 conv_dmap<64,128>
+  int head_fwd2 = 1;                    // heads with Cin = 32: the register-weights kernel (0: the LDS-weights one)
   int wgd_ks_slow = 1;                  // wgrad_dmap block order: K slice slowest (blocks that read the same pixels share an XCD's L2)
   int wgrad_group = 7;                  // 1 wgrad_kernel, 2 wgrad_taps<32>, 4 wgrad_taps<64>, 8 wgrad_dmap (off: three members at once thrash the L2, 27.6 vs 24.6 us each)
 };

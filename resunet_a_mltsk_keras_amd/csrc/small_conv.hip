@@ -192,6 +192,257 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned char* x, c
   }
 }
 
+// ---- head forward, second form (Cin = 32: the reference's heads) -------------------------------------------------------------
+// CGI = Cin / VEC lanes share a pixel: each loads ONE 16-byte piece (a wave reads 1 KiB runs), keeps its slice of the weights in
+// registers (the first form re-read them from LDS: 192 broadcast reads per pixel, 22 us for a 59 MB pass), the partial dot products
+// are folded over the CGI lanes by xor shuffles, every lane finishes the activation, and lane cp stores / accounts for the classes
+// cp, cp + CGI: logits, probabilities, and - LOSS - the Tanimoto moments and the accuracy / confusion counts of those classes.
+template <typename T, int CO, bool LOSS>
+__global__ __launch_bounds__(256) void head_fwd2_kernel(const unsigned char* x, const float* __restrict__ w, const float* __restrict__ b,
+                                                         float* z, float* p, const float* __restrict__ y, double* sums, double* metrics,
+                                                         long long HW, int pix_per_block, int Cin, int Cout, int act) {
+  constexpr int VEC = ET<T>::VEC;
+  constexpr int CGI = 32 / VEC;                       // 4 (bf16) or 8 (fp32) lanes per pixel
+  constexpr int PL = 256 / CGI;                       // pixels per pass and block
+  constexpr int NOWN = (8 + CGI - 1) / CGI;           // classes a lane owns: cp, cp + CGI
+  __shared__ float sh[4 * 56];
+  const int cp = threadIdx.x % CGI, pl = threadIdx.x / CGI;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  float wr[CO][VEC], bias[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    bias[co] = (co < Cout && b) ? b[co] : 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) wr[co][j] = co < Cout ? w[co * Cin + cp * VEC + j] : 0.f;
+  }
+  float ts[NOWN][6], mt[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int o = 0; o < NOWN; ++o)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ts[o][k] = 0.f;
+  long long i = (long long)blockIdx.x * pix_per_block + pl;
+  long long iend = (long long)(blockIdx.x + 1) * pix_per_block; if (iend > HW) iend = HW;
+  for (; i < iend; i += PL) {
+    const long long m = (long long)n * HW + i;
+    const uint4 xq = ldg16(x + ((size_t)m * CGI + cp) * 16);
+    float yv[NOWN];
+    if constexpr (LOSS) {
+#pragma unroll
+      for (int o = 0; o < NOWN; ++o) yv[o] = (cp + o * CGI) < Cout ? y[m * Cout + cp + o * CGI] : 0.f;
+    }
+    float xv[VEC], acc[CO];
+    ET<T>::unpack(xq, xv);
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) a = fmaf(xv[j], wr[co][j], a);
+#pragma unroll
+      for (int o = 1; o < CGI; o <<= 1) a += __shfl_xor(a, o, 64);
+      acc[co] = a + bias[co];
+    }
+    float pr[CO];
+    if (act == RUA_ACT_SOFTMAX) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) if (co < Cout) mx = fmaxf(mx, acc[co]);
+      float s_ = 0.f;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) { pr[co] = co < Cout ? expf(acc[co] - mx) : 0.f; s_ += pr[co]; }
+      const float inv = 1.f / s_;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) pr[co] *= inv;
+    } else if (act == RUA_ACT_SIGMOID) {
+#pragma unroll
+      for (int co = 0; co < CO; ++co) pr[co] = 1.f / (1.f + expf(-acc[co]));
+    } else {
+#pragma unroll
+      for (int co = 0; co < CO; ++co) pr[co] = acc[co];
+    }
+    // this lane's classes: select from the register arrays with compile-time indices
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+      float zo = 0.f, po = 0.f;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) if (co % CGI == cp && co / CGI == o) { zo = acc[co]; po = pr[co]; }
+      const int c = cp + o * CGI;
+      if (c < Cout) {
+        if (z) z[m * Cout + c] = zo;
+        p[m * Cout + c] = po;
+        if constexpr (LOSS) {
+          const float a = po, l = yv[o], q = 1.f - a, mm = 1.f - l;
+          ts[o][0] += a; ts[o][1] += mm; ts[o][2] = fmaf(a, l, ts[o][2]);
+          ts[o][3] += a * a + l * l; ts[o][4] = fmaf(q, mm, ts[o][4]); ts[o][5] += q * q + mm * mm;
+          const bool t = l > 0.5f, qq = a > 0.5f;
+          mt[1] += (t && qq); mt[2] += (!t && qq); mt[3] += (!t && !qq); mt[4] += (t && !qq);
+        }
+      }
+    }
+    if constexpr (LOSS) {
+      if (metrics) {                                  // categorical accuracy: argmax p (every lane has all of p) vs argmax y (spread over the lanes)
+        int ip = 0; float bp = pr[0];
+#pragma unroll
+        for (int co = 1; co < CO; ++co) if (co < Cout && pr[co] > bp) { bp = pr[co]; ip = co; }
+        float by = -INFINITY; int iy = 1 << 20;
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) { const int c = cp + o * CGI; if (c < Cout && (yv[o] > by)) { by = yv[o]; iy = c; } }
+#pragma unroll
+        for (int o = 1; o < CGI; o <<= 1) {
+          const float ov = __shfl_xor(by, o, 64); const int oi = __shfl_xor(iy, o, 64);
+          if (ov > by || (ov == by && oi < iy)) { by = ov; iy = oi; }     // first maximum wins, as a scan in class order
+        }
+        if (cp == 0) mt[0] += (ip == iy);
+      }
+    }
+  }
+  if constexpr (LOSS) {
+    // lanes with the same cp (stride CGI in the wave) hold partial sums of the same classes
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int of = CGI; of < 64; of <<= 1) ts[o][k] += __shfl_xor(ts[o][k], of, 64);
+      }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) mt[k] = wave_sum(mt[k]);
+    if (lane < CGI) {
+#pragma unroll
+      for (int o = 0; o < NOWN; ++o) {
+        const int c = cp + o * CGI;
+        if (c < 8) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) sh[wid * 56 + c * 6 + k] = ts[o][k];
+        }
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sh[wid * 56 + 48 + k] = mt[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 53) {
+      const int e = threadIdx.x;
+      const double t = (double)sh[e] + (double)sh[56 + e] + (double)sh[112 + e] + (double)sh[168 + e];
+      if (e < 48) { const int c = e / 6, k = e % 6; if (c < Cout && sums) unsafeAtomicAdd(&sums[((size_t)n * Cout + c) * 6 + k], t); }
+      else if (metrics) unsafeAtomicAdd(&metrics[e - 48], t);
+    }
+  }
+}
+
+template <typename T, bool LOSS>
+static void launch_head_fwd2(const void* x, const float* w, const float* b, float* z, float* p, const float* y, double* sums, double* metrics,
+                             int B, int64_t HW, int Cin, int Cout, int act, hipStream_t st) {
+  int64_t per_sample = (4 * (int64_t)rua_cu_count() + B - 1) / B; if (per_sample < 1) per_sample = 1;      // ~4 blocks per CU over the batch
+  constexpr int PL = 256 / (32 / ET<T>::VEC);
+  int64_t ppb = (HW + per_sample - 1) / per_sample; if (ppb < PL) ppb = PL;
+  ppb = (ppb + PL - 1) / PL * PL;
+  const int gx = (int)((HW + ppb - 1) / ppb);
+#define RUA_HEAD2(CO_) hipLaunchKernelGGL((head_fwd2_kernel<T, CO_, LOSS>), dim3(gx, B), dim3(256), 0, st, (const unsigned char*)x, w, b, z, p, y, sums, metrics, (long long)HW, (int)ppb, Cin, Cout, act)
+  if (Cout == 6) RUA_HEAD2(6); else if (Cout == 3) RUA_HEAD2(3); else RUA_HEAD2(8);
+#undef RUA_HEAD2
+}
+
+// head_fwd with the loss moments in its epilogue: the probabilities are in registers when the Tanimoto sums (and the accuracy /
+// confusion counts of the 'seg' head) need them, so rua_tanimoto_sums / rua_seg_metrics do not read p again (four + one passes
+// over 12.6 MB and five launches per step).  A block stays inside ONE sample (blockIdx.y): sums[n][c][6] as rua_tanimoto_sums
+// defines them, metrics[5] as rua_seg_metrics.
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_loss_kernel(const unsigned char* x, const float* __restrict__ w, const float* __restrict__ b,
+                                                             float* z, float* p, const float* __restrict__ y, double* sums, double* metrics,
+                                                             long long HW, int pix_per_block, int Cin, int Cout, int act) {
+  constexpr int VEC = ET<T>::VEC;
+  extern __shared__ float sw[];                       // [Cout][Cin] + [Cout], then [4 waves][53]
+  float* sh = sw + Cout * Cin + Cout;
+  for (int i = threadIdx.x; i < Cout * Cin; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < Cout; i += 256) sw[Cout * Cin + i] = b ? b[i] : 0.f;
+  __syncthreads();
+  const int CGI = Cin / VEC;
+  const int n = blockIdx.y;
+  float ts[8][6], mt[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ts[c][k] = 0.f;
+  long long i = (long long)blockIdx.x * pix_per_block + threadIdx.x;
+  long long iend = (long long)(blockIdx.x + 1) * pix_per_block; if (iend > HW) iend = HW;
+  for (; i < iend; i += 256) {
+    const long long m = (long long)n * HW + i;
+    float yv[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) yv[co] = co < Cout ? y[m * Cout + co] : 0.f;
+    float acc[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) acc[co] = co < Cout ? sw[Cout * Cin + co] : 0.f;
+    for (int cp = 0; cp < CGI; ++cp) {
+      float xv[VEC];
+      ET<T>::unpack(ldg16(x + ((size_t)m * CGI + cp) * 16), xv);
+#pragma unroll
+      for (int co = 0; co < 8; ++co) {
+        if (co < Cout) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[co] = fmaf(xv[j], sw[co * Cin + cp * VEC + j], acc[co]);
+        }
+      }
+    }
+    float pr[8];
+    if (act == RUA_ACT_SOFTMAX) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int co = 0; co < 8; ++co) if (co < Cout) mx = fmaxf(mx, acc[co]);
+      float s_ = 0.f;
+#pragma unroll
+      for (int co = 0; co < 8; ++co) { pr[co] = co < Cout ? expf(acc[co] - mx) : 0.f; s_ += pr[co]; }
+      const float inv = 1.f / s_;
+#pragma unroll
+      for (int co = 0; co < 8; ++co) pr[co] *= inv;
+    } else if (act == RUA_ACT_SIGMOID) {
+#pragma unroll
+      for (int co = 0; co < 8; ++co) pr[co] = 1.f / (1.f + expf(-acc[co]));
+    } else {
+#pragma unroll
+      for (int co = 0; co < 8; ++co) pr[co] = acc[co];
+    }
+#pragma unroll
+    for (int co = 0; co < 8; ++co) if (co < Cout) { if (z) z[m * Cout + co] = acc[co]; p[m * Cout + co] = pr[co]; }
+    // moments (rua_tanimoto_sums) and counts (rua_seg_metrics) of this pixel
+    int ip = 0, iy = 0; float bp = pr[0], by = yv[0];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c < Cout) {
+        const float a = pr[c], l = yv[c], q = 1.f - a, mm = 1.f - l;
+        ts[c][0] += a; ts[c][1] += mm; ts[c][2] = fmaf(a, l, ts[c][2]);
+        ts[c][3] += a * a + l * l; ts[c][4] = fmaf(q, mm, ts[c][4]); ts[c][5] += q * q + mm * mm;
+        if (a > bp) { bp = a; ip = c; }
+        if (l > by) { by = l; iy = c; }
+        const bool t = l > 0.5f, qq = a > 0.5f;
+        mt[1] += (t && qq); mt[2] += (!t && qq); mt[3] += (!t && !qq); mt[4] += (t && !qq);
+      }
+    }
+    mt[0] += (ip == iy);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();                                    // (the weights in sw are dead; sh is behind them anyway)
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (c < Cout) { const float v = wave_sum(ts[c][k]); if (lane == 0) sh[wid * 53 + c * 6 + k] = v; }
+    }
+  if (metrics) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const float v = wave_sum(mt[k]); if (lane == 0) sh[wid * 53 + 48 + k] = v; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 53) {
+    const int e = threadIdx.x;
+    const double t = (double)sh[e] + (double)sh[53 + e] + (double)sh[106 + e] + (double)sh[159 + e];
+    if (e < 48) { const int c = e / 6, k = e % 6; if (c < Cout && sums) unsafeAtomicAdd(&sums[((size_t)n * Cout + c) * 6 + k], t); }
+    else if (metrics) unsafeAtomicAdd(&metrics[e - 48], t);
+  }
+}
+
 template <typename T, int CO>      // CO: output channels held in registers (exact for the reference's 6 classes / 3 colour bands, else 8)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, const float* __restrict__ dz, const float* __restrict__ w,
                                                         unsigned char* dx, int accumulate_dx, float* dw, float* db, float* partial,
@@ -311,9 +562,41 @@ extern "C" int rua_head_fwd(const void* x, const float* w, const float* b, float
   const size_t smem = (size_t)(Cout * Cin + Cout) * 4;
   int64_t g = (M + 255) / 256; if (g > 4096) g = 4096;
   hipStream_t st = (hipStream_t)stream;
+  if (Cin == 32 && g_tune.head_fwd2) {                  // the reference's heads: weights in registers, a pixel shared by Cin / VEC lanes
+    if (dtype == RUA_BF16) launch_head_fwd2<bf16_t, false>(x, w, b, z, p, nullptr, nullptr, nullptr, 1, M, Cin, Cout, act, st);
+    else launch_head_fwd2<float, false>(x, w, b, z, p, nullptr, nullptr, nullptr, 1, M, Cin, Cout, act, st);
+    RUA_LAUNCH_CHECK("rua_head_fwd");
+    return RUA_OK;
+  }
   if (dtype == RUA_BF16) hipLaunchKernelGGL((head_fwd_kernel<bf16_t>), dim3((int)g), dim3(256), smem, st, (const unsigned char*)x, w, b, z, p, (long long)M, Cin, Cout, act);
   else hipLaunchKernelGGL((head_fwd_kernel<float>), dim3((int)g), dim3(256), smem, st, (const unsigned char*)x, w, b, z, p, (long long)M, Cin, Cout, act);
   RUA_LAUNCH_CHECK("rua_head_fwd");
+  return RUA_OK;
+}
+
+extern "C" int rua_head_fwd_loss(const void* x, const float* w, const float* b, float* z, float* p, const float* y, double* tanimoto_sums,
+                                 double* metrics, int B, int64_t HW, int Cin, int Cout, int act, int dtype, void* stream) {
+  RUA_CHECK_ARG(x && w && p && y && B > 0 && HW > 0, "rua_head_fwd_loss: bad arguments");
+  RUA_CHECK_ARG(tanimoto_sums || metrics, "rua_head_fwd_loss: nothing to accumulate (use rua_head_fwd)");
+  const int vec = dtype == RUA_BF16 ? 8 : 4;
+  RUA_CHECK_ARG(Cin % vec == 0 && Cin <= 256, "rua_head_fwd_loss: Cin=%d must be a multiple of %d (<=256)", Cin, vec);
+  RUA_CHECK_ARG(Cout >= 1 && Cout <= 8, "rua_head_fwd_loss: Cout=%d must be in 1..8", Cout);
+  const size_t smem = (size_t)(Cout * Cin + Cout + 4 * 53) * 4;
+  // ~2 blocks per CU over the batch; every block ends in <= 53 fp64 atomics on its sample's sums
+  int64_t per_sample = (2 * (int64_t)rua_cu_count() + B - 1) / B; if (per_sample < 1) per_sample = 1;
+  int64_t ppb = (HW + per_sample - 1) / per_sample; if (ppb < 256) ppb = 256;
+  ppb = (ppb + 255) / 256 * 256;
+  const int gx = (int)((HW + ppb - 1) / ppb);
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 32 && g_tune.head_fwd2) {
+    if (dtype == RUA_BF16) launch_head_fwd2<bf16_t, true>(x, w, b, z, p, y, tanimoto_sums, metrics, B, HW, Cin, Cout, act, st);
+    else launch_head_fwd2<float, true>(x, w, b, z, p, y, tanimoto_sums, metrics, B, HW, Cin, Cout, act, st);
+    RUA_LAUNCH_CHECK("rua_head_fwd_loss");
+    return RUA_OK;
+  }
+  if (dtype == RUA_BF16) hipLaunchKernelGGL((head_fwd_loss_kernel<bf16_t>), dim3(gx, B), dim3(256), smem, st, (const unsigned char*)x, w, b, z, p, y, tanimoto_sums, metrics, (long long)HW, (int)ppb, Cin, Cout, act);
+  else hipLaunchKernelGGL((head_fwd_loss_kernel<float>), dim3(gx, B), dim3(256), smem, st, (const unsigned char*)x, w, b, z, p, y, tanimoto_sums, metrics, (long long)HW, (int)ppb, Cin, Cout, act);
+  RUA_LAUNCH_CHECK("rua_head_fwd_loss");
   return RUA_OK;
 }
 

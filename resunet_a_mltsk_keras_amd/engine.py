@@ -1139,9 +1139,20 @@ class Graph:
         lay = self.Lconv([x.C], cout, 1, name=name, mfma=False)
         z = self.new(x.N, x.H, x.W, cout, f32=True)
         p = self.new(x.N, x.H, x.W, cout, f32=True)
-        F.add("rua_head_fwd", x.ptr, self.P(lay["segs"][0]["off"]), self.P(lay["bias"]), z.ptr, p.ptr, x.M, x.C, cout, act, self.dt)
         y = self.new(x.N, x.H, x.W, cout, f32=True)           # label buffer (host uploads into it)
         h = dict(name=hname, x=x, z=z, p=p, y=y, lay=lay, act=act, C=cout, slot=len(self.heads))
+        sp = self.e.loss
+        tani = sp is not None and sp.kind.get(hname) == L.LOSS_TANIMOTO
+        if sp is not None and not self.dry and self.e.fuse_head_loss and (tani or hname == "seg"):
+            # the Tanimoto moments (and the 'seg' head's accuracy / confusion counts) in the head's own epilogue: p is not read again
+            if tani:
+                h["sums"] = self.salloc(x.N * cout * 6)
+            if hname == "seg":
+                h["metrics_done"] = True
+            F.add("rua_head_fwd_loss", x.ptr, self.P(lay["segs"][0]["off"]), self.P(lay["bias"]), z.ptr, p.ptr, y.ptr, h.get("sums"),
+                  self.e.scalars_ptr + 8 * 8 if hname == "seg" else None, x.N, x.H * x.W, x.C, cout, act, self.dt)
+        else:
+            F.add("rua_head_fwd", x.ptr, self.P(lay["segs"][0]["off"]), self.P(lay["bias"]), z.ptr, p.ptr, x.M, x.C, cout, act, self.dt)
         self.heads.append(h)
         return h
 
@@ -1154,10 +1165,12 @@ class Graph:
         slot = self.e.scalars_ptr + h["slot"] * 8
         coef = None
         if kind == L.LOSS_TANIMOTO:
-            sums = self.salloc(B * Cc * 6)
             coef = self.alloc((B * Cc * 3,), torch.float32, zero=True)
             LP.keep.append(coef)
-            LP.add("rua_tanimoto_sums", h["p"].ptr, h["y"].ptr, B, HW, Cc, sums)
+            sums = h.get("sums")
+            if sums is None:                                # (the head's forward did not take the moments itself)
+                sums = self.salloc(B * Cc * 6)
+                LP.add("rua_tanimoto_sums", h["p"].ptr, h["y"].ptr, B, HW, Cc, sums)
             LP.add("rua_tanimoto_finalize", sums, B, HW, Cc, wgt / B, slot, coef.data_ptr(), None)
             h["norm"] = 1.0
         else:
@@ -1254,7 +1267,8 @@ class Graph:
             self.head_loss(h)
         self.cur_tag = self.loss_plan.scope = None
         seg = self.outputs["seg"]
-        self.loss_plan.add("rua_seg_metrics", seg["p"].ptr, seg["y"].ptr, seg["x"].M, seg["C"], self.e.scalars_ptr + 8 * 8)
+        if not seg.get("metrics_done"):
+            self.loss_plan.add("rua_seg_metrics", seg["p"].ptr, seg["y"].ptr, seg["x"].M, seg["C"], self.e.scalars_ptr + 8 * 8)
         if self.training:
             for step in reversed(self.back_steps):
                 step()
@@ -1278,6 +1292,7 @@ class Engine:
                              "channels and the MFMA epilogue stores 8-channel pieces)")
         self.dev = None
         self.fuse_bn = os.environ.get("RUA_FUSE_BN", "1") != "0"     # normalise-on-load ResBlocks where the library offers it
+        self.fuse_head_loss = os.environ.get("RUA_FUSE_HEAD_LOSS", "1") != "0"   # Tanimoto moments / seg metrics in the heads' forward epilogue
         self.pool_pyramid = os.environ.get("RUA_POOL_PYRAMID", "1") != "0"   # PSPPooling: the 2 / 4 / 8 poolings (and their adjoints) in single passes
         self.fold_bn = os.environ.get("RUA_FOLD_BN", "1") != "0"     # ... and their coefficient launches folded into the convs' prologues
         self.defer_reduce = os.environ.get("RUA_DEFER_REDUCE", "1") != "0"     # weight-gradient partials summed by batched launches

@@ -1179,3 +1179,40 @@ def test_pooling_pyramid_passes_equal_the_separate_launches(dt):
         assert rel_err(sp[k].float().cpu().numpy(), exp) < tol(dt), k
     # shapes the pyramid cannot serve are refused
     assert lib.raw("rua_sumpool_pyramid")(xd.data_ptr(), sp[2].data_ptr(), sp[4].data_ptr(), sp[8].data_ptr(), N, 36, W, Cc, dt, None) != 0
+
+
+@pytest.mark.parametrize("dt,act,Cout", [(L.RUA_BF16, L.ACT_SOFTMAX, 6), (L.RUA_BF16, L.ACT_SIGMOID, 3), (L.RUA_F32, L.ACT_SOFTMAX, 6), (L.RUA_BF16, L.ACT_SIGMOID, 6)])
+def test_head_forward_with_loss_moments_equals_the_separate_passes(dt, act, Cout):
+    """rua_head_fwd_loss = rua_head_fwd + rua_tanimoto_sums + rua_seg_metrics in one pass: logits and probabilities bit-identical,
+    the fp64 moments / counts equal up to the order of the fp32 partial sums."""
+    rng = np.random.default_rng(31 + Cout)
+    lib = L.lib()
+    B, Hh, Ww, Cin = 3, 40, 52, 32                                            # HW = 2080: blocks that end inside a sample
+    HW, M = Hh * Ww, B * Hh * Ww
+    x = to_dev(rng.standard_normal((M, Cin)).astype(np.float32), dt)
+    w = torch.from_numpy((rng.standard_normal((Cout, Cin)) / 4).astype(np.float32)).to(dev())
+    b = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32)).to(dev())
+    lab = np.eye(Cout, dtype=np.float32)[rng.integers(0, Cout, size=M)]
+    if act == L.ACT_SIGMOID:
+        lab = (rng.random((M, Cout)) > 0.6).astype(np.float32)
+    y = torch.from_numpy(lab).to(dev())
+    z0 = torch.empty((M, Cout), device=dev()); p0 = torch.empty((M, Cout), device=dev())
+    lib.call("rua_head_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), z0.data_ptr(), p0.data_ptr(), M, Cin, Cout, act, dt, stream())
+    s0 = torch.zeros(B * Cout * 6, dtype=torch.float64, device=dev()); m0 = torch.zeros(5, dtype=torch.float64, device=dev())
+    lib.call("rua_tanimoto_sums", p0.data_ptr(), y.data_ptr(), B, HW, Cout, s0.data_ptr(), stream())
+    lib.call("rua_seg_metrics", p0.data_ptr(), y.data_ptr(), M, Cout, m0.data_ptr(), stream())
+    z1 = torch.empty_like(z0); p1 = torch.empty_like(p0)
+    s1 = torch.zeros_like(s0); m1 = torch.zeros_like(m0)
+    lib.call("rua_head_fwd_loss", x.data_ptr(), w.data_ptr(), b.data_ptr(), z1.data_ptr(), p1.data_ptr(), y.data_ptr(), s1.data_ptr(), m1.data_ptr(),
+             B, HW, Cin, Cout, act, dt, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z0) and torch.equal(p1, p0)
+    assert np.allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=1e-5, atol=1e-3)
+    assert np.array_equal(m1.cpu().numpy(), m0.cpu().numpy())                 # counts: exact
+    assert m1[0].item() > 0 and abs(m1[1:].sum().item() - M * Cout) < 0.5     # TP + FP + TN + FN = every (pixel, class)
+    # moments only / counts only
+    s2 = torch.zeros_like(s0)
+    lib.call("rua_head_fwd_loss", x.data_ptr(), w.data_ptr(), b.data_ptr(), None, p1.data_ptr(), y.data_ptr(), s2.data_ptr(), None, B, HW, Cin, Cout, act, dt, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(s2, s1) or np.allclose(s2.cpu().numpy(), s1.cpu().numpy(), rtol=1e-6, atol=1e-4)
+    assert lib.raw("rua_head_fwd_loss")(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, p1.data_ptr(), y.data_ptr(), None, None, B, HW, Cin, Cout, act, dt, None) != 0
