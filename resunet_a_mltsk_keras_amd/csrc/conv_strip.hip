@@ -58,10 +58,12 @@ __device__ __forceinline__ void conv_strip32_body(const StripK& q) {
   const int H = p.H, W = p.W, d = q.d;
 
   // ---- job: (image, strip, residue class, segment of the chain) ------------------------------------------------------
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  // (grouped launch: the grid is the largest member's, padded to a multiple of 8 so that block x of every member runs on XCD
+  // x & 7; the renumbering below is over THIS member's jobs - over the whole grid a short member would land on the first XCDs only)
+  const int nwg = q.njobs, bid = blockIdx.x;
+  if (bid >= nwg) return;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int job = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);     // neighbours in a chain share an XCD's L2
-  if (job >= q.njobs) return;                           // (grouped launch: the grid is the largest member's)
   const int chain = job / q.spc, seg = job - chain * q.spc;
   const int r_ = chain % d, tq = chain / d;
   const int x0 = (tq % q.strips) * SW, n_ = tq / q.strips;
@@ -401,7 +403,7 @@ template <int NW, bool HAS_EP, int R> static int launch_strip_members(const Stri
     StripKG g;
     int grid = 0, smem = 0;
     for (int i = 0; i < m; ++i) { g.k[i] = ks[i]; if (ks[i].njobs > grid) grid = ks[i].njobs; if (smems[i] > smem) smem = smems[i]; }
-    hipLaunchKernelGGL((conv_strip32_g<NW, HAS_EP, R>), dim3(grid, m), dim3(NW * 64), smem, st, g);
+    hipLaunchKernelGGL((conv_strip32_g<NW, HAS_EP, R>), dim3((grid + 7) / 8 * 8, m), dim3(NW * 64), smem, st, g);
   }
   RUA_LAUNCH_CHECK("conv_strip32");
   return RUA_OK;
@@ -422,8 +424,11 @@ int rua_strip_group_flush(hipStream_t st, int* grids) {
   for (int i = 0; i < c.n && rc == RUA_OK; ++i) {
     if (done[i]) continue;
     StripK ks[RUA_MAX_BRANCH]; int sm[RUA_MAX_BRANCH], m = 0;
+    // one grid takes the largest member's LDS size for every block: only members that keep their own number of blocks per CU
+    // under it go together (128-pixel strips at d = 1 run two blocks per CU, at d = 31 one: grouped, d = 1 lost half its occupancy)
+    const int per_cu = (160 * 1024) / c.smem[i];
     for (int j = i; j < c.n; ++j)
-      if (!done[j] && c.variant[j] == c.variant[i]) { ks[m] = c.k[j]; sm[m] = c.smem[j]; ++m; done[j] = true; }
+      if (!done[j] && c.variant[j] == c.variant[i] && (160 * 1024) / c.smem[j] == per_cu) { ks[m] = c.k[j]; sm[m] = c.smem[j]; ++m; done[j] = true; }
     rc = launch_strip_variant(c.variant[i], ks, sm, m, st);
     if (grids) ++*grids;
   }
