@@ -256,9 +256,18 @@ def test_conv_wgrad(case, dt):
     d.dy, d.Cout, d.H, d.W = dyd.data_ptr(), Cout, H, W
     d.N, d.stride, d.dil, d.taps, d.dtype = N, stride, dil, taps, dt
     d.dw = dw.data_ptr()
-    if dt == L.RUA_BF16 and case[:5] in ((4, 32, 32, 256, 256), (4, 64, 64, 128, 128)):
+    if dt == L.RUA_BF16 and case[:5] == (4, 32, 32, 256, 256):
         assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 2
-    L.lib().call("rua_conv_wgrad", C.byref(d), stream())
+    nine = dt == L.RUA_BF16 and case[:5] == (4, 64, 64, 128, 128)
+    if nine:                                                  # 9 tiles: wgrad_kernel by default (faster inside the step); still served by wgrad_dmap on request
+        assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 0
+        L.lib().set_tuning(wgd_mintiles=9)
+        assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 2
+    try:
+        L.lib().call("rua_conv_wgrad", C.byref(d), stream())
+    finally:
+        if nine:
+            L.lib().set_tuning(wgd_mintiles=10)
     torch.cuda.synchronize()
     w = torch.zeros((taps, Cout, Cs), dtype=torch.float64, requires_grad=True)
     y = ref_conv_nhwc(rnd(dt, a).double(), w, None, dil, taps, stride)
@@ -745,18 +754,22 @@ def test_conv_halo_lattice_tiles(H, W, dil, Cs, mode):
         d.aux, d.aux_mode, d.mscale, d.mshift, d.accumulate, d.stats_mode = ad.data_ptr(), 2, scd.data_ptr(), shd.data_ptr(), 1, 2
         exp = (conv + rnd(dt, y0).double().numpy()) * ((a * sc + sh) > 0)
         s2 = (exp * a).sum(axis=(0, 1, 2))
-    # (C = 64 takes conv_halo only at d = 1 by default, where it wins; RUA_HALO64_MAXD=31 routes the other dilations through it)
+    # (C = 64: conv_halo serves every dilation on request - rua_set_tuning("halo64_maxd", 31) - and none by default)
     # C = 32 with a row that splits into 128 / 256-pixel strips and one epilogue stream goes to conv_strip (its own test below)
     strip = Cs == 32 and W % 128 == 0 and mode == "residual_stats"
-    if Cs == 32 or dil == 1:
+    if Cs == 32:
         assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == (5 if strip else 3)
     if strip:
         lib.set_tuning(conv_strip=0)                             # this test is about conv_halo: route the shape back to it
         assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 3
+    if Cs == 64:                                                 # conv_halo<64> is off by default (the grouped conv_igemm grid takes d = 1 too)
+        assert lib.raw("rua_conv_kernel_id")(C.byref(d)) != 3
+        lib.set_tuning(halo64_maxd=31)
+        assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 3
     try:
         lib.call("rua_conv_fwd", C.byref(d), stream())
     finally:
-        lib.set_tuning(conv_strip=1)
+        lib.set_tuning(conv_strip=1, halo64_maxd=0)
     torch.cuda.synchronize()
     got = y.float().cpu().numpy()
     assert rel_err(got, exp) < tol(dt)
