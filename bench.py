@@ -1,7 +1,11 @@
-#!/usr/bin/env python
 """Headline benchmark: training patches/sec of the ResUnet-a multitask path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per
+GPU, what the driver does), or started plainly - then THIS process, which has made no GPU call, starts exactly that
+launcher as a child process (never exec), relays rank 0's JSON line and exits with the child's status
+(/root/reference/train_ISPRS.py:347,432: MirroredStrategy over the node's GPUs).
 
 A step = one full train_on_batch on one resident synthetic batch per GPU: forward (training-mode BN),
 Tanimoto-dual losses on the four heads, backward, gradient all-reduce (N>1), Adam update, bf16 weight
@@ -17,7 +21,8 @@ import sys
 import time
 
 import numpy as np
-import torch
+
+torch = None          # imported by main() AFTER the self-launch branch: the launching parent never initialises the GPU
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,6 +37,7 @@ WORKLOADS = {
 DEPTH = {"cfg4": 7}
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming copy)
 
 
 def conv_flops(desc):
@@ -82,6 +88,40 @@ def committed_rocprof_avg(kernel, args):
     return t["avg_us"].get(kernel)
 
 
+def entry_bytes(name, args):
+    """Algorithmic HBM bytes of one C-ABI launch = every activation tensor its descriptor names, once (weights and
+    per-channel vectors included where they are not negligible); None for entries without a descriptor rule."""
+    es = lambda dt: 2 if dt == 1 else 4
+    if name in ("rua_conv_fwd", "rua_conv_fwd_group"):
+        ds = [args[0]._obj] if name == "rua_conv_fwd" else [args[0][i] for i in range(args[1])]
+        tot = 0
+        for d in ds:
+            e = es(d.dtype)
+            for i in range(d.nseg):
+                sg = d.seg[i]
+                tot += d.N * sg.Hs * sg.Ws * sg.C * e + sg.taps * sg.C * d.Cout * e
+            tot += d.N * d.H * d.W * d.Cout * e * (2 if (d.accumulate or d.out_stride > 1) else 1)       # output (read back when accumulating)
+            if d.aux_mode:
+                tot += d.N * d.H * d.W * d.Cout * e
+        return float(tot)
+    if name in ("rua_conv_wgrad", "rua_conv_wgrad_group"):
+        ds = [args[0]._obj] if name == "rua_conv_wgrad" else [args[0][i] for i in range(args[1])]
+        return float(sum((d.N * d.Hs * d.Ws * d.C + d.N * d.H * d.W * d.Cout) * es(d.dtype) + d.taps * d.C * d.Cout * 4 for d in ds))
+    if name == "rua_bn_fwd":
+        d = args[0]._obj
+        if not d.x:
+            return 0.0
+        return float(d.M * d.C * es(d.dtype) * (1 + d.nb))
+    if name == "rua_bn_bwd":
+        d = args[0]._obj
+        return float(d.M * d.C * es(d.dtype) * (d.nb + 1 + (1 if d.dskip else 0) + 1 + (1 if d.accumulate else 0)))
+    if name in ("rua_col_stats",):
+        return float(args[1] * args[2] * es(args[5]))
+    if name in ("rua_col_stats2",):
+        return float(2 * args[5] * args[6] * es(args[9]))
+    return None
+
+
 def profile_kernels(eng, g, dtype):
     """One extra (untimed) step with an event pair around every conv / wgrad launch on the launch stream.
     Returns per-kernel-instantiation totals: {name: [launches, seconds, flops]}."""
@@ -91,6 +131,8 @@ def profile_kernels(eng, g, dtype):
     sp = C.c_void_p(s)
     tname = "bf16" if dtype == "bf16" else "f32"
     rec = []
+    other = []                                              # every C-ABI entry: (name, e0, e1, algorithmic bytes[, flops])
+    kbytes = {}                                             # MFMA kernel row -> algorithmic bytes of its launches
     mid = lib.raw("rua_profile_mid_event")
     ev_new, ev_rec, ev_us, ev_del = (lib.raw("rua_prof_event_" + n) for n in ("create", "record", "elapsed_us", "destroy"))
     events = []
@@ -190,13 +232,23 @@ def profile_kernels(eng, g, dtype):
                 else:
                     rec.append((kn, e0, e1, fl, tag))
             else:
+                e0 = mark()
                 rc = fn(*args, sp)
+                e1 = mark()
+                other.append((name, e0, e1, entry_bytes(name, args)))
+            if name in ("rua_conv_fwd", "rua_conv_wgrad", "rua_conv_fwd_group", "rua_conv_wgrad_group"):
+                other.append((name, e0, e1, entry_bytes(name, args), fl))      # the whole call (incl. a split-K finisher)
+                kbytes[kn] = kbytes.get(kn, 0.0) + (entry_bytes(name, args) or 0.0)
             if rc != 0:
                 lib.check(rc, name)
+    e0 = mark()
     eng.optimizer_step(1.0 / eng.world)
+    e1 = mark()
+    other.append(("rua_adam_step" if eng.loss.optimizer == "adam" else "rua_sgd_step", e0, e1,
+                  float(eng.params.n) * (32.0 if eng.loss.optimizer == "adam" else 24.0)))
     # Second instrumented step: one marker where the composite (ResBlock) changes, nothing inside the blocks - the block
     # times carry no per-kernel brackets.  A composite's launches are contiguous in the plan.
-    scopes = {}                                             # (pass, scope) -> [first event, last event, conv+wgrad FLOPs]
+    scopes = {}                                             # (pass, scope) -> [first event, last event, conv+wgrad FLOPs, tensor-pass bytes]
     eng._zero_arena(g, s)
     eng._prep_weights(s)
     for pname, plan in (("fwd", g.fwd), ("loss", g.loss_plan), ("bwd", g.bwd)):
@@ -208,10 +260,12 @@ def profile_kernels(eng, g, dtype):
                 if cur is not None:
                     scopes[(pname, cur)][1] = ev
                 if sc is not None:
-                    scopes[(pname, sc)] = [ev, None, 0.0]
+                    scopes[(pname, sc)] = [ev, None, 0.0, 0.0]
                 cur = sc
             if fn is None:
                 continue
+            if sc is not None:
+                scopes[(pname, sc)][3] += entry_bytes(name, args) or 0.0
             if sc is not None and name in ("rua_conv_fwd", "rua_conv_wgrad"):
                 scopes[(pname, sc)][2] += conv_flops(args[0]._obj) if name == "rua_conv_fwd" else wgrad_flops(args[0]._obj)
             elif sc is not None and name == "rua_conv_fwd_group":
@@ -234,7 +288,13 @@ def profile_kernels(eng, g, dtype):
         t[0] += nl[0] if nl else 1; t[1] += max(us(e0, e1) * 1e-6 - ov, 1e-7); t[2] += fl
     out["_event_overhead_us"] = ov * 1e6
     # whole composites (every launch of a ResBlock: BN passes, convolutions, weight / data gradients), forward and backward
-    out["_blocks"] = {f"{pn}:{sc}": (max(us(e0, e1) * 1e-6 - ov, 1e-7), fl) for (pn, sc), (e0, e1, fl) in scopes.items() if e1 is not None}
+    out["_blocks"] = {f"{pn}:{sc}": (max(us(e0, e1) * 1e-6 - ov, 1e-7), fl, by) for (pn, sc), (e0, e1, fl, by) in scopes.items() if e1 is not None}
+    ent = {}
+    for name, e0, e1, by, *fl in other:
+        t = ent.setdefault(name, [0, 0.0, 0.0, 0.0])
+        t[0] += 1; t[1] += max(us(e0, e1) * 1e-6 - ov, 1e-7); t[2] += by or 0.0; t[3] += fl[0] if fl else 0.0
+    out["_entries"] = ent
+    out["_kbytes"] = kbytes
     log(f"event bracket calibration: one fill {t1:.2f} us, two fills {t2:.2f} us, empty pair {empty_us:.2f} us -> overhead {ov * 1e6:.2f} us")
     if os.environ.get("RUA_BENCH_DETAIL"):
         groups = {}
@@ -273,9 +333,11 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sample_steps=2):
+def cpu_baseline(sample_steps=6):
     """CPU oracle (PyTorch-CPU fp32 restatement of the Keras graph) on BASELINE config 1:
-    256x256x3, 6 classes, single task, bs 4, weighted CE, Adam — full train steps on all host cores."""
+    256x256x3, 6 classes, single task, bs 4, weighted CE, Adam - full train steps on all host cores.
+    BASELINE.md section 2 asks for 10 / >= 50 / median of 3; at ~3.5 s per step that is impractical inside the default
+    run, so this is a bounded sample (one warm-up, `sample_steps` timed steps) and says so: min / median / max are reported."""
     from oracle import resuneta_ref as ref
     from resunet_a_mltsk_keras_amd.synthetic import make_batch
     cores = host_cores()
@@ -289,17 +351,100 @@ def cpu_baseline(sample_steps=2):
     t0 = time.time()
     tr.train_on_batch(x, y)                                    # warm-up
     log(f"cpu warm-up step {time.time() - t0:.1f} s")
-    t0 = time.time()
+    per = []
     for _ in range(sample_steps):
+        t0 = time.time()
         tr.train_on_batch(x, y)
-        log(f"cpu step done at {time.time() - t0:.1f} s")
-    dt = time.time() - t0
-    return {"value": round(4 * sample_steps / dt, 3), "unit": "patches/s", "cores": cores, "kind": "port",
+        per.append(time.time() - t0)
+        log(f"cpu step {per[-1]:.2f} s")
+    srt = sorted(per)
+    med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    return {"value": round(4 / med, 3), "unit": "patches/s", "cores": cores, "kind": "port",
+            "step_s": {"min": round(srt[0], 3), "median": round(med, 3), "max": round(srt[-1], 3), "n": len(srt)},
+            "value_range": [round(4 / srt[-1], 3), round(4 / srt[0], 3)],
             "sample": f"{sample_steps} full train steps (fwd+loss+bwd+Adam) of config 1 (256x256x3, 6 classes, bs 4, fp32) "
-                      f"after 1 warm-up step, PyTorch-CPU oracle standing in for Keras-CPU"}
+                      f"after 1 warm-up step; value = 4 patches / median step; PyTorch-CPU oracle standing in for Keras-CPU"}
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: start the N ranks as a CHILD process (the form the driver
+    itself uses), relay rank 0's JSON line, return the child's status.  Nothing here touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = os.environ.get("RUA_BENCH_CHILD") or os.path.abspath(__file__)      # RUA_BENCH_CHILD: the CPU test's stub rank program
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this pool (RCCL needs it)
+    log("starting " + " ".join(cmd))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for out in proc.stdout:                                      # rank 0 prints ONE JSON line on stdout; everything else is stderr
+        out = out.rstrip("\n")
+        if out.startswith("{") and line is None:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        log("the ranks finished without a result line")
+        rc = 1
+    return rc
+
+
+def build_engine(workload, dtype, batch, rank, world, args):
+    from resunet_a_mltsk_keras_amd import _lib as L
+    from resunet_a_mltsk_keras_amd.engine import Engine, LossSpec, ModelConfig
+    from resunet_a_mltsk_keras_amd.synthetic import make_batch
+    patch, ch, ncls, mt, bs, _ = WORKLOADS[workload]
+    B = batch or bs
+    depth = DEPTH.get(workload, 6)
+    eng = Engine(ModelConfig(input_shape=(patch, patch, ch), num_classes=ncls, multitasking=mt, depth=depth), dtype=dtype, seed=0)
+    heads = ["seg", "bound", "dist", "color"]
+    eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in heads}, weight={h: 1.0 for h in heads}, optimizer="adam", lr=1e-3))
+    if world > 1 or args.force_dp:
+        from resunet_a_mltsk_keras_amd.dist import DataParallel
+        DataParallel(eng, bucket_mb=args.bucket_mb, overlap=not args.no_overlap)
+    x, y = make_batch(B, patch, ch, ncls, mt, seed=1234 + rank)
+    return eng, x, y, B, depth
+
+
+def also_run(workload, dtype, steps, args):
+    """A short run of another BASELINE configuration on this GPU (the `also` block of the N = 1 line): same step, same
+    protocol in small (3 warm-up steps incl. plan recording + graph capture, `steps` timed steps between device synchronises)."""
+    import gc
+    t_all = time.time()
+    eng, x, y, B, depth = build_engine(workload, dtype, 0, 0, 1, args)
+    eng.train_step(x, y, fetch=False)
+    for _ in range(2):
+        eng.train_step(None, None, fetch=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_step(None, None, fetch=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = eng._results(eng.graph(B, True))
+    gfl = WORKLOADS[workload][5]
+    peak = BF16_DENSE_PEAK_TFLOPS if dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+    out = {"workload": workload, "dtype": dtype, "per_gpu_batch": B, "steps": steps, "ms_per_step": round(1e3 * dt / steps, 3),
+           "patches_per_s": round(B * steps / dt, 1), "model_tflops_per_s": round(B * steps / dt * gfl / 1e3, 1),
+           "frac_of_peak": round(B * steps / dt * gfl / 1e3 / peak, 4), "loss_last_step": round(res[0], 5),
+           "wall_s_incl_build": None}
+    del eng, x, y
+    gc.collect()
+    torch.cuda.empty_cache()
+    out["wall_s_incl_build"] = round(time.time() - t_all, 1)
+    return out
 
 
 def main():
+    global torch
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -309,16 +454,23 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each; the median block is reported (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other BASELINE configurations (N = 1 line)")
+    ap.add_argument("--also-steps", type=int, default=10)
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=25.0)
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (RCCL group of one rank) on one GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))              # BEFORE anything imports torch.cuda state: the parent stays off the GPU
+
+    import torch as _torch
+    torch = _torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        sys.exit(f"--gpus {args.gpus} inside a launcher of WORLD_SIZE={world}: the two must agree")
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
@@ -328,22 +480,10 @@ def main():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
                                 device_id=torch.device("cuda", local))
 
-    from resunet_a_mltsk_keras_amd import _lib as L
-    from resunet_a_mltsk_keras_amd.engine import Engine, LossSpec, ModelConfig
-    from resunet_a_mltsk_keras_amd.synthetic import make_batch
-
     patch, ch, ncls, mt, bs, gflop_patch = WORKLOADS[args.workload]
-    B = args.batch or bs
-    depth = DEPTH.get(args.workload, 6)
-    eng = Engine(ModelConfig(input_shape=(patch, patch, ch), num_classes=ncls, multitasking=mt, depth=depth), dtype=args.dtype, seed=0)
-    heads = ["seg", "bound", "dist", "color"]
-    eng.compile(LossSpec(kind={h: L.LOSS_TANIMOTO for h in heads}, weight={h: 1.0 for h in heads}, optimizer="adam", lr=1e-3))
+    eng, x, y, B, depth = build_engine(args.workload, args.dtype, args.batch, rank, world, args)
     if os.environ.get("RUA_LANES"):                             # experiment: ResBlock branches on parallel graph branches
         eng.use_lanes = True
-    if world > 1 or args.force_dp:
-        from resunet_a_mltsk_keras_amd.dist import DataParallel
-        DataParallel(eng, bucket_mb=args.bucket_mb, overlap=not args.no_overlap)
-    x, y = make_batch(B, patch, ch, ncls, mt, seed=1234 + rank)
     t_build = time.time()
     eng.train_step(x, y, fetch=False)                           # builds the plan, uploads the resident batch
     torch.cuda.synchronize()
@@ -389,7 +529,7 @@ def main():
                   else f"training patches/sec ({patch}x{patch}, {ch}-ch, bs={B}/GPU)",
         "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic", "timed_blocks": len(block_dt),
+        "dtype": args.dtype, "data": "synthetic", "h2d": "excluded, batch resident", "timed_blocks": len(block_dt),
         "block_ms_per_step": [round(1e3 * d / args.steps, 3) for d in block_dt],
         "config": {"workload": f"{args.workload}: ResUnet-a d{depth} {'multitask (seg+bound+dist+color) Tanimoto-dual' if mt else 'single-task seg Tanimoto-dual'}, "
                                f"{patch}x{patch}x{ch}, {ncls} classes, Adam, full train step (fwd+loss+bwd+allreduce+update)",
@@ -402,45 +542,89 @@ def main():
         peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
         ev_ov = prof.pop("_event_overhead_us")
         blocks = prof.pop("_blocks")
+        entries = prof.pop("_entries")
+        kbytes = prof.pop("_kbytes")
         dom = max((kv for kv in prof.items() if kv[1][2] > 0), key=lambda kv: kv[1][1])   # second launches (no FLOPs) are rows, not candidates
         kn, (n, sec, fl) = dom
+        rp = committed_rocprof_avg(kn, args)
         out["roofline"] = {
             "bound": "mfma", "kernel": kn, "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
             "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
             "achieved": round(fl / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4),
             "traffic": measured_traffic(kn, args), "traffic_unit": "HBM bytes per launch (profiles/traffic.json: rocprofv3 PMC)",
+            "clock": "HIP events on the launch stream around every launch, calibrated bracket overhead subtracted",
             "event_pair_overhead_us_subtracted": round(ev_ov, 2),
-            "rocprof_avg_us_committed_profile": committed_rocprof_avg(kn, args),
+            "rocprof_avg_us_committed_profile": rp,
+            # the same fraction on the committed profile's clock (rocprofv3 --kernel-trace --stats average of this kernel)
+            "frac_rocprof_clock": round(fl / n / (rp * 1e-6) / 1e12 / peak, 4) if rp else None,
             "all_mfma_kernels": {k: {"launches": v[0], "ms_per_step": round(1e3 * v[1], 3), "tflops": round(v[2] / v[1] / 1e12, 2)}
                                  for k, v in sorted(prof.items())},
             "whole_step_frac_of_peak": round(value / world * gflop_patch / 1e3 / peak, 4),
         }
+        # the largest row of the step REGARDLESS of FLOPs: every C-ABI entry timed the same way (an HBM-bound entry is priced
+        # against the HBM roof with its algorithmic bytes = the tensors its descriptor names, each once)
+        rows = {k: (v[0], v[1], kbytes.get(k, 0.0), v[2]) for k, v in prof.items()}           # the convolution kernels, per instantiation
+        rows.update({k: tuple(v) for k, v in entries.items() if not k.startswith("rua_conv")})  # + every other C-ABI entry
+        en, (eln, esec, ebytes, efl) = max(rows.items(), key=lambda kv: kv[1][1])
+        out["roofline"]["dominant_any"] = {
+            "entry": en, "launches_per_step": eln, "ms_per_step": round(1e3 * esec, 3), "avg_launch_us": round(1e6 * esec / eln, 2),
+            "bound": "mfma" if efl > 0 else "hbm",
+            "algorithmic_bytes_per_launch": round(ebytes / eln) if ebytes else None,
+            "achieved_gb_s": round(ebytes / esec / 1e9, 1) if ebytes else None, "hbm_peak_gb_s": HBM_PEAK_GBS,
+            "hbm_frac": round(ebytes / esec / 1e9 / HBM_PEAK_GBS, 4) if ebytes else None,
+            "mfma_frac": round(efl / esec / 1e12 / peak, 4) if efl > 0 else None,
+        }
+        out["roofline"]["all_entries"] = {k: {"launches": v[0], "ms_per_step": round(1e3 * v[1], 3),
+                                              "gb_s": round(v[2] / v[1] / 1e9, 1) if v[2] else None}
+                                          for k, v in sorted(entries.items(), key=lambda kv: -kv[1][1])}
         # north-star sub-metric: the d6 residual atrous block = ResBlock(32,[1,3,15,31]) at full resolution (model2.py:102),
         # its 8 convolutions + BatchNorm passes, forward; and the same for every ResBlock of the network (SURVEY 7 hard-part 2:
         # per-level fractions), forward and backward.  FLOPs: conv (fwd), data + weight gradient (bwd), nothing else counted.
         lv = []
         for key in sorted(k for k in blocks if k.startswith("fwd:") and "ResBlock" in k):
-            sec, fl = blocks[key]
+            sec, fl, by = blocks[key]
             row = {"block": key[4:], "fwd_gflop": round(fl / 1e9, 2), "fwd_us": round(1e6 * sec, 1), "fwd_frac": round(fl / sec / 1e12 / peak, 4)}
             if "bwd:" + key[4:] in blocks:
-                bsec, bfl = blocks["bwd:" + key[4:]]
+                bsec, bfl, _ = blocks["bwd:" + key[4:]]
                 row.update({"bwd_gflop": round(bfl / 1e9, 2), "bwd_us": round(1e6 * bsec, 1), "bwd_frac": round(bfl / bsec / 1e12 / peak, 4)})
             lv.append(row)
         top = next((r for r in lv if r["block"].startswith("enc1:")), None)
         if top is not None:
+            sec, fl, by = blocks["fwd:" + top["block"]]
             out["roofline"]["d6_block"] = {"block": top["block"], "gflop": top["fwd_gflop"], "us": top["fwd_us"], "frac": top["fwd_frac"],
-                                           "target_frac": 0.40, "pass": "forward, batch %d, every launch of the block (BN + 8 convs)" % B}
+                                           "target_frac": 0.40, "pass": "forward, batch %d, every launch of the block (BN + 8 convs)" % B,
+                                           # its real limiter: the tensor passes the training-mode BatchNorm barrier leaves
+                                           "hbm": {"bound": "hbm", "tensor_pass_bytes": round(by), "achieved_gb_s": round(by / sec / 1e9, 1),
+                                                   "peak_gb_s": HBM_PEAK_GBS, "frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                                   "note": "bytes = every tensor each launch of the block reads or writes, once per launch"}}
         out["roofline"]["resblocks"] = lv
         # every other composite of the step (stem, stride-2 convs, PSPPooling, upsample + combine, heads, losses): microseconds only
         comp = {}
-        for key, (sec, fl) in blocks.items():
+        for key, (sec, fl, _) in blocks.items():
             pn, sc = key.split(":", 1)
             if "ResBlock" not in sc:
                 comp.setdefault(sc, {})[pn + "_us"] = round(1e6 * sec, 1)
         out["roofline"]["other_composites"] = comp
-        out["roofline"]["composites_total_us"] = round(1e6 * sum(sec for sec, _ in blocks.values()), 1)
-        if not args.no_cpu_baseline and world == 1:            # the CPU oracle is timed at N=1 only (the other ranks would idle)
+        out["roofline"]["composites_total_us"] = round(1e6 * sum(v[0] for v in blocks.values()), 1)
+    if world == 1 and not args.force_dp and rank == 0:
+        if not args.no_also and args.workload == "cfg3" and args.dtype == "bf16" and not args.batch:
+            # the other BASELINE configurations, short runs on the same GPU right after the headline one
+            del eng, x, y, g0
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            also = {}
+            for name, wl, dt_ in (("cfg3_f32", "cfg3", "f32"), ("cfg2", "cfg2", "bf16"), ("cfg5", "cfg5", "bf16"), ("cfg4", "cfg4", "bf16")):
+                try:
+                    also[name] = also_run(wl, dt_, args.also_steps, args)
+                    log(f"also {name}: {also[name]['ms_per_step']} ms/step, {also[name]['patches_per_s']} patches/s")
+                except Exception as exc:                       # never lose the headline line to an extra
+                    also[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                    log(f"also {name} failed: {also[name]['error']}")
+            out["also"] = also
+        if not args.no_cpu_baseline:                            # the CPU oracle is timed at N=1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -137,6 +137,7 @@ struct ConvGroupCapture {
 extern thread_local ConvGroupCapture* g_conv_group;
 int rua_strip_group_flush(hipStream_t st, int* grids); // conv_strip.hip: issues the conv_strip members captured since the group began (+1 on *grids per launch)
 int rua_strip_group_pending(void);                     // members captured and not yet issued
+void rua_strip_group_reset(void);                      // drops captured members (group entry, error paths)
 // conv_strip.hip
 bool rua_pick_strip(const rua_conv_desc* d);
 int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st);

@@ -1139,7 +1139,7 @@ template <typename T, int BM, int BN> static int launch_conv(const ConvK& k, int
   // zeros back after consuming the sums, so no memset is launched per convolution.
   const int smem_now = conv_smem_base<T, BM, BN>() + ((k.nunits * 16 + 255) / 256) * 256;     // unit table sized to this launch
   if (g_conv_group && (g_tune.conv_group & 2) && k.ksplit == 1 && sizeof(T) == 2 && BM == 256 && BN == 64) {           // the C = 64 level's 3x3 convs
-    if (!g_conv_group->add(3, (unsigned)(nbm * k.nbn), smem_now, k)) return RUA_ERR_ARG;
+    if (!g_conv_group->add(3, (unsigned)(nbm * k.nbn), smem_now, k)) { rua_set_error("rua_conv_fwd_group: more than %d captured members", RUA_MAX_BRANCH); return RUA_ERR_ARG; }
     return RUA_OK;
   }
   hipLaunchKernelGGL((conv_igemm<T, BM, BN>), dim3(nbm * k.nbn * k.ksplit), dim3(256), smem_now, st, k);
@@ -1228,7 +1228,7 @@ template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, 
   }
   constexpr int smem = conv_dmap_smem<BM, BN>();
   if (g_conv_group && (g_tune.conv_group & (BM == 128 ? 4 : 8)) && k.ksplit == 1 && ROWB == 64) {
-    if (!g_conv_group->add(BM == 128 ? 1 : 2, (unsigned)(k.nbm * k.nbn), smem, k)) return RUA_ERR_ARG;
+    if (!g_conv_group->add(BM == 128 ? 1 : 2, (unsigned)(k.nbm * k.nbn), smem, k)) { rua_set_error("rua_conv_fwd_group: more than %d captured members", RUA_MAX_BRANCH); return RUA_ERR_ARG; }
     return RUA_OK;
   }
   hipLaunchKernelGGL((conv_dmap<BM, BN, ROWB>), dim3(k.nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
@@ -1741,11 +1741,12 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
   }
   ConvGroupCapture cap;
   cap.n = 0;
+  rua_strip_group_reset();                                  // nothing stale from a group that failed half-way
   g_conv_group = &cap;
   int rc = RUA_OK;
   for (int i = 0; i < n && rc == RUA_OK; ++i) rc = rua_conv_fwd(d + i, stream);      // non-groupable members launch right here
   g_conv_group = nullptr;
-  if (rc != RUA_OK) return rc;
+  if (rc != RUA_OK) { rua_strip_group_reset(); return rc; }  // captured members are dropped, not issued by the next group
   int grids = n - cap.n - rua_strip_group_pending();        // members no launcher captured were launched one by one above
   rc = rua_strip_group_flush(st, &grids);
   if (rc != RUA_OK) return rc;
@@ -2470,7 +2471,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
     c.post[i] = d->defer ? 0 : 1; c.part[i] = k.scratch; c.dw[i] = d->dw; c.CC[i] = CC; c.parts[i] = gx; c.rblocks[i] = rblocks; c.ndw[i] = 0;
     return RUA_OK;
   }
-  static bool attr32 = false, attr64 = false;
+  static thread_local bool attr32 = false, attr64 = false;
   if (CC == 32) {
     if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr32 = true; }
     hipLaunchKernelGGL((wgrad_taps_kernel<32>), dim3(gx, gy), dim3(768), smem, st, k);

@@ -417,6 +417,7 @@ static int launch_strip_variant(int variant, const StripK* ks, const int* smems,
   }
 }
 int rua_strip_group_pending(void) { return g_strip_cap.n; }
+void rua_strip_group_reset(void) { g_strip_cap.n = 0; }
 int rua_strip_group_flush(hipStream_t st, int* grids) {
   StripCapture& c = g_strip_cap;
   bool done[RUA_MAX_BRANCH] = {false};

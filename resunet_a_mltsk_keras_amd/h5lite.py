@@ -386,6 +386,16 @@ class _Reader:
                     raise H5Error("shared attribute messages")
                 k, v = self.attribute(p)
                 attrs[k] = v
+            elif t == 0x0015:
+                # Attribute Info: libhdf5 moves ALL attributes of an object into dense storage (fractal heap + v2 B-tree) once one
+                # exceeds 64 KiB - the `model_config` JSON of a full ResUnet-a `model.save` can.  Not read here: say so instead
+                # of returning an object that silently has no attributes.
+                aflags = self.d[p + 1]
+                heap = self.u("Q", p + 2 + (2 if aflags & 1 else 0))[0]
+                if heap != 0xFFFFFFFFFFFFFFFF:
+                    raise H5Error("dense attribute storage (an attribute over 64 KiB, e.g. a large model_config): not supported by this "
+                                  "reader - save the weights alone (model.save_weights) or pass load_model(path, input_shape=...) a "
+                                  "weights-only file")
         kinds = {t for t, *_ in msgs}
         if 0x0011 in kinds:
             p = next(p for t, p, *_ in msgs if t == 0x0011)
@@ -429,7 +439,11 @@ def read_h5(path: str) -> Group:
         data = f.read()
     try:
         return _Reader(data).root()
-    except (struct.error, IndexError) as exc:
+    except (struct.error, IndexError, RecursionError, MemoryError, OverflowError, UnicodeDecodeError) as exc:
+        raise H5Error(f"{path}: truncated or malformed HDF5 file ({type(exc).__name__}: {exc})") from None
+    except ValueError as exc:
+        if isinstance(exc, H5Error):
+            raise
         raise H5Error(f"{path}: truncated or malformed HDF5 file ({exc})") from None
 
 
@@ -479,8 +493,11 @@ def keras_weights_from_group(g: Group) -> Dict[str, np.ndarray]:
     return out
 
 
-def keras_group_from_weights(weights: Dict[str, np.ndarray]) -> Group:
-    """The inverse: variables 'layer/var:0' (a ':0' is appended when missing) -> a group in the layout Keras' load_weights reads."""
+def keras_group_from_weights(weights: Dict[str, np.ndarray], layer_order: Optional[List[str]] = None) -> Group:
+    """The inverse: variables 'layer/var:0' (a ':0' is appended when missing) -> a group in the layout Keras' load_weights reads.
+    layer_order: the layers' names in the order of Keras' `model.layers` (keras_graph.weighted_layer_order): Keras' topological
+    `load_weights` zips `layer_names` with the model's weighted layers, so the attribute must list them by graph depth, not by
+    creation; without it the dict's own order is kept (fine for `load_weights(path, by_name=True)`, which matches names)."""
     g = Group()
     order: Dict[str, List[str]] = {}
     for name, a in weights.items():
@@ -488,11 +505,17 @@ def keras_group_from_weights(weights: Dict[str, np.ndarray]) -> Group:
         layer = name.split("/")[0]
         order.setdefault(layer, []).append(name)
         g.require_group(layer).set(name, np.asarray(a, dtype=np.float32))
-    width = max(len(n) for n in order)
-    g.attrs["layer_names"] = np.array([n.encode("utf8") for n in order], dtype=f"S{width}")
+    names = list(order)
+    if layer_order is not None:
+        if sorted(layer_order) != sorted(names):
+            odd = sorted(set(layer_order) ^ set(names))
+            raise H5Error(f"layer_order does not name exactly the layers of the weights (differs at {odd[:4]})")
+        names = list(layer_order)
+    width = max(len(n) for n in names)
+    g.attrs["layer_names"] = np.array([n.encode("utf8") for n in names], dtype=f"S{width}")
     g.attrs["backend"] = b"tensorflow"
     g.attrs["keras_version"] = b"2.4.0"
-    for layer, names in order.items():
-        w = max(len(n) for n in names)
-        g.children[layer].attrs["weight_names"] = np.array([n.encode("utf8") for n in names], dtype=f"S{w}")
+    for layer, wn in order.items():
+        w = max(len(n) for n in wn)
+        g.children[layer].attrs["weight_names"] = np.array([n.encode("utf8") for n in wn], dtype=f"S{w}")
     return g

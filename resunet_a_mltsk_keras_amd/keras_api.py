@@ -321,8 +321,15 @@ class Model:
         root.attrs["keras_version"] = b"2.4.0"
         root.attrs["backend"] = b"tensorflow"
         root.attrs["rua_checkpoint"] = json.dumps(meta).encode("utf8")
-        root.children["model_weights"] = h5lite.keras_group_from_weights(e.get_weights())
+        root.children["model_weights"] = h5lite.keras_group_from_weights(e.get_weights(), self._keras_layer_order())
         h5lite.write_h5(path, root)
+
+    def _keras_layer_order(self):
+        """The weighted layers in the order of Keras' `model.layers` (graph depth, keras_graph.py): what a topological
+        `load_weights` on the TensorFlow side zips the file's `layer_names` with."""
+        from . import keras_graph
+        c = self.cfg
+        return keras_graph.weighted_layer_order(c.input_shape[1], c.multitasking, c.variant, c.depth)
 
     def get_weights_dict(self) -> Dict[str, np.ndarray]:
         return self.engine.get_weights()
@@ -339,7 +346,7 @@ class Model:
             np.savez(path, **{k + ":0": v for k, v in self.engine.get_weights().items()})
             return
         from . import h5lite
-        h5lite.write_h5(path, h5lite.keras_group_from_weights(self.engine.get_weights()))
+        h5lite.write_h5(path, h5lite.keras_group_from_weights(self.engine.get_weights(), self._keras_layer_order()))
 
     def load_weights(self, path):
         if str(path).endswith(".npz"):

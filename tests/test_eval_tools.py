@@ -49,3 +49,23 @@ def test_metrics_match_hand_count():
     assert rec == pytest.approx([50.0, 100.0, 100 * 2 / 3])
     assert prec == pytest.approx([50.0, 75.0, 100.0])
     assert f1[1] == pytest.approx(100 * 2 * 0.75 / 1.75)
+
+
+@pytest.mark.parametrize("run", [0, 1])
+def test_metric_functions_reproduce_the_numbers_the_reference_printed(run):
+    """The only numbers the reference holds for this repository's paths: two confusion matrices of the ISPRS test tile and the
+    accuracy / F1 / recall / precision utils.compute_metrics printed from the same label vectors
+    (/root/reference/infos_training_train_on_batch.txt:77-88, 104-116; utils.py:52-57 = test_ISPRS.py:39-45).  Label vectors
+    with exactly that confusion matrix must give exactly those metrics through this repository's compute_metrics_hw."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_confusion.json")))["runs"][run]
+    cm = np.asarray(gold["confusion"], np.int64)
+    n = cm.shape[0]
+    true = np.repeat(np.repeat(np.arange(n), n), cm.reshape(-1))          # cell (i, j) -> cm[i, j] pixels of class i predicted j
+    pred = np.repeat(np.tile(np.arange(n), n), cm.reshape(-1))
+    from sklearn.metrics import confusion_matrix
+    assert np.array_equal(confusion_matrix(true, pred), cm)
+    acc, f1, rec, prec = ev.compute_metrics_hw(true, pred)
+    assert acc == pytest.approx(gold["accuracy"], rel=1e-12)
+    for got, name in ((f1, "f1score"), (rec, "recall"), (prec, "precision")):
+        assert np.allclose(got, gold[name], rtol=0, atol=1e-6), (name, got, gold[name])     # printed with 8 decimals

@@ -136,3 +136,68 @@ def test_keras_file_configuration_is_read_off_the_variables():
         assert _cfg_from_keras_file(root, shifted, None).input_shape == (64, 64, 6)
         with pytest.raises(ValueError, match="fit neither"):                      # the PSP branch count depends on the input width (model2.py:49-53)
             _cfg_from_keras_file(h.Group(), shifted, (256, 256, 6))
+
+
+# -- Keras' layer order (a topological load_weights on the TensorFlow side zips layer_names with model.layers) ------
+def test_keras_graph_names_equal_the_parameter_store_names_in_creation_order():
+    from resunet_a_mltsk_keras_amd import keras_graph
+    from resunet_a_mltsk_keras_amd.engine import Engine, ModelConfig
+    for shape, mt, variant, depth in (((256, 256, 6), True, "model2", 6), ((128, 128, 7), False, "model2", 6), ((64, 64, 3), True, "model", 6),
+                                      ((512, 512, 6), True, "model2", 7), ((256, 256, 3), False, "model", 6)):
+        ps = Engine.param_layout(ModelConfig(shape, 6, mt, variant, 32, depth))
+        mine = []
+        for e in ps.entries:
+            if e["layer"] not in mine:
+                mine.append(e["layer"])
+        kg = keras_graph.build(shape[1], mt, variant, depth)
+        assert kg.names_in_creation_order(weighted_only=True) == mine, (shape, mt, variant, depth)
+        order = kg.names_in_model_order(weighted_only=True)
+        assert sorted(order) == sorted(mine) and order != mine          # same layers, Keras lists them by depth
+
+
+def test_keras_model_layers_order_of_a_resblock_is_by_depth_then_first_reach():
+    """Hand-derived from functional.py::_map_graph_network on model2.py:15-34 with two branches: depth decreases along a
+    branch, both branches share depths, and inside one depth the layer reached first by the depth-first walk from the Add
+    (inputs in list order [x, branch0, branch1]) comes first."""
+    from resunet_a_mltsk_keras_amd.keras_graph import KerasGraph
+    g = KerasGraph()
+    x = g.add("conv", [g.add("input", [])])
+    outs = [x]
+    for _ in range(2):
+        t = g.add("bn", [x]); t = g.add("act", [t]); t = g.add("conv", [t]); t = g.add("bn", [t]); t = g.add("act", [t]); t = g.add("conv", [t])
+        outs.append(t)
+    g.outputs = {"out": g.add("add", outs)}
+    assert g.names_in_model_order() == [
+        "input_1", "conv2d",
+        "batch_normalization", "batch_normalization_2", "activation", "activation_2", "conv2d_1", "conv2d_3",
+        "batch_normalization_1", "batch_normalization_3", "activation_1", "activation_3", "conv2d_2", "conv2d_4", "add"]
+
+
+def test_exported_layer_names_follow_keras_depth_order_and_round_trip(tmp_path):
+    from resunet_a_mltsk_keras_amd import keras_graph
+    from resunet_a_mltsk_keras_amd.engine import Engine, ModelConfig
+    cfg = ModelConfig((64, 64, 3), 4, True, "model2", 32, 6)
+    ps = Engine.param_layout(cfg)
+    rng = np.random.default_rng(3)                                   # the layout is what is tested: small stand-in arrays under the real names
+    w = {e["name"]: rng.random(3).astype(np.float32) for e in ps.entries}
+    w.update({s_["name"]: rng.random(2).astype(np.float32) for s_ in ps.state})
+    order = keras_graph.weighted_layer_order(64, True, "model2", 6)
+    path = str(tmp_path / "w.h5")
+    h.write_h5(path, h.keras_group_from_weights(w, order))
+    root = h.read_h5(path)
+    names = [n.decode() if isinstance(n, bytes) else str(n) for n in root.attrs["layer_names"]]
+    assert names == order
+    # the four first BatchNorms of the top ResBlock come before any of its convolutions (they share a depth)
+    assert names[:6] == ["conv2d", "batch_normalization", "batch_normalization_2", "batch_normalization_4", "batch_normalization_6", "conv2d_1"]
+    back = h.keras_weights_from_group(root)
+    assert set(back) == {k + ":0" for k in w} and all(np.array_equal(back[k + ":0"], v) for k, v in w.items())
+    with pytest.raises(h.H5Error):
+        h.keras_group_from_weights(w, order[:-1])
+
+
+def test_attribute_over_64k_is_refused_by_name_not_read_as_empty():
+    """tests/golden/dense_attr.h5 (make_dense_attr_h5.py): libhdf5 stores an attribute over 64 KiB only in the new file format;
+    the reader must name what it cannot read instead of returning a root without attributes; garbage raises H5Error too."""
+    with pytest.raises(h.H5Error, match="superblock version|dense attribute"):
+        h.read_h5(os.path.join(GOLD, "dense_attr.h5"))
+    assert h.is_hdf5(os.path.join(GOLD, "dense_attr.h5"))

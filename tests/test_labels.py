@@ -165,3 +165,28 @@ def test_hsv_fixed_point_tables_stay_within_one_unit_of_the_real_formula():
     ref = cv_naive.hsv_float(rgb)
     dh = np.abs(got[..., 0] - ref[..., 0]); dh = np.minimum(dh, 180 - dh)              # hue wraps at 180
     assert dh.max() <= 1.0 and np.abs(got[..., 1] - ref[..., 1]).max() <= 1.0 and np.array_equal(got[..., 2], ref[..., 2])
+
+
+def test_third_party_pins():
+    """labels.py against scipy 1.7 / scikit-image 0.18 run under the container's second interpreter
+    (tests/golden/make_labels_thirdparty.py -> labels_thirdparty.npz; /root/reference/multitasking_utils.py:6-35,
+    preprocess_save_patches_ISPRS.py:223-228): distance transform + min-max exact to float32 rounding, cross dilation bit for
+    bit (3x3 and 5x5 elements), 8-bit HSV within one unit of the quantised real-valued formula (hue on the 180-circle)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "labels_thirdparty.npz"))
+    names = [k[5:] for k in g.files if k.startswith("mask_")]
+    assert len(names) >= 7
+    for n in names:
+        m = g["mask_" + n]
+        d = lb.get_distance_label(np.stack([m, 1 - m], axis=-1).astype(np.float32))
+        assert np.allclose(d[:, :, 0], g["dist_" + n], rtol=0, atol=2e-7), n
+        e = g["edge_" + n]
+        assert np.array_equal(lb.dilate_cross(e, (3, 3)), g["dil3_" + n]), n
+        assert np.array_equal(lb.dilate_cross(e, (5, 5)), g["dil5_" + n]), n
+    got = lb.rgb_to_hsv_u8(g["rgb"]).astype(np.int32)
+    exp = g["hsv_u8"].astype(np.int32)
+    dh = np.abs(got[..., 0] - exp[..., 0])
+    dh = np.minimum(dh, 180 - dh)
+    grey = exp[..., 1] == 0                                        # hue of a grey pixel is a convention (0 in both)
+    assert dh[~grey].max() <= 1 and np.abs(got[..., 1:] - exp[..., 1:]).max() <= 1
+    assert (dh == 0).mean() > 0.8 and (got[..., 2] == exp[..., 2]).all()      # V = max(r, g, b) exactly

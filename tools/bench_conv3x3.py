@@ -1,7 +1,7 @@
-#!/usr/bin/env python
 """Micro-benchmark of the top-level 3x3 convolutions through the C ABI: conv_strip (row streaming) against conv_halo
 (tile by tile) on the shapes of the d6 residual atrous block (8 x 256 x 256 x 32, dilations 1 / 3 / 15 / 31), forward
-(BatchNorm + ReLU on load, statistics) and data gradient (ReLU mask from aux, statistics).  Usage: python tools/bench_conv3x3.py"""
+(BatchNorm + ReLU on load, statistics) and data gradient (ReLU mask from aux, statistics).  Usage: python tools/bench_conv3x3.py   (under rocprofv3: `rocprofv3 ... -- python3 tools/bench_conv3x3.py`, never the
+script itself - an interpreter hop after the profiler initialised the GPU is an exec this pool forbids)"""
 import ctypes as C
 import os
 import sys
