@@ -104,6 +104,15 @@ def entry_bytes(name, args):
             if d.aux_mode:
                 tot += d.N * d.H * d.W * d.Cout * e
         return float(tot)
+    if name == "rua_conv_fwd_sum":                          # n convolutions summed into one output (conv_band32: written once)
+        from resunet_a_mltsk_keras_amd import _lib as L
+        ds = [args[0][i] for i in range(args[1])]
+        e = es(ds[0].dtype)
+        px = ds[0].N * ds[0].H * ds[0].W
+        tot = sum(px * d.seg[0].C * e + d.seg[0].taps * d.seg[0].C * d.Cout * e for d in ds)
+        one = L.lib().raw("rua_conv_sum_last_kernel")() == 1
+        tot += px * ds[0].Cout * e * ((1 if one else 2 * len(ds) - 1) + (1 if ds[0].aux_mode else 0))
+        return float(tot)
     if name in ("rua_conv_wgrad", "rua_conv_wgrad_group"):
         ds = [args[0]._obj] if name == "rua_conv_wgrad" else [args[0][i] for i in range(args[1])]
         return float(sum((d.N * d.Hs * d.Ws * d.C + d.N * d.H * d.W * d.Cout) * es(d.dtype) + d.taps * d.C * d.Cout * 4 for d in ds))
@@ -191,6 +200,15 @@ def profile_kernels(eng, g, dtype):
                     kn = f"{kn.replace('_g<', '<')} ({n} members in {grids} launches)"
                 fl = sum(conv_flops(arr[i]) for i in range(n))
                 rec.append((kn, e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.seg[0].taps * d0.seg[0].C, 0, f"group of {n}"), nl))
+            elif name == "rua_conv_fwd_sum":               # the branches' second convs summed on chip: one launch (conv_band32) or n
+                arr, n = args
+                e0 = mark()
+                rc = fn(*args, sp)
+                e1 = mark()
+                one = lib.raw("rua_conv_sum_last_kernel")() == 1
+                kn, nl = ("conv_band32", 1) if one else (f"conv_strip<{arr[0].Cout}>", n)
+                fl = sum(conv_flops(arr[i]) for i in range(n))
+                rec.append((kn, e0, e1, fl, (arr[0].N * arr[0].H * arr[0].W, arr[0].Cout, n * 9 * arr[0].seg[0].C, 0, f"sum of {n}"), nl))
             elif name == "rua_conv_wgrad_group":          # the branches' weight gradients in one grid (reductions deferred)
                 arr, n = args
                 e0 = mark()
@@ -236,7 +254,7 @@ def profile_kernels(eng, g, dtype):
                 rc = fn(*args, sp)
                 e1 = mark()
                 other.append((name, e0, e1, entry_bytes(name, args)))
-            if name in ("rua_conv_fwd", "rua_conv_wgrad", "rua_conv_fwd_group", "rua_conv_wgrad_group"):
+            if name in ("rua_conv_fwd", "rua_conv_wgrad", "rua_conv_fwd_group", "rua_conv_wgrad_group", "rua_conv_fwd_sum"):
                 other.append((name, e0, e1, entry_bytes(name, args), fl))      # the whole call (incl. a split-K finisher)
                 kbytes[kn] = kbytes.get(kn, 0.0) + (entry_bytes(name, args) or 0.0)
             if rc != 0:
@@ -268,7 +286,7 @@ def profile_kernels(eng, g, dtype):
                 scopes[(pname, sc)][3] += entry_bytes(name, args) or 0.0
             if sc is not None and name in ("rua_conv_fwd", "rua_conv_wgrad"):
                 scopes[(pname, sc)][2] += conv_flops(args[0]._obj) if name == "rua_conv_fwd" else wgrad_flops(args[0]._obj)
-            elif sc is not None and name == "rua_conv_fwd_group":
+            elif sc is not None and name in ("rua_conv_fwd_group", "rua_conv_fwd_sum"):
                 scopes[(pname, sc)][2] += sum(conv_flops(args[0][i]) for i in range(args[1]))
             elif sc is not None and name == "rua_conv_wgrad_group":
                 scopes[(pname, sc)][2] += sum(wgrad_flops(args[0][i]) for i in range(args[1]))
@@ -505,11 +523,13 @@ def main():
     # SURVEY 8d protocol: 10 warm-up steps, then 3 timed blocks of >= 50 steps, each bracketed by barrier + device
     # synchronise on both sides and taken as the MAX over ranks; the MEDIAN block is the reported one.
     block_dt = []
+    host_issue = 0.0                                            # host time spent INSIDE train_step (issue only: nothing in it waits for the GPU)
     for _ in range(max(args.blocks, 1)):
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             eng.train_step(None, None, fetch=False)
+        host_issue += time.perf_counter() - t0
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -535,6 +555,11 @@ def main():
                                f"{patch}x{patch}x{ch}, {ncls} classes, Adam, full train step (fwd+loss+bwd+allreduce+update)",
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss_last_step": round(res[0], 5)},
         "model_tflops_per_s": round(value * gflop_patch / 1e3, 2),
+        # host time per step inside train_step (whole-step HIP graph at N = 1; eager C-ABI launches + bucket hooks under data parallel).
+        # An upper bound of the issue cost: once the HIP queue is full the calls wait for the GPU (back-pressure), nothing else in them does
+        "host_in_train_step_ms_per_step": round(1e3 * host_issue / (args.steps * max(args.blocks, 1)), 3),
+        "step_path": ("hip-graph (whole step)" if (eng.use_graph and eng.dist is None) else
+                      ("hip-graph pieces + eager collectives" if (eng.use_graph and eng.dp_graph) else "eager launches + bucketed all-reduce overlapped with backward")),
     }
     # every rank runs the instrumented pass (its keep-busy steps contain the gradient all-reduces); rank 0 reports
     prof = profile_kernels(eng, eng.graph(B, True), args.dtype)

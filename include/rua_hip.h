@@ -104,6 +104,14 @@ int rua_conv_fwd(const rua_conv_desc* d, void* stream);
  * rua_conv_fwd calls; members that land on the same kernel are issued as ONE grid (no drain / launch gap between the branches) */
 int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream);
 int rua_conv_group_last_grids(void);             /* grids the calling thread's latest rua_conv_fwd_group issued (1: all members in one) */
+/* The n-ary Add of a ResBlock (model2.py:26-31: out = x_input + sum of the branches) with the sum kept ON CHIP: n (<= RUA_MAX_BRANCH)
+ * single-segment convolutions into the SAME output y = aux_0 + sum_i conv_i - the results of n rua_conv_fwd calls of which member 0
+ * writes (accumulate 0, optional residual aux_mode 1) and members i > 0 accumulate (accumulate 1, no aux).  Every member carries its
+ * own normalise-on-load (in_fold, or in_scale / in_shift, + in_relu: the same kind for all members) and bias.  Where the shape allows
+ * (bf16, C = Cout = 32, 3x3, dilation <= 32, W % 128 == 0, H % 8 == 0, >= 65536 pixels, no statistics / output ReLU) this is ONE
+ * launch of conv_band32 that writes y once; otherwise the members are launched one by one (same results). */
+int rua_conv_fwd_sum(const rua_conv_desc* d, int n, void* stream);
+int rua_conv_sum_last_kernel(void);              /* 1: the calling thread's latest rua_conv_fwd_sum ran as one conv_band32 launch */
 int rua_conv_smem_bytes(const rua_conv_desc* d);
 int64_t rua_conv_workspace_bytes(const rua_conv_desc* d);   /* bytes of ONE slab (N*H*W*Cout fp32); split-K uses up to 32 */
 /* profiling only (bench.py): timing events without the system-scope release a default event performs when recorded */

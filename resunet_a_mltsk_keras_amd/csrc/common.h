@@ -80,6 +80,8 @@ struct RuaTuning {
   // grouped launches of a ResBlock's dilation branches, one bit per kernel family (0: every member launches on its own)
   int conv_group = 15;                  // 1 conv_strip, 2 conv_igemm<bf16,256,64>, 4 conv_dmap<128,128>, 8 conv_dmap<64,128>
   int head_fwd2 = 1;                    // heads with Cin = 32: the register-weights kernel (0: the LDS-weights one)
+  int band_dbg = 0;                     // experiments only (tools/bench_conv_band.py): 1 rows from an L2-resident region, 2 no BatchNorm pass
+  int conv_band = 1;                    // rua_conv_fwd_sum: the branches' second convs of a C = 32 ResBlock as ONE launch with the sum kept on chip (conv_band32)
   int wgd_ks_slow = 1;                  // wgrad_dmap block order: K slice slowest (blocks that read the same pixels share an XCD's L2)
   int wgrad_group = 7;                  // 1 wgrad_kernel, 2 wgrad_taps<32>, 4 wgrad_taps<64>, 8 wgrad_dmap (off: three members at once thrash the L2, 27.6 vs 24.6 us each)
 };

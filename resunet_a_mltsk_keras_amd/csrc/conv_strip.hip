@@ -188,10 +188,22 @@ __device__ __forceinline__ void conv_strip32_body(const StripK& q) {
     unsigned char* slot = x_slot(rho);
     // all pieces are read first (one LDS round trip for the row instead of one per piece: piece by piece the dependent
     // read -> arithmetic -> write chains cost ~1000 cycles per row and wave), then normalised, then written back
+    // RAW reads, one wait for the three: in front of a C++ LDS load hipcc waits for the LDS-DMAs issued before it (seen in the ISA
+    // as `s_waitcnt vmcnt(2)` right behind the counted wait: everything but the last stage's two stores, i.e. the whole ring,
+    // drained at every stage with BatchNorm on load); these pieces' own DMAs have landed (counted wait above)
     uint4 raw[NPX];
+    {
+      static_assert(NPX == 3, "the asm block reads three pieces");
+      unsigned pa[NPX];
 #pragma unroll
-    for (int k = 0; k < NPX; ++k)
-      raw[k] = *reinterpret_cast<const uint4*>(xok[k] ? slot + xdst[k] + lane * 16 : sDump + wv * 1024 + lane * 16);
+      for (int k = 0; k < NPX; ++k)
+        pa[k] = (unsigned)(size_t)(lds_void_p)(xok[k] ? slot + xdst[k] + lane * 16 : sDump + wv * 1024 + lane * 16);
+      u32x4_t rw0, rw1, rw2;
+      asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(rw0), "=&v"(rw1), "=&v"(rw2) : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]) : "memory");
+      raw[0] = make_uint4(rw0[0], rw0[1], rw0[2], rw0[3]); raw[1] = make_uint4(rw1[0], rw1[1], rw1[2], rw1[3]);
+      raw[2] = make_uint4(rw2[0], rw2[1], rw2[2], rw2[3]);
+    }
 #pragma unroll
     for (int k = 0; k < NPX; ++k) {
       float f[8];

@@ -612,6 +612,18 @@ class Graph:
         plan.keep.append(arr)
         plan.add("rua_conv_fwd_group", arr, len(descs))
 
+    def conv_sum(self, plan: Plan, descs: List):
+        """Convolutions into ONE output, summed (member 0 writes, the others accumulate): rua_conv_fwd_sum."""
+        if len(descs) == 1:
+            plan.keep.append(descs[0])
+            plan.add("rua_conv_fwd", C.byref(descs[0]))
+            return
+        arr = (L.ConvDesc * len(descs))()
+        for i, dsc in enumerate(descs):
+            C.memmove(C.byref(arr, i * C.sizeof(L.ConvDesc)), C.byref(dsc), C.sizeof(L.ConvDesc))
+        plan.keep.append(arr)
+        plan.add("rua_conv_fwd_sum", arr, len(descs))
+
     def dgrad_desc(self, dy: Ten, wd_ptr, cin: int, dil: int, taps: int, out: Ten, accumulate: int, mask=None, stats2=None,
                    stat_aux=None, out_stride: int = 1):
         d = L.ConvDesc()
@@ -831,9 +843,11 @@ class Graph:
         else:
             coef2, fold2 = self.bn_coefs(F, x, [l[2] for l in lay], st1, cnt), [None] * nb
         out = self.like(x)
-        for bi, (d, l, y, c2, f2) in enumerate(zip(dils, lay, y1, coef2, fold2)):
-            self.conv(F, [(y, 0, d, 9)], [l[3]["segs"][0]], nf, self.P(l[3]["bias"]), out, in_bn=c2, in_fold=f2,
-                      residual=x if (v2 and bi == 0) else None, accumulate=1 if bi > 0 else 0)
+        # out = x + sum of the branches' second convs: ONE call, the sum kept on chip where the library has the kernel for it
+        # (rua_conv_fwd_sum -> conv_band32: out written once); otherwise the members run one by one, member 0 with the residual
+        self.conv_sum(F, [self.conv_desc([(y, 0, d, 9)], [l[3]["segs"][0]], nf, self.P(l[3]["bias"]), out, in_bn=c2, in_fold=f2,
+                                         residual=x if (v2 and bi == 0) else None, accumulate=1 if bi > 0 else 0)
+                          for bi, (d, l, y, c2, f2) in enumerate(zip(dils, lay, y1, coef2, fold2))])
         F.scope = None
         if not tr:
             return out

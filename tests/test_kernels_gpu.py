@@ -1233,3 +1233,119 @@ def test_head_forward_with_loss_moments_equals_the_separate_passes(dt, act, Cout
     torch.cuda.synchronize()
     assert torch.equal(s2, s1) or np.allclose(s2.cpu().numpy(), s1.cpu().numpy(), rtol=1e-6, atol=1e-4)
     assert lib.raw("rua_head_fwd_loss")(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, p1.data_ptr(), y.data_ptr(), None, None, B, HW, Cin, Cout, act, dt, None) != 0
+
+
+BAND_CASES = [
+    # N, H, W, dilations, normalise-on-load kind, residual
+    (2, 256, 256, [1, 3, 15, 31], "fold", True),      # the d6 residual atrous block's second convs (8-wave blocks, 256-pixel strips)
+    (1, 256, 256, [1, 3, 15, 31], "scale", True),     # evaluation mode: coefficients given
+    (4, 128, 128, [1, 3, 15, 31], "fold", True),      # cfg5's rows: 4-wave blocks
+    (1, 512, 512, [1, 3, 15, 31], "fold", False),     # two strips per row (the halo columns are real data), no residual (model.py graph)
+    (1, 256, 256, [31, 32], "none", True),            # two members, the largest dilation the halo holds, plain reads
+    (1, 264, 384, [3, 15, 1], "scale", True),         # H, W no powers of two: 33 bands, three 128-pixel strips
+]
+
+
+@pytest.mark.parametrize("N,H,W,dils,kind,res", BAND_CASES)
+def test_conv_sum_band_kernel(N, H, W, dils, kind, res):
+    """rua_conv_fwd_sum -> conv_band32 (model2.py:26-31: out = x_input + sum of the branches' second convolutions, every branch
+    reading relu(BatchNorm(y1_b)) normalised on load): one launch, accumulators of an 8-row band in registers over all branches,
+    the output written once.  Against (a) a float64 evaluation on the bf16-rounded operands (each branch's normalised input rounded
+    to bf16 as it is in LDS, zero padding AFTER the activation) and (b) the same members through separate accumulating launches;
+    folded BatchNorms: published coefficients and moving statistics against the coefficient launch."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(H + W + len(dils) + sum(dils))
+    Cs, nb, M = 32, len(dils), N * H * W
+    xs = [(1.2 * rng.standard_normal((N, H, W, Cs)) + 0.2 * b).astype(np.float32) for b in range(nb)]
+    ws = [(rng.standard_normal((9, Cs, Cs)) / np.sqrt(9 * Cs * nb)).astype(np.float32) for _ in range(nb)]
+    biases = [rng.standard_normal(Cs).astype(np.float32) for _ in range(nb)]
+    aux = rng.standard_normal((N, H, W, Cs)).astype(np.float32)
+    gam = [(0.5 + rng.random(Cs)).astype(np.float32) for _ in range(nb)]
+    bet = [(0.3 * rng.standard_normal(Cs)).astype(np.float32) for _ in range(nb)]
+    xd = [to_dev(a, dt) for a in xs]; wd = [to_dev(a, dt) for a in ws]
+    bd = [torch.from_numpy(a).to(dev()) for a in biases]
+    ad = to_dev(aux, dt)
+    gd = [torch.from_numpy(a).to(dev()) for a in gam]; btd = [torch.from_numpy(a).to(dev()) for a in bet]
+    R = 8
+    stats = []
+    for b in range(nb):
+        st = torch.zeros(R * 2 * Cs, dtype=torch.float64, device=dev())
+        lib.call("rua_col_stats", xd[b].data_ptr(), M, Cs, st.data_ptr(), R, dt, stream())
+        stats.append(st)
+    # the coefficient launch as the reference for the folded path (and the source of in_scale / in_shift for the given-coefficient path)
+    coef_ref, mm_ref, mv_ref = [], [], []
+    for b in range(nb):
+        mm = torch.full((Cs,), 0.25, dtype=torch.float32, device=dev()); mv = torch.full((Cs,), 2.0, dtype=torch.float32, device=dev())
+        co = torch.zeros(4, Cs, dtype=torch.float32, device=dev())
+        q = L.BnFwdDesc()
+        q.x, q.M, q.C, q.dtype, q.nb, q.relu, q.training = None, M, Cs, dt, 1, 1, 1
+        q.stats, q.replicas, q.count, q.bessel_n, q.momentum, q.eps = stats[b].data_ptr(), R, float(M), float(M), 0.99, 1e-3
+        br = q.br[0]
+        br.gamma, br.beta, br.moving_mean, br.moving_var = gd[b].data_ptr(), btd[b].data_ptr(), mm.data_ptr(), mv.data_ptr()
+        br.scale, br.shift, br.mean, br.rstd, br.out = (co[0].data_ptr(), co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), None)
+        lib.call("rua_bn_fwd", C.byref(q), stream())
+        coef_ref.append(co); mm_ref.append(mm); mv_ref.append(mv)
+    torch.cuda.synchronize()
+
+    def run(entry, use_kind):
+        y = torch.full((N, H, W, Cs), 7.0, dtype=torch.bfloat16, device=dev())          # garbage the first member must overwrite
+        arr = (L.ConvDesc * nb)()
+        keep = []
+        pub = []
+        for b in range(nb):
+            d = arr[b]
+            d.nseg = 1
+            s = d.seg[0]
+            s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = xd[b].data_ptr(), wd[b].data_ptr(), Cs, H, W, 0, dils[b], 9
+            d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cs, 1, dt
+            d.y, d.out_stride, d.OH, d.OW, d.bias = y.data_ptr(), 1, H, W, bd[b].data_ptr()
+            d.accumulate = 1 if b > 0 else 0
+            if b == 0 and res:
+                d.aux, d.aux_mode = ad.data_ptr(), 1
+            if use_kind == "fold":
+                mm = torch.full((Cs,), 0.25, dtype=torch.float32, device=dev()); mv = torch.full((Cs,), 2.0, dtype=torch.float32, device=dev())
+                co = torch.zeros(4, Cs, dtype=torch.float32, device=dev())
+                f = L.BnFold()
+                f.stats, f.replicas, f.count, f.bessel_n, f.eps, f.momentum = stats[b].data_ptr(), R, float(M), float(M), 1e-3, 0.99
+                f.gamma, f.beta, f.moving_mean, f.moving_var = gd[b].data_ptr(), btd[b].data_ptr(), mm.data_ptr(), mv.data_ptr()
+                f.scale, f.shift, f.mean, f.rstd = (co[i].data_ptr() for i in range(4))
+                d.in_fold, d.in_relu = C.addressof(f), 1
+                keep.append(f); pub.append((co, mm, mv))
+            elif use_kind == "scale":
+                d.in_scale, d.in_shift, d.in_relu = coef_ref[b][0].data_ptr(), coef_ref[b][1].data_ptr(), 1
+        if entry == "sum":
+            lib.call("rua_conv_fwd_sum", arr, nb, stream())
+            ran = lib.raw("rua_conv_sum_last_kernel")()
+        else:
+            for b in range(nb):
+                lib.call("rua_conv_fwd", C.byref(arr[b]), stream())
+            ran = 0
+        torch.cuda.synchronize()
+        return y.float().cpu().numpy(), ran, pub
+
+    got, ran, pub = run("sum", kind)
+    assert ran == 1                                            # the band kernel, not the member-by-member path
+    sep, _, _ = run("each", kind)
+    exp = rnd(dt, aux).double().numpy() if res else 0.0
+    for b in range(nb):
+        xin = rnd(dt, xs[b])
+        if kind != "none":
+            sc, sh = coef_ref[b][0].cpu(), coef_ref[b][1].cpu()
+            xin = torch.relu(xin * sc + sh).to(torch.bfloat16).float()
+        exp = exp + ref_conv_nhwc(xin, rnd(dt, ws[b]), None, dils[b], 9).numpy() + biases[b].astype(np.float64)
+    assert rel_err(got, exp) < 1e-2, rel_err(got, exp)          # one bf16 rounding of the output (the separate launches round it nb times)
+    assert rel_err(sep, exp) < tol(dt)
+    assert rel_err(got, sep) < tol(dt)
+    if kind == "fold":
+        for b in range(nb):
+            co, mm, mv = pub[b]
+            assert np.allclose(co.cpu().numpy(), coef_ref[b].cpu().numpy(), rtol=2e-6, atol=1e-7)
+            assert np.allclose(mm.cpu().numpy(), mm_ref[b].cpu().numpy(), rtol=1e-6) and np.allclose(mv.cpu().numpy(), mv_ref[b].cpu().numpy(), rtol=1e-6)
+    # with the tuning switch off, or a member the kernel does not take, the members run one by one - same numbers
+    lib.set_tuning(conv_band=0)
+    try:
+        off, ran_off, _ = run("sum", kind)
+    finally:
+        lib.set_tuning(conv_band=1)
+    assert ran_off == 0 and np.array_equal(off, sep)
