@@ -1033,9 +1033,32 @@ extern "C" int rua_cast_to_f32(const void* x, float* y, int64_t elems, int dtype
   if (e != hipSuccess) { rua_set_error("rua_cast_to_f32: %s", hipGetErrorString(e)); return RUA_ERR_LAUNCH; }
   return RUA_OK;
 }
+// zero fill as an ordinary kernel (16-byte stores; head / tail bytes one by one): see rua_fill_zero
+__global__ __launch_bounds__(256) void fill_zero_kernel(unsigned char* p, long long bytes) {
+  const long long head = ((16 - ((size_t)p & 15)) & 15) < bytes ? ((16 - ((size_t)p & 15)) & 15) : bytes;
+  const long long n16 = (bytes - head) / 16;
+  uint4* q = reinterpret_cast<uint4*>(p + head);
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) q[i] = z;
+  if (blockIdx.x == 0) {
+    for (long long i = threadIdx.x; i < head; i += blockDim.x) p[i] = 0;
+    for (long long i = head + n16 * 16 + threadIdx.x; i < bytes; i += blockDim.x) p[i] = 0;
+  }
+}
 extern "C" int rua_fill_zero(void* p, int64_t bytes, void* stream) {
   RUA_CHECK_ARG(p && bytes >= 0, "rua_fill_zero: bad arguments");
   if (bytes == 0) return RUA_OK;
+  if (g_tune.fill_kernel) {
+    // A KERNEL, not hipMemsetAsync: captured into a HIP graph a memset becomes a memset node, and graphs that hold memset nodes,
+    // replayed back to back with only stream-event operations in between, corrupted the piecewise data-parallel step on this stack
+    // (tools/dp_graph_check.py)
+    long long blocks = (bytes / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4 * rua_cu_count()) blocks = 4 * rua_cu_count();
+    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char*)p, (long long)bytes);
+    RUA_LAUNCH_CHECK("rua_fill_zero");
+    return RUA_OK;
+  }
   hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
   if (e != hipSuccess) { rua_set_error("rua_fill_zero: %s", hipGetErrorString(e)); return RUA_ERR_LAUNCH; }
   return RUA_OK;

@@ -1367,6 +1367,7 @@ class Engine:
         # HIP-graph pieces and immune to the graph-launch / stream-event hazard described in _graph_step_dp); RUA_DP_GRAPH=1
         # selects the pieces.
         self.dp_graph = os.environ.get("RUA_DP_GRAPH", "0") == "1"
+        self.dp_fence = os.environ.get("RUA_DP_FENCE", "0") == "1"      # experiments only (tools/dp_graph_check.py): an eager kernel behind every piece replay
         self.scalars_ptr = self.stats_arena.data_ptr()
         self.t = 0
         self.weights_dirty = True
@@ -1639,13 +1640,16 @@ class Engine:
         red.begin()
         for pi, (cap, buckets) in enumerate(pieces):
             cap.replay()
-            # One eager kernel between a graph launch and the event choreography of the collectives.  Measured on this
-            # stack (ROCm 7.0 / torch 2.10): a graph launch followed DIRECTLY by cross-stream event record / wait operations
-            # (what an all-reduce is at the stream level; with one rank it is nothing else) corrupted the step in 40-60 % of
-            # 13-step runs (NaN parameters), with or without bucket overlap and even behind a device synchronise; with an
-            # ordinary kernel launch after every replay: 0 of 20.  The eager data-parallel path and the single-GPU graph
-            # (no collectives between graphs) were never affected.
-            self._dp_fence.zero_()
+            # (History, DESIGN.md section 6: with hipMemsetAsync captured as memset NODES - the statistics-arena fill at the head of the
+            # first piece, the gradient fills of the stride-2 convolutions - these back-to-back piece replays corrupted the step on
+            # some boxes of the pool, deterministically per process and NOT as an ordering problem: a device synchronise between the
+            # replays did not help, an eager kernel launch between them did, and so does what is in place now - rua_fill_zero is an
+            # ordinary kernel, no graph holds a memset node.  tools/dp_graph_check.py reproduces all of it; RUA_DP_FENCE=1 brings the
+            # eager kernel back for experiments.)
+            if self.dp_fence:
+                self._dp_fence.zero_()
+            elif os.environ.get("RUA_DP_SYNC") == "1":          # experiment (tools/dp_graph_check.py): a device synchronise instead
+                torch.cuda.synchronize()
             if pi == 0:
                 # same collective order as the eager path (forward_backward): BN moving statistics first - they are final
                 # once the forward (inside the first piece) has run - then the gradient buckets

@@ -1349,3 +1349,23 @@ def test_conv_sum_band_kernel(N, H, W, dils, kind, res):
     finally:
         lib.set_tuning(conv_band=1)
     assert ran_off == 0 and np.array_equal(off, sep)
+
+
+@pytest.mark.parametrize("offset,nbytes", [(0, 1 << 20), (4, 1000), (3, 37), (16, 16), (8, 5), (0, 3 * (1 << 20) + 7), (1, 15)])
+def test_fill_zero_is_a_kernel_and_exact_at_the_edges(offset, nbytes):
+    """rua_fill_zero runs as an ordinary kernel (tuning key fill_kernel, default 1) so that captured HIP graphs hold no memset nodes
+    (memset nodes corrupted the piecewise data-parallel step on this stack; tools/dp_graph_check.py).  Exactly
+    [p, p + bytes) is cleared for any alignment / length; the bytes around it stay; the hipMemsetAsync path (fill_kernel=0) agrees."""
+    lib = L.lib()
+    assert lib.get_tuning("fill_kernel") == 1
+    for mode in (1, 0):
+        lib.set_tuning(fill_kernel=mode)
+        try:
+            buf = torch.full((offset + nbytes + 64,), 0xAB, dtype=torch.uint8, device=dev())
+            lib.call("rua_fill_zero", buf.data_ptr() + offset, nbytes, stream())
+            torch.cuda.synchronize()
+            h = buf.cpu().numpy()
+            assert (h[offset:offset + nbytes] == 0).all() and (h[:offset] == 0xAB).all() and (h[offset + nbytes:] == 0xAB).all(), mode
+        finally:
+            lib.set_tuning(fill_kernel=1)
+    lib.call("rua_fill_zero", buf.data_ptr(), 0, stream())           # zero bytes: nothing launched, no error

@@ -492,4 +492,4 @@ def test_cfg3_full_size_gradients_fp32_vs_float64_oracle_and_bf16_at_batch8():
     assert np.median(dist) < BF16_GRAD_MEDIAN_B8 and dist.max() < BF16_GRAD_MAX_B8 and np.median(cos) > BF16_GRAD_COS_B8
 
 
-BF16_GRAD_MEDIAN_B8, BF16_GRAD_MAX_B8, BF16_GRAD_COS_B8 = 0.5, 2.0, 0.5      # loose until measured on the GPU (set from the first run)
+BF16_GRAD_MEDIAN_B8, BF16_GRAD_MAX_B8, BF16_GRAD_COS_B8 = 0.10, 0.6, 0.95     # measured: median 0.053 / p90 0.198 / max 0.321 of a tensor's scale, cosine median 0.976 / min 0.906 (batch 1: median 0.17)

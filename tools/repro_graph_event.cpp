@@ -90,6 +90,50 @@ int main(int argc, char** argv) {
       total_bad += variant != 2 ? bad_iters : 0;
     }
   }
-  printf("RESULT %s\n", total_bad ? "event completes before the graph: reproduced" : "not reproduced with this pattern");
+  // ---- second pattern: what the piecewise step really does.  Graph G1 (writers) and graph G2 (its dependent readers) are launched on
+  // the SAME stream; between them only the event choreography of an asynchronous collective: record on A, wait on B, a small kernel
+  // on B (the one-rank all-reduce), and - as in the engine - A does NOT wait for B before launching G2.  Stream order alone must make
+  // G2 see what G1 wrote.
+  hipGraph_t g2; hipGraphExec_t ge2;
+  CK(hipStreamBeginCapture(A, hipStreamCaptureModeThreadLocal));
+  for (int k = 0; k < nk; ++k) hipLaunchKernelGGL(check, dim3(64), dim3(256), 0, A, buf + k * n, n, counter, stale);
+  CK(hipStreamEndCapture(A, &g2));
+  CK(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
+  int total_bad2 = 0;
+  for (int variant = 0; variant < 4; ++variant) {
+    CK(hipMemset(counter, 0, 4)); CK(hipMemset(buf, 0xff, nk * n * 4)); CK(hipMemset(stale, 0, 4));
+    CK(hipDeviceSynchronize());
+    int bad_iters = 0;
+    std::vector<hipEvent_t> evs;
+    for (int it = 0; it < iters; ++it) {
+      hipEvent_t e1, e2;
+      CK(hipEventCreateWithFlags(&e1, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+      evs.push_back(e1); evs.push_back(e2);
+      CK(hipGraphLaunch(ge, A));
+      if (variant == 1 || variant == 3) hipLaunchKernelGGL(trivial, dim3(1), dim3(64), 0, A, dummy);
+      if (variant != 2) {                                    // variant 2: nothing between the two graph launches (control)
+        CK(hipEventRecord(e1, A));
+        CK(hipStreamWaitEvent(B, e1, 0));
+        hipLaunchKernelGGL(trivial, dim3(1), dim3(64), 0, B, dummy);
+        CK(hipEventRecord(e2, B));
+        if (variant == 3) CK(hipStreamWaitEvent(A, e2, 0));
+      }
+      CK(hipGraphLaunch(ge2, A));
+      unsigned h = 0;
+      CK(hipMemcpyAsync(&h, stale, 4, hipMemcpyDeviceToHost, A));
+      CK(hipStreamSynchronize(A));
+      CK(hipStreamSynchronize(B));
+      bad_iters += h != 0;
+      if (h) CK(hipMemset(stale, 0, 4));
+      if ((it & 255) == 255) { for (hipEvent_t e : evs) CK(hipEventDestroy(e)); evs.clear(); }
+    }
+    for (hipEvent_t e : evs) CK(hipEventDestroy(e));
+    static const char* names2[4] = {"G1, events, G2", "G1, kernel, events, G2", "G1, G2 (control)", "G1, kernel, events, wait back, G2"};
+    printf("graph -> graph  %-36s stale iterations: %d of %d\n", names2[variant], bad_iters, iters);
+    fflush(stdout);
+    total_bad2 += bad_iters;
+  }
+  printf("RESULT %s ; %s\n", total_bad ? "event completes before the graph: reproduced" : "event after graph: not reproduced",
+         total_bad2 ? "dependent graph runs ahead of its predecessor: reproduced" : "graph -> graph order: not reproduced");
   return 0;
 }
