@@ -358,7 +358,8 @@ extern "C" int rua_bn_bwd_apply(int nb, const void* const* g, const float* const
 // Fused BatchNorm: statistics -> coefficients in the prologue of every block (no separate finalize launch);
 // block 0 also publishes the coefficients for later kernels (ReLU masks of data-gradient epilogues, backward) and
 // updates the moving statistics / parameter gradients.
-template <typename T>
+// NB > 0: the branch count, coefficients in registers (needs 256 % CG == 0); NB == 0: any shape, coefficients read from the LDS table
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, long long pieces, int CG) {
   constexpr int VEC = ET<T>::VEC;
   extern __shared__ float tab[];                       // [nb][2][C] scale/shift, then [2][C] mean/rstd
@@ -405,18 +406,48 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, lo
   if (p.br[0].out == nullptr) return;                  // coefficients only
   const unsigned char* x = (const unsigned char*)p.x;
   const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += stride) {
-    const int c = (int)(i % CG) * VEC;
-    float xv[VEC];
-    ET<T>::unpack(ldg16(x + i * 16), xv);
-    for (int b = 0; b < p.nb; ++b) {
-      float o[VEC];
+  if constexpr (NB > 0) {
+    // 256 % CG == 0 (the launcher checked): a thread stays on ONE channel group for the whole sweep, so its coefficients live in
+    // registers - the per-piece reads of the LDS table (8 consecutive floats per lane, lanes on different groups: the 0.65 LDS
+    // bank-conflict share of the round-2 profile) are gone from the loop
+    const int c = (int)(threadIdx.x % CG) * VEC;
+    float sc[NB][VEC], sh[NB][VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        o[j] = fmaf(tab[(b * 2) * C + c + j], xv[j], tab[(b * 2 + 1) * C + c + j]);
-        if (p.relu) o[j] = fmaxf(o[j], 0.f);
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { sc[b][j] = tab[(b * 2) * C + c + j]; sh[b][j] = tab[(b * 2 + 1) * C + c + j]; }
+    unsigned char* outs[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) outs[b] = (unsigned char*)p.br[b].out;
+    const bool relu = p.relu != 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += stride) {
+      float xv[VEC];
+      ET<T>::unpack(ldg16(x + i * 16), xv);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          o[j] = fmaf(sc[b][j], xv[j], sh[b][j]);
+          if (relu) o[j] = fmaxf(o[j], 0.f);
+        }
+        stg16(outs[b] + i * 16, ET<T>::pack(o));
       }
-      stg16((unsigned char*)p.br[b].out + i * 16, ET<T>::pack(o));
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += stride) {
+      const int c = (int)(i % CG) * VEC;
+      float xv[VEC];
+      ET<T>::unpack(ldg16(x + i * 16), xv);
+      for (int b = 0; b < p.nb; ++b) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          o[j] = fmaf(tab[(b * 2) * C + c + j], xv[j], tab[(b * 2 + 1) * C + c + j]);
+          if (p.relu) o[j] = fmaxf(o[j], 0.f);
+        }
+        stg16((unsigned char*)p.br[b].out + i * 16, ET<T>::pack(o));
+      }
     }
   }
 }
@@ -445,15 +476,23 @@ extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream) {
   if ((long long)d->replicas * d->C >= 512 && g > cap) g = cap;      // the prologue re-reads replicas*C*2 doubles per block
   if (coef_only) g = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == RUA_BF16) hipLaunchKernelGGL((bn_fwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, *d, pieces, CG);
-  else hipLaunchKernelGGL((bn_fwd_kernel<float>), dim3(g), dim3(256), smem, st, *d, pieces, CG);
+  const int nbk = (!coef_only && CG <= 256 && 256 % CG == 0 && g_tune.bn_regs) ? d->nb : 0;
+#define RUA_BN_FWD_GO(T_, NB_) hipLaunchKernelGGL((bn_fwd_kernel<T_, NB_>), dim3(g), dim3(256), smem, st, *d, pieces, CG)
+  if (d->dtype == RUA_BF16) {
+    switch (nbk) { case 1: RUA_BN_FWD_GO(bf16_t, 1); break; case 2: RUA_BN_FWD_GO(bf16_t, 2); break; case 3: RUA_BN_FWD_GO(bf16_t, 3); break;
+                   case 4: RUA_BN_FWD_GO(bf16_t, 4); break; default: RUA_BN_FWD_GO(bf16_t, 0); }
+  } else {
+    switch (nbk) { case 1: RUA_BN_FWD_GO(float, 1); break; case 2: RUA_BN_FWD_GO(float, 2); break; case 3: RUA_BN_FWD_GO(float, 3); break;
+                   case 4: RUA_BN_FWD_GO(float, 4); break; default: RUA_BN_FWD_GO(float, 0); }
+  }
+#undef RUA_BN_FWD_GO
   RUA_LAUNCH_CHECK("rua_bn_fwd");
   return RUA_OK;
 }
 
 // (Measured and rejected, same-box A/B: issuing the sweep's first loads before the coefficient prologue and double-buffering the
 // sweep in registers - 9.70 vs 9.68 ms per step; the blocks of one launch already overlap each other's prologue.)
-template <typename T>
+template <typename T, int NB, bool MASKED>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, long long pieces, int CG) {
   constexpr int VEC = ET<T>::VEC;
   extern __shared__ float tab[];                       // [nb][3][C] : A, ms, mt ; then [2][C] : sumB, sumC
@@ -489,6 +528,62 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, lo
   float sk[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) sk[j] = 0.f;
+  if constexpr (NB > 0) {
+    // coefficients of this thread's channel group in registers for the whole sweep (see bn_fwd_kernel): no LDS reads in the loop
+    const int c = (int)(threadIdx.x % CG) * VEC;
+    float cA[NB][VEC], cS[MASKED ? NB : 1][VEC], cT[MASKED ? NB : 1][VEC], cB[VEC], cC[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { cB[j] = tB[c + j]; cC[j] = tB[C + c + j]; }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        cA[b][j] = tab[(b * 3) * C + c + j];
+        if constexpr (MASKED) { cS[b][j] = tab[(b * 3 + 1) * C + c + j]; cT[b][j] = tab[(b * 3 + 2) * C + c + j]; }
+      }
+    const unsigned char* gp[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) gp[b] = (const unsigned char*)p.br[b].g;
+    const bool accum = p.accumulate != 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += stride) {
+      // every load of the piece is issued before the first use
+      const uint4 xr = ldg16(x + i * 16);
+      uint4 gr[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) gr[b] = ldg16(gp[b] + i * 16);
+      uint4 dr = make_uint4(0, 0, 0, 0), ar = make_uint4(0, 0, 0, 0);
+      if (dskip) dr = ldg16(dskip + i * 16);
+      if (accum) ar = ldg16(dx + i * 16);
+      float xv[VEC], acc[VEC];
+      ET<T>::unpack(xr, xv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(cB[j], xv[j], cC[j]);
+      if (dskip) {
+        float dd[VEC];
+        ET<T>::unpack(dr, dd);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { acc[j] += dd[j]; sk[j] += dd[j]; }
+      }
+      if (accum) {
+        float dd[VEC];
+        ET<T>::unpack(ar, dd);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += dd[j];
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float gv[VEC];
+        ET<T>::unpack(gr[b], gv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          bool on = true;
+          if constexpr (MASKED) on = fmaf(cS[b][j], xv[j], cT[b][j]) > 0.f;
+          acc[j] = fmaf(cA[b][j], on ? gv[j] : 0.f, acc[j]);
+        }
+      }
+      stg16(dx + i * 16, ET<T>::pack(acc));
+    }
+  } else {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += stride) {
     const int c = (int)(i % CG) * VEC;
     float xv[VEC], acc[VEC];
@@ -517,6 +612,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, lo
       }
     }
     stg16(dx + i * 16, ET<T>::pack(acc));
+  }
   }
   if (p.skip_stats && dskip) {                           // uniform: fold the block's partial sums through LDS, one fp64 add per channel
     __syncthreads();                                     // the coefficient table is dead
@@ -560,8 +656,18 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
   const int cap = cap_env > 0 ? cap_env : (pieces >= (1ll << 20) ? 4 : 2) * rua_cu_count();      // 1024 / 512 on MI355X
   if ((long long)rmax * d->C * d->nb >= 512 && g > cap) g = cap;
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == RUA_BF16) hipLaunchKernelGGL((bn_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, *d, pieces, CG);
-  else hipLaunchKernelGGL((bn_bwd_kernel<float>), dim3(g), dim3(256), smem, st, *d, pieces, CG);
+  const int nbk = (CG <= 256 && 256 % CG == 0 && g_tune.bn_regs) ? d->nb : 0;
+  const bool mk = d->masked != 0;
+#define RUA_BN_BWD_GO(T_, NB_, MK_) hipLaunchKernelGGL((bn_bwd_kernel<T_, NB_, MK_>), dim3(g), dim3(256), smem, st, *d, pieces, CG)
+#define RUA_BN_BWD_SW(T_) switch (nbk * 2 + (mk ? 1 : 0)) { \
+    case 2: RUA_BN_BWD_GO(T_, 1, false); break; case 3: RUA_BN_BWD_GO(T_, 1, true); break; \
+    case 4: RUA_BN_BWD_GO(T_, 2, false); break; case 5: RUA_BN_BWD_GO(T_, 2, true); break; \
+    case 6: RUA_BN_BWD_GO(T_, 3, false); break; case 7: RUA_BN_BWD_GO(T_, 3, true); break; \
+    case 8: RUA_BN_BWD_GO(T_, 4, false); break; case 9: RUA_BN_BWD_GO(T_, 4, true); break; \
+    default: RUA_BN_BWD_GO(T_, 0, false); }
+  if (d->dtype == RUA_BF16) { RUA_BN_BWD_SW(bf16_t) } else { RUA_BN_BWD_SW(float) }
+#undef RUA_BN_BWD_SW
+#undef RUA_BN_BWD_GO
   RUA_LAUNCH_CHECK("rua_bn_bwd");
   return RUA_OK;
 }
