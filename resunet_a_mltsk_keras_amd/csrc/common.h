@@ -76,7 +76,7 @@ struct RuaTuning {
                                                               grouped conv_igemm grid the d = 1 branch costs less: +0.35 % on the step */, conv_dmap = 1, dmap_target = 0, dmap_fused_finish = 0, dmap_rowb = 64, dmap_bm64 = 1;
   int wgrad_pw = 1, wgpw_blocks = 0, wgpw_r = 0, wgd_blocks = 0, wgrad_dmap = 1, wgd_mintiles = 10 /* 9 took the 64x64x128 level too: a wash alone, -0.55 % in the step since its K slabs (28 x 0.6 MB) */, wgrad_blocks = 0;
   int bn_grid = 0, tani_vec = 1, metrics_blocks = 0, stem_blocks = 0, head_blocks = 0;
-  int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0;
+  int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0, strip_group_share = 1;
   // grouped launches of a ResBlock's dilation branches, one bit per kernel family (0: every member launches on its own)
   int conv_group = 15;                  // 1 conv_strip, 2 conv_igemm<bf16,256,64>, 4 conv_dmap<128,128>, 8 conv_dmap<64,128>
   int head_fwd2 = 1;                    // heads with Cin = 32: the register-weights kernel (0: the LDS-weights one)
@@ -131,6 +131,7 @@ struct ConvKG { ConvK k[RUA_MAX_BRANCH]; };           // members of a grouped la
 static_assert(sizeof(ConvKG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 // capture mode of the launchers (rua_conv_fwd_group): a groupable launch is recorded instead of issued
 struct ConvGroupCapture {
+  int members;   // convolutions in the group being captured (launchers that size their grid by the CU count share the chip)
   int n; int kind[RUA_MAX_BRANCH]; unsigned grid[RUA_MAX_BRANCH]; int smem[RUA_MAX_BRANCH]; ConvK k[RUA_MAX_BRANCH];
   bool add(int kd, unsigned g, int sm, const ConvK& kk) {
     if (n >= RUA_MAX_BRANCH) return false;

@@ -1741,6 +1741,7 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
   }
   ConvGroupCapture cap;
   cap.n = 0;
+  cap.members = n;
   rua_strip_group_reset();                                  // nothing stale from a group that failed half-way
   g_conv_group = &cap;
   int rc = RUA_OK;

@@ -142,6 +142,9 @@ __device__ __forceinline__ void conv_strip32_body(const StripK& q) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(sc8[j]), "+v"(sh8[j]));
   __syncthreads();                                      // tab
+  float bias16[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) bias16[k] = tab[(k & 3) + 8 * (k >> 2) + 4 * kh];
 
   unsigned xrel[NPX]; int xdst[NPX]; bool xok[NPX];
 #pragma unroll
@@ -208,14 +211,17 @@ __device__ __forceinline__ void conv_strip32_body(const StripK& q) {
     for (int k = 0; k < NPX; ++k) {
       float f[8];
       ET<T>::unpack(raw[k], f);
-      if (p.in_relu) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(sc8[j], f[j], sh8[j]), 0.f);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = fmaf(sc8[j], f[j], sh8[j]);
-      }
+      for (int j = 0; j < 8; ++j) f[j] = fmaf(sc8[j], f[j], sh8[j]);
       raw[k] = ET<T>::pack(f);
+      if (p.in_relu) {
+        // ReLU on the packed pairs (the kernel is bound by vector issue, not by HBM): a negative bf16 is a negative int16, max with 0
+        // clears it - one v_pk_max_i16 per pair instead of two v_max_f32; relu(round(x)) == round(relu(x))
+        typedef __attribute__((ext_vector_type(2))) short s16x2;
+        const s16x2 z = {0, 0};
+        auto relu2 = [&](unsigned v) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z)); };
+        raw[k].x = relu2(raw[k].x); raw[k].y = relu2(raw[k].y); raw[k].z = relu2(raw[k].z); raw[k].w = relu2(raw[k].w);
+      }
     }
 #pragma unroll
     for (int k = 0; k < NPX; ++k)
@@ -263,9 +269,11 @@ __device__ __forceinline__ void conv_strip32_body(const StripK& q) {
     issue_x(i + R - 2);                                  // into the slot of row i - 2
     issue_ep(i + RA - 1);                                // into the slot of epilogue row i - 1
 
+    // the accumulator starts at the bias of its channels (acc[k]: channel (k & 3) + 8 * (k >> 2) + 4 * kh): the 16 adds of the
+    // epilogue and their LDS table reads are gone
     f32x16 acc;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 16; ++k) acc[k] = bias16[k];
     // the six fragments of window row ty + 1 are read while the six MFMAs of row ty execute (left alone, hipcc reads one
     // fragment, waits for it, issues one MFMA: the LDS latency 18 times per stage)
     bf16x8 fx[2][3][2];
@@ -307,8 +315,6 @@ __device__ __forceinline__ void conv_strip32_body(const StripK& q) {
     for (int g = 0; g < 2; ++g) {
       const int co = 16 * g + 8 * kh;
       float a8[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[g][j] += tab[co + j];
       if constexpr (HAS_EP) {
         ET<T>::unpack(*reinterpret_cast<const uint4*>(erow + eoff[g]), a8);
         if (p.aux_mode == 0) {                            // the stream is the old output: accumulate
@@ -463,7 +469,11 @@ int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st
   RUA_CHECK_ARG(q.slot_bytes <= 3 * nw * 1024, "conv_strip: dilation %d too large for a %d-pixel strip", dil, sw);
   q.nchains = d->N * q.strips * dil;
   const int ny = (d->H + dil - 1) / dil;               // lattice rows of the longest chain
-  int spc = rua_cu_count() / q.nchains;                // one round of blocks where the chains allow it
+  // one round of blocks where the chains allow it; the members of a grouped launch share that round (tuning key strip_group_share:
+  // four members of 256 blocks each ran four blocks per CU back to back, every one with its own prologue, window fill and
+  // statistics fold - longer segments amortise them)
+  const int share = (g_conv_group && (g_tune.conv_group & 1) && g_tune.strip_group_share) ? g_conv_group->members : 1;
+  int spc = rua_cu_count() / (q.nchains * share);
   if (spc < 1) spc = 1;
   if (spc > (ny + 3) / 4) spc = (ny + 3) / 4;          // >= 4 rows per segment (a segment re-reads two window rows)
   if (spc < 1) spc = 1;
