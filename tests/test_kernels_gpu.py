@@ -1000,7 +1000,10 @@ def test_conv_group_equals_separate_launches(shape):
     torch.cuda.synchronize()
     for i in range(len(dils)):
         assert torch.equal(keep[4 * i + 2], sep[i][0]), (i, dils[i])
-        assert np.allclose(keep[4 * i + 3].cpu().numpy().reshape(32, -1).sum(0), sep[i][1].cpu().numpy().reshape(32, -1).sum(0), rtol=1e-9)
+        # (outputs bit-identical; the statistics are fp32 per-lane partial sums over a block's rows folded in fp64: the members of a
+        # grouped conv_strip launch share one round of blocks - longer chain segments than a launch on its own - so the partial sums
+        # are taken over other row sets and differ in their last fp32 bits)
+        assert np.allclose(keep[4 * i + 3].cpu().numpy().reshape(32, -1).sum(0), sep[i][1].cpu().numpy().reshape(32, -1).sum(0), rtol=2e-6)
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 256, 32, [1, 3, 15, 31], True), (4, 128, 128, 64, [1, 3, 15, 31], False), (8, 32, 32, 256, [1, 3, 15], False),
