@@ -154,6 +154,11 @@ typedef struct rua_wgrad_desc {
    * slabs) does NOT launch its reduction; `workspace` must then stay untouched until rua_wgrad_reduce_batch has consumed the
    * record rua_wgrad_plan() returns for this descriptor (one workspace per deferred call; size: rua_wgrad_workspace_bytes). */
   int32_t defer;
+  /* Members of a rua_conv_wgrad_group call: how many weight gradients share the launch (0 / 1: this one alone).  The all-taps
+   * kernel sizes its persistent grid for a share of the chip - one round of blocks for the whole group, 1 / group_members of the
+   * block partials to write and to reduce.  Set it on every member (rua_wgrad_plan must see the same value as the launch). */
+  int32_t group_members;
+  int32_t pad_group;
 } rua_wgrad_desc;
 typedef struct rua_wgrad_pending {
   int32_t kind;                /* 0: nothing to reduce (single writer / wgrad_pw), 1: all-taps partials, 2: K-slice slabs,

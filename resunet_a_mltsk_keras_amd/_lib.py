@@ -36,7 +36,7 @@ class BnFold(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [("a", vp), ("C", i32), ("Hs", i32), ("Ws", i32), ("dy", vp), ("Cout", i32), ("H", i32), ("W", i32),
                 ("N", i32), ("stride", i32), ("dil", i32), ("taps", i32), ("dtype", i32), ("dw", vp), ("workspace", vp), ("workspace_bytes", i64),
-                ("in_scale", vp), ("in_shift", vp), ("in_relu", i32), ("defer", i32)]
+                ("in_scale", vp), ("in_shift", vp), ("in_relu", i32), ("defer", i32), ("group_members", i32), ("pad_group", i32)]
 
 
 class WgradPending(C.Structure):

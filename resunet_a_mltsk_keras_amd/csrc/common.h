@@ -80,6 +80,7 @@ struct RuaTuning {
   // grouped launches of a ResBlock's dilation branches, one bit per kernel family (0: every member launches on its own)
   int conv_group = 15;                  // 1 conv_strip, 2 conv_igemm<bf16,256,64>, 4 conv_dmap<128,128>, 8 conv_dmap<64,128>
   int head_fwd2 = 1;                    // heads with Cin = 32: the register-weights kernel (0: the LDS-weights one)
+  int wgrad_taps_share = 1;             // all-taps weight gradients of a group share one round of blocks (rua_wgrad_desc.group_members)
   int bn_regs = 1;                      // BatchNorm sweeps with the thread's coefficients in registers (0: read from the LDS table per piece)
   int fill_kernel = 1;                  // rua_fill_zero as a kernel, not hipMemsetAsync: no memset nodes in captured graphs (0: experiments, tools/dp_graph_check.py)
   int band_dbg = 0;                     // experiments only (tools/bench_conv_band.py): 1 rows from an L2-resident region, 2 no BatchNorm pass

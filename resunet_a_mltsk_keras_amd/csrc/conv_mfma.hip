@@ -2444,7 +2444,10 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   k.NPG = (CC == 32) ? 4 : 2;                          // 12 waves per block either way (3 kernel rows x CC/32 halves per group)
   const int gy = CC / 32;
   const int ncu = rua_cu_count();
-  const int target = (ncu / gy) * k.NPG;               // pixel groups wanted: one block per CU and output-channel half
+  // the members of a grouped launch share ONE round of blocks (four members of 256 blocks each ran four rounds, every block with
+  // its own prologue and 36 - 74 KB of partials to write and to reduce): tuning key wgrad_taps_share
+  const int share = (g_tune.wgrad_taps_share && (g_tune.wgrad_group & (CC == 32 ? 2 : 4)) && d->group_members > 1) ? d->group_members : 1;
+  const int target = (ncu / gy) * k.NPG / share;       // pixel groups wanted: one block per CU and output-channel half
   k.strips = d->W / 64;
   k.nchains = d->N * k.strips * d->dil;
   const int ny = (d->H + d->dil - 1) / d->dil;         // lattice rows of the longest chain
@@ -2455,7 +2458,8 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   k.spc = (ny + k.seglen - 1) / k.seglen;
   k.njobs = k.nchains * k.spc;
   int gx = (k.njobs + k.NPG - 1) / k.NPG;
-  if (gx > ncu / gy) gx = ncu / gy;                    // one block per CU and output-channel half; extra jobs are queued
+  if (gx > ncu / gy / share) gx = ncu / gy / share;    // one block per CU and output-channel half (of this member's share); extra jobs are queued
+  if (gx < 1) gx = 1;
   k.gx = gx;
   k.nworkers = gx * k.NPG;
   k.jpw = (k.njobs + k.nworkers - 1) / k.nworkers;

@@ -643,8 +643,9 @@ class Graph:
         return d
 
     def wgrad_desc(self, plan: Plan, a: Ten, dy: Ten, dw_off: int, stride: int, dil: int, taps: int, in_bn: Optional["Coef"] = None,
-                   may_flush: bool = True):
+                   may_flush: bool = True, group: int = 0):
         d = L.WgradDesc()
+        d.group_members = group                            # members of the rua_conv_wgrad_group call this descriptor belongs to
         d.a, d.C, d.Hs, d.Ws = a.ptr, a.C, a.H, a.W
         if in_bn is not None:                               # a is read as relu(scale * a + shift) (normalise on load)
             d.in_scale, d.in_shift, d.in_relu = in_bn.scale, in_bn.shift, 1
@@ -677,7 +678,7 @@ class Graph:
             for sp in specs:
                 self.wgrad(plan, *sp)
             return
-        descs = [self.wgrad_desc(plan, *sp, may_flush=(i == 0)) for i, sp in enumerate(specs)]
+        descs = [self.wgrad_desc(plan, *sp, may_flush=(i == 0), group=len(specs)) for i, sp in enumerate(specs)]
         arr = (L.WgradDesc * len(descs))()
         for i, dsc in enumerate(descs):
             C.memmove(C.byref(arr, i * C.sizeof(L.WgradDesc)), C.byref(dsc), C.sizeof(L.WgradDesc))

@@ -1081,6 +1081,33 @@ def test_wgrad_group_equals_separate_launches(shape):
     for i in range(len(dils)):
         assert torch.equal(keep[3 * i + 2], sep[i]), ("deferred", i, dils[i])
         keep[3 * i + 2].zero_()
+    # group_members: the all-taps members share ONE round of blocks (1 / n of the block partials each, longer chain segments) - same
+    # gradient up to the order the fp32 partial sums are taken in, and the deferred record must name the smaller number of partials
+    for mode in ("own reduction", "deferred"):
+        for d in descs:
+            d.group_members, d.defer = len(descs), (1 if mode == "deferred" else 0)
+        recs = []
+        for d in descs:
+            r = L.WgradPending()
+            lib.call("rua_wgrad_plan", C.byref(d), C.byref(r))
+            recs.append(r)
+        lib.call("rua_conv_wgrad_group", as_array(), len(descs), stream())
+        if mode == "deferred":
+            table = (L.WgradPending * len(recs))()
+            blocks = 0
+            for i, r in enumerate(recs):
+                r.block_begin = blocks
+                blocks += r.blocks
+                C.memmove(C.byref(table, i * C.sizeof(L.WgradPending)), C.byref(r), C.sizeof(L.WgradPending))
+            tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev())
+            lib.call("rua_wgrad_reduce_batch", tdev.data_ptr(), len(recs), blocks, stream())
+        torch.cuda.synchronize()
+        for i in range(len(dils)):
+            got, exp = keep[3 * i + 2].cpu().numpy(), sep[i].cpu().numpy()
+            assert np.abs(got - exp).max() <= 2e-5 * np.abs(exp).max() + 1e-6, (mode, i, dils[i], float(np.abs(got - exp).max()))
+            keep[3 * i + 2].zero_()
+    for d in descs:
+        d.group_members = 0
     # shared workspace: not groupable, still correct
     for d in descs:
         d.defer = 0
