@@ -2881,7 +2881,9 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   const long long tiles = (long long)k.ntc * k.nti * d->taps;
   // K split: every slice adds the whole dW tile with fp32 atomics (~1.3 TB/s chip-wide), so slices x |dW| must stay
   // small: ~512 blocks fill the chip; 2048 blocks meant 33 MB of atomics (~25 us) per launch.
-  const int target = g_tune.wgrad_blocks > 0 ? g_tune.wgrad_blocks : 2 * rua_cu_count();      // 512 on MI355X
+  // (the members of a grouped launch share the ~512 blocks: a third / quarter of the K slices and of their slabs each)
+  const int wshare = (g_tune.wgrad_kernel_share && (g_tune.wgrad_group & 1) && d->group_members > 1 && d->dtype == RUA_BF16) ? d->group_members : 1;
+  const int target = (g_tune.wgrad_blocks > 0 ? g_tune.wgrad_blocks : 2 * rua_cu_count()) / wshare;      // 512 on MI355X
   long long want = target / tiles; if (want < 1) want = 1;
   long long stages = (k.M + 63) / 64;
   if (want > stages) want = stages;
