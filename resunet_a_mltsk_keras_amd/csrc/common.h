@@ -80,6 +80,7 @@ struct RuaTuning {
   // grouped launches of a ResBlock's dilation branches, one bit per kernel family (0: every member launches on its own)
   int conv_group = 15;                  // 1 conv_strip, 2 conv_igemm<bf16,256,64>, 4 conv_dmap<128,128>, 8 conv_dmap<64,128>
   int head_fwd2 = 1;                    // heads with Cin = 32: the register-weights kernel (0: the LDS-weights one)
+  int dmap_group_bm128 = 0;             // grouped conv_dmap members keep 128-row tiles where the group as a whole fills the chip: measured no gain (8.308 vs 8.290 ms per step), off
   int wgrad_kernel_share = 0;           // the same for the K-split weight gradients (wgrad_kernel) of a group: measured SLOWER (8.47 vs 8.28 ms per step: that kernel is not persistent, fewer K slices = fewer blocks to hide latency with), off
   int wgrad_taps_share = 1;             // all-taps weight gradients of a group share one round of blocks (rua_wgrad_desc.group_members)
   int bn_regs = 1;                      // BatchNorm sweeps with the thread's coefficients in registers (0: read from the LDS table per piece)

@@ -1680,7 +1680,10 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     // the unsplit half-chip case (32x32 level: 128 tiles of 128 x 128, 36 stages): 64-row tiles put a block on every CU
     // (measured there: 25.5 / 23.7 / 22.6 us vs 30.1 / 30.0 / 28.6 for d = 1 / d = 15 / plain)
     const int bm64 = g_tune.dmap_bm64;
-    if (bm64 && k.ksplit == 1 && tiles < target && tiles * 2 >= target) {
+    // (the members of a grouped launch fill the chip together: 3 x 128 tiles of 128 x 128 need no 64-row tiles, which stage
+    //  50 % more bytes per FLOP; tuning key dmap_group_bm128)
+    const bool group_fills = g_tune.dmap_group_bm128 && g_conv_group && (g_tune.conv_group & 4) && (long long)g_conv_group->members * tiles >= target;
+    if (bm64 && k.ksplit == 1 && tiles < target && tiles * 2 >= target && !group_fills) {
       k.nbm = (int)((k.M + 63) / 64);
       return launch_conv_dmap<64, 128, 64>(k, st);
     }
