@@ -6,12 +6,12 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 OUT=gpurun_out/r03prof; mkdir -p $OUT profiles/r03
 python3 bench.py > profiles/r03/bench_unprofiled.json 2> $OUT/bench_unprofiled.err || exit 2
 echo "unprofiled bench done"
-python3 bench.py --dtype f32 --steps 20 --warmup 5 --no-cpu-baseline > profiles/r03/bench_f32.json 2> $OUT/bench_f32.err || exit 3
+python3 bench.py --dtype f32 --steps 20 --warmup 5 --no-cpu-baseline --no-also > profiles/r03/bench_f32.json 2> $OUT/bench_f32.err || exit 3
 echo "fp32 bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 3 --blocks 1 --no-cpu-baseline > profiles/r03/bench.json 2> $OUT/bench_trace.err || exit 4
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 3 --blocks 1 --no-cpu-baseline --no-also > profiles/r03/bench.json 2> $OUT/bench_trace.err || exit 4
 cp $(ls $OUT/trace/*/*_kernel_stats.csv | head -1) profiles/r03/kernel_stats.csv || exit 5
 echo "kernel trace done"
-tools/pmc_kernel.sh r03 -- bench.py --steps 2 --warmup 1 --blocks 1 --no-cpu-baseline || exit 6
+tools/pmc_kernel.sh r03 -- bench.py --steps 2 --warmup 1 --blocks 1 --no-cpu-baseline --no-also || exit 6
 python3 tools/pmc_summary.py gpurun_out/pmc_r03 profiles/r03/counters_raw.json > $OUT/pmc_summary.txt || exit 7
 python3 profiles/summarize_r03.py || exit 8
 echo "r03 profile set complete"

@@ -1,10 +1,10 @@
-"""Markdown rows of DESIGN.md's per-kernel table from profiles/r02/counters.json.  usage: python profiles/design_table.py [min_ms]"""
+"""Markdown rows of DESIGN.md's per-kernel table from profiles/<round>/counters.json.  usage: python profiles/design_table.py [min_ms] [round, default r03]"""
 import json
 import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-c = json.load(open(os.path.join(HERE, "r02", "counters.json")))
+c = json.load(open(os.path.join(HERE, sys.argv[2] if len(sys.argv) > 2 else "r03", "counters.json")))
 min_ms = float(sys.argv[1]) if len(sys.argv) > 1 else 0.13
 print("| kernel | launches/step | avg µs | ms/step | wait | stall | mfma | LDS conflicts | HBM MB rd / wr |")
 print("|---|---:|---:|---:|---:|---:|---:|---:|---|")

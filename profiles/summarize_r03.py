@@ -12,10 +12,32 @@ CXXFILT = next((c for c in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "/usr/bin/llv
 
 
 def short(nm):
-    if nm.startswith("_Z"):
-        nm = subprocess.run([CXXFILT, nm.replace(".kd", "").replace("DF16b", "u6__bf16")], capture_output=True, text=True).stdout.strip() or nm
-    nm = re.sub(r"^void\s+", "", nm)
-    return re.sub(r"\(.*$", "", nm).replace("__bf16", "bf16").replace(" ", "").replace(".kd", "")
+    """Kernel name as the sources spell it.  Our kernel templates take only types (bf16 / float), ints and bools, so the Itanium
+    mangling is decoded by hand (llvm-cxxfilt of ROCm 7.2 garbles `DF16b` followed by integer arguments)."""
+    nm = nm.replace(".kd", "")
+    m = re.match(r"^_Z(\d+)", nm)
+    if not m:
+        nm = nm.replace("bool _Accum, int, E", "bf16,1")          # rocprofv3's own demangler on <__bf16, 1, ...> (DF16b Li1E)
+        nm = re.sub(r"^void\s+", "", nm)
+        return re.sub(r"\(.*$", "", nm).replace("__bf16", "bf16").replace(" ", "")
+    n = int(m.group(1))
+    base, rest = nm[m.end():m.end() + n], nm[m.end() + n:]
+    if not rest.startswith("I"):
+        return base
+    args, i = [], 1
+    while i < len(rest) and rest[i] != "E":
+        if rest.startswith("DF16b", i):
+            args.append("bf16"); i += 5
+        elif rest[i] == "f":
+            args.append("float"); i += 1
+        elif rest.startswith("Lb", i):
+            args.append("true" if rest[i + 2] == "1" else "false"); i += 4
+        elif rest.startswith("Li", i):
+            j = rest.index("E", i)
+            args.append(rest[i + 2:j].replace("n", "-")); i = j + 1
+        else:
+            return subprocess.run([CXXFILT, nm], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "") or nm
+    return base + "<" + ",".join(args) + ">"
 
 
 raw = json.load(open(os.path.join(HERE, "r03", "counters_raw.json")))
