@@ -111,7 +111,9 @@ int rua_conv_group_last_grids(void);             /* grids the calling thread's l
  * (bf16, C = Cout = 32, 3x3, dilation <= 32, W % 128 == 0, H % 8 == 0, >= 65536 pixels, no statistics / output ReLU) this is ONE
  * launch of conv_band32 that writes y once; otherwise the members are launched one by one (same results). */
 int rua_conv_fwd_sum(const rua_conv_desc* d, int n, void* stream);
-int rua_conv_sum_last_kernel(void);              /* 1: the calling thread's latest rua_conv_fwd_sum ran as one conv_band32 launch */
+int rua_conv_sum_last_kernel(void);              /* the calling thread's latest rua_conv_fwd_sum: 1 one conv_band32 launch, 2 one conv_band64 launch (C = Cout = 64,
+                                                    W % 128 == 0, H % 4 == 0), 0 member by member */
+int rua_conv_sum_kernel(const rua_conv_desc* d, int n);   /* the same answer for a set of members, without launching anything */
 int rua_conv_smem_bytes(const rua_conv_desc* d);
 int64_t rua_conv_workspace_bytes(const rua_conv_desc* d);   /* bytes of ONE slab (N*H*W*Cout fp32); split-K uses up to 32 */
 /* profiling only (bench.py): timing events without the system-scope release a default event performs when recorded */

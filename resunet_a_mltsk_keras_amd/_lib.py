@@ -85,6 +85,7 @@ _SIGS = {
     "rua_conv_group_last_grids": ([], i32),
     "rua_conv_fwd_sum": ([C.POINTER(ConvDesc), i32, vp], i32),
     "rua_conv_sum_last_kernel": ([], i32),
+    "rua_conv_sum_kernel": ([C.POINTER(ConvDesc), i32], i32),
     "rua_conv_wgrad_group": ([C.POINTER(WgradDesc), i32, vp], i32),
     "rua_wgrad_group_last_grids": ([], i32),
     "rua_profile_mid_event": ([vp], None),

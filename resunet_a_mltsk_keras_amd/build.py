@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librua_hip.so")
-SOURCES = ["conv_mfma.hip", "conv_strip.hip", "conv_band.hip", "elementwise.hip", "small_conv.hip", "loss_optim.hip", "capi.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_strip.hip", "conv_band.hip", "conv_band64.hip", "elementwise.hip", "small_conv.hip", "loss_optim.hip", "capi.cpp"]
 
 
 def needs_build():

@@ -86,6 +86,7 @@ struct RuaTuning {
   int bn_regs = 1;                      // BatchNorm sweeps with the thread's coefficients in registers (0: read from the LDS table per piece)
   int fill_kernel = 1;                  // rua_fill_zero as a kernel, not hipMemsetAsync: no memset nodes in captured graphs (0: experiments, tools/dp_graph_check.py)
   int band_dbg = 0;                     // experiments only (tools/bench_conv_band.py): 1 rows from an L2-resident region, 2 no BatchNorm pass
+  int conv_band64 = 1;                  // ... and of a C = 64 ResBlock (conv_band64)
   int conv_band = 1;                    // rua_conv_fwd_sum: the branches' second convs of a C = 32 ResBlock as ONE launch with the sum kept on chip (conv_band32)
   int wgd_ks_slow = 1;                  // wgrad_dmap block order: K slice slowest (blocks that read the same pixels share an XCD's L2)
   int wgrad_group = 7;                  // 1 wgrad_kernel, 2 wgrad_taps<32>, 4 wgrad_taps<64>, 8 wgrad_dmap (off: three members at once thrash the L2, 27.6 vs 24.6 us each)
@@ -146,6 +147,9 @@ extern thread_local ConvGroupCapture* g_conv_group;
 int rua_strip_group_flush(hipStream_t st, int* grids); // conv_strip.hip: issues the conv_strip members captured since the group began (+1 on *grids per launch)
 int rua_strip_group_pending(void);                     // members captured and not yet issued
 void rua_strip_group_reset(void);                      // drops captured members (group entry, error paths)
+// conv_band64.hip
+bool rua_band64_ok(const rua_conv_desc* d, int n);
+int rua_launch_band64(const rua_conv_desc* d, int n, hipStream_t st);
 // conv_strip.hip
 bool rua_pick_strip(const rua_conv_desc* d);
 int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st);

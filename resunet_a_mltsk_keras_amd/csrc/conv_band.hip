@@ -370,7 +370,7 @@ template <int NW, int BR, int R, bool FULLW> __global__ __launch_bounds__(NW * 6
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 static thread_local int g_sum_last_kernel = 0;
-extern "C" int rua_conv_sum_last_kernel(void) { return g_sum_last_kernel; }   // 1: the calling thread's latest rua_conv_fwd_sum ran conv_band32
+extern "C" int rua_conv_sum_last_kernel(void) { return g_sum_last_kernel; }   // the calling thread's latest rua_conv_fwd_sum: 1 conv_band32, 2 conv_band64, 0 member by member
 
 static bool band_ok(const rua_conv_desc* d, int n) {
   if (!g_tune.conv_band || n < 1 || n > RUA_MAX_BRANCH) return false;
@@ -392,10 +392,21 @@ static bool band_ok(const rua_conv_desc* d, int n) {
   return true;
 }
 
+// which kernel rua_conv_fwd_sum would run for these members, without launching: 0 member by member, 1 conv_band32, 2 conv_band64
+extern "C" int rua_conv_sum_kernel(const rua_conv_desc* d, int n) {
+  if (!d || n < 1 || n > RUA_MAX_BRANCH) return 0;
+  return rua_band64_ok(d, n) ? 2 : (band_ok(d, n) ? 1 : 0);
+}
+
 extern "C" int rua_conv_fwd_sum(const rua_conv_desc* d, int n, void* stream) {
   RUA_CHECK_ARG(d && n >= 1 && n <= RUA_MAX_BRANCH, "rua_conv_fwd_sum: 1..%d members", RUA_MAX_BRANCH);
   hipStream_t st = (hipStream_t)stream;
   g_sum_last_kernel = 0;
+  if (rua_band64_ok(d, n)) {                              // the C = 64 level (conv_band64.hip)
+    const int rc = rua_launch_band64(d, n, st);
+    if (rc == RUA_OK) g_sum_last_kernel = 2;
+    return rc;
+  }
   if (!band_ok(d, n)) {                                   // same results from the members' own launches (member i > 0 accumulates)
     for (int i = 0; i < n; ++i) {
       RUA_CHECK_ARG(d[i].y == d[0].y && (i == 0 || d[i].accumulate), "rua_conv_fwd_sum: members after the first must accumulate into the same output");
@@ -429,7 +440,7 @@ extern "C" int rua_conv_fwd_sum(const rua_conv_desc* d, int n, void* stream) {
   q.N = a.N; q.H = a.H; q.W = a.W;
   q.xbytes = (unsigned)((size_t)a.N * a.H * a.W * 32 * 2);
   RUA_CHECK_ARG((size_t)a.N * a.H * a.W * 32 * 2 < 0x80000000ull, "rua_conv_fwd_sum: tensor of 2 GiB or more");
-  constexpr int BR = 8, R = 6;
+  constexpr int BR = 8, R = 4;                          // a 4-slot ring: 2 rows in flight measured FASTER than 4 (6 slots): 78 - 82 vs 84 - 93 us
   const int sw = a.W % 256 == 0 ? 256 : 128, nw = sw / 32;
   q.strips = a.W / sw;
   q.bands = a.H / BR;
@@ -439,9 +450,14 @@ extern "C" int rua_conv_fwd_sum(const rua_conv_desc* d, int n, void* stream) {
   const bool fullw = q.strips == 1;
   static thread_local bool attr[4] = {false, false, false, false};
 #define RUA_BAND_GO(NW_, FW_, SLOT_) do { \
-    if (!attr[SLOT_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band32<NW_, 8, 6, FW_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[SLOT_] = true; } \
-    hipLaunchKernelGGL((conv_band32<NW_, 8, 6, FW_>), dim3(q.njobs), dim3(NW_ * 64), smem, st, q); } while (0)
-  if (nw == 8 && fullw) RUA_BAND_GO(8, true, 0);
+    if (!attr[SLOT_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band32<NW_, 8, 4, FW_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[SLOT_] = true; } \
+    hipLaunchKernelGGL((conv_band32<NW_, 8, 4, FW_>), dim3(q.njobs), dim3(NW_ * 64), smem, st, q); } while (0)
+  if (nw == 8 && fullw && (q.dbg & 8)) {                 // experiment: the 6-slot ring (4 rows in flight instead of 2)
+    static thread_local bool a6 = false;
+    const int smem6 = 6 * (sw + 64) * 64 + 18 * 1024 + nw * 1024 + (4 * 64 + 32) * 4;
+    if (!a6) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band32<8, 8, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a6 = true; }
+    hipLaunchKernelGGL((conv_band32<8, 8, 6, true>), dim3(q.njobs), dim3(512), smem6, st, q);
+  } else if (nw == 8 && fullw) RUA_BAND_GO(8, true, 0);
   else if (nw == 8) RUA_BAND_GO(8, false, 1);
   else if (fullw) RUA_BAND_GO(4, true, 2);
   else RUA_BAND_GO(4, false, 3);

@@ -779,14 +779,30 @@ class Graph:
         # the branches are independent until the final sum: their first convs go out as one grouped call
         self.conv_group(F, [self.conv_desc([(a, 0, d, 9)], l[1]["segs"], nf, self.P(l[1]["bias"]), y, stats=st)
                             for d, l, a, y, st in zip(dils, lay, a1, y1, st1)])
-        coef2, a2 = [], []
-        for l, y, st in zip(lay, y1, st1):
-            o2, c2l = self.bn_fwd(F, y, [l[2]], True, st, cnt)
-            coef2.append(c2l[0]); a2.append(o2[0])
         out = self.like(x)
-        biases = [self.P(l[3]["bias"]) for l in lay]        # the concatenated conv's bias = sum of the branches' biases
-        self.conv(F, [(a, 0, d, 9) for a, d in zip(a2, dils)], [l[3]["segs"][0] for l in lay], nf, biases[0], out,
-                  residual=x if v2 else None, bias_more=biases[1:])
+        # Second stage.  Where the library sums the branches on chip with every BatchNorm applied on load (rua_conv_fwd_sum ->
+        # conv_band64 at the C = 64 level) no normalised copy of a first-conv output is written: ONE launch instead of a
+        # rua_bn_fwd per branch + the concatenated conv; the weight gradients then normalise y1_b on load as well.
+        sum2 = self.second_stage_sum_ok(x, y1, nf, dils, lay, out)
+        if sum2:
+            nb = len(dils)
+            if tr and self.e.fold_bn:
+                cf2 = [self.bn_fold(F, l[2], st, cnt) for l, st in zip(lay, st1)]
+                coef2, fold2 = [c for c, _ in cf2], [f for _, f in cf2]
+            else:
+                coef2, fold2 = self.bn_coefs(F, x, [l[2] for l in lay], st1, cnt), [None] * nb
+            a2 = [None] * nb
+            self.conv_sum(F, [self.conv_desc([(y, 0, d, 9)], [l[3]["segs"][0]], nf, self.P(l[3]["bias"]), out, in_bn=c2, in_fold=f2,
+                                             residual=x if (v2 and bi == 0) else None, accumulate=1 if bi > 0 else 0)
+                              for bi, (d, l, y, c2, f2) in enumerate(zip(dils, lay, y1, coef2, fold2))])
+        else:
+            coef2, a2 = [], []
+            for l, y, st in zip(lay, y1, st1):
+                o2, c2l = self.bn_fwd(F, y, [l[2]], True, st, cnt)
+                coef2.append(c2l[0]); a2.append(o2[0])
+            biases = [self.P(l[3]["bias"]) for l in lay]        # the concatenated conv's bias = sum of the branches' biases
+            self.conv(F, [(a, 0, d, 9) for a, d in zip(a2, dils)], [l[3]["segs"][0] for l in lay], nf, biases[0], out,
+                      residual=x if v2 else None, bias_more=biases[1:])
         F.scope = None
         if not tr:
             return out
@@ -797,7 +813,10 @@ class Graph:
             dO = out.grad
             if not v2:
                 self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])      # (model2: summed by the final bn_bwd, which reads dO as the skip gradient)
-            self.wgrad_group(Bp, [(a_2, dO, l[3]["segs"][0]["off"], 1, d, 9, None) for d, l, a_2 in zip(dils, lay, a2)])
+            if sum2:                                           # y1_b normalised on load by the weight gradient too
+                self.wgrad_group(Bp, [(y, dO, l[3]["segs"][0]["off"], 1, d, 9, c2) for d, l, y, c2 in zip(dils, lay, y1, coef2)])
+            else:
+                self.wgrad_group(Bp, [(a_2, dO, l[3]["segs"][0]["off"], 1, d, 9, None) for d, l, a_2 in zip(dils, lay, a2)])
             g2s = [self.like(x) for _ in dils]
             s2s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
             self.conv_group(Bp, [self.dgrad_desc(dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
@@ -817,6 +836,37 @@ class Graph:
             Bp.scope = None
         self.back_steps.append(back)
         return out
+
+    def second_stage_sum_ok(self, x: Ten, y1: List[Ten], nf: int, dils: List[int], lay, out: Ten) -> bool:
+        """Does the library run `out = x + sum_b conv(relu(BN2_b(y1_b)))` as ONE launch with the BatchNorms applied on load
+        (rua_conv_sum_kernel), and the matching weight gradient with y1_b normalised on load (the all-taps kernel)?  Asked of the
+        library, not guessed."""
+        if self.dry or self.dt != L.RUA_BF16 or not self.e.fuse_bn or len(dils) < 1:
+            return False
+        arr = (L.ConvDesc * len(dils))()
+        dummy = L.BnFold()
+        for bi, (d, y) in enumerate(zip(dils, y1)):
+            q = arr[bi]
+            q.nseg = 1
+            sg = q.seg[0]
+            sg.x, sg.w, sg.C, sg.Hs, sg.Ws, sg.up_shift, sg.dil, sg.taps = y.ptr, y.ptr, y.C, y.H, y.W, 0, d, 9
+            q.N, q.H, q.W, q.Cout, q.stride, q.dtype = x.N, x.H, x.W, nf, 1, self.dt
+            q.y, q.out_stride, q.OH, q.OW = out.ptr, 1, x.H, x.W
+            q.accumulate = 1 if bi > 0 else 0
+            q.in_fold, q.in_relu = C.addressof(dummy), 1
+        lib = L.lib()
+        if lib.raw("rua_conv_sum_kernel")(arr, len(dils)) == 0:
+            return False
+        w = L.WgradDesc()
+        w.a, w.C, w.Hs, w.Ws, w.dy, w.Cout, w.H, w.W = x.ptr, x.C, x.H, x.W, x.ptr, nf, x.H, x.W
+        w.N, w.stride, w.taps, w.dtype = x.N, 1, 9, self.dt
+        sc = self.e.scratches[0]
+        w.workspace, w.workspace_bytes = sc.data_ptr(), sc.numel() * 4
+        for d in dils:
+            w.dil = d
+            if lib.raw("rua_wgrad_kind")(C.byref(w)) != 1:
+                return False
+        return True
 
     def resblock_fused(self, x: Ten, nf: int, dils: List[int], lay, scope: str) -> Ten:
         """The same ResBlock (model2.py:15-34) with every BatchNorm + ReLU applied ON LOAD by the consuming kernel: no

@@ -1273,20 +1273,28 @@ BAND_CASES = [
     (1, 512, 512, [1, 3, 15, 31], "fold", False),     # two strips per row (the halo columns are real data), no residual (model.py graph)
     (1, 256, 256, [31, 32], "none", True),            # two members, the largest dilation the halo holds, plain reads
     (1, 264, 384, [3, 15, 1], "scale", True),         # H, W no powers of two: 33 bands, three 128-pixel strips
+    # C = Cout = 64 (conv_band64: 8 waves = 4 pixel tiles x 2 output-channel halves, 4-row bands, weights staged per kernel row)
+    (2, 128, 128, [1, 3, 15, 31], "fold", True, 64),  # the level-2 ResBlock's second convs
+    (1, 128, 128, [1, 3, 15, 31], "scale", True, 64),
+    (1, 256, 256, [1, 3, 15, 31], "fold", False, 64), # two strips per row, no residual
+    (1, 132, 384, [32, 1], "none", True, 64),         # three strips, 33 bands, plain reads: comparable with the member-by-member path
+    (1, 128, 128, [3], "fold", True, 64),             # one member
 ]
 
 
-@pytest.mark.parametrize("N,H,W,dils,kind,res", BAND_CASES)
-def test_conv_sum_band_kernel(N, H, W, dils, kind, res):
+@pytest.mark.parametrize("case", BAND_CASES)
+def test_conv_sum_band_kernel(case):
     """rua_conv_fwd_sum -> conv_band32 (model2.py:26-31: out = x_input + sum of the branches' second convolutions, every branch
     reading relu(BatchNorm(y1_b)) normalised on load): one launch, accumulators of an 8-row band in registers over all branches,
     the output written once.  Against (a) a float64 evaluation on the bf16-rounded operands (each branch's normalised input rounded
     to bf16 as it is in LDS, zero padding AFTER the activation) and (b) the same members through separate accumulating launches;
     folded BatchNorms: published coefficients and moving statistics against the coefficient launch."""
+    N, H, W, dils, kind, res = case[:6]
+    Cs = case[6] if len(case) > 6 else 32
     dt = L.RUA_BF16
     lib = L.lib()
-    rng = np.random.default_rng(H + W + len(dils) + sum(dils))
-    Cs, nb, M = 32, len(dils), N * H * W
+    rng = np.random.default_rng(H + W + len(dils) + sum(dils) + Cs)
+    nb, M = len(dils), N * H * W
     xs = [(1.2 * rng.standard_normal((N, H, W, Cs)) + 0.2 * b).astype(np.float32) for b in range(nb)]
     ws = [(rng.standard_normal((9, Cs, Cs)) / np.sqrt(9 * Cs * nb)).astype(np.float32) for _ in range(nb)]
     biases = [rng.standard_normal(Cs).astype(np.float32) for _ in range(nb)]
@@ -1344,6 +1352,7 @@ def test_conv_sum_band_kernel(N, H, W, dils, kind, res):
                 keep.append(f); pub.append((co, mm, mv))
             elif use_kind == "scale":
                 d.in_scale, d.in_shift, d.in_relu = coef_ref[b][0].data_ptr(), coef_ref[b][1].data_ptr(), 1
+        run.arr = arr
         if entry == "sum":
             lib.call("rua_conv_fwd_sum", arr, nb, stream())
             ran = lib.raw("rua_conv_sum_last_kernel")()
@@ -1355,8 +1364,10 @@ def test_conv_sum_band_kernel(N, H, W, dils, kind, res):
         return y.float().cpu().numpy(), ran, pub
 
     got, ran, pub = run("sum", kind)
-    assert ran == 1                                            # the band kernel, not the member-by-member path
-    sep, _, _ = run("each", kind)
+    assert ran == (1 if Cs == 32 else 2)                       # the band kernel (conv_band32 / conv_band64), not the member-by-member path
+    assert lib.raw("rua_conv_sum_kernel")(run.arr, nb) == ran
+    has_sep = Cs == 32 or kind == "none"                       # (no single-conv kernel normalises on load at C = 64: nothing to compare with there)
+    sep = run("each", kind)[0] if has_sep else None
     exp = rnd(dt, aux).double().numpy() if res else 0.0
     for b in range(nb):
         xin = rnd(dt, xs[b])
@@ -1365,20 +1376,22 @@ def test_conv_sum_band_kernel(N, H, W, dils, kind, res):
             xin = torch.relu(xin * sc + sh).to(torch.bfloat16).float()
         exp = exp + ref_conv_nhwc(xin, rnd(dt, ws[b]), None, dils[b], 9).numpy() + biases[b].astype(np.float64)
     assert rel_err(got, exp) < 1e-2, rel_err(got, exp)          # one bf16 rounding of the output (the separate launches round it nb times)
-    assert rel_err(sep, exp) < tol(dt)
-    assert rel_err(got, sep) < tol(dt)
+    if has_sep:
+        assert rel_err(sep, exp) < tol(dt)
+        assert rel_err(got, sep) < tol(dt)
     if kind == "fold":
         for b in range(nb):
             co, mm, mv = pub[b]
             assert np.allclose(co.cpu().numpy(), coef_ref[b].cpu().numpy(), rtol=2e-6, atol=1e-7)
             assert np.allclose(mm.cpu().numpy(), mm_ref[b].cpu().numpy(), rtol=1e-6) and np.allclose(mv.cpu().numpy(), mv_ref[b].cpu().numpy(), rtol=1e-6)
     # with the tuning switch off, or a member the kernel does not take, the members run one by one - same numbers
-    lib.set_tuning(conv_band=0)
-    try:
-        off, ran_off, _ = run("sum", kind)
-    finally:
-        lib.set_tuning(conv_band=1)
-    assert ran_off == 0 and np.array_equal(off, sep)
+    if has_sep:
+        lib.set_tuning(conv_band=0, conv_band64=0)
+        try:
+            off, ran_off, _ = run("sum", kind)
+        finally:
+            lib.set_tuning(conv_band=1, conv_band64=1)
+        assert ran_off == 0 and np.array_equal(off, sep)
 
 
 @pytest.mark.parametrize("offset,nbytes", [(0, 1 << 20), (4, 1000), (3, 37), (16, 16), (8, 5), (0, 3 * (1 << 20) + 7), (1, 15)])

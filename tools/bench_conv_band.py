@@ -2,7 +2,7 @@
 the grouped first convolutions (conv_strip32_g: four dilations, BatchNorm + ReLU on load, statistics) and the summed second
 convolutions - rua_conv_fwd_sum as ONE conv_band32 launch against the four accumulating conv_strip launches.
 Usage: python tools/bench_conv_band.py      (under rocprofv3: `rocprofv3 ... -- python3 tools/bench_conv_band.py`)
-Environment: BB_SHAPE=N,H,W  BB_DILS=1,3,15,31  BB_REPS=50  BB_ONLY=first|sum|each"""
+Environment: BB_SHAPE=N,H,W  BB_C=32|64  BB_DILS=1,3,15,31  BB_REPS=50  BB_ONLY=first|sum|each  (C = 64: conv_band64 only)"""
 import ctypes as C
 import os
 import sys
@@ -20,7 +20,7 @@ def main():
     dils = [int(v) for v in os.environ.get("BB_DILS", "1,3,15,31").split(",")]
     reps = int(os.environ.get("BB_REPS", "50"))
     only = os.environ.get("BB_ONLY")
-    Cc, nb, M = 32, len(dils), N * H * W
+    Cc, nb, M = int(os.environ.get("BB_C", "32")), len(dils), N * H * W
     g = torch.Generator(device="cpu").manual_seed(0)
     x = torch.randn((N, H, W, Cc), generator=g).to(dev).to(torch.bfloat16)
     y1 = [torch.randn((N, H, W, Cc), generator=g).to(dev).to(torch.bfloat16) for _ in range(nb)]
@@ -85,7 +85,7 @@ def main():
         print(f"{name:46s} {us:7.1f} us  {flops / us / 1e6:6.0f} TF/s  {passes} tensor passes = {passes * mb / us / 1e3 * 1e3:6.0f} GB/s", flush=True)
 
     print(f"{N}x{H}x{W}x{Cc}, dilations {dils}: {flops / 1e9:.1f} GFLOP per stage, {mb:.1f} MB per tensor")
-    if only in (None, "first"):
+    if only in (None, "first") and Cc == 32:
         timed("first convs, grouped (conv_strip32_g)", lambda: lib.call("rua_conv_fwd_group", first, nb, s), 2 * nb)
     if only in (None, "sum"):
         lib.set_tuning(conv_band=1)
@@ -93,8 +93,8 @@ def main():
             lib.set_tuning(band_dbg=dbg)
             timed(f"second convs, rua_conv_fwd_sum (conv_band32) dbg={dbg}", lambda: lib.call("rua_conv_fwd_sum", second, nb, s), nb + 2)
         lib.set_tuning(band_dbg=0)
-        assert lib.raw("rua_conv_sum_last_kernel")() == 1
-    if only in (None, "each"):
+        assert lib.raw("rua_conv_sum_last_kernel")() == (1 if Cc == 32 else 2)
+    if only in (None, "each") and Cc == 32:
         lib.set_tuning(conv_band=0)
         timed("second convs, member by member (conv_strip32)", lambda: lib.call("rua_conv_fwd_sum", second, nb, s), 3 * nb)
         lib.set_tuning(conv_band=1)
