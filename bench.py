@@ -95,11 +95,13 @@ def entry_bytes(name, args):
     if name in ("rua_conv_fwd", "rua_conv_fwd_group"):
         ds = [args[0]._obj] if name == "rua_conv_fwd" else [args[0][i] for i in range(args[1])]
         tot = 0
+        seen = set()                                        # a tensor several members read (the ResBlock input of the first convs) counts once
         for d in ds:
             e = es(d.dtype)
             for i in range(d.nseg):
                 sg = d.seg[i]
-                tot += d.N * sg.Hs * sg.Ws * sg.C * e + sg.taps * sg.C * d.Cout * e
+                tot += (0 if sg.x in seen else d.N * sg.Hs * sg.Ws * sg.C * e) + sg.taps * sg.C * d.Cout * e
+                seen.add(sg.x)
             tot += d.N * d.H * d.W * d.Cout * e * (2 if (d.accumulate or d.out_stride > 1) else 1)       # output (read back when accumulating)
             if d.aux_mode:
                 tot += d.N * d.H * d.W * d.Cout * e
@@ -110,7 +112,7 @@ def entry_bytes(name, args):
         e = es(ds[0].dtype)
         px = ds[0].N * ds[0].H * ds[0].W
         tot = sum(px * d.seg[0].C * e + d.seg[0].taps * d.seg[0].C * d.Cout * e for d in ds)
-        one = L.lib().raw("rua_conv_sum_last_kernel")() == 1
+        one = L.lib().raw("rua_conv_sum_last_kernel")() in (1, 2)
         tot += px * ds[0].Cout * e * ((1 if one else 2 * len(ds) - 1) + (1 if ds[0].aux_mode else 0))
         return float(tot)
     if name in ("rua_conv_wgrad", "rua_conv_wgrad_group"):
@@ -194,7 +196,9 @@ def profile_kernels(eng, g, dtype):
                 kn = (f"conv_igemm_g<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap_g<{bm_},{bn_}>", f"conv_halo<{d0.Cout}>", "conv_pw", f"conv_strip_g<{d0.Cout}>")[kid]
                 grids = lib.raw("rua_conv_group_last_grids")()
                 nl = 1
-                if grids == n and all(lib.raw("rua_conv_kernel_id")(C.byref(arr[i])) == kid for i in range(n)):
+                if lib.raw("rua_conv_group_last_band")() == 1:   # C = 64: the members as ONE row-streaming launch
+                    kn = "conv_band64m"
+                elif grids == n and all(lib.raw("rua_conv_kernel_id")(C.byref(arr[i])) == kid for i in range(n)):
                     kn, nl = kn.replace("_g<", "<"), n     # not grouped: n launches of the plain kernel
                 elif grids != 1:                            # members the launchers could not put into one grid
                     kn = f"{kn.replace('_g<', '<')} ({n} members in {grids} launches)"
@@ -205,8 +209,8 @@ def profile_kernels(eng, g, dtype):
                 e0 = mark()
                 rc = fn(*args, sp)
                 e1 = mark()
-                one = lib.raw("rua_conv_sum_last_kernel")() == 1
-                kn, nl = ("conv_band32", 1) if one else (f"conv_strip<{arr[0].Cout}>", n)
+                which = lib.raw("rua_conv_sum_last_kernel")()
+                kn, nl = (("conv_band32", "conv_band64")[which - 1], 1) if which else (f"conv_strip<{arr[0].Cout}>", n)
                 fl = sum(conv_flops(arr[i]) for i in range(n))
                 rec.append((kn, e0, e1, fl, (arr[0].N * arr[0].H * arr[0].W, arr[0].Cout, n * 9 * arr[0].seg[0].C, 0, f"sum of {n}"), nl))
             elif name == "rua_conv_wgrad_group":          # the branches' weight gradients in one grid (reductions deferred)

@@ -104,6 +104,11 @@ int rua_conv_fwd(const rua_conv_desc* d, void* stream);
  * rua_conv_fwd calls; members that land on the same kernel are issued as ONE grid (no drain / launch gap between the branches) */
 int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream);
 int rua_conv_group_last_grids(void);             /* grids the calling thread's latest rua_conv_fwd_group issued (1: all members in one) */
+/* C = Cout = 64, 3x3, bf16, W % 128 == 0, H % 4 == 0: the members run as ONE conv_band64m launch (row streaming, 4-row bands, every
+ * member normalised on load by its own in_fold / in_scale, its own bias / ReLU mask / statistics epilogue) - the only path on which
+ * normalise-on-load is served at 64 channels.  rua_conv_group_band_ok asks without launching; ..._last_band reports the last call. */
+int rua_conv_group_band_ok(const rua_conv_desc* d, int n);
+int rua_conv_group_last_band(void);
 /* The n-ary Add of a ResBlock (model2.py:26-31: out = x_input + sum of the branches) with the sum kept ON CHIP: n (<= RUA_MAX_BRANCH)
  * single-segment convolutions into the SAME output y = aux_0 + sum_i conv_i - the results of n rua_conv_fwd calls of which member 0
  * writes (accumulate 0, optional residual aux_mode 1) and members i > 0 accumulate (accumulate 1, no aux).  Every member carries its

@@ -83,6 +83,8 @@ _SIGS = {
     "rua_conv_fused_input_ok": ([C.POINTER(ConvDesc)], i32),
     "rua_conv_last_ksplit": ([], i32),
     "rua_conv_group_last_grids": ([], i32),
+    "rua_conv_group_band_ok": ([C.POINTER(ConvDesc), i32], i32),
+    "rua_conv_group_last_band": ([], i32),
     "rua_conv_fwd_sum": ([C.POINTER(ConvDesc), i32, vp], i32),
     "rua_conv_sum_last_kernel": ([], i32),
     "rua_conv_sum_kernel": ([C.POINTER(ConvDesc), i32], i32),

@@ -86,6 +86,7 @@ struct RuaTuning {
   int bn_regs = 1;                      // BatchNorm sweeps with the thread's coefficients in registers (0: read from the LDS table per piece)
   int fill_kernel = 1;                  // rua_fill_zero as a kernel, not hipMemsetAsync: no memset nodes in captured graphs (0: experiments, tools/dp_graph_check.py)
   int band_dbg = 0;                     // experiments only (tools/bench_conv_band.py): 1 rows from an L2-resident region, 2 no BatchNorm pass
+  int conv_band64m = 1;                 // the independent 3x3 convs of a C = 64 ResBlock (first convs, data gradients) as ONE conv_band64m launch
   int conv_band64 = 1;                  // ... and of a C = 64 ResBlock (conv_band64)
   int conv_band = 1;                    // rua_conv_fwd_sum: the branches' second convs of a C = 32 ResBlock as ONE launch with the sum kept on chip (conv_band32)
   int wgd_ks_slow = 1;                  // wgrad_dmap block order: K slice slowest (blocks that read the same pixels share an XCD's L2)
@@ -150,6 +151,8 @@ void rua_strip_group_reset(void);                      // drops captured members
 // conv_band64.hip
 bool rua_band64_ok(const rua_conv_desc* d, int n);
 int rua_launch_band64(const rua_conv_desc* d, int n, hipStream_t st);
+bool rua_band64m_ok(const rua_conv_desc* d, int n);    // independent members (rua_conv_fwd_group) as one conv_band64m launch
+int rua_launch_band64m(const rua_conv_desc* d, int n, hipStream_t st);
 // conv_strip.hip
 bool rua_pick_strip(const rua_conv_desc* d);
 int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st);

@@ -27,13 +27,21 @@ struct Band64K {
   int d[RUA_MAX_BRANCH];
   const unsigned char* res;
   unsigned char* y;
+  // MULTI (rua_conv_fwd_group): every member has its own output and epilogue
+  unsigned char* ym[RUA_MAX_BRANCH];
+  const unsigned char* aux[RUA_MAX_BRANCH];          // ReLU-mask source (aux_mode 2) or null
+  const float* mscale[RUA_MAX_BRANCH]; const float* mshift[RUA_MAX_BRANCH];
+  double* stats[RUA_MAX_BRANCH]; int stats_mode[RUA_MAX_BRANCH]; int stats_R[RUA_MAX_BRANCH];
   int N, H, W, strips, bands, njobs;
   unsigned xbytes;
   int dbg;                                  // experiments (tuning key band_dbg): 2 no BatchNorm pass, 4 no row DMAs in the loop
 };
 static_assert(sizeof(Band64K) <= 4096, "kernel arguments are limited to 4 KiB");
 
-template <int BR, int R, bool FULLW>
+// MULTI: the members are INDEPENDENT convolutions (the first convolutions of the branches, or their data gradients: rua_conv_fwd_group) -
+// each with its own output, bias, optional ReLU mask from an aux tensor and statistics; the band's accumulators are written out and
+// cleared after every member's three phases.  Not MULTI: the members are summed into one output (rua_conv_fwd_sum).
+template <int BR, int R, bool FULLW, bool MULTI>
 __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
   typedef bf16_t T;
   constexpr int C = 64, NW = 8, NT = NW * 64, SW = 128, HALO = 32, PXB = C * 2;
@@ -49,6 +57,8 @@ __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sW = smem + R * SLOT;                                // [2][WPIECES][64 lanes][16 B]
   float* tab = reinterpret_cast<float*>(sW + 2 * WBUF);               // [nb][2][64] scale, shift ; [64] bias sum at 4 * 128
+  float* tabm = tab + 4 * 128 + 64;                                   // MULTI: [nb][3][64] bias, mask scale, mask shift
+  float* sred = tabm + 4 * 192;                                       // MULTI: [8 waves][64] statistics partials of a member
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,6 +118,14 @@ __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
       tab[i * 128 + tid] = q.in_scale[i] ? q.in_scale[i][tid] : 1.f;
       tab[i * 128 + 64 + tid] = q.in_shift[i] ? q.in_shift[i][tid] : 0.f;
     }
+  }
+  if constexpr (MULTI) {
+    if (tid < 64)
+      for (int i = 0; i < nb; ++i) {
+        tabm[i * 192 + tid] = q.bias[i] ? q.bias[i][tid] : 0.f;
+        tabm[i * 192 + 64 + tid] = (q.aux[i] && q.mscale[i]) ? q.mscale[i][tid] : 1.f;
+        tabm[i * 192 + 128 + tid] = (q.aux[i] && q.mshift[i]) ? q.mshift[i][tid] : 0.f;
+      }
   }
   __syncthreads();
   const bool bn = q.has_bn != 0 && !(q.dbg & 2);
@@ -201,6 +219,18 @@ __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
   };
 
   const int o = pxt * 32 + pl;                                        // this lane's output pixel inside the strip
+  const size_t pixg = (size_t)((n_ * H + h0) * W + x0 + o);           // ... and in the tensor (row h0 of the band)
+  // MULTI: a member's per-channel statistics, summed over the block (the waves' partials are in sred since the member's epilogue)
+  auto stats_flush = [&](int b) {
+    if (tid < 128 && q.stats_mode[b] != 0) {
+      const int ch = tid >> 6, ln = tid & 63, idx = ln & 31, khh = ln >> 5;
+      float t = 0.f;
+#pragma unroll
+      for (int p4 = 0; p4 < 4; ++p4) t += sred[(p4 * 2 + ch) * 64 + ln];
+      const int st = idx >> 4, c = ch * 32 + 16 * ((idx >> 3) & 1) + 8 * khh + (idx & 7);
+      unsafeAtomicAdd(&q.stats[b][(size_t)(job & (q.stats_R[b] - 1)) * 2 * C + st * C + c], (double)t);
+    }
+  };
   f32x16 acc[BR];
 #pragma unroll
   for (int r = 0; r < BR; ++r)
@@ -245,6 +275,9 @@ __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
       __builtin_amdgcn_s_barrier();                      // everyone's pieces of row s are normalised; every wave is done with row s - 1
+      if constexpr (MULTI) {
+        if (r == 0 && ph > 0 && ph % 3 == 0) stats_flush(ph / 3 - 1);      // the member that just finished: its partials are visible now
+      }
       if (r == 0) {
         // this wave's fragments of the kernel row (its output-channel half): landed long ago (issued two phases back), visible since the barrier
         const unsigned char* wb = sW + (ph & 1) * WBUF + coh * 1024 + lane * 16;
@@ -270,7 +303,10 @@ __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
       for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fx[tx][ks] = *reinterpret_cast<const bf16x8*>(row + boff[tx] + ((((ks * 2 + kh) ^ bsw[tx])) * 16));
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");
+      if (MULTI && r < 2 && ph > 0 && ph % 3 == 0)       // the 2 BR stores of the member epilogue are younger than row s + 1's DMAs for two stages
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT + 2 * BR) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");
       if (tv) tr_read(r + 1 < BR ? cur : nxt, so_nxt, sa, sb, ha, hb, rw);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -290,13 +326,97 @@ __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
       __builtin_amdgcn_sched_barrier(0);
       so_iss = so_cur; so_cur = so_nxt; so_nxt = so_nxt + SLOT == (unsigned)(R * SLOT) ? 0u : so_nxt + SLOT;
     }
+    if constexpr (MULTI) {
+      if (ph % 3 == 2) {
+        // ---- member epilogue: bias, ReLU mask from the aux tensor, statistics, one write of the member's band; accumulators cleared
+        const int b = ph / 3;
+        const unsigned char* auxp = q.aux[b];
+        unsigned char* yp = q.ym[b];
+        const int smode = q.stats_mode[b];
+        const float* tb = tabm + b * 192;
+        float s1[2][8], s2[2][8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s1[g][j] = 0.f; s2[g][j] = 0.f; }
+        uint4 av[2][2];
+        auto load_aux = [&](int r, uint4* dst) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            dst[g] = auxp ? ldg16(auxp + ((pixg + (size_t)r * W) * C + coh * 32 + 16 * g + 8 * kh) * 2) : make_uint4(0, 0, 0, 0);
+        };
+        load_aux(0, av[0]);
+#pragma unroll
+        for (int r = 0; r < BR; ++r) {
+          if (r + 1 < BR) load_aux(r + 1, av[(r + 1) & 1]);
+          float v[2][8];
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float a = acc[r][(2 * g) * 4 + j], b2 = acc[r][(2 * g + 1) * 4 + j];
+              if (g == 0 && j == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+              else asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+              v[g][j] = a;
+              v[g][4 + j] = b2;
+            }
+          unsigned char* yrow = yp + ((pixg + (size_t)r * W) * C) * 2;
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int co = coh * 32 + 16 * g + 8 * kh;
+            float a8[8];
+            ET<T>::unpack(av[r & 1][g], a8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g][j] += tb[co + j];
+            if (auxp) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[g][j] = (fmaf(tb[64 + co + j], a8[j], tb[128 + co + j]) > 0.f) ? v[g][j] : 0.f;
+            }
+            if (smode == 1) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], v[g][j], s2[g][j]); }
+            } else if (smode == 2) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], a8[j], s2[g][j]); }
+            }
+            stg16(yrow + co * 2, ET<T>::pack(v[g]));
+          }
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[r][k] = 0.f;
+        }
+        if (smode != 0) {
+          // 32 partial sums per lane over its pixel's rows -> per-channel sums over the wave's 32 pixels by a transposing butterfly (31
+          // exchanges: after the step with distance k a lane keeps the half of the values its bit k selects), lane l ends with value l
+          float vals[32];
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { vals[g * 8 + j] = s1[g][j]; vals[16 + g * 8 + j] = s2[g][j]; }
+#pragma unroll
+          for (int k = 16; k >= 1; k >>= 1) {
+            const bool hi = (pl & k) != 0;
+#pragma unroll
+            for (int i = 0; i < k; ++i) {
+              const float send = hi ? vals[i] : vals[i + k];
+              const float keep = hi ? vals[i + k] : vals[i];
+              vals[i] = keep + __shfl_xor(send, k, 64);
+            }
+          }
+          sred[wv * 64 + lane] = vals[0];
+        }
+      }
+    }
     cur = nxt;
     nxt = phase(ph + 2);
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");       // the over-issued DMAs of the last stages
 
+  if constexpr (MULTI) {                                               // the last member's statistics
+    __syncthreads();
+    stats_flush(nb - 1);
+    return;
+  }
   // ---- epilogue: bias sum + residual, one write of the band (this wave: 32 pixels x its 32 output channels) -------------------
-  const size_t pixg = (size_t)((n_ * H + h0) * W + x0 + o);
   uint4 rv[2][2];
   auto load_res = [&](int r, uint4* dst) {
 #pragma unroll
@@ -331,7 +451,8 @@ __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
   }
 }
 
-template <int BR, int R, bool FULLW> __global__ __launch_bounds__(512) void conv_band64(const Band64K q) { conv_band64_body<BR, R, FULLW>(q); }
+template <int BR, int R, bool FULLW> __global__ __launch_bounds__(512) void conv_band64(const Band64K q) { conv_band64_body<BR, R, FULLW, false>(q); }
+template <int BR, int R, bool FULLW> __global__ __launch_bounds__(512) void conv_band64m(const Band64K q) { conv_band64_body<BR, R, FULLW, true>(q); }
 
 // ---- host side (called by rua_conv_fwd_sum, conv_band.hip) ---------------------------------------------------------------------
 bool rua_band64_ok(const rua_conv_desc* d, int n) {
@@ -384,8 +505,8 @@ int rua_launch_band64(const rua_conv_desc* d, int n, hipStream_t st) {
   q.strips = a.W / 128;
   q.bands = a.H / BR;
   q.njobs = a.N * q.strips * q.bands;
-  const int smem = R * 192 * 128 + 2 * 24 * 1024 + (4 * 128 + 64) * 4;
-  static_assert(4 * 192 * 128 + 2 * 24 * 1024 + (4 * 128 + 64) * 4 <= 160 * 1024, "LDS budget");
+  const int smem = R * 192 * 128 + 2 * 24 * 1024 + (4 * 128 + 64 + 4 * 192 + 8 * 64) * 4;
+  static_assert(4 * 192 * 128 + 2 * 24 * 1024 + (4 * 128 + 64 + 4 * 192 + 8 * 64) * 4 <= 160 * 1024, "LDS budget");
   static thread_local bool attr[2] = {false, false};
   if (q.strips == 1) {
     if (!attr[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64<BR, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
@@ -395,5 +516,73 @@ int rua_launch_band64(const rua_conv_desc* d, int n, hipStream_t st) {
     hipLaunchKernelGGL((conv_band64<BR, R, false>), dim3(q.njobs), dim3(512), smem, st, q);
   }
   RUA_LAUNCH_CHECK("conv_band64");
+  return RUA_OK;
+}
+
+// ---- MULTI: independent members (rua_conv_fwd_group) ---------------------------------------------------------------------------
+bool rua_band64m_ok(const rua_conv_desc* d, int n) {
+  if (!g_tune.conv_band64m || n < 2 || n > RUA_MAX_BRANCH) return false;
+  const rua_conv_desc& a = d[0];
+  if (a.dtype != RUA_BF16 || a.W % 128 != 0 || a.H % 4 != 0 || (long long)a.N * a.H * a.W < 16384) return false;
+  for (int i = 0; i < n; ++i) {
+    const rua_conv_desc& m = d[i];
+    const rua_conv_seg& g = m.seg[0];
+    if (m.nseg != 1 || m.dtype != RUA_BF16 || g.taps != 9 || g.up_shift != 0 || g.C != 64 || m.Cout != 64 || m.stride != 1 ||
+        m.out_stride != 1 || m.OH != m.H || m.OW != m.W || g.Hs != m.H || g.Ws != m.W || g.dil < 1 || g.dil > 32) return false;
+    if (m.N != a.N || m.H != a.H || m.W != a.W || !m.y) return false;
+    for (int j = 0; j < i; ++j) if (d[j].y == m.y) return false;               // independent outputs
+    if (m.accumulate || m.out_relu || m.bias_more[0] || m.bias_more[1] || m.bias_more[2]) return false;
+    if (!(m.aux_mode == 0 || (m.aux_mode == 2 && m.aux))) return false;
+    if (m.stats_mode != 0 && (!m.stats || m.stats_replicas < 1 || (m.stats_replicas & (m.stats_replicas - 1)))) return false;
+    if (m.stats_mode == 2 && m.aux_mode != 2) return false;
+    if (m.stats_mode < 0 || m.stats_mode > 2) return false;
+    if ((m.in_fold != nullptr) != (a.in_fold != nullptr) || (m.in_scale != nullptr) != (a.in_scale != nullptr) || m.in_relu != a.in_relu) return false;
+    if (m.in_fold && (m.in_scale || m.in_shift)) return false;
+  }
+  return true;
+}
+
+int rua_launch_band64m(const rua_conv_desc* d, int n, hipStream_t st) {
+  Band64K q;
+  memset(&q, 0, sizeof(q));
+  q.nb = n;
+  for (int i = 0; i < n; ++i) {
+    const rua_conv_desc& m = d[i];
+    q.x[i] = (const unsigned char*)m.seg[0].x; q.w[i] = (const unsigned char*)m.seg[0].w; q.bias[i] = m.bias;
+    q.in_scale[i] = m.in_scale; q.in_shift[i] = m.in_shift; q.d[i] = m.seg[0].dil;
+    q.ym[i] = (unsigned char*)m.y;
+    q.aux[i] = m.aux_mode == 2 ? (const unsigned char*)m.aux : nullptr;
+    q.mscale[i] = m.mscale; q.mshift[i] = m.mshift;
+    q.stats[i] = m.stats; q.stats_mode[i] = m.stats ? m.stats_mode : 0; q.stats_R[i] = m.stats_replicas > 0 ? m.stats_replicas : 1;
+    if (m.in_fold) {
+      q.f[i] = *m.in_fold;
+      const rua_bn_fold& f = q.f[i];
+      RUA_CHECK_ARG(f.stats && f.replicas >= 1 && f.count > 0 && f.gamma && f.beta && f.scale && f.shift, "rua_conv_fwd_group: incomplete in_fold");
+      RUA_CHECK_ARG((f.moving_mean == nullptr) == (f.moving_var == nullptr), "rua_conv_fwd_group: in_fold needs both moving statistics or neither");
+    }
+  }
+  for (int i = n; i < RUA_MAX_BRANCH; ++i) { q.d[i] = 1; q.stats_R[i] = 1; }
+  const rua_conv_desc& a = d[0];
+  q.dbg = g_tune.band_dbg;
+  q.has_fold = a.in_fold ? 1 : 0;
+  q.has_bn = (a.in_fold || a.in_scale) ? 1 : 0;
+  q.in_relu = a.in_relu;
+  q.N = a.N; q.H = a.H; q.W = a.W;
+  RUA_CHECK_ARG((size_t)a.N * a.H * a.W * 64 * 2 < 0x7FFFFF00ull, "rua_conv_fwd_group: tensor of 2 GiB or more");
+  q.xbytes = (unsigned)((size_t)a.N * a.H * a.W * 64 * 2);
+  constexpr int BR = 4, R = 4;
+  q.strips = a.W / 128;
+  q.bands = a.H / BR;
+  q.njobs = a.N * q.strips * q.bands;
+  const int smem = R * 192 * 128 + 2 * 24 * 1024 + (4 * 128 + 64 + 4 * 192 + 8 * 64) * 4;
+  static thread_local bool attr[2] = {false, false};
+  if (q.strips == 1) {
+    if (!attr[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64m<BR, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
+    hipLaunchKernelGGL((conv_band64m<BR, R, true>), dim3(q.njobs), dim3(512), smem, st, q);
+  } else {
+    if (!attr[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64m<BR, R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1] = true; }
+    hipLaunchKernelGGL((conv_band64m<BR, R, false>), dim3(q.njobs), dim3(512), smem, st, q);
+  }
+  RUA_LAUNCH_CHECK("conv_band64m");
   return RUA_OK;
 }

@@ -1716,7 +1716,11 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
 // grid are then issued as ONE grid (blockIdx.y = member), the rest one by one.  Results are those of n separate calls.
 thread_local ConvGroupCapture* g_conv_group = nullptr;
 static thread_local int g_group_last_grids = 0;
-extern "C" int rua_conv_group_last_grids(void) { return g_group_last_grids; }   // grids the calling thread's latest rua_conv_fwd_group issued (1: one grid for all members)
+static thread_local int g_group_last_band = 0;
+extern "C" int rua_conv_group_last_grids(void) { return g_group_last_grids; }
+extern "C" int rua_conv_group_last_band(void) { return g_group_last_band; }      // 1: the calling thread's latest rua_conv_fwd_group ran as one conv_band64m launch
+// would rua_conv_fwd_group run these members as one conv_band64m launch (which honours in_fold / in_scale of every member)?
+extern "C" int rua_conv_group_band_ok(const rua_conv_desc* d, int n) { return (d && rua_band64m_ok(d, n)) ? 1 : 0; }   // grids the calling thread's latest rua_conv_fwd_group issued (1: one grid for all members)
 
 template <typename KG, typename F1, typename FG>
 static int issue_group(const ConvGroupCapture& c, const int* idx, int m, F1 single, FG grouped, int smem_attr, hipStream_t st, const char* what) {
@@ -1738,6 +1742,12 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
   RUA_CHECK_ARG(d && n >= 1 && n <= RUA_MAX_BRANCH, "rua_conv_fwd_group: 1..%d members", RUA_MAX_BRANCH);
   hipStream_t st = (hipStream_t)stream;
   g_group_last_grids = n;
+  g_group_last_band = 0;
+  if (rua_band64m_ok(d, n)) {                               // the C = 64 level: one row-streaming launch for all members (conv_band64.hip)
+    const int rc = rua_launch_band64m(d, n, st);
+    if (rc == RUA_OK) { g_group_last_grids = 1; g_group_last_band = 1; }
+    return rc;
+  }
   if (n == 1 || !g_tune.conv_group) {
     for (int i = 0; i < n; ++i) { const int rc = rua_conv_fwd(d + i, stream); if (rc != RUA_OK) return rc; }
     return RUA_OK;

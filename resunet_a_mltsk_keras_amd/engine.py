@@ -771,7 +771,7 @@ class Graph:
         cnt = x.M
         if tr and x.stats is None:
             x.stats = self.col_stats(F, x)
-        if all(self.fused_input_ok(x, nf, d) for d in dils):
+        if all(self.fused_input_ok(x, nf, d) for d in dils) or self.group_fused_ok(x, nf, dils):
             return self.resblock_fused(x, nf, dils, lay, scope)
         a1, coef1 = self.bn_fwd(F, x, [l[0] for l in lay], True, x.stats, cnt)
         y1 = [self.like(x) for _ in dils]
@@ -836,6 +836,42 @@ class Graph:
             Bp.scope = None
         self.back_steps.append(back)
         return out
+
+    def group_fused_ok(self, x: Ten, nf: int, dils: List[int]) -> bool:
+        """The C = 64 level: no single convolution normalises on load there, but rua_conv_fwd_group runs the branches' first convs
+        (and their data gradients) as ONE conv_band64m launch that does, rua_conv_fwd_sum the second convs (conv_band64), and the
+        all-taps weight gradient normalises on load as well - then the whole ResBlock takes the normalise-on-load path."""
+        if self.dry or self.dt != L.RUA_BF16 or not self.e.fuse_bn or len(dils) < 2:
+            return False
+        lib = L.lib()
+        arr = (L.ConvDesc * len(dils))()
+        dummy = L.BnFold()
+        outs = [self.e.scratches[0].data_ptr() + 4096 * (i + 1) for i in range(len(dils))]       # distinct, never dereferenced
+        for bi, d in enumerate(dils):
+            q = arr[bi]
+            q.nseg = 1
+            sg = q.seg[0]
+            sg.x, sg.w, sg.C, sg.Hs, sg.Ws, sg.up_shift, sg.dil, sg.taps = x.ptr, x.ptr, x.C, x.H, x.W, 0, d, 9
+            q.N, q.H, q.W, q.Cout, q.stride, q.dtype = x.N, x.H, x.W, nf, 1, self.dt
+            q.y, q.out_stride, q.OH, q.OW = outs[bi], 1, x.H, x.W
+            q.in_fold, q.in_relu = C.addressof(dummy), 1
+        if lib.raw("rua_conv_group_band_ok")(arr, len(dils)) != 1:
+            return False
+        for bi in range(len(dils)):                          # ... and the second convs as one summed launch
+            arr[bi].y = outs[0]
+            arr[bi].accumulate = 1 if bi > 0 else 0
+        if lib.raw("rua_conv_sum_kernel")(arr, len(dils)) == 0:
+            return False
+        w = L.WgradDesc()
+        w.a, w.C, w.Hs, w.Ws, w.dy, w.Cout, w.H, w.W = x.ptr, x.C, x.H, x.W, x.ptr, nf, x.H, x.W
+        w.N, w.stride, w.taps, w.dtype = x.N, 1, 9, self.dt
+        sc = self.e.scratches[0]
+        w.workspace, w.workspace_bytes = sc.data_ptr(), sc.numel() * 4
+        for d in dils:
+            w.dil = d
+            if lib.raw("rua_wgrad_kind")(C.byref(w)) != 1:
+                return False
+        return True
 
     def second_stage_sum_ok(self, x: Ten, y1: List[Ten], nf: int, dils: List[int], lay, out: Ten) -> bool:
         """Does the library run `out = x + sum_b conv(relu(BN2_b(y1_b)))` as ONE launch with the BatchNorms applied on load

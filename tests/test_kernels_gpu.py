@@ -953,7 +953,7 @@ def test_wgrad_deferred_batched_reduction_is_bit_identical():
                                    (6, 128, 128, 32, [1, 3, 15, 31])])
 def test_conv_group_equals_separate_launches(shape):
     """rua_conv_fwd_group: the dilation branches of a ResBlock in one call.  Members on the same kernel (conv_dmap at the
-    64x64x128 level, conv_strip at 256x256x32, conv_igemm at 128x128x64) share ONE grid; members the launcher cannot group
+    64x64x128 level, conv_strip at 256x256x32) share ONE grid, the 128x128x64 level runs as ONE conv_band64m launch; members the launcher cannot group
     (split-K at 16x16x512) run one by one.  Either way the results are bit-identical to separate rua_conv_fwd calls."""
     N, H, W, Cs, dils = shape
     dt = L.RUA_BF16
@@ -998,7 +998,13 @@ def test_conv_group_equals_separate_launches(shape):
     # their own jobs
     assert lib.raw("rua_conv_group_last_grids")() == (len(dils) if Cs == 512 else 2 if (Cs == 32 and W == 128) else 1)
     torch.cuda.synchronize()
+    band = lib.raw("rua_conv_group_last_band")() == 1          # 128x128x64: the group is ONE conv_band64m launch - another kernel than the
+    assert band == (Cs == 64)                                  # members' own (conv_igemm), another fp32 summation order
     for i in range(len(dils)):
+        if band:
+            assert rel_err(keep[4 * i + 2].float().cpu().numpy(), sep[i][0].float().cpu().numpy()) < tol(dt), (i, dils[i])
+            assert np.allclose(keep[4 * i + 3].cpu().numpy().reshape(32, -1).sum(0), sep[i][1].cpu().numpy().reshape(32, -1).sum(0), rtol=1e-3, atol=1e-2)
+            continue
         assert torch.equal(keep[4 * i + 2], sep[i][0]), (i, dils[i])
         # (outputs bit-identical; the statistics are fp32 per-lane partial sums over a block's rows folded in fp64: the members of a
         # grouped conv_strip launch share one round of blocks - longer chain segments than a launch on its own - so the partial sums
@@ -1412,3 +1418,124 @@ def test_fill_zero_is_a_kernel_and_exact_at_the_edges(offset, nbytes):
         finally:
             lib.set_tuning(fill_kernel=1)
     lib.call("rua_fill_zero", buf.data_ptr(), 0, stream())           # zero bytes: nothing launched, no error
+
+
+BAND64M_CASES = [
+    # N, H, W, dilations, kind: "first" = the branches' first convs (shared input, per-branch BatchNorm on load, bias, statistics sum v / sum v^2),
+    #                           "dgrad" = their data gradients (own inputs, ReLU mask from an aux tensor, statistics sum g / sum g * aux)
+    (2, 128, 128, [1, 3, 15, 31], "first"),
+    (2, 128, 128, [1, 3, 15, 31], "dgrad"),
+    (1, 256, 256, [3, 31], "first"),                  # two strips per row, two members
+    (1, 132, 128, [1, 15, 32], "dgrad"),              # 33 bands, three members
+    (1, 128, 128, [1, 3, 15, 31], "first_scale"),     # evaluation mode: coefficients given, no statistics
+]
+
+
+@pytest.mark.parametrize("N,H,W,dils,kind", BAND64M_CASES)
+def test_conv_group_band64_multi(N, H, W, dils, kind):
+    """rua_conv_fwd_group at C = Cout = 64 -> conv_band64m: the independent 3x3 convolutions of a level-2 ResBlock (model2.py:17-24 first
+    convs of every dilation branch; their data gradients) as ONE row-streaming launch, every member with its own normalise-on-load,
+    bias, ReLU mask and statistics.  Against float64 convolutions of the bf16-rounded operands (and, for the data-gradient form,
+    against the members run one by one on the implicit-GEMM kernel: outputs to bf16 rounding, statistics to fp32 partial-sum order)."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(H + W + len(dils) + len(kind))
+    Cs, nb, M = 64, len(dils), N * H * W
+    first = kind.startswith("first")
+    xs = [(1.1 * rng.standard_normal((N, H, W, Cs)) + 0.1).astype(np.float32) for _ in range(1 if first else nb)]
+    ws = [(rng.standard_normal((9, Cs, Cs)) / np.sqrt(9 * Cs)).astype(np.float32) for _ in range(nb)]
+    biases = [rng.standard_normal(Cs).astype(np.float32) for _ in range(nb)]
+    auxs = [rng.standard_normal((N, H, W, Cs)).astype(np.float32) for _ in range(nb)]
+    gam = [(0.5 + rng.random(Cs)).astype(np.float32) for _ in range(nb)]
+    bet = [(0.3 * rng.standard_normal(Cs)).astype(np.float32) for _ in range(nb)]
+    msc = [(0.5 + rng.random(Cs)).astype(np.float32) for _ in range(nb)]
+    msh = [(0.3 * rng.standard_normal(Cs)).astype(np.float32) for _ in range(nb)]
+    xd = [to_dev(a, dt) for a in xs]; wd = [to_dev(a, dt) for a in ws]; ad = [to_dev(a, dt) for a in auxs]
+    dv = lambda a: torch.from_numpy(a).to(dev())
+    bd, gd, btd, mscd, mshd = ([dv(a) for a in lst] for lst in (biases, gam, bet, msc, msh))
+    R = 8
+    st_in = torch.zeros(R * 2 * Cs, dtype=torch.float64, device=dev())
+    lib.call("rua_col_stats", xd[0].data_ptr(), M, Cs, st_in.data_ptr(), R, dt, stream())
+    # the per-branch BatchNorm coefficients of the shared input, as the coefficient launch makes them (batch statistics, eps 1e-3)
+    x0 = rnd(dt, xs[0]).double().numpy().reshape(M, Cs)
+    mean, var = x0.mean(0), x0.var(0)
+    coef_ref = []
+    for b in range(nb):
+        sc = gam[b] / np.sqrt(var + 1e-3)
+        coef_ref.append(torch.from_numpy(np.stack([sc, bet[b] - mean * sc]).astype(np.float32)).to(dev()))
+    torch.cuda.synchronize()
+
+    def build(with_norm):
+        ys = [torch.full((N, H, W, Cs), 3.0, dtype=torch.bfloat16, device=dev()) for _ in range(nb)]
+        sts = [torch.zeros(R * 2 * Cs, dtype=torch.float64, device=dev()) for _ in range(nb)]
+        arr = (L.ConvDesc * nb)()
+        keep = []
+        for b in range(nb):
+            d = arr[b]
+            d.nseg = 1
+            s = d.seg[0]
+            src = xd[0] if first else xd[b]
+            s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = src.data_ptr(), wd[b].data_ptr(), Cs, H, W, 0, dils[b], 9
+            d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cs, 1, dt
+            d.y, d.out_stride, d.OH, d.OW = ys[b].data_ptr(), 1, H, W
+            if first:
+                d.bias = bd[b].data_ptr()
+                if kind == "first":
+                    d.stats, d.stats_mode, d.stats_replicas = sts[b].data_ptr(), 1, R
+                    if with_norm:
+                        mm = torch.zeros(Cs, device=dev()); mv = torch.ones(Cs, device=dev()); co = torch.zeros(4, Cs, dtype=torch.float32, device=dev())
+                        f = L.BnFold()
+                        f.stats, f.replicas, f.count, f.bessel_n, f.eps, f.momentum = st_in.data_ptr(), R, float(M), float(M), 1e-3, 0.99
+                        f.gamma, f.beta, f.moving_mean, f.moving_var = gd[b].data_ptr(), btd[b].data_ptr(), mm.data_ptr(), mv.data_ptr()
+                        f.scale, f.shift, f.mean, f.rstd = (co[i].data_ptr() for i in range(4))
+                        d.in_fold, d.in_relu = C.addressof(f), 1
+                        keep += [f, mm, mv, co]
+                elif with_norm:
+                    d.in_scale, d.in_shift, d.in_relu = coef_ref[b][0].data_ptr(), coef_ref[b][1].data_ptr(), 1
+            else:
+                d.aux, d.aux_mode, d.mscale, d.mshift = ad[b].data_ptr(), 2, mscd[b].data_ptr(), mshd[b].data_ptr()
+                d.stats, d.stats_mode, d.stats_replicas = sts[b].data_ptr(), 2, R
+        return arr, ys, sts, keep
+
+    arr, ys, sts, keep = build(True)
+    assert lib.raw("rua_conv_group_band_ok")(arr, nb) == 1
+    lib.call("rua_conv_fwd_group", arr, nb, stream())
+    assert lib.raw("rua_conv_group_last_band")() == 1 and lib.raw("rua_conv_group_last_grids")() == 1
+    torch.cuda.synchronize()
+    if kind == "first":                                       # every member published its coefficients and moved its moving statistics once
+        for b in range(nb):
+            f, mm, mv, co = keep[4 * b:4 * b + 4]
+            assert np.allclose(co[:2].cpu().numpy(), coef_ref[b].cpu().numpy(), rtol=1e-4, atol=1e-5), b
+            assert np.allclose(mm.cpu().numpy(), 0.01 * mean, rtol=1e-4, atol=1e-6), b
+            assert np.allclose(mv.cpu().numpy(), 0.99 + 0.01 * var * M / (M - 1), rtol=1e-4), b
+    for b in range(nb):
+        xin = rnd(dt, xs[0] if first else xs[b])
+        if first:
+            sc, sh = coef_ref[b][0].cpu(), coef_ref[b][1].cpu()
+            xin = torch.relu(xin * sc + sh).to(torch.bfloat16).float()
+        exp = ref_conv_nhwc(xin, rnd(dt, ws[b]), None, dils[b], 9).numpy()
+        a = rnd(dt, auxs[b]).double().numpy()
+        if first:
+            exp = exp + biases[b].astype(np.float64)
+            s2 = (exp ** 2).sum(axis=(0, 1, 2))
+        else:
+            exp = exp * ((a * msc[b] + msh[b]) > 0)
+            s2 = (exp * a).sum(axis=(0, 1, 2))
+        got = ys[b].float().cpu().numpy()
+        assert rel_err(got, exp) < tol(dt), (b, rel_err(got, exp))
+        if kind != "first_scale":
+            stv = sts[b].cpu().numpy().reshape(R, 2 * Cs).sum(0)
+            assert rel_err(stv[:Cs], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4, b
+            assert rel_err(stv[Cs:], s2) < 5 * tol(dt) + 1e-4, b
+    if not first:                                              # the same members through the implicit-GEMM kernel, one grid or one by one
+        lib.set_tuning(conv_band64m=0)
+        try:
+            arr2, ys2, sts2, _ = build(True)
+            lib.call("rua_conv_fwd_group", arr2, nb, stream())
+            assert lib.raw("rua_conv_group_last_band")() == 0
+            torch.cuda.synchronize()
+        finally:
+            lib.set_tuning(conv_band64m=1)
+        for b in range(nb):
+            assert rel_err(ys[b].float().cpu().numpy(), ys2[b].float().cpu().numpy()) < tol(dt)
+            assert np.allclose(sts[b].cpu().numpy().reshape(R, -1).sum(0), sts2[b].cpu().numpy().reshape(R, -1).sum(0), rtol=1e-3, atol=1e-2)
