@@ -109,6 +109,9 @@ int rua_conv_group_last_grids(void);             /* grids the calling thread's l
  * normalise-on-load is served at 64 channels.  rua_conv_group_band_ok asks without launching; ..._last_band reports the last call. */
 int rua_conv_group_band_ok(const rua_conv_desc* d, int n);
 int rua_conv_group_last_band(void);
+/* Members on conv_dmap (bf16, Cout >= 128, C % 64 == 0, no K split) with the same tiles run BACK TO BACK inside one grid (conv_dmap_chain:
+ * a block walks every member over its pixel tile, the LDS-DMA ring never drains between members); ..._last_chain = how many did (0: none). */
+int rua_conv_group_last_chain(void);
 /* The n-ary Add of a ResBlock (model2.py:26-31: out = x_input + sum of the branches) with the sum kept ON CHIP: n (<= RUA_MAX_BRANCH)
  * single-segment convolutions into the SAME output y = aux_0 + sum_i conv_i - the results of n rua_conv_fwd calls of which member 0
  * writes (accumulate 0, optional residual aux_mode 1) and members i > 0 accumulate (accumulate 1, no aux).  Every member carries its

@@ -85,6 +85,7 @@ _SIGS = {
     "rua_conv_group_last_grids": ([], i32),
     "rua_conv_group_band_ok": ([C.POINTER(ConvDesc), i32], i32),
     "rua_conv_group_last_band": ([], i32),
+    "rua_conv_group_last_chain": ([], i32),
     "rua_conv_fwd_sum": ([C.POINTER(ConvDesc), i32, vp], i32),
     "rua_conv_sum_last_kernel": ([], i32),
     "rua_conv_sum_kernel": ([C.POINTER(ConvDesc), i32], i32),

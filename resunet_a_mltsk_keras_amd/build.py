@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "librua_hip.so")
+OUT = os.environ.get("RUA_BUILD_OUT") or os.path.join(HERE, "librua_hip.so")      # RUA_BUILD_OUT / RUA_BUILD_FLAGS: experiment builds (A/B through RUA_LIB_PATH)
 SOURCES = ["conv_mfma.hip", "conv_strip.hip", "conv_band.hip", "conv_band64.hip", "elementwise.hip", "small_conv.hip", "loss_optim.hip", "capi.cpp"]
 
 
@@ -25,10 +25,12 @@ def build(force=False, verbose=True):
     if not os.path.exists(hipcc):
         raise RuntimeError(f"hipcc not found at {hipcc}")
     objs, procs = [], []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    extra = os.environ.get("RUA_BUILD_FLAGS", "").split()
+    bdir = os.path.join(HERE, "build" + ("_" + "".join(c if c.isalnum() else "_" for c in "".join(extra)) if extra else ""))
+    os.makedirs(bdir, exist_ok=True)
     for s in SOURCES:
-        o = os.path.join(HERE, "build", s + ".o")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
+        o = os.path.join(bdir, s + ".o")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + extra + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)
     for s, p in procs:

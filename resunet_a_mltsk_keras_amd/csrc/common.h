@@ -80,6 +80,9 @@ struct RuaTuning {
   // grouped launches of a ResBlock's dilation branches, one bit per kernel family (0: every member launches on its own)
   int conv_group = 15;                  // 1 conv_strip, 2 conv_igemm<bf16,256,64>, 4 conv_dmap<128,128>, 8 conv_dmap<64,128>
   int head_fwd2 = 1;                    // heads with Cin = 32: the register-weights kernel (0: the LDS-weights one)
+  int dmap_spread = 1;                  // conv_dmap<128,128>: DMA instructions issued between the MFMAs (conv_dmap_s, four stage buffers)
+  int epi_fast = 1;                     // conv_dmap: compile-time forms of the epilogue for whole tiles (conv_epilogue KIND)
+  int dmap_chain = 0;                   // grouped conv_dmap members back to back inside one block (conv_dmap_chain): bit 0 the 128-row tiles, bit 1 the 64-row tiles
   int dmap_group_bm128 = 0;             // grouped conv_dmap members keep 128-row tiles where the group as a whole fills the chip: measured no gain (8.308 vs 8.290 ms per step), off
   int wgrad_kernel_share = 0;           // the same for the K-split weight gradients (wgrad_kernel) of a group: measured SLOWER (8.47 vs 8.28 ms per step: that kernel is not persistent, fewer K slices = fewer blocks to hide latency with), off
   int wgrad_taps_share = 1;             // all-taps weight gradients of a group share one round of blocks (rua_wgrad_desc.group_members)
@@ -130,6 +133,7 @@ struct ConvK {
   int nbn, nbm, ksplit, stages_per_split; float* ws;
   int* cnt;      // per-tile ticket counters (all zero between launches) for the in-launch split-K reduction, or null
   const float* in_scale; const float* in_shift; int in_relu;     // per-input-channel affine (+ ReLU) applied to segment 0 on load (conv_strip)
+  int epi_fast;  // tuning key epi_fast: whole tiles of the LDS-DMA kernels leave through the compile-time forms of the epilogue
 };
 typedef __attribute__((address_space(3))) void* lds_void_p;
 struct ConvKG { ConvK k[RUA_MAX_BRANCH]; };           // members of a grouped launch: blockIdx.y picks one

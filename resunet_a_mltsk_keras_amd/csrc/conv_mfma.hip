@@ -39,9 +39,27 @@ template <typename T, int BM, int BN> __host__ __device__ constexpr int conv_sme
 // 8-channel pieces per thread: bias, accumulate, residual / ReLU mask from aux, output ReLU, per-channel
 // statistics (fp32 partials -> wave shuffles -> LDS -> one fp64 atomic per channel and block), 16-byte stores.
 // SLABS: `src` is the first of p.ksplit fp32 slabs (stride M*Cout floats) whose sum is the tile (split-K finisher).
-template <typename T, int BM, int BN, bool SLABS = false>
+#ifdef RUA_DMAP_DBG_TS                                 // (debug build: phase timestamps of block 0 / thread 0 of conv_dmap, read by rua_debug_ts)
+__device__ unsigned long long g_dbg_ts[32];
+#define RUA_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_dbg_ts[i] = clock64(); g_dbg_ts[16 + (i)] = wall_clock64(); } } while (0)
+extern "C" int rua_debug_ts(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_ts), sizeof(g_dbg_ts)); }
+#else
+#define RUA_TS(i) do { } while (0)
+#endif
+// KIND > 0: the descriptor's flags as COMPILE-TIME constants for the forms the LDS-DMA kernels meet on whole tiles with a dense output
+// (conv_epi_kind below: every row and channel of the tile exists, out_stride 1, no output ReLU, no accumulate): KIND = 1 + aux_mode +
+// 3 * stats_mode, instantiated for bias + statistics sum v / sum v^2 (a ResBlock's first convs), ReLU mask from aux + statistics sum g /
+// sum g*aux (data gradients), residual add from aux (the summed second convs), plain.  The generic form spends ~5 us per 128 x 128 tile with one wave per SIMD - per-piece
+// branches on kernel arguments, their scalar loads and waits (measured: rounds of tools/bench_conv_levels.py with the epilogue run 1x / 3x
+// / not at all) - as much as a third of a 9.7 GFLOP convolution.
+template <typename T, int BM, int BN, bool SLABS = false, int KIND = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int n0, int bm_i, const float* src, int sstride, float* sred,
                                               const int* rowtab = nullptr, int nrows = BM, float* carry = nullptr, bool last = true) {
+  constexpr bool FULL = KIND > 0;
+  const int aux_mode = FULL ? (KIND - 1) % 3 : p.aux_mode;
+  const int stats_mode = FULL ? (KIND - 1) / 3 : p.stats_mode;
+  const int accumulate = FULL ? 0 : p.accumulate;
+  const int out_relu = FULL ? 0 : p.out_relu;
   constexpr int CG = BN / 8;
   constexpr int ROWS_PP = 256 / CG;
   constexpr int EP = BM / ROWS_PP;
@@ -49,7 +67,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
   const int HW = p.H * p.W;
   const int cg = tid % CG, r0 = tid / CG;
   const int co = n0 + cg * 8;
-  const bool cok = co < p.Cout;
+  const bool cok = FULL || co < p.Cout;
   float s1[8], s2[8], bias8[8], ms8[8], mt8[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; bias8[j] = 0.f; ms8[j] = 1.f; mt8[j] = 0.f; }
@@ -57,6 +75,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = carry[j]; s2[j] = carry[8 + j]; }
   }
+#ifdef RUA_EPI_DBG_NOVEC
+  if (p.M < 0)
+#endif
   if (cok) {
     if (p.bias) {
 #pragma unroll
@@ -68,7 +89,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
           for (int j = 0; j < 8; ++j) bias8[j] += p.bias_more[q][co + j];
         }
     }
-    if (p.aux_mode == 2) {
+    if (aux_mode == 2) {
       if (p.mscale) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) ms8[j] = p.mscale[co + j];
@@ -79,7 +100,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
       }
     }
   }
-  const bool plain_out = (p.out_stride == 1 && p.OH == p.H && p.OW == p.W);
+  const bool plain_out = FULL || (p.out_stride == 1 && p.OH == p.H && p.OW == p.W);
   // pass 1: addresses, and ALL global loads of this thread's pieces (aux, old output) issued back to back - one exposed
   // memory latency per thread instead of one per piece (the pieces are independent; a load-use pair per loop iteration
   // serialised them: 4-6 dependent HBM round trips per thread)
@@ -92,7 +113,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
     const int row = r0 + e * ROWS_PP;
     long long m = m0 + row;
     if (rowtab) m = (row < nrows) ? (long long)rowtab[row] : -1;      // tile row -> pixel table (lattice tiles of conv_halo)
-    if (!(m >= 0 && m < p.M && cok)) m = -1;
+    if (!FULL && !(m >= 0 && m < p.M && cok)) m = -1;
     mrow[e] = (int)m;
     ooff[e] = 0;
     if (m >= 0) {
@@ -103,16 +124,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
         const int n = mm / HW, rem = mm - n * HW, h = rem / p.W, w = rem - h * p.W;
         ooff[e] = (unsigned)(((n * p.OH + h * p.out_stride) * p.OW + w * p.out_stride) * p.Cout + co);
       }
-      if (p.aux_mode != 0) {
+      if (aux_mode != 0) {
 #pragma unroll
         for (int v_ = 0; v_ < NV; ++v_) araw[e][v_] = ldg16(p.aux + ((size_t)m * p.Cout + co) * sizeof(T) + v_ * 16);
       }
-      if (p.accumulate) {
+      if (accumulate) {
 #pragma unroll
         for (int v_ = 0; v_ < NV; ++v_) oraw[e][v_] = ldg16(p.y + (size_t)ooff[e] * sizeof(T) + v_ * 16);
       }
     }
   }
+  RUA_TS(4);
   // pass 2: arithmetic, statistics, stores
 #pragma unroll
   for (int e = 0; e < EP; ++e) {
@@ -133,43 +155,50 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += bias8[j];
       float a8[8];
-      if (p.accumulate) {
+      if (accumulate) {
         float o8[8];
 #pragma unroll
         for (int v_ = 0; v_ < NV; ++v_) ET<T>::unpack(oraw[e][v_], o8 + v_ * 4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += o8[j];
       }
-      if (p.aux_mode != 0) {
+      if (aux_mode != 0) {
 #pragma unroll
         for (int v_ = 0; v_ < NV; ++v_) ET<T>::unpack(araw[e][v_], a8 + v_ * 4);
       }
-      if (p.aux_mode == 1) {
+      if (aux_mode == 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += a8[j];
-      } else if (p.aux_mode == 2) {
+      } else if (aux_mode == 2) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (fmaf(ms8[j], a8[j], mt8[j]) > 0.f) ? v[j] : 0.f;
       }
-      if (p.out_relu) {
+      if (out_relu) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       }
-      if (p.stats_mode == 1) {
+      if (stats_mode == 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
-      } else if (p.stats_mode == 2) {
+      } else if (stats_mode == 2) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], a8[j], s2[j]); }
       }
+#ifdef RUA_EPI_DBG_NOSTORE                             // (timing experiments on the epilogue's latency chain; results are garbage)
+      if (v[0] == 123.456f)
+#endif
       store8<T>(p.y, ooff[e], v);
     }
   }
+  RUA_TS(5);
   if (carry) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { carry[j] = s1[j]; carry[8 + j] = s2[j]; }
   }
-  if (p.stats_mode != 0 && last) {
+#ifdef RUA_EPI_DBG_NOSTATS
+  if (s1[0] == 123.456f)
+#endif
+  if (stats_mode != 0 && last) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -187,6 +216,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, long long m0, int 
       if (c < p.Cout) unsafeAtomicAdd(&p.stats[(size_t)(bm_i & (p.stats_R - 1)) * 2 * p.Cout + (k >> 3) * p.Cout + c], (double)t);
     }
   }
+}
+
+// which compile-time form of the epilogue serves this tile size (0: the generic one); kernel-side mirror of the host's choice
+template <int BM, int BN>
+__device__ __forceinline__ int conv_epi_kind(const ConvK& p) {
+  if (!p.epi_fast || p.M % BM != 0 || p.Cout % BN != 0 || p.out_stride != 1 || p.OH != p.H || p.OW != p.W || p.out_relu || p.accumulate) return 0;
+  if (p.aux_mode > 2 || p.stats_mode > 2 || (p.stats_mode != 0 && p.stats == nullptr)) return 0;
+  return 1 + p.aux_mode + 3 * p.stats_mode;
+}
+// the epilogue of a whole tile through its compile-time form where one applies
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void conv_epilogue_pick(const ConvK& p, long long m0, int n0, int bm_i, const float* src, int sstride, float* sred,
+                                                   float* carry = nullptr, bool last = true) {
+  const int kind = conv_epi_kind<BM, BN>(p);
+  if (kind == 4) conv_epilogue<T, BM, BN, false, 4>(p, m0, n0, bm_i, src, sstride, sred, nullptr, BM, carry, last);        // bias, statistics
+  else if (kind == 9) conv_epilogue<T, BM, BN, false, 9>(p, m0, n0, bm_i, src, sstride, sred, nullptr, BM, carry, last);   // mask, statistics 2
+  else if (kind == 2) conv_epilogue<T, BM, BN, false, 2>(p, m0, n0, bm_i, src, sstride, sred, nullptr, BM, carry, last);   // residual
+  else if (kind == 1) conv_epilogue<T, BM, BN, false, 1>(p, m0, n0, bm_i, src, sstride, sred, nullptr, BM, carry, last);   // plain
+  else conv_epilogue<T, BM, BN>(p, m0, n0, bm_i, src, sstride, sred, nullptr, BM, carry, last);
 }
 
 template <typename T, int BM, int BN>
@@ -697,18 +745,39 @@ __global__ __launch_bounds__(256) void conv_dma(const ConvK p) {
 //   iteration s, k-steps 0..2 : read fragments of k-step kk+1, MFMA k-step kk
 //   k-step 3                  : vmcnt(PER_STAGE) [stage s+1 landed] ; lgkmcnt(0) [my reads of stage s done] ; s_barrier ;
 //                               DMA stage s+3 into the buffer of stage s ; read fragments (s+1, 0) ; MFMA k-step 3
-template <int BM, int BN, int ROWB>
-__device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
+#ifndef RUA_DMAP_NBUF
+#define RUA_DMAP_NBUF 3                                   // stage buffers of the LDS-DMA ring (NBUF - 1 stages in flight)
+#endif
+// CHAIN (conv_dmap_chain): the members of a grouped launch (same pixel tiles, same output channels: the dilation branches of a
+// ResBlock) run BACK TO BACK inside one block - the K iteration walks member after member without ever letting the DMA ring run
+// dry, and at a member boundary the accumulators leave through an epilogue of their own (LDS behind the ring, two half tiles)
+// while the first stages of the next member are already in flight.  Measured motive (tools/bench_conv_levels.py, 8 x 64 x 64 x
+// 128): three members as one K x 3 launch 45 - 48 us, as three blocks per CU (conv_dmap_g) 66 - 70 us - a block turnover
+// (epilogue, exit, dispatch, prologue, ring refill from cold) costs ~11 us of a ~22 us member.
+// SPREAD: the DMA instructions of a stage are issued a quarter per k-step BETWEEN the MFMAs instead of in one burst behind the stage barrier.
+// Motive (tools/dmap_phases.py, in-kernel timestamps, 8 x 64 x 64 x 128): the K loop takes 11.96 us, without its DMA instructions 7.2 us,
+// without its MFMAs 6.1 us - the two do NOT overlap: the texture path takes one 1-KiB DMA instruction per ~10.6 ns and CU, all four waves issue
+// their eight right behind the barrier and sit in the issue queue ~0.3 us per stage with the MFMA pipes drained.  Four stage buffers: the
+// quarters of stage s + 3 go into the buffer of stage s - 1 while stage s multiplies.
+template <int BM, int BN, int ROWB, bool CHAIN = false, bool SPREAD = false>
+__device__ __forceinline__ void conv_dmap_body(const ConvK* pk, int nmem) {
   typedef bf16_t T;
+  const ConvK& p = pk[0];                               // geometry (the same for every member of a chain)
   // a stage = 64 channels, 4 k-steps of 16.  ROWB = 128: one LDS image [rows][128 B], every DMA row a full line;
   // ROWB = 64: two sub-images [2][rows][64 B] (32 channels each)
-  constexpr int NBUF = 3, KS = 4;
+  constexpr int NBUF = SPREAD ? 4 : RUA_DMAP_NBUF, KS = 4;
   constexpr int NSUB = 128 / ROWB, SPR = ROWB / 16, RPI = 1024 / ROWB;      // sub-images, 16-B slots per row, rows per DMA instruction
   constexpr int SW = (ROWB == 64) ? 2 : 1;                                  // swizzle: slot = piece ^ ((row >> SW) & (SPR - 1))
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int AI = BM / (4 * RPI), BI = BN / (4 * RPI);                   // DMA instructions per wave per sub-image
+#if defined(RUA_DMAP_DBG_SKIPB)                        // (timing experiments: the DMA INSTRUCTIONS of one operand left out - results are garbage)
+  constexpr int PER_STAGE = NSUB * AI;
+#elif defined(RUA_DMAP_DBG_SKIPA)
+  constexpr int PER_STAGE = NSUB * BI;
+#else
   constexpr int PER_STAGE = NSUB * (AI + BI);
+#endif
   constexpr int WN = 2, WM = 2;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int CSTR = BN + 4;
@@ -716,6 +785,7 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sC = reinterpret_cast<float*>(smem);
 
+  RUA_TS(0);
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
@@ -759,8 +829,9 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
   int abase[AI];
   unsigned atap[AI], btap[BI];
   __amdgpu_buffer_rsrc_t rx = make_rsrc(p.seg[0].x, p.seg[0].xbytes), rw = make_rsrc(p.seg[0].w, p.seg[0].wbytes);
+  int im = 0;                                           // CHAIN: the member the DMA cursor is in
   auto enter_segment = [&]() {
-    const SegK sg = p.seg[u_seg];
+    const SegK sg = pk[im].seg[u_seg];
     rx = make_rsrc(sg.x, sg.xbytes); rw = make_rsrc(sg.w, sg.wbytes);
     s_taps = sg.taps; s_nchunk = sg.nchunk >> 1; s_C = sg.C; s_Ws = sg.Ws; s_dil = sg.dil;
     sHL = (unsigned)(sg.Hs << sg.up); sWL = (unsigned)(sg.Ws << sg.up);
@@ -777,12 +848,22 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
     const int ex = (dh * s_Ws + dw) * s_C;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const bool ok = av[i] && (unsigned)(ah[i] + dh) < sHL && (unsigned)(aw[i] + dw) < sWL;
+      bool ok = av[i] && (unsigned)(ah[i] + dh) < sHL && (unsigned)(aw[i] + dw) < sWL;
+#ifdef RUA_DMAP_DBG_A3                                 // timing experiment only (wrong results): the input staged for one tap of three
+      ok = ok && (s_taps != 9 || u_tap % 3 == 0);
+#endif
+#ifdef RUA_DMAP_DBG_A0
+      ok = false;
+#endif
       atap[i] = ok ? (unsigned)((abase[i] + ex) * 2) : OOB;
     }
 #pragma unroll
-    for (int j = 0; j < BI; ++j)
+    for (int j = 0; j < BI; ++j) {
       btap[j] = bv[j] ? (unsigned)(((u_tap * p.Cout + n0 + brow[j]) * s_C + bqv[j]) * 2) : OOB;
+#ifdef RUA_DMAP_DBG_B0                                 // timing experiment only: no weight bytes at all
+      btap[j] = OOB;
+#endif
+    }
   };
   int st_left = 0;                                      // real stages of this block not yet issued
   // DMA the next stage of the K range into `buf` and step the iteration state; past the end of the range the
@@ -790,27 +871,41 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
   // (the explicit (unsigned) casts on the offsets are load-bearing: without them hipcc 7.2 silently drops the HOST stub
   //  of this kernel template - the implicit unsigned->int conversion of a template-dependent array element in a builtin
   //  argument fails substitution on the host pass only)
-  auto issue_next = [&](int buf) {
+  // part < 0: the whole stage; part 0..3 (SPREAD): that quarter of its DMA instructions, the iteration state steps behind the last one
+  auto issue_next = [&](int buf, int part = -1) {
     unsigned char* sA = smem + buf * STAGE;
     unsigned char* sB = sA + A_BYTES;
     const bool live = st_left > 0;
+#ifndef RUA_DMAP_DBG_NODMA                             // (timing experiment: the kernel without its staging traffic)
 #pragma unroll
     for (int u = 0; u < NSUB; ++u) {
       const unsigned co = (unsigned)(u_chunk * 128 + u * ROWB);            // 64 channels * 2 bytes per stage
+#ifndef RUA_DMAP_DBG_SKIPA
 #pragma unroll
       for (int i = 0; i < AI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sA + (u * BM + (wid * AI + i) * RPI) * ROWB), 16,
-                                                 (unsigned)(live ? atap[i] + co : OOB), 0, 0, 0);
+        if (part < 0 || ((u * (AI + BI) + i) * 4) / PER_STAGE == part)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sA + (u * BM + (wid * AI + i) * RPI) * ROWB), 16,
+                                                   (unsigned)(live ? atap[i] + co : OOB), 0, 0, 0);
+#endif
+#ifndef RUA_DMAP_DBG_SKIPB
 #pragma unroll
       for (int j = 0; j < BI; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_p)(sB + (u * BN + (wid * BI + j) * RPI) * ROWB), 16,
-                                                 (unsigned)(live ? btap[j] + co : OOB), 0, 0, 0);
+        if (part < 0 || ((u * (AI + BI) + AI + j) * 4) / PER_STAGE == part)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_p)(sB + (u * BN + (wid * BI + j) * RPI) * ROWB), 16,
+                                                   (unsigned)(live ? btap[j] + co : OOB), 0, 0, 0);
+#endif
     }
+#endif
+    if (part >= 0 && part < 3) return;
     if (live && --st_left > 0) {
       u_chunk += 1;
       if (u_chunk >= s_nchunk) {
         u_chunk = 0;
-        if (++u_tap == s_taps) { u_tap = 0; ++u_seg; enter_segment(); }
+        if (++u_tap == s_taps) {
+          u_tap = 0; ++u_seg;
+          if (CHAIN && u_seg == pk[im].nseg) { u_seg = 0; ++im; }
+          enter_segment();
+        }
         enter_tap();
       }
     }
@@ -839,12 +934,14 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
     for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(sS + fb_off + (u * BN + b * 32) * ROWB + slot);
   };
 
-  const int nstages_all = p.nunits / 2;
-  const int st_begin = ks_i * p.stages_per_split;
-  int nstages = st_begin + p.stages_per_split;
+  int nstages_all = p.nunits / 2;
+  if (CHAIN)
+    for (int m = 1; m < nmem; ++m) nstages_all += pk[m].nunits / 2;
+  const int st_begin = CHAIN ? 0 : ks_i * p.stages_per_split;
+  int nstages = CHAIN ? nstages_all : st_begin + p.stages_per_split;
   if (nstages > nstages_all) nstages = nstages_all;
   const int nst = nstages - st_begin;
-  {
+  if (!CHAIN) {
     const int unit = st_begin * 2;
     int sgi = 0;
     while (sgi + 1 < p.nseg && unit >= p.seg[sgi + 1].ubegin) ++sgi;
@@ -853,14 +950,17 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
   }
   st_left = nst;
   enter_segment(); enter_tap();
-  issue_next(0);
-  issue_next(1);
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STAGE) : "memory");
+  static_assert(!SPREAD || PER_STAGE % 4 == 0, "SPREAD: a stage's DMA instructions split into four equal parts");
+#pragma unroll
+  for (int b = 0; b < NBUF - 1; ++b) issue_next(b);
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * PER_STAGE) : "memory");
   __builtin_amdgcn_s_barrier();
-  issue_next(2);
+  if (!SPREAD) issue_next(NBUF - 1);
   bf16x8 fa[2][TM], fb[2][TN];
   load_frags(0, 0, fa[0], fb[0]);
   int buf = 0;
+  int cm = 0, c_left = p.nunits / 2;                    // CHAIN: the member the MFMA cursor is in, its stages left
+  RUA_TS(1);
   for (int st = 0; st < nst; ++st) {
     int nxt = buf + 1; if (nxt == NBUF) nxt = 0;
 #pragma unroll
@@ -868,22 +968,65 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
       const int cur = kk & 1;
       if (kk < KS - 1) {
         load_frags(buf, kk + 1, fa[cur ^ 1], fb[cur ^ 1]);
+      } else if (SPREAD) {                             // in flight here: stages s + 1, s + 2 and three quarters of s + 3
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" :: "n"(2 * PER_STAGE - PER_STAGE / 4) : "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(nxt, 0, fa[cur ^ 1], fb[cur ^ 1]);
       } else {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" :: "n"(PER_STAGE) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" :: "n"((NBUF - 2) * PER_STAGE) : "memory");
         __builtin_amdgcn_s_barrier();
         issue_next(buf);
         load_frags(nxt, 0, fa[cur ^ 1], fb[cur ^ 1]);
       }
+#ifndef RUA_DMAP_DBG_NOMFMA                            // (timing experiment: the staging skeleton alone)
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
+#endif
+      if (SPREAD) issue_next(buf == 0 ? NBUF - 1 : buf - 1, kk);      // a quarter of stage s + 3 into the buffer stage s - 1 left
     }
     buf = nxt;
+    if (CHAIN) {
+      if (--c_left == 0) {                              // the member's last stage: its tile leaves, the ring keeps running
+        const ConvK& q = pk[cm];
+#ifdef RUA_DMAP_DBG_NOEPI                              // (timing experiment: no epilogue at all - results are garbage)
+        if (q.M > 0) { if (acc[0][0][0] == 123.456f) q.y[0] = 1; ++cm; if (cm < nmem) c_left = pk[cm].nunits / 2; continue; }
+#endif
+        float* sCh = reinterpret_cast<float*>(smem + NBUF * STAGE);
+        float carry[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) carry[j] = 0.f;
+#pragma unroll
+        for (int h = 0; h < WM; ++h) {
+          if (wm == h) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+              for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                  sCh[(a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh) * CSTR + wn * (BN / WN) + b * 32 + lr] = acc[a][b][i];
+          }
+          __syncthreads();
+          conv_epilogue_pick<T, BM / WM, BN>(q, m0 + h * (BM / WM), n0, bm_i, sCh, CSTR, sCh + (BM / WM) * CSTR, carry, h == WM - 1);
+          __syncthreads();
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+        if (++cm < nmem) c_left = pk[cm].nunits / 2;
+      }
+    }
   }
+  RUA_TS(2);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (CHAIN) return;
 
   if (p.ksplit > 1) {
 #pragma unroll
@@ -922,6 +1065,9 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
     conv_epilogue<T, BM, BN, true>(p, m0, n0, bm_i, p.ws + (size_t)m0 * p.Cout + n0, p.Cout, sC + BM * CSTR);
     return;
   }
+#ifdef RUA_DMAP_DBG_NOEPI
+  if (p.M > 0) { if (acc[0][0][0] == 123.456f) p.y[0] = 1; return; }
+#endif
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -933,18 +1079,32 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK& p) {
         sC[row * CSTR + col] = acc[a][b][i];
       }
   __syncthreads();
-  conv_epilogue<T, BM, BN>(p, m0, n0, bm_i, sC, CSTR, sC + BM * CSTR);
+  RUA_TS(3);
+#ifdef RUA_DMAP_DBG_EPI2                               // (timing experiment: the epilogue run p.ksplit + 2 times - is its cost execution or cold instruction fetch?)
+#pragma unroll 1
+  for (int rep = 0; rep < p.ksplit + 1; ++rep) { conv_epilogue<T, BM, BN>(p, m0, n0, bm_i, sC, CSTR, sC + BM * CSTR); __syncthreads(); }
+#endif
+  conv_epilogue_pick<T, BM, BN>(p, m0, n0, bm_i, sC, CSTR, sC + BM * CSTR);
+  RUA_TS(6);
 }
 
 
 
-template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap(const ConvK p) { conv_dmap_body<BM, BN, ROWB>(p); }
-template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap_g(const ConvKG g) { conv_dmap_body<BM, BN, ROWB>(g.k[blockIdx.y]); }
+template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap(const ConvK p) { conv_dmap_body<BM, BN, ROWB>(&p, 1); }
+template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap_g(const ConvKG g) { conv_dmap_body<BM, BN, ROWB>(&g.k[blockIdx.y], 1); }
+template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap_s(const ConvK p) { conv_dmap_body<BM, BN, ROWB, false, true>(&p, 1); }
+template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap_gs(const ConvKG g) { conv_dmap_body<BM, BN, ROWB, false, true>(&g.k[blockIdx.y], 1); }
+template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap_chain(const ConvKG g, int nmem) { conv_dmap_body<BM, BN, ROWB, true>(g.k, nmem); }
 
-template <int BM, int BN> static constexpr int conv_dmap_smem() {
+template <int BM, int BN, int NBUF = RUA_DMAP_NBUF> static constexpr int conv_dmap_smem() {
   constexpr int STAGE = 2 * (BM + BN) * 64;
   constexpr int EPI = BM * (BN + 4) * 4 + 4 * (BN / 8) * 16 * 4;
-  return ((3 * STAGE > EPI ? 3 * STAGE : EPI) + 15) / 16 * 16;
+  return ((NBUF * STAGE > EPI ? NBUF * STAGE : EPI) + 15) / 16 * 16;
+}
+
+// conv_dmap_chain: the ring stays live during a member's epilogue, whose half tile and reduction scratch sit behind it
+template <int BM, int BN> static constexpr int conv_dmap_chain_smem() {
+  return (RUA_DMAP_NBUF * 2 * (BM + BN) * 64 + (BM / 2) * (BN + 4) * 4 + 4 * (BN / 8) * 16 * 4 + 15) / 16 * 16;
 }
 
 template <int BM, int BN> static constexpr int conv_dma_base() {
@@ -1224,14 +1384,23 @@ template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, 
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dmap<BM, BN, ROWB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               conv_dmap_smem<BM, BN>());
+    if constexpr (BM == 128 && ROWB == 64)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dmap_s<BM, BN, ROWB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                conv_dmap_smem<BM, BN, 4>());
     attr_set = true;
   }
-  constexpr int smem = conv_dmap_smem<BM, BN>();
+  const bool spread = BM == 128 && ROWB == 64 && g_tune.dmap_spread;      // DMA instructions between the MFMAs (four stage buffers)
+  const int smem = spread ? conv_dmap_smem<BM, BN, 4>() : conv_dmap_smem<BM, BN>();
   if (g_conv_group && (g_tune.conv_group & (BM == 128 ? 4 : 8)) && k.ksplit == 1 && ROWB == 64) {
-    if (!g_conv_group->add(BM == 128 ? 1 : 2, (unsigned)(k.nbm * k.nbn), smem, k)) { rua_set_error("rua_conv_fwd_group: more than %d captured members", RUA_MAX_BRANCH); return RUA_ERR_ARG; }
+    if (!g_conv_group->add(BM == 128 ? (spread ? 3 : 1) : 2, (unsigned)(k.nbm * k.nbn), smem, k)) { rua_set_error("rua_conv_fwd_group: more than %d captured members", RUA_MAX_BRANCH); return RUA_ERR_ARG; }
     return RUA_OK;
   }
-  hipLaunchKernelGGL((conv_dmap<BM, BN, ROWB>), dim3(k.nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
+  if constexpr (BM == 128 && ROWB == 64) {
+    if (spread) hipLaunchKernelGGL((conv_dmap_s<BM, BN, ROWB>), dim3(k.nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
+    else hipLaunchKernelGGL((conv_dmap<BM, BN, ROWB>), dim3(k.nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
+  } else {
+    hipLaunchKernelGGL((conv_dmap<BM, BN, ROWB>), dim3(k.nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
+  }
   RUA_LAUNCH_CHECK("conv_dmap");
   if (k.ksplit > 1 && k.cnt == nullptr) {
     launch_splitk_finish<bf16_t>(k, st);
@@ -1626,6 +1795,7 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   k.stats_R = d->stats_replicas < 1 ? 1 : d->stats_replicas;
   RUA_CHECK_ARG((k.stats_R & (k.stats_R - 1)) == 0, "rua_conv_fwd: stats_replicas must be a power of two");
   k.in_scale = d->in_scale; k.in_shift = d->in_shift; k.in_relu = d->in_relu;
+  k.epi_fast = g_tune.epi_fast;
   hipStream_t st = (hipStream_t)stream;
   if (rua_pick_strip(d)) {
     k.nbn = 1; k.nbm = 1; k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr; k.cnt = nullptr;
@@ -1683,7 +1853,10 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     // (the members of a grouped launch fill the chip together: 3 x 128 tiles of 128 x 128 need no 64-row tiles, which stage
     //  50 % more bytes per FLOP; tuning key dmap_group_bm128)
     const bool group_fills = g_tune.dmap_group_bm128 && g_conv_group && (g_tune.conv_group & 4) && (long long)g_conv_group->members * tiles >= target;
-    if (bm64 && k.ksplit == 1 && tiles < target && tiles * 2 >= target && !group_fills) {
+    // (dmap_bm64 & 2, experiment: the members of a group whose 128-row tiles fill the chip exactly once take 64-row tiles too - two blocks
+    //  per CU, one in its epilogue while the other multiplies)
+    const bool group64 = (bm64 & 2) && g_conv_group && k.ksplit == 1 && tiles == target;
+    if (((bm64 & 1) && k.ksplit == 1 && tiles < target && tiles * 2 >= target && !group_fills) || group64) {
       k.nbm = (int)((k.M + 63) / 64);
       return launch_conv_dmap<64, 128, 64>(k, st);
     }
@@ -1718,6 +1891,8 @@ thread_local ConvGroupCapture* g_conv_group = nullptr;
 static thread_local int g_group_last_grids = 0;
 static thread_local int g_group_last_band = 0;
 extern "C" int rua_conv_group_last_grids(void) { return g_group_last_grids; }
+static thread_local int g_group_last_chain = 0;
+extern "C" int rua_conv_group_last_chain(void) { return g_group_last_chain; }    // members the latest rua_conv_fwd_group ran back to back inside one conv_dmap_chain grid (0: none)
 extern "C" int rua_conv_group_last_band(void) { return g_group_last_band; }      // 1: the calling thread's latest rua_conv_fwd_group ran as one conv_band64m launch
 // would rua_conv_fwd_group run these members as one conv_band64m launch (which honours in_fold / in_scale of every member)?
 extern "C" int rua_conv_group_band_ok(const rua_conv_desc* d, int n) { return (d && rua_band64m_ok(d, n)) ? 1 : 0; }   // grids the calling thread's latest rua_conv_fwd_group issued (1: one grid for all members)
@@ -1738,11 +1913,32 @@ static int issue_group(const ConvGroupCapture& c, const int* idx, int m, F1 sing
   return RUA_OK;
 }
 
+// conv_dmap_chain: the captured conv_dmap members as ONE grid of the members' common size, every block walking all of them
+static bool chain_ok(const ConvGroupCapture& c, const int* idx, int m) {
+  const ConvK& a = c.k[idx[0]];
+  for (int i = 0; i < m; ++i) {
+    const ConvK& k = c.k[idx[i]];
+    if (k.ksplit != 1 || k.M != a.M || k.Cout != a.Cout || k.nbm != a.nbm || k.nbn != a.nbn || k.H != a.H || k.W != a.W || k.stride != a.stride) return false;
+  }
+  return true;
+}
+template <typename FC>
+static int issue_chain(const ConvGroupCapture& c, const int* idx, int m, FC kern, int smem, int slot, hipStream_t st) {
+  static thread_local bool attr[2] = {false, false};
+  if (!attr[slot]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr[slot] = true; }
+  ConvKG g;
+  for (int i = 0; i < m; ++i) g.k[i] = c.k[idx[i]];
+  hipLaunchKernelGGL(kern, dim3(c.grid[idx[0]]), dim3(256), smem, st, g, m);
+  RUA_LAUNCH_CHECK("conv_dmap_chain");
+  return RUA_OK;
+}
+
 extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
   RUA_CHECK_ARG(d && n >= 1 && n <= RUA_MAX_BRANCH, "rua_conv_fwd_group: 1..%d members", RUA_MAX_BRANCH);
   hipStream_t st = (hipStream_t)stream;
   g_group_last_grids = n;
   g_group_last_band = 0;
+  g_group_last_chain = 0;
   if (rua_band64m_ok(d, n)) {                               // the C = 64 level: one row-streaming launch for all members (conv_band64.hip)
     const int rc = rua_launch_band64m(d, n, st);
     if (rc == RUA_OK) { g_group_last_grids = 1; g_group_last_band = 1; }
@@ -1770,7 +1966,12 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
     int idx[RUA_MAX_BRANCH], m = 0;
     for (int j = i; j < cap.n; ++j)
       if (!done[j] && cap.kind[j] == cap.kind[i] && cap.grid[j] == cap.grid[i] && cap.smem[j] == cap.smem[i]) { idx[m++] = j; done[j] = true; }
-    if (cap.kind[i] == 1) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap<128, 128, 64>, conv_dmap_g<128, 128, 64>, conv_dmap_smem<128, 128>(), st, "conv_dmap (group)");
+    const bool chain = m >= 2 && (cap.kind[i] == 1 || cap.kind[i] == 2) && (g_tune.dmap_chain & cap.kind[i]) && chain_ok(cap, idx, m);
+    if (chain) g_group_last_chain = m;
+    if (chain && cap.kind[i] == 1) rc = issue_chain(cap, idx, m, conv_dmap_chain<128, 128, 64>, conv_dmap_chain_smem<128, 128>(), 0, st);
+    else if (chain) rc = issue_chain(cap, idx, m, conv_dmap_chain<64, 128, 64>, conv_dmap_chain_smem<64, 128>(), 1, st);
+    else if (cap.kind[i] == 1) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap<128, 128, 64>, conv_dmap_g<128, 128, 64>, conv_dmap_smem<128, 128>(), st, "conv_dmap (group)");
+    else if (cap.kind[i] == 3) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap_s<128, 128, 64>, conv_dmap_gs<128, 128, 64>, conv_dmap_smem<128, 128, 4>(), st, "conv_dmap_s (group)");
     else if (cap.kind[i] == 2) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap<64, 128, 64>, conv_dmap_g<64, 128, 64>, conv_dmap_smem<64, 128>(), st, "conv_dmap (group)");
     else rc = issue_group<ConvKG>(cap, idx, m, conv_igemm<bf16_t, 256, 64>, conv_igemm_g<bf16_t, 256, 64>, conv_smem<bf16_t, 256, 64>(), st, "conv_igemm (group)");
     if (rc != RUA_OK) return rc;

@@ -950,7 +950,7 @@ def test_wgrad_deferred_batched_reduction_is_bit_identical():
 
 
 @pytest.mark.parametrize("shape", [(8, 64, 64, 128, [1, 3, 15]), (2, 256, 256, 32, [1, 3, 15, 31]), (4, 128, 128, 64, [3, 15, 31]), (8, 16, 16, 512, [1, 3]),
-                                   (6, 128, 128, 32, [1, 3, 15, 31])])
+                                   (6, 128, 128, 32, [1, 3, 15, 31]), (8, 32, 32, 256, [1, 3, 15]), (3, 24, 40, 128, [1, 15])])
 def test_conv_group_equals_separate_launches(shape):
     """rua_conv_fwd_group: the dilation branches of a ResBlock in one call.  Members on the same kernel (conv_dmap at the
     64x64x128 level, conv_strip at 256x256x32) share ONE grid, the 128x128x64 level runs as ONE conv_band64m launch; members the launcher cannot group
@@ -985,6 +985,7 @@ def test_conv_group_equals_separate_launches(shape):
     sep = []
     for d in descs:
         lib.call("rua_conv_fwd", C.byref(d), stream())
+    split = lib.raw("rua_conv_last_ksplit")() > 1               # K-split members are launched one by one
     torch.cuda.synchronize()
     for i in range(len(dils)):
         sep.append((keep[4 * i + 2].clone(), keep[4 * i + 3].clone()))
@@ -996,8 +997,9 @@ def test_conv_group_equals_separate_launches(shape):
     # 16x16x512: split-K members launch one by one; 128-pixel strips (W = 128): d = 31 needs more LDS than two blocks per CU allow,
     # so it does not share a grid with d = 1, 3, 15 (which run two per CU); members of unequal job counts are renumbered each over
     # their own jobs
-    assert lib.raw("rua_conv_group_last_grids")() == (len(dils) if Cs == 512 else 2 if (Cs == 32 and W == 128) else 1)
+    assert lib.raw("rua_conv_group_last_grids")() == (len(dils) if split else 2 if (Cs == 32 and W == 128) else 1)
     torch.cuda.synchronize()
+    assert lib.raw("rua_conv_group_last_chain")() == 0
     band = lib.raw("rua_conv_group_last_band")() == 1          # 128x128x64: the group is ONE conv_band64m launch - another kernel than the
     assert band == (Cs == 64)                                  # members' own (conv_igemm), another fp32 summation order
     for i in range(len(dils)):
@@ -1010,6 +1012,21 @@ def test_conv_group_equals_separate_launches(shape):
         # grouped conv_strip launch share one round of blocks - longer chain segments than a launch on its own - so the partial sums
         # are taken over other row sets and differ in their last fp32 bits)
         assert np.allclose(keep[4 * i + 3].cpu().numpy().reshape(32, -1).sum(0), sep[i][1].cpu().numpy().reshape(32, -1).sum(0), rtol=2e-6)
+    if Cs >= 128 and not split:
+        # tuning key dmap_chain (off by default: measured no gain): conv_dmap members with the same tiles walk back to back through ONE
+        # grid, a block running every member over its pixel tile with the DMA ring kept alive across the epilogues - bit-identical
+        for i in range(len(dils)):
+            keep[4 * i + 2].zero_(); keep[4 * i + 3].zero_()
+        lib.set_tuning(dmap_chain=3, dmap_spread=0)             # (the chain is built on the burst-issue form of the kernel)
+        try:
+            lib.call("rua_conv_fwd_group", arr, len(descs), stream())
+            assert lib.raw("rua_conv_group_last_chain")() == len(dils) and lib.raw("rua_conv_group_last_grids")() == 1
+            torch.cuda.synchronize()
+        finally:
+            lib.set_tuning(dmap_chain=0, dmap_spread=1)
+        for i in range(len(dils)):
+            assert torch.equal(keep[4 * i + 2], sep[i][0]), (i, dils[i])
+            assert np.array_equal(keep[4 * i + 3].cpu().numpy().reshape(32, -1).sum(0), sep[i][1].cpu().numpy().reshape(32, -1).sum(0))
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 256, 32, [1, 3, 15, 31], True), (4, 128, 128, 64, [1, 3, 15, 31], False), (8, 32, 32, 256, [1, 3, 15], False),

@@ -8,6 +8,7 @@ for r in $(seq $reps); do for v in $vals; do
   python - "$key=$v" <<'PY' | tee -a gpurun_out/ab.log
 import json, sys
 j = json.loads(open("gpurun_out/ab_line.json").read().strip().splitlines()[-1])
-print(sys.argv[1], j["ms_per_step"], j["value"], flush=True)
+k = j["roofline"]["all_mfma_kernels"]
+print(sys.argv[1], j["ms_per_step"], j["value"], {n: k[n]["ms_per_step"] for n in k if n.startswith(("conv_dmap", "wgrad_dmap"))}, flush=True)
 PY
 done; done
