@@ -759,8 +759,13 @@ __global__ __launch_bounds__(256) void conv_dma(const ConvK p) {
 // without its MFMAs 6.1 us - the two do NOT overlap: the texture path takes one 1-KiB DMA instruction per ~10.6 ns and CU, all four waves issue
 // their eight right behind the barrier and sit in the issue queue ~0.3 us per stage with the MFMA pipes drained.  Four stage buffers: the
 // quarters of stage s + 3 go into the buffer of stage s - 1 while stage s multiplies.
-template <int BM, int BN, int ROWB, bool CHAIN = false, bool SPREAD = false>
+// SPEC (conv_dmap_w): 512 threads - waves 0-3 read fragments and multiply, waves 4-7 issue the DMA instructions (each the share wave
+// w - 4 issues in the other forms), wait for their landing and meet the consumers at the stage barrier.  A consumer never stands in the
+// texture path's issue queue, a producer never holds an MFMA back; after the K loop the producers end and the four consumer waves run
+// the epilogue (a barrier counts only the waves of a workgroup that are still alive).
+template <int BM, int BN, int ROWB, bool CHAIN = false, bool SPREAD = false, bool SPEC = false>
 __device__ __forceinline__ void conv_dmap_body(const ConvK* pk, int nmem) {
+  static_assert(!(SPEC && (CHAIN || SPREAD)), "conv_dmap: one issue form at a time");
   typedef bf16_t T;
   const ConvK& p = pk[0];                               // geometry (the same for every member of a chain)
   // a stage = 64 channels, 4 k-steps of 16.  ROWB = 128: one LDS image [rows][128 B], every DMA row a full line;
@@ -794,7 +799,9 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK* pk, int nmem) {
   const int ks_i = vid / (p.nbn * p.nbm);
   const long long m0 = (long long)bm_i * BM;
   const int n0 = bn_i * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = SPEC && wid0 >= 4;
+  const int wid = SPEC ? (wid0 & 3) : wid0;             // consumer w multiplies the tile quarter of wave w, producer w + 4 issues wave w's DMA share
   const int HW = p.H * p.W;
 
   // LDS image: [row][8 slots of 16 B]; slot = piece ^ ((row >> 1) & 7) makes the ds_read_b128 fragment reads
@@ -950,12 +957,31 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK* pk, int nmem) {
   }
   st_left = nst;
   enter_segment(); enter_tap();
+  if (SPEC && producer) {                               // ---- the DMA waves: issue, wait for the landing, meet the consumers at the barrier
+    issue_next(0);
+    issue_next(1);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STAGE) : "memory");
+    __builtin_amdgcn_s_barrier();                       // stage 0 is in LDS
+    issue_next(2);
+    int pbuf = 0;
+    for (int st = 0; st < nst; ++st) {
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STAGE) : "memory");     // stage st + 1 landed (st + 2 stays in flight)
+      __builtin_amdgcn_s_barrier();                     // ... and every consumer has read its last fragment of stage st
+      issue_next(pbuf);                                 // stage st + 3 into the buffer of stage st
+      pbuf = pbuf + 1 == NBUF ? 0 : pbuf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the zero fills issued past the end of the K range too: the epilogue reuses this LDS
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
   static_assert(!SPREAD || PER_STAGE % 4 == 0, "SPREAD: a stage's DMA instructions split into four equal parts");
+  if (!SPEC) {
 #pragma unroll
-  for (int b = 0; b < NBUF - 1; ++b) issue_next(b);
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * PER_STAGE) : "memory");
+    for (int b = 0; b < NBUF - 1; ++b) issue_next(b);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * PER_STAGE) : "memory");
+  }
   __builtin_amdgcn_s_barrier();
-  if (!SPREAD) issue_next(NBUF - 1);
+  if (!SPREAD && !SPEC) issue_next(NBUF - 1);
   bf16x8 fa[2][TM], fb[2][TN];
   load_frags(0, 0, fa[0], fb[0]);
   int buf = 0;
@@ -968,6 +994,10 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK* pk, int nmem) {
       const int cur = kk & 1;
       if (kk < KS - 1) {
         load_frags(buf, kk + 1, fa[cur ^ 1], fb[cur ^ 1]);
+      } else if (SPEC) {                               // the producers waited for stage s + 1; they refill this buffer behind the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(nxt, 0, fa[cur ^ 1], fb[cur ^ 1]);
       } else if (SPREAD) {                             // in flight here: stages s + 1, s + 2 and three quarters of s + 3
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" :: "n"(2 * PER_STAGE - PER_STAGE / 4) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -1024,7 +1054,8 @@ __device__ __forceinline__ void conv_dmap_body(const ConvK* pk, int nmem) {
     }
   }
   RUA_TS(2);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  if (SPEC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (CHAIN) return;
 
@@ -1094,6 +1125,8 @@ template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_
 template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap_g(const ConvKG g) { conv_dmap_body<BM, BN, ROWB>(&g.k[blockIdx.y], 1); }
 template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap_s(const ConvK p) { conv_dmap_body<BM, BN, ROWB, false, true>(&p, 1); }
 template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap_gs(const ConvKG g) { conv_dmap_body<BM, BN, ROWB, false, true>(&g.k[blockIdx.y], 1); }
+template <int BM, int BN, int ROWB> __global__ __launch_bounds__(512) void conv_dmap_w(const ConvK p) { conv_dmap_body<BM, BN, ROWB, false, false, true>(&p, 1); }
+template <int BM, int BN, int ROWB> __global__ __launch_bounds__(512) void conv_dmap_gw(const ConvKG g) { conv_dmap_body<BM, BN, ROWB, false, false, true>(&g.k[blockIdx.y], 1); }
 template <int BM, int BN, int ROWB> __global__ __launch_bounds__(256) void conv_dmap_chain(const ConvKG g, int nmem) { conv_dmap_body<BM, BN, ROWB, true>(g.k, nmem); }
 
 template <int BM, int BN, int NBUF = RUA_DMAP_NBUF> static constexpr int conv_dmap_smem() {
@@ -1387,13 +1420,30 @@ template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, 
     if constexpr (BM == 128 && ROWB == 64)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dmap_s<BM, BN, ROWB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 conv_dmap_smem<BM, BN, 4>());
+    if constexpr (ROWB == 64)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dmap_w<BM, BN, ROWB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                conv_dmap_smem<BM, BN>());
     attr_set = true;
   }
-  const bool spread = BM == 128 && ROWB == 64 && g_tune.dmap_spread;      // DMA instructions between the MFMAs (four stage buffers)
+  // DMA waves beside the MFMA waves (conv_dmap_w, 512 threads): the 128-row tiles (2); the 64-row tiles run two blocks per CU that already
+  // fill each other's gaps and would lose the second block to the register file (6: measured 0.39 vs 0.33 ms per step on their group launches)
+  const bool spec = ROWB == 64 && (g_tune.dmap_spread & 2) && (BM == 128 || (g_tune.dmap_spread & 4));
+  const bool spread = BM == 128 && ROWB == 64 && g_tune.dmap_spread == 1; // DMA instructions between the MFMAs of the same waves (four stage buffers)
   const int smem = spread ? conv_dmap_smem<BM, BN, 4>() : conv_dmap_smem<BM, BN>();
   if (g_conv_group && (g_tune.conv_group & (BM == 128 ? 4 : 8)) && k.ksplit == 1 && ROWB == 64) {
-    if (!g_conv_group->add(BM == 128 ? (spread ? 3 : 1) : 2, (unsigned)(k.nbm * k.nbn), smem, k)) { rua_set_error("rua_conv_fwd_group: more than %d captured members", RUA_MAX_BRANCH); return RUA_ERR_ARG; }
+    if (!g_conv_group->add(BM == 128 ? (spec ? 4 : spread ? 3 : 1) : (spec ? 5 : 2), (unsigned)(k.nbm * k.nbn), smem, k)) { rua_set_error("rua_conv_fwd_group: more than %d captured members", RUA_MAX_BRANCH); return RUA_ERR_ARG; }
     return RUA_OK;
+  }
+  if constexpr (ROWB == 64) {
+    if (spec) {
+      hipLaunchKernelGGL((conv_dmap_w<BM, BN, ROWB>), dim3(k.nbm * k.nbn * k.ksplit), dim3(512), smem, st, k);
+      RUA_LAUNCH_CHECK("conv_dmap_w");
+      if (k.ksplit > 1 && k.cnt == nullptr) {
+        launch_splitk_finish<bf16_t>(k, st);
+        RUA_LAUNCH_CHECK("conv_splitk_finish");
+      }
+      return RUA_OK;
+    }
   }
   if constexpr (BM == 128 && ROWB == 64) {
     if (spread) hipLaunchKernelGGL((conv_dmap_s<BM, BN, ROWB>), dim3(k.nbm * k.nbn * k.ksplit), dim3(256), smem, st, k);
@@ -1898,16 +1948,16 @@ extern "C" int rua_conv_group_last_band(void) { return g_group_last_band; }     
 extern "C" int rua_conv_group_band_ok(const rua_conv_desc* d, int n) { return (d && rua_band64m_ok(d, n)) ? 1 : 0; }   // grids the calling thread's latest rua_conv_fwd_group issued (1: one grid for all members)
 
 template <typename KG, typename F1, typename FG>
-static int issue_group(const ConvGroupCapture& c, const int* idx, int m, F1 single, FG grouped, int smem_attr, hipStream_t st, const char* what) {
+static int issue_group(const ConvGroupCapture& c, const int* idx, int m, F1 single, FG grouped, int smem_attr, hipStream_t st, const char* what, int threads = 256) {
   if (m == 1) {
-    hipLaunchKernelGGL(single, dim3(c.grid[idx[0]]), dim3(256), c.smem[idx[0]], st, c.k[idx[0]]);
+    hipLaunchKernelGGL(single, dim3(c.grid[idx[0]]), dim3(threads), c.smem[idx[0]], st, c.k[idx[0]]);
   } else {
     static thread_local bool attr[8] = {false};
     const int slot = c.kind[idx[0]];
     if (!attr[slot]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grouped), hipFuncAttributeMaxDynamicSharedMemorySize, smem_attr); attr[slot] = true; }
     KG g;
     for (int i = 0; i < m; ++i) g.k[i] = c.k[idx[i]];
-    hipLaunchKernelGGL(grouped, dim3(c.grid[idx[0]], m), dim3(256), c.smem[idx[0]], st, g);
+    hipLaunchKernelGGL(grouped, dim3(c.grid[idx[0]], m), dim3(threads), c.smem[idx[0]], st, g);
   }
   RUA_LAUNCH_CHECK(what);
   return RUA_OK;
@@ -1971,6 +2021,8 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
     if (chain && cap.kind[i] == 1) rc = issue_chain(cap, idx, m, conv_dmap_chain<128, 128, 64>, conv_dmap_chain_smem<128, 128>(), 0, st);
     else if (chain) rc = issue_chain(cap, idx, m, conv_dmap_chain<64, 128, 64>, conv_dmap_chain_smem<64, 128>(), 1, st);
     else if (cap.kind[i] == 1) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap<128, 128, 64>, conv_dmap_g<128, 128, 64>, conv_dmap_smem<128, 128>(), st, "conv_dmap (group)");
+    else if (cap.kind[i] == 4) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap_w<128, 128, 64>, conv_dmap_gw<128, 128, 64>, conv_dmap_smem<128, 128>(), st, "conv_dmap_w (group)", 512);
+    else if (cap.kind[i] == 5) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap_w<64, 128, 64>, conv_dmap_gw<64, 128, 64>, conv_dmap_smem<64, 128>(), st, "conv_dmap_w (group)", 512);
     else if (cap.kind[i] == 3) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap_s<128, 128, 64>, conv_dmap_gs<128, 128, 64>, conv_dmap_smem<128, 128, 4>(), st, "conv_dmap_s (group)");
     else if (cap.kind[i] == 2) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap<64, 128, 64>, conv_dmap_g<64, 128, 64>, conv_dmap_smem<64, 128>(), st, "conv_dmap (group)");
     else rc = issue_group<ConvKG>(cap, idx, m, conv_igemm<bf16_t, 256, 64>, conv_igemm_g<bf16_t, 256, 64>, conv_smem<bf16_t, 256, 64>(), st, "conv_igemm (group)");

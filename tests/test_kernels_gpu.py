@@ -1556,3 +1556,53 @@ def test_conv_group_band64_multi(N, H, W, dils, kind):
         for b in range(nb):
             assert rel_err(ys[b].float().cpu().numpy(), ys2[b].float().cpu().numpy()) < tol(dt)
             assert np.allclose(sts[b].cpu().numpy().reshape(R, -1).sum(0), sts2[b].cpu().numpy().reshape(R, -1).sum(0), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("N,H,W,Cs,Cout,dil", [(8, 64, 64, 128, 128, 3), (4, 32, 32, 256, 256, 15), (8, 16, 16, 512, 512, 1), (2, 40, 24, 192, 128, 1)])
+def test_conv_dmap_issue_forms_are_bit_identical(N, H, W, Cs, Cout, dil):
+    """conv_dmap's three ways of issuing a stage's DMA instructions (tuning key dmap_spread: 0 one burst behind the stage barrier, 1 a
+    quarter per k-step between the MFMAs with four stage buffers - the default -, 2 / 6 by DMA waves of their own beside the MFMA waves,
+    512-thread blocks) stage the same bytes and multiply in the same order: outputs and statistics are bit for bit the same, with and
+    without a K split, and form 0 is the one the fp64 comparisons of test_conv_fwd were written against."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(Cs + dil)
+    x = to_dev(rng.standard_normal((N, H, W, Cs)).astype(np.float32), dt)
+    aux = to_dev(rng.standard_normal((N, H, W, Cout)).astype(np.float32), dt)
+    w = to_dev((rng.standard_normal((9, Cout, Cs)) / np.sqrt(9 * Cs)).astype(np.float32), dt)
+    bias = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32)).to(dev())
+    sc = torch.from_numpy((0.5 + rng.random(Cout)).astype(np.float32)).to(dev()); sh = torch.from_numpy((0.3 * rng.standard_normal(Cout)).astype(np.float32)).to(dev())
+    ws = torch.zeros(8 << 20, dtype=torch.float32, device=dev())
+    res = {}
+    try:
+        for form in (0, 1, 2, 6):
+            lib.set_tuning(dmap_spread=form)
+            outs = []
+            for kind in ("bias", "mask"):
+                y = torch.zeros((N, H, W, Cout), dtype=torch.bfloat16, device=dev())
+                stats = torch.zeros(8 * 2 * Cout, dtype=torch.float64, device=dev())
+                d = L.ConvDesc()
+                d.nseg = 1
+                s = d.seg[0]
+                s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = x.data_ptr(), w.data_ptr(), Cs, H, W, 0, dil, 9
+                d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cout, 1, dt
+                d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+                d.stats, d.stats_replicas = stats.data_ptr(), 8
+                if kind == "bias":
+                    d.bias, d.stats_mode = bias.data_ptr(), 1
+                else:
+                    d.aux, d.aux_mode, d.mscale, d.mshift, d.stats_mode = aux.data_ptr(), 2, sc.data_ptr(), sh.data_ptr(), 2
+                d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+                assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 2
+                lib.call("rua_conv_fwd", C.byref(d), stream())
+                torch.cuda.synchronize()
+                outs.append((y, stats.cpu().numpy().reshape(8, -1).sum(0)))
+            res[form] = outs
+    finally:
+        lib.set_tuning(dmap_spread=1)
+    exp = ref_conv_nhwc(rnd(dt, x.float().cpu().numpy()), rnd(dt, w.float().cpu().numpy()), None, dil, 9).numpy() + bias.cpu().numpy().astype(np.float64)
+    assert rel_err(res[0][0][0].float().cpu().numpy(), exp) < tol(dt)
+    for form in (1, 2, 6):
+        for k in range(2):
+            assert torch.equal(res[form][k][0], res[0][k][0]), (form, k)
+            assert np.array_equal(res[form][k][1], res[0][k][1]), (form, k)
