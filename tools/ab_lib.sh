@@ -10,6 +10,6 @@ for r in $(seq $reps); do for l in $libs; do
 import json, sys
 j = json.loads(open("gpurun_out/ab_line.json").read().strip().splitlines()[-1])
 k = j["roofline"]["all_mfma_kernels"]
-print(sys.argv[1], j["ms_per_step"], j["value"], {n: k[n]["ms_per_step"] for n in k if n.startswith("conv_dmap")}, flush=True)
+print(sys.argv[1], j["ms_per_step"], j["value"], {n: k[n]["ms_per_step"] for n in k if n.startswith(("conv_dmap", "wgrad_dmap"))}, flush=True)
 PY
 done; done
