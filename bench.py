@@ -88,6 +88,23 @@ def committed_rocprof_avg(kernel, args):
     return t["avg_us"].get(kernel)
 
 
+def dmap_name(bm, bn, grouped):
+    """The LDS-DMA conv kernel as rocprofv3 names it: its issue form (tuning key dmap_spread) picks the instantiation."""
+    from resunet_a_mltsk_keras_amd import _lib as L
+    sp = L.lib().get_tuning("dmap_spread")
+    form = "w" if (sp & 2 and (bm == 128 or sp & 4)) else "s" if (sp == 1 and bm == 128) else ""
+    if grouped:
+        return f"conv_dmap_g{form}<{bm},{bn}>"
+    return f"conv_dmap_{form}<{bm},{bn}>" if form else f"conv_dmap<{bm},{bn}>"
+
+
+def ungrouped(kn):
+    for a, b in (("conv_dmap_gs<", "conv_dmap_s<"), ("conv_dmap_gw<", "conv_dmap_w<"), ("_g<", "<")):
+        if a in kn:
+            return kn.replace(a, b)
+    return kn
+
+
 def entry_bytes(name, args):
     """Algorithmic HBM bytes of one C-ABI launch = every activation tensor its descriptor names, once (weights and
     per-channel vectors included where they are not negligible); None for entries without a descriptor rule."""
@@ -118,14 +135,12 @@ def entry_bytes(name, args):
     if name in ("rua_conv_wgrad", "rua_conv_wgrad_group"):
         ds = [args[0]._obj] if name == "rua_conv_wgrad" else [args[0][i] for i in range(args[1])]
         return float(sum((d.N * d.Hs * d.Ws * d.C + d.N * d.H * d.W * d.Cout) * es(d.dtype) + d.taps * d.C * d.Cout * 4 for d in ds))
-    if name == "rua_bn_fwd":
-        d = args[0]._obj
-        if not d.x:
-            return 0.0
-        return float(d.M * d.C * es(d.dtype) * (1 + d.nb))
-    if name == "rua_bn_bwd":
-        d = args[0]._obj
-        return float(d.M * d.C * es(d.dtype) * (d.nb + 1 + (1 if d.dskip else 0) + 1 + (1 if d.accumulate else 0)))
+    if name in ("rua_bn_fwd", "rua_bn_fwd_group"):
+        ds = [args[0]._obj] if name == "rua_bn_fwd" else [args[0][i] for i in range(args[1])]
+        return float(sum(d.M * d.C * es(d.dtype) * (1 + d.nb) for d in ds if d.x))
+    if name in ("rua_bn_bwd", "rua_bn_bwd_group"):
+        ds = [args[0]._obj] if name == "rua_bn_bwd" else [args[0][i] for i in range(args[1])]
+        return float(sum(d.M * d.C * es(d.dtype) * (d.nb + 1 + (1 if d.dskip else 0) + 1 + (1 if d.accumulate else 0)) for d in ds))
     if name in ("rua_col_stats",):
         return float(args[1] * args[2] * es(args[5]))
     if name in ("rua_col_stats2",):
@@ -193,15 +208,15 @@ def profile_kernels(eng, g, dtype):
                 kid = lib.raw("rua_conv_kernel_id")(C.byref(d0))
                 bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d0)), lib.raw('rua_conv_tile_bn')(C.byref(d0))
                 # rocprofv3 names the grouped grids conv_igemm_g<...>, conv_dmap_g<...>, conv_strip32_g<...>
-                kn = (f"conv_igemm_g<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap_g<{bm_},{bn_}>", f"conv_halo<{d0.Cout}>", "conv_pw", f"conv_strip_g<{d0.Cout}>")[kid]
+                kn = (f"conv_igemm_g<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", dmap_name(bm_, bn_, True), f"conv_halo<{d0.Cout}>", "conv_pw", f"conv_strip_g<{d0.Cout}>")[kid]
                 grids = lib.raw("rua_conv_group_last_grids")()
                 nl = 1
                 if lib.raw("rua_conv_group_last_band")() == 1:   # C = 64: the members as ONE row-streaming launch
                     kn = "conv_band64m"
                 elif grids == n and all(lib.raw("rua_conv_kernel_id")(C.byref(arr[i])) == kid for i in range(n)):
-                    kn, nl = kn.replace("_g<", "<"), n     # not grouped: n launches of the plain kernel
+                    kn, nl = ungrouped(kn), n              # not grouped: n launches of the plain kernel
                 elif grids != 1:                            # members the launchers could not put into one grid
-                    kn = f"{kn.replace('_g<', '<')} ({n} members in {grids} launches)"
+                    kn = f"{ungrouped(kn)} ({n} members in {grids} launches)"
                 fl = sum(conv_flops(arr[i]) for i in range(n))
                 rec.append((kn, e0, e1, fl, (d0.N * d0.H * d0.W, d0.Cout, d0.seg[0].taps * d0.seg[0].C, 0, f"group of {n}"), nl))
             elif name == "rua_conv_fwd_sum":               # the branches' second convs summed on chip: one launch (conv_band32) or n
@@ -241,7 +256,7 @@ def profile_kernels(eng, g, dtype):
                 if name == "rua_conv_fwd":
                     bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d)), lib.raw('rua_conv_tile_bn')(C.byref(d))
                     two = fired
-                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", f"conv_dmap<{bm_},{bn_}>", f"conv_halo<{d.Cout}>", "conv_pw", f"conv_strip<{d.Cout}>")[kid]
+                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", dmap_name(bm_, bn_, False), f"conv_halo<{d.Cout}>", "conv_pw", f"conv_strip<{d.Cout}>")[kid]
                     kk = sum(d.seg[i].taps * d.seg[i].C for i in range(d.nseg))
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "") + (" splitk" if two else "")
                     fl, tag, second = conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags), f"conv_splitk_finish<{tname}>"

@@ -118,7 +118,11 @@ _SIGS = {
     "rua_bn_bwd_apply": ([i32, PP, PP, PP, PP, PP, PP, i32, vp, vp, vp, i32, i64, i32, i32, vp], i32),
     "rua_stats_to_f32": ([vp, i32, i32, PP, i32, vp], i32),
     "rua_bn_fwd": ([C.POINTER(BnFwdDesc), vp], i32),
+    "rua_bn_fwd_group": ([C.POINTER(BnFwdDesc), i32, vp], i32),
+    "rua_bn_fwd_group_last_grids": ([], i32),
     "rua_bn_bwd": ([C.POINTER(BnBwdDesc), vp], i32),
+    "rua_bn_bwd_group": ([C.POINTER(BnBwdDesc), i32, vp], i32),
+    "rua_bn_bwd_group_last_grids": ([], i32),
     "rua_maxpool_fwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "rua_maxpool_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "rua_sumpool": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),

@@ -1431,7 +1431,7 @@ template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, 
   const bool spread = BM == 128 && ROWB == 64 && g_tune.dmap_spread == 1; // DMA instructions between the MFMAs of the same waves (four stage buffers)
   const int smem = spread ? conv_dmap_smem<BM, BN, 4>() : conv_dmap_smem<BM, BN>();
   if (g_conv_group && (g_tune.conv_group & (BM == 128 ? 4 : 8)) && k.ksplit == 1 && ROWB == 64) {
-    if (!g_conv_group->add(BM == 128 ? (spec ? 4 : spread ? 3 : 1) : (spec ? 5 : 2), (unsigned)(k.nbm * k.nbn), smem, k)) { rua_set_error("rua_conv_fwd_group: more than %d captured members", RUA_MAX_BRANCH); return RUA_ERR_ARG; }
+    if (!g_conv_group->add(BM == 128 ? (spec ? 4 : spread ? 6 : 1) : (spec ? 5 : 2),     /* capture kinds: 1 / 2 conv_dmap 128- / 64-row tiles, 3 conv_igemm<256,64>, 4 / 5 conv_dmap_w, 6 conv_dmap_s */ (unsigned)(k.nbm * k.nbn), smem, k)) { rua_set_error("rua_conv_fwd_group: more than %d captured members", RUA_MAX_BRANCH); return RUA_ERR_ARG; }
     return RUA_OK;
   }
   if constexpr (ROWB == 64) {
@@ -2023,7 +2023,7 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
     else if (cap.kind[i] == 1) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap<128, 128, 64>, conv_dmap_g<128, 128, 64>, conv_dmap_smem<128, 128>(), st, "conv_dmap (group)");
     else if (cap.kind[i] == 4) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap_w<128, 128, 64>, conv_dmap_gw<128, 128, 64>, conv_dmap_smem<128, 128>(), st, "conv_dmap_w (group)", 512);
     else if (cap.kind[i] == 5) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap_w<64, 128, 64>, conv_dmap_gw<64, 128, 64>, conv_dmap_smem<64, 128>(), st, "conv_dmap_w (group)", 512);
-    else if (cap.kind[i] == 3) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap_s<128, 128, 64>, conv_dmap_gs<128, 128, 64>, conv_dmap_smem<128, 128, 4>(), st, "conv_dmap_s (group)");
+    else if (cap.kind[i] == 6) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap_s<128, 128, 64>, conv_dmap_gs<128, 128, 64>, conv_dmap_smem<128, 128, 4>(), st, "conv_dmap_s (group)");
     else if (cap.kind[i] == 2) rc = issue_group<ConvKG>(cap, idx, m, conv_dmap<64, 128, 64>, conv_dmap_g<64, 128, 64>, conv_dmap_smem<64, 128>(), st, "conv_dmap (group)");
     else rc = issue_group<ConvKG>(cap, idx, m, conv_igemm<bf16_t, 256, 64>, conv_igemm_g<bf16_t, 256, 64>, conv_smem<bf16_t, 256, 64>(), st, "conv_igemm (group)");
     if (rc != RUA_OK) return rc;

@@ -360,7 +360,7 @@ extern "C" int rua_bn_bwd_apply(int nb, const void* const* g, const float* const
 // updates the moving statistics / parameter gradients.
 // NB > 0: the branch count, coefficients in registers (needs 256 % CG == 0); NB == 0: any shape, coefficients read from the LDS table
 template <typename T, int NB>
-__global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, long long pieces, int CG) {
+__device__ __forceinline__ void bn_fwd_body(const rua_bn_fwd_desc& p, long long pieces, int CG) {
   constexpr int VEC = ET<T>::VEC;
   extern __shared__ float tab[];                       // [nb][2][C] scale/shift, then [2][C] mean/rstd
   const int C = p.C;
@@ -452,6 +452,51 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, lo
   }
 }
 
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, long long pieces, int CG) { bn_fwd_body<T, NB>(p, pieces, CG); }
+// rua_bn_fwd_group: independent one-branch BatchNorm applications of equal shape (the second BatchNorms of a ResBlock's dilation branches
+// where they are materialised: model2.py:21, levels 3 - 6) as ONE grid - blockIdx.y picks the member
+struct BnFwdG { rua_bn_fwd_desc k[RUA_MAX_BRANCH]; };
+static_assert(sizeof(BnFwdG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fwd_kernel_g(const BnFwdG g, long long pieces, int CG) { bn_fwd_body<T, 1>(g.k[blockIdx.y], pieces, CG); }
+
+extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream);
+static thread_local int g_bn_fwd_group_last = 0;
+extern "C" int rua_bn_fwd_group_last_grids(void) { return g_bn_fwd_group_last; }
+extern "C" int rua_bn_fwd_group(const rua_bn_fwd_desc* d, int n, void* stream) {
+  RUA_CHECK_ARG(d && n >= 1 && n <= RUA_MAX_BRANCH, "rua_bn_fwd_group: 1..%d members", RUA_MAX_BRANCH);
+  const int vec = d[0].dtype == RUA_BF16 ? 8 : 4;
+  bool one = n > 1 && g_tune.bn_bwd_group && d[0].C % vec == 0 && d[0].C / vec <= 256 && 256 % (d[0].C / vec) == 0 && g_tune.bn_regs &&
+             (d[0].dtype == RUA_F32 || d[0].dtype == RUA_BF16) && (size_t)4 * d[0].C * 4 <= 64 * 1024;
+  for (int i = 0; i < n && one; ++i) {
+    const rua_bn_fwd_desc& m = d[i];
+    const rua_bn_branch& br = m.br[0];
+    one = m.x && m.nb == 1 && m.M == d[0].M && m.M > 0 && m.C == d[0].C && m.dtype == d[0].dtype && m.training == d[0].training && br.out &&
+          br.gamma && br.beta && br.scale && br.shift && (!m.training || (m.count > 0 && (br.stats ? br.replicas >= 1 : (m.stats && m.replicas >= 1)))) &&
+          (m.training || (br.moving_mean && br.moving_var));
+  }
+  g_bn_fwd_group_last = n;
+  if (!one) {                                            // same results member by member
+    for (int i = 0; i < n; ++i) { const int rc = rua_bn_fwd(d + i, stream); if (rc != RUA_OK) return rc; }
+    return RUA_OK;
+  }
+  const int CG = d[0].C / vec;
+  const size_t smem = (size_t)(1 * 2 + 2) * d[0].C * 4;
+  const long long pieces = d[0].M * CG;
+  int g = grid_for(pieces);
+  const int cap = 2 * rua_cu_count() / (n > 2 ? 2 : 1);
+  if (g > cap) g = cap;
+  BnFwdG a;
+  for (int i = 0; i < n; ++i) a.k[i] = d[i];
+  hipStream_t st = (hipStream_t)stream;
+  if (d[0].dtype == RUA_BF16) hipLaunchKernelGGL((bn_fwd_kernel_g<bf16_t>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
+  else hipLaunchKernelGGL((bn_fwd_kernel_g<float>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
+  RUA_LAUNCH_CHECK("rua_bn_fwd_group");
+  g_bn_fwd_group_last = 1;
+  return RUA_OK;
+}
+
 extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream) {
   RUA_CHECK_ARG(d && d->nb >= 1 && d->nb <= RUA_MAX_BRANCH && d->M > 0 && d->C > 0, "rua_bn_fwd: bad arguments");
   const bool coef_only = d->br[0].out == nullptr;
@@ -493,7 +538,7 @@ extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream) {
 // (Measured and rejected, same-box A/B: issuing the sweep's first loads before the coefficient prologue and double-buffering the
 // sweep in registers - 9.70 vs 9.68 ms per step; the blocks of one launch already overlap each other's prologue.)
 template <typename T, int NB, bool MASKED>
-__global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, long long pieces, int CG) {
+__device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long pieces, int CG) {
   constexpr int VEC = ET<T>::VEC;
   extern __shared__ float tab[];                       // [nb][3][C] : A, ms, mt ; then [2][C] : sumB, sumC
   const int C = p.C;
@@ -628,6 +673,55 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, lo
       unsafeAtomicAdd(&p.skip_stats[(size_t)(blockIdx.x & (p.skip_replicas - 1)) * 2 * C + ch], (double)t);
     }
   }
+}
+
+template <typename T, int NB, bool MASKED>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, long long pieces, int CG) { bn_bwd_body<T, NB, MASKED>(p, pieces, CG); }
+// rua_bn_bwd_group: independent one-branch BatchNorm backwards of equal shape (the second BatchNorms of a ResBlock's dilation branches:
+// model2.py:21-22, one per branch, each with its own gradient, input and output) as ONE grid - blockIdx.y picks the member
+struct BnBwdG { rua_bn_bwd_desc k[RUA_MAX_BRANCH]; };
+static_assert(sizeof(BnBwdG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
+template <typename T, bool MASKED>
+__global__ __launch_bounds__(256) void bn_bwd_kernel_g(const BnBwdG g, long long pieces, int CG) { bn_bwd_body<T, 1, MASKED>(g.k[blockIdx.y], pieces, CG); }
+
+extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream);
+static thread_local int g_bn_bwd_group_last = 0;
+extern "C" int rua_bn_bwd_group_last_grids(void) { return g_bn_bwd_group_last; }     // grids the calling thread's latest rua_bn_bwd_group issued
+extern "C" int rua_bn_bwd_group(const rua_bn_bwd_desc* d, int n, void* stream) {
+  RUA_CHECK_ARG(d && n >= 1 && n <= RUA_MAX_BRANCH, "rua_bn_bwd_group: 1..%d members", RUA_MAX_BRANCH);
+  const int vec = d[0].dtype == RUA_BF16 ? 8 : 4;
+  bool one = n > 1 && g_tune.bn_bwd_group && d[0].C % vec == 0 && d[0].C / vec <= 256 && 256 % (d[0].C / vec) == 0 && g_tune.bn_regs;
+  for (int i = 0; i < n && one; ++i) {
+    const rua_bn_bwd_desc& m = d[i];
+    one = m.x && m.dx && m.nb == 1 && m.M == d[0].M && m.C == d[0].C && m.dtype == d[0].dtype && m.masked == d[0].masked && !m.skip_stats && m.count > 0 &&
+          m.br[0].g && m.br[0].stats2 && m.br[0].replicas >= 1 && m.br[0].gamma && m.br[0].mean && m.br[0].rstd &&
+          (d[0].dtype == RUA_F32 || d[0].dtype == RUA_BF16);
+  }
+  g_bn_bwd_group_last = n;
+  if (!one) {                                            // same results member by member
+    for (int i = 0; i < n; ++i) { const int rc = rua_bn_bwd(d + i, stream); if (rc != RUA_OK) return rc; }
+    return RUA_OK;
+  }
+  const int CG = d[0].C / vec;
+  const size_t smem = (size_t)(1 * 3 + 2) * d[0].C * 4;
+  const long long pieces = d[0].M * CG;
+  int g = grid_for(pieces);
+  const int cap = (pieces >= (1ll << 20) ? 4 : 2) * rua_cu_count() / (n > 2 ? 2 : 1);    // the members fill the chip together
+  if (g > cap) g = cap;
+  BnBwdG a;
+  for (int i = 0; i < n; ++i) a.k[i] = d[i];
+  hipStream_t st = (hipStream_t)stream;
+  const bool mk = d[0].masked != 0;
+  if (d[0].dtype == RUA_BF16) {
+    if (mk) hipLaunchKernelGGL((bn_bwd_kernel_g<bf16_t, true>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
+    else hipLaunchKernelGGL((bn_bwd_kernel_g<bf16_t, false>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
+  } else {
+    if (mk) hipLaunchKernelGGL((bn_bwd_kernel_g<float, true>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
+    else hipLaunchKernelGGL((bn_bwd_kernel_g<float, false>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
+  }
+  RUA_LAUNCH_CHECK("rua_bn_bwd_group");
+  g_bn_bwd_group_last = 1;
+  return RUA_OK;
 }
 
 extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {

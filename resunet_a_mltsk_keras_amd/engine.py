@@ -456,7 +456,7 @@ class Graph:
         plan.add("rua_bn_apply", x.ptr, len(coefs), sc, sh, 1 if relu else 0, ou, x.M, x.C, self.dt)
         return outs
 
-    def bn_fwd(self, plan: Plan, x: Ten, bns: List[dict], relu: bool, stats: Optional[Stat], count, bessel=None):
+    def bn_fwd(self, plan: Plan, x: Ten, bns: List[dict], relu: bool, stats: Optional[Stat], count, bessel=None, defer: Optional[List] = None):
         """[relu](BN_b(x)) for every branch b in ONE launch: coefficients from the statistics in the kernel prologue,
         published to `Coef` buffers (block 0) for the ReLU masks / backward; moving statistics updated in training."""
         outs = [self.like(x) for _ in bns]
@@ -471,8 +471,30 @@ class Graph:
             b = d.br[i]
             b.gamma, b.beta, b.moving_mean, b.moving_var = self.P(bn["gamma"]), self.P(bn["beta"]), self.S(bn["mm"]), self.S(bn["mv"])
             b.scale, b.shift, b.mean, b.rstd, b.out = c.scale, c.shift, c.mean, c.rstd, o.ptr
-        plan.keep += [d] + coefs
+        plan.keep += coefs
+        if defer is not None:                                # the caller issues several as one rua_bn_fwd_group
+            defer.append(d)
+            return outs, coefs
+        plan.keep.append(d)
         plan.add("rua_bn_fwd", C.byref(d))
+        return outs, coefs
+
+    def bn_fwd_group(self, plan: Plan, items: List[tuple], relu: bool, count):
+        """[relu](BN(x_i)) for several tensors of equal shape, each with its own BatchNorm and statistics, as ONE launch: items = (x, bn, stats);
+        returns ([out_i], [coef_i])."""
+        ds, outs, coefs = [], [], []
+        for x, bn, st in items:
+            o, c = self.bn_fwd(plan, x, [bn], relu, st, count, defer=ds)
+            outs.append(o[0]); coefs.append(c[0])
+        if len(ds) == 1:
+            plan.keep.append(ds[0])
+            plan.add("rua_bn_fwd", C.byref(ds[0]))
+        else:
+            arr = (L.BnFwdDesc * len(ds))()
+            for i, d in enumerate(ds):
+                C.memmove(C.byref(arr, i * C.sizeof(L.BnFwdDesc)), C.byref(d), C.sizeof(L.BnFwdDesc))
+            plan.keep.append(arr)
+            plan.add("rua_bn_fwd_group", arr, len(ds))
         return outs, coefs
 
     def bn_coefs(self, plan: Plan, like: Ten, bns: List[dict], stats: List[Optional[Stat]], count, bessel=None) -> List[Coef]:
@@ -494,7 +516,7 @@ class Graph:
         return coefs
 
     def bn_bwd(self, plan: Plan, gs: List[Ten], coefs: List[Coef], bns: List[dict], stats2: List[Stat], x: Ten, out: Ten,
-               accumulate: int, count, dskip: Optional[Ten] = None, masked=False, skip_bias: Optional[List[int]] = None):
+               accumulate: int, count, dskip: Optional[Ten] = None, masked=False, skip_bias: Optional[List[int]] = None, defer: Optional[List] = None):
         """dx (=|+=) [dskip] + sum_b BN-backward_b(g_b) in ONE launch; dgamma/dbeta added by block 0.
         skip_bias: bias offsets whose gradient is the per-channel sum of dskip - accumulated by this launch while it reads
         dskip anyway (instead of a col_stats pass over the same tensor), converted by one rua_stats_to_f32."""
@@ -516,10 +538,30 @@ class Graph:
             blocks = max(1, min(1024, x.M * (x.C // self.vec) // 256))
             st = self.stat(x.C, blocks, burst=True)
             d.skip_stats, d.skip_replicas = st.ptr, st.R
+        if defer is not None:                                # the caller issues several as one rua_bn_bwd_group
+            assert st is None
+            defer.append(d)
+            return
         plan.keep.append(d)
         plan.add("rua_bn_bwd", C.byref(d))
         if st is not None:
             self.stats_to_grads(plan, st, x.C, skip_bias)
+
+    def bn_bwd_group(self, plan: Plan, items: List[tuple]):
+        """The one-branch BatchNorm backwards of a ResBlock's dilation branches (their second BatchNorms: own gradient, own input, own
+        output) as ONE launch: items = (g, coef, bn, stats2, x, out, count)."""
+        ds: List = []
+        for g, c, bn, s2, x, out, cnt in items:
+            self.bn_bwd(plan, [g], [c], [bn], [s2], x, out, 0, cnt, defer=ds)
+        if len(ds) == 1:
+            plan.keep.append(ds[0])
+            plan.add("rua_bn_bwd", C.byref(ds[0]))
+            return
+        arr = (L.BnBwdDesc * len(ds))()
+        for i, d in enumerate(ds):
+            C.memmove(C.byref(arr, i * C.sizeof(L.BnBwdDesc)), C.byref(d), C.sizeof(L.BnBwdDesc))
+        plan.keep.append(arr)
+        plan.add("rua_bn_bwd_group", arr, len(ds))
 
     def conv(self, plan: Plan, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual: Optional[Ten] = None,
              out_relu=False, stats=None, bias_more=(), in_bn: Optional["Coef"] = None, accumulate: int = 0, in_fold=None):
@@ -796,10 +838,7 @@ class Graph:
                                              residual=x if (v2 and bi == 0) else None, accumulate=1 if bi > 0 else 0)
                               for bi, (d, l, y, c2, f2) in enumerate(zip(dils, lay, y1, coef2, fold2))])
         else:
-            coef2, a2 = [], []
-            for l, y, st in zip(lay, y1, st1):
-                o2, c2l = self.bn_fwd(F, y, [l[2]], True, st, cnt)
-                coef2.append(c2l[0]); a2.append(o2[0])
+            a2, coef2 = self.bn_fwd_group(F, [(y, l[2], st) for l, y, st in zip(lay, y1, st1)], True, cnt)
             biases = [self.P(l[3]["bias"]) for l in lay]        # the concatenated conv's bias = sum of the branches' biases
             self.conv(F, [(a, 0, d, 9) for a, d in zip(a2, dils)], [l[3]["segs"][0] for l in lay], nf, biases[0], out,
                       residual=x if v2 else None, bias_more=biases[1:])
@@ -822,8 +861,7 @@ class Graph:
             self.conv_group(Bp, [self.dgrad_desc(dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
                                  for d, l, y, c2, g2, s2 in zip(dils, lay, y1, coef2, g2s, s2s)])
             dy1s = [self.like(x) for _ in dils]
-            for l, y, c2, g2, s2, dy1 in zip(lay, y1, coef2, g2s, s2s, dy1s):
-                self.bn_bwd(Bp, [g2], [c2], [l[2]], [s2], y, dy1, 0, cnt)
+            self.bn_bwd_group(Bp, [(g2, c2, l[2], s2, y, dy1, cnt) for l, y, c2, g2, s2, dy1 in zip(lay, y1, coef2, g2s, s2s, dy1s)])
             # no bias gradient launch: the output of a BN backward sums to zero per channel, so d b1 == 0 exactly
             self.wgrad_group(Bp, [(a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9, None) for d, l, a_1, dy1 in zip(dils, lay, a1, dy1s)])
             g1s = g2s                                          # g2 is dead after its bn_bwd: reuse the storage
@@ -951,8 +989,7 @@ class Graph:
             self.conv_group(Bp, [self.dgrad_desc(dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
                                  for d, l, y, c2, g2, s2 in zip(dils, lay, y1, coef2, g2s, s2s)])
             dy1s = [self.like(x) for _ in dils]
-            for l, y, c2, g2, s2, dy1 in zip(lay, y1, coef2, g2s, s2s, dy1s):
-                self.bn_bwd(Bp, [g2], [c2], [l[2]], [s2], y, dy1, 0, cnt)
+            self.bn_bwd_group(Bp, [(g2, c2, l[2], s2, y, dy1, cnt) for l, y, c2, g2, s2, dy1 in zip(lay, y1, coef2, g2s, s2s, dy1s)])
             self.wgrad_group(Bp, [(x, dy1, l[1]["segs"][0]["off"], 1, d, 9, c1) for d, l, c1, dy1 in zip(dils, lay, coef1, dy1s)])
             g1s = g2s
             s1s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]

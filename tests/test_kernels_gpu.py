@@ -950,7 +950,8 @@ def test_wgrad_deferred_batched_reduction_is_bit_identical():
 
 
 @pytest.mark.parametrize("shape", [(8, 64, 64, 128, [1, 3, 15]), (2, 256, 256, 32, [1, 3, 15, 31]), (4, 128, 128, 64, [3, 15, 31]), (8, 16, 16, 512, [1, 3]),
-                                   (6, 128, 128, 32, [1, 3, 15, 31]), (8, 32, 32, 256, [1, 3, 15]), (3, 24, 40, 128, [1, 15])])
+                                   (6, 128, 128, 32, [1, 3, 15, 31]), (8, 32, 32, 256, [1, 3, 15]), (3, 24, 40, 128, [1, 15]),
+                                   (32, 64, 64, 64, [1, 3, 15, 31]), (5, 64, 64, 64, [1, 15])])     # C = 64 off the 128-pixel rows: conv_igemm_g
 def test_conv_group_equals_separate_launches(shape):
     """rua_conv_fwd_group: the dilation branches of a ResBlock in one call.  Members on the same kernel (conv_dmap at the
     64x64x128 level, conv_strip at 256x256x32) share ONE grid, the 128x128x64 level runs as ONE conv_band64m launch; members the launcher cannot group
@@ -1001,7 +1002,7 @@ def test_conv_group_equals_separate_launches(shape):
     torch.cuda.synchronize()
     assert lib.raw("rua_conv_group_last_chain")() == 0
     band = lib.raw("rua_conv_group_last_band")() == 1          # 128x128x64: the group is ONE conv_band64m launch - another kernel than the
-    assert band == (Cs == 64)                                  # members' own (conv_igemm), another fp32 summation order
+    assert band == (Cs == 64 and W % 128 == 0)                 # members' own (conv_igemm), another fp32 summation order
     for i in range(len(dils)):
         if band:
             assert rel_err(keep[4 * i + 2].float().cpu().numpy(), sep[i][0].float().cpu().numpy()) < tol(dt), (i, dils[i])
@@ -1606,3 +1607,93 @@ def test_conv_dmap_issue_forms_are_bit_identical(N, H, W, Cs, Cout, dil):
         for k in range(2):
             assert torch.equal(res[form][k][0], res[0][k][0]), (form, k)
             assert np.array_equal(res[form][k][1], res[0][k][1]), (form, k)
+
+
+@pytest.mark.parametrize("M,Cc,n", [(8 * 64 * 64, 128, 3), (2 * 128 * 128, 64, 4), (600, 32, 2)])
+def test_bn_bwd_group_equals_separate_launches(M, Cc, n):
+    """rua_bn_bwd_group: the one-branch BatchNorm backwards of a ResBlock's dilation branches (model2.py:21-22: one BatchNorm per branch
+    behind its first conv) in ONE grid; outputs and dgamma / dbeta bit for bit those of n rua_bn_bwd calls."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(M + Cc)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+    xs = [to_dev((rng.standard_normal((M, Cc)) * 1.3 + 0.2).astype(np.float32), dt) for _ in range(n)]
+    gs = [to_dev(rng.standard_normal((M, Cc)).astype(np.float32), dt) for _ in range(n)]
+    gam = [f(rng.uniform(0.5, 1.5, Cc)) for _ in range(n)]
+    coef = [torch.zeros(4, Cc, device=dev()) for _ in range(n)]
+    for b in range(n):                                       # any consistent coefficients serve: scale, shift, mean, rstd
+        xm = xs[b].float()
+        mean, var = xm.mean(0), xm.var(0, unbiased=False)
+        coef[b][2], coef[b][3] = mean, torch.rsqrt(var + 1e-3)
+        coef[b][0] = gam[b] * coef[b][3]
+        coef[b][1] = 0.1 - mean * coef[b][0]
+    st2 = [torch.zeros(4 * 2 * Cc, dtype=torch.float64, device=dev()) for _ in range(n)]
+    for b in range(n):
+        lib.call("rua_col_stats2", gs[b].data_ptr(), xs[b].data_ptr(), coef[b][0].data_ptr(), coef[b][1].data_ptr(), 1, M, Cc, st2[b].data_ptr(), 4, dt, stream())
+    res = []
+    for grouped in (False, True):
+        dxs = [torch.zeros((M, Cc), dtype=torch.bfloat16, device=dev()) for _ in range(n)]
+        dg = [torch.zeros(Cc, device=dev()) for _ in range(n)]; db = [torch.zeros(Cc, device=dev()) for _ in range(n)]
+        arr = (L.BnBwdDesc * n)()
+        for b in range(n):
+            e = arr[b]
+            e.x, e.dx, e.M, e.C, e.dtype, e.nb, e.masked, e.accumulate, e.count = xs[b].data_ptr(), dxs[b].data_ptr(), M, Cc, dt, 1, 1, 0, float(M)
+            br = e.br[0]
+            br.g, br.stats2, br.replicas, br.gamma = gs[b].data_ptr(), st2[b].data_ptr(), 4, gam[b].data_ptr()
+            br.scale, br.shift, br.mean, br.rstd = [coef[b][i].data_ptr() for i in range(4)]
+            br.dgamma, br.dbeta = dg[b].data_ptr(), db[b].data_ptr()
+        if grouped:
+            lib.call("rua_bn_bwd_group", arr, n, stream())
+            assert lib.raw("rua_bn_bwd_group_last_grids")() == 1
+        else:
+            for b in range(n):
+                lib.call("rua_bn_bwd", C.byref(arr[b]), stream())
+        torch.cuda.synchronize()
+        res.append((dxs, dg, db))
+    for b in range(n):
+        assert torch.equal(res[0][0][b], res[1][0][b]), b
+        assert torch.equal(res[0][1][b], res[1][1][b]) and torch.equal(res[0][2][b], res[1][2][b]), b
+    assert float(res[1][0][0].float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("M,Cc,n,training", [(8 * 64 * 64, 128, 3, 1), (8 * 32 * 32, 256, 3, 0), (700, 32, 2, 1)])
+def test_bn_fwd_group_equals_separate_launches(M, Cc, n, training):
+    """rua_bn_fwd_group: the second BatchNorms of a ResBlock's dilation branches where they are materialised (model2.py:21: one per branch, own input,
+    own statistics) in ONE grid; outputs, published coefficients and moving statistics bit for bit those of n rua_bn_fwd calls."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(M + Cc)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+    xs = [to_dev((rng.standard_normal((M, Cc)) * 1.3 + 0.2).astype(np.float32), dt) for _ in range(n)]
+    gam = [f(rng.uniform(0.5, 1.5, Cc)) for _ in range(n)]; bet = [f(rng.standard_normal(Cc)) for _ in range(n)]
+    sts = [torch.zeros(4 * 2 * Cc, dtype=torch.float64, device=dev()) for _ in range(n)]
+    for b in range(n):
+        lib.call("rua_col_stats", xs[b].data_ptr(), M, Cc, sts[b].data_ptr(), 4, dt, stream())
+    res = []
+    for grouped in (False, True):
+        outs = [torch.zeros((M, Cc), dtype=torch.bfloat16, device=dev()) for _ in range(n)]
+        co = [torch.zeros(4, Cc, device=dev()) for _ in range(n)]
+        mm = [f(np.full(Cc, 0.25)) for _ in range(n)]; mv = [f(np.full(Cc, 2.0)) for _ in range(n)]
+        arr = (L.BnFwdDesc * n)()
+        for b in range(n):
+            q = arr[b]
+            q.x, q.M, q.C, q.dtype, q.nb, q.relu, q.training = xs[b].data_ptr(), M, Cc, dt, 1, 1, training
+            q.stats, q.replicas, q.count, q.bessel_n, q.momentum, q.eps = sts[b].data_ptr(), 4, float(M), float(M), 0.99, 1e-3
+            br = q.br[0]
+            br.gamma, br.beta, br.moving_mean, br.moving_var = gam[b].data_ptr(), bet[b].data_ptr(), mm[b].data_ptr(), mv[b].data_ptr()
+            br.scale, br.shift, br.mean, br.rstd, br.out = (co[b][0].data_ptr(), co[b][1].data_ptr(), co[b][2].data_ptr(), co[b][3].data_ptr(), outs[b].data_ptr())
+        if grouped:
+            lib.call("rua_bn_fwd_group", arr, n, stream())
+            assert lib.raw("rua_bn_fwd_group_last_grids")() == 1
+        else:
+            for b in range(n):
+                lib.call("rua_bn_fwd", C.byref(arr[b]), stream())
+        torch.cuda.synchronize()
+        res.append((outs, co, mm, mv))
+    for b in range(n):
+        for k in range(4):
+            assert torch.equal(res[0][k][b], res[1][k][b]), (b, k)
+    assert float(res[1][0][0].float().abs().sum()) > 0
+    xr = xs[0].float()
+    if training:
+        assert np.allclose(res[1][2][0].cpu().numpy(), 0.25 * 0.99 + 0.01 * xr.mean(0).cpu().numpy(), rtol=1e-4, atol=1e-6)
