@@ -265,7 +265,7 @@ typedef struct rua_bn_fwd_desc {
   rua_bn_branch br[RUA_MAX_BRANCH];
 } rua_bn_fwd_desc;
 int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream);
-/* n (<= RUA_MAX_BRANCH) independent one-branch BatchNorm applications of equal shape as ONE grid (the results of n rua_bn_fwd calls; members that
+/* n (<= RUA_MAX_BRANCH) independent one-branch BatchNorm applications of equal channel count (any pixel counts) as ONE grid (the results of n rua_bn_fwd calls; members that
  * cannot share a grid are launched one by one).  Tuning key bn_bwd_group switches both this and rua_bn_bwd_group. */
 int rua_bn_fwd_group(const rua_bn_fwd_desc* d, int n, void* stream);
 int rua_bn_fwd_group_last_grids(void);
@@ -281,8 +281,8 @@ typedef struct rua_bn_bwd_desc {
   int32_t skip_replicas, pad2; /* the convs whose output the skip tensor is the gradient of: model2.py:27-31) - saves a pass over dskip */
 } rua_bn_bwd_desc;
 int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream);
-/* n (<= RUA_MAX_BRANCH) independent one-branch BatchNorm backwards of equal shape - the second BatchNorms of a ResBlock's dilation
- * branches (model2.py:21-22), each with its own gradient, input and output - as ONE grid (the results of n rua_bn_bwd calls; members
+/* n (<= RUA_MAX_BRANCH) independent one-branch BatchNorm backwards of equal channel count (any pixel counts) - the second BatchNorms of a
+ * ResBlock's dilation branches (model2.py:21-22), the branch BatchNorms of a PSPPooling (model2.py:56-66), each with its own gradient, input and output - as ONE grid (the results of n rua_bn_bwd calls; members
  * that cannot share a grid - several branches, skip statistics, unequal shapes - are launched one by one).  ..._last_grids: 1 or n. */
 int rua_bn_bwd_group(const rua_bn_bwd_desc* d, int n, void* stream);
 int rua_bn_bwd_group_last_grids(void);

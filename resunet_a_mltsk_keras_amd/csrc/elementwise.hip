@@ -456,10 +456,10 @@ template <typename T, int NB>
 __global__ __launch_bounds__(256) void bn_fwd_kernel(const rua_bn_fwd_desc p, long long pieces, int CG) { bn_fwd_body<T, NB>(p, pieces, CG); }
 // rua_bn_fwd_group: independent one-branch BatchNorm applications of equal shape (the second BatchNorms of a ResBlock's dilation branches
 // where they are materialised: model2.py:21, levels 3 - 6) as ONE grid - blockIdx.y picks the member
-struct BnFwdG { rua_bn_fwd_desc k[RUA_MAX_BRANCH]; };
+struct BnFwdG { rua_bn_fwd_desc k[RUA_MAX_BRANCH]; long long pieces[RUA_MAX_BRANCH]; };
 static_assert(sizeof(BnFwdG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 template <typename T>
-__global__ __launch_bounds__(256) void bn_fwd_kernel_g(const BnFwdG g, long long pieces, int CG) { bn_fwd_body<T, 1>(g.k[blockIdx.y], pieces, CG); }
+__global__ __launch_bounds__(256) void bn_fwd_kernel_g(const BnFwdG g, int CG) { bn_fwd_body<T, 1>(g.k[blockIdx.y], g.pieces[blockIdx.y], CG); }
 
 extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream);
 static thread_local int g_bn_fwd_group_last = 0;
@@ -472,7 +472,7 @@ extern "C" int rua_bn_fwd_group(const rua_bn_fwd_desc* d, int n, void* stream) {
   for (int i = 0; i < n && one; ++i) {
     const rua_bn_fwd_desc& m = d[i];
     const rua_bn_branch& br = m.br[0];
-    one = m.x && m.nb == 1 && m.M == d[0].M && m.M > 0 && m.C == d[0].C && m.dtype == d[0].dtype && m.training == d[0].training && br.out &&
+    one = m.x && m.nb == 1 && m.M > 0 && m.C == d[0].C && m.dtype == d[0].dtype && m.training == d[0].training && m.relu == d[0].relu && br.out &&
           br.gamma && br.beta && br.scale && br.shift && (!m.training || (m.count > 0 && (br.stats ? br.replicas >= 1 : (m.stats && m.replicas >= 1)))) &&
           (m.training || (br.moving_mean && br.moving_var));
   }
@@ -483,15 +483,15 @@ extern "C" int rua_bn_fwd_group(const rua_bn_fwd_desc* d, int n, void* stream) {
   }
   const int CG = d[0].C / vec;
   const size_t smem = (size_t)(1 * 2 + 2) * d[0].C * 4;
-  const long long pieces = d[0].M * CG;
+  BnFwdG a;
+  long long pieces = 0;
+  for (int i = 0; i < n; ++i) { a.k[i] = d[i]; a.pieces[i] = d[i].M * CG; if (a.pieces[i] > pieces) pieces = a.pieces[i]; }
   int g = grid_for(pieces);
   const int cap = 2 * rua_cu_count() / (n > 2 ? 2 : 1);
   if (g > cap) g = cap;
-  BnFwdG a;
-  for (int i = 0; i < n; ++i) a.k[i] = d[i];
   hipStream_t st = (hipStream_t)stream;
-  if (d[0].dtype == RUA_BF16) hipLaunchKernelGGL((bn_fwd_kernel_g<bf16_t>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
-  else hipLaunchKernelGGL((bn_fwd_kernel_g<float>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
+  if (d[0].dtype == RUA_BF16) hipLaunchKernelGGL((bn_fwd_kernel_g<bf16_t>), dim3(g, n), dim3(256), smem, st, a, CG);
+  else hipLaunchKernelGGL((bn_fwd_kernel_g<float>), dim3(g, n), dim3(256), smem, st, a, CG);
   RUA_LAUNCH_CHECK("rua_bn_fwd_group");
   g_bn_fwd_group_last = 1;
   return RUA_OK;
@@ -679,10 +679,10 @@ template <typename T, int NB, bool MASKED>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, long long pieces, int CG) { bn_bwd_body<T, NB, MASKED>(p, pieces, CG); }
 // rua_bn_bwd_group: independent one-branch BatchNorm backwards of equal shape (the second BatchNorms of a ResBlock's dilation branches:
 // model2.py:21-22, one per branch, each with its own gradient, input and output) as ONE grid - blockIdx.y picks the member
-struct BnBwdG { rua_bn_bwd_desc k[RUA_MAX_BRANCH]; };
+struct BnBwdG { rua_bn_bwd_desc k[RUA_MAX_BRANCH]; long long pieces[RUA_MAX_BRANCH]; };     // members of unequal pixel counts (the PSPPooling branches) sweep their own range
 static_assert(sizeof(BnBwdG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 template <typename T, bool MASKED>
-__global__ __launch_bounds__(256) void bn_bwd_kernel_g(const BnBwdG g, long long pieces, int CG) { bn_bwd_body<T, 1, MASKED>(g.k[blockIdx.y], pieces, CG); }
+__global__ __launch_bounds__(256) void bn_bwd_kernel_g(const BnBwdG g, int CG) { bn_bwd_body<T, 1, MASKED>(g.k[blockIdx.y], g.pieces[blockIdx.y], CG); }
 
 extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream);
 static thread_local int g_bn_bwd_group_last = 0;
@@ -693,7 +693,7 @@ extern "C" int rua_bn_bwd_group(const rua_bn_bwd_desc* d, int n, void* stream) {
   bool one = n > 1 && g_tune.bn_bwd_group && d[0].C % vec == 0 && d[0].C / vec <= 256 && 256 % (d[0].C / vec) == 0 && g_tune.bn_regs;
   for (int i = 0; i < n && one; ++i) {
     const rua_bn_bwd_desc& m = d[i];
-    one = m.x && m.dx && m.nb == 1 && m.M == d[0].M && m.C == d[0].C && m.dtype == d[0].dtype && m.masked == d[0].masked && !m.skip_stats && m.count > 0 &&
+    one = m.x && m.dx && m.nb == 1 && m.M > 0 && m.C == d[0].C && m.dtype == d[0].dtype && m.masked == d[0].masked && !m.skip_stats && m.count > 0 &&
           m.br[0].g && m.br[0].stats2 && m.br[0].replicas >= 1 && m.br[0].gamma && m.br[0].mean && m.br[0].rstd &&
           (d[0].dtype == RUA_F32 || d[0].dtype == RUA_BF16);
   }
@@ -704,20 +704,20 @@ extern "C" int rua_bn_bwd_group(const rua_bn_bwd_desc* d, int n, void* stream) {
   }
   const int CG = d[0].C / vec;
   const size_t smem = (size_t)(1 * 3 + 2) * d[0].C * 4;
-  const long long pieces = d[0].M * CG;
+  BnBwdG a;
+  long long pieces = 0;                                   // the grid is sized for the largest member (the sweep is grid-stride)
+  for (int i = 0; i < n; ++i) { a.k[i] = d[i]; a.pieces[i] = d[i].M * CG; if (a.pieces[i] > pieces) pieces = a.pieces[i]; }
   int g = grid_for(pieces);
   const int cap = (pieces >= (1ll << 20) ? 4 : 2) * rua_cu_count() / (n > 2 ? 2 : 1);    // the members fill the chip together
   if (g > cap) g = cap;
-  BnBwdG a;
-  for (int i = 0; i < n; ++i) a.k[i] = d[i];
   hipStream_t st = (hipStream_t)stream;
   const bool mk = d[0].masked != 0;
   if (d[0].dtype == RUA_BF16) {
-    if (mk) hipLaunchKernelGGL((bn_bwd_kernel_g<bf16_t, true>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
-    else hipLaunchKernelGGL((bn_bwd_kernel_g<bf16_t, false>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
+    if (mk) hipLaunchKernelGGL((bn_bwd_kernel_g<bf16_t, true>), dim3(g, n), dim3(256), smem, st, a, CG);
+    else hipLaunchKernelGGL((bn_bwd_kernel_g<bf16_t, false>), dim3(g, n), dim3(256), smem, st, a, CG);
   } else {
-    if (mk) hipLaunchKernelGGL((bn_bwd_kernel_g<float, true>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
-    else hipLaunchKernelGGL((bn_bwd_kernel_g<float, false>), dim3(g, n), dim3(256), smem, st, a, pieces, CG);
+    if (mk) hipLaunchKernelGGL((bn_bwd_kernel_g<float, true>), dim3(g, n), dim3(256), smem, st, a, CG);
+    else hipLaunchKernelGGL((bn_bwd_kernel_g<float, false>), dim3(g, n), dim3(256), smem, st, a, CG);
   }
   RUA_LAUNCH_CHECK("rua_bn_bwd_group");
   g_bn_bwd_group_last = 1;

@@ -479,6 +479,29 @@ class Graph:
         plan.add("rua_bn_fwd", C.byref(d))
         return outs, coefs
 
+    def issue_bn_fwd(self, plan: Plan, ds: List):
+        """The deferred rua_bn_fwd descriptors `ds` as one rua_bn_fwd_group launch."""
+        if len(ds) == 1:
+            plan.keep.append(ds[0])
+            plan.add("rua_bn_fwd", C.byref(ds[0]))
+        elif ds:
+            arr = (L.BnFwdDesc * len(ds))()
+            for i, d in enumerate(ds):
+                C.memmove(C.byref(arr, i * C.sizeof(L.BnFwdDesc)), C.byref(d), C.sizeof(L.BnFwdDesc))
+            plan.keep.append(arr)
+            plan.add("rua_bn_fwd_group", arr, len(ds))
+
+    def issue_bn_bwd(self, plan: Plan, ds: List):
+        if len(ds) == 1:
+            plan.keep.append(ds[0])
+            plan.add("rua_bn_bwd", C.byref(ds[0]))
+        elif ds:
+            arr = (L.BnBwdDesc * len(ds))()
+            for i, d in enumerate(ds):
+                C.memmove(C.byref(arr, i * C.sizeof(L.BnBwdDesc)), C.byref(d), C.sizeof(L.BnBwdDesc))
+            plan.keep.append(arr)
+            plan.add("rua_bn_bwd_group", arr, len(ds))
+
     def bn_fwd_group(self, plan: Plan, items: List[tuple], relu: bool, count):
         """[relu](BN(x_i)) for several tensors of equal shape, each with its own BatchNorm and statistics, as ONE launch: items = (x, bn, stats);
         returns ([out_i], [coef_i])."""
@@ -486,15 +509,7 @@ class Graph:
         for x, bn, st in items:
             o, c = self.bn_fwd(plan, x, [bn], relu, st, count, defer=ds)
             outs.append(o[0]); coefs.append(c[0])
-        if len(ds) == 1:
-            plan.keep.append(ds[0])
-            plan.add("rua_bn_fwd", C.byref(ds[0]))
-        else:
-            arr = (L.BnFwdDesc * len(ds))()
-            for i, d in enumerate(ds):
-                C.memmove(C.byref(arr, i * C.sizeof(L.BnFwdDesc)), C.byref(d), C.sizeof(L.BnFwdDesc))
-            plan.keep.append(arr)
-            plan.add("rua_bn_fwd_group", arr, len(ds))
+        self.issue_bn_fwd(plan, ds)
         return outs, coefs
 
     def bn_coefs(self, plan: Plan, like: Ten, bns: List[dict], stats: List[Optional[Stat]], count, bessel=None) -> List[Coef]:
@@ -553,15 +568,7 @@ class Graph:
         ds: List = []
         for g, c, bn, s2, x, out, cnt in items:
             self.bn_bwd(plan, [g], [c], [bn], [s2], x, out, 0, cnt, defer=ds)
-        if len(ds) == 1:
-            plan.keep.append(ds[0])
-            plan.add("rua_bn_bwd", C.byref(ds[0]))
-            return
-        arr = (L.BnBwdDesc * len(ds))()
-        for i, d in enumerate(ds):
-            C.memmove(C.byref(arr, i * C.sizeof(L.BnBwdDesc)), C.byref(d), C.sizeof(L.BnBwdDesc))
-        plan.keep.append(arr)
-        plan.add("rua_bn_bwd_group", arr, len(ds))
+        self.issue_bn_bwd(plan, ds)
 
     def conv(self, plan: Plan, segs, layer_segs, cout, bias_ptr, out: Ten, stride=1, residual: Optional[Ten] = None,
              out_relu=False, stats=None, bias_more=(), in_bn: Optional["Coef"] = None, accumulate: int = 0, in_fold=None):
@@ -1023,25 +1030,25 @@ class Graph:
             self.back_steps.append(back)
         return y
 
-    def bn_node(self, x: Ten, bn, relu: bool, count=None, bessel=None, stats=None):
+    def bn_node(self, x: Ten, bn, relu: bool, count=None, bessel=None, stats=None, defer: Optional[List] = None):
         """y = [relu](BN(x)) materialised; returns (y, coef, backward(fused: bool)).
         If the single consumer's dgrad wrote g (masked) and statistics itself, `fused` skips both."""
         F, tr = self.fwd, self.training
         cnt = count or x.M
         if tr and stats is None:
             stats = x.stats if x.stats is not None else self.col_stats(F, x)
-        ys, coefs = self.bn_fwd(F, x, [bn], relu, stats, cnt, bessel)
+        ys, coefs = self.bn_fwd(F, x, [bn], relu, stats, cnt, bessel, defer=defer)     # defer: the caller issues several as one group launch
         y, coef = ys[0], coefs[0]
         node = dict(x=x, y=y, coef=coef, bn=bn, relu=relu, cnt=cnt, s2=None, fused=False)
 
-        def back():
+        def back(defer=None):
             Bp = self.bwd
             g = y.grad
             if not node["fused"]:
                 node["s2"] = self.stat(x.C, self.stat_blocks(x), burst=True)
                 Bp.add("rua_col_stats2", g.ptr, x.ptr, coef.scale, coef.shift, 1 if relu else 0, x.M, x.C, node["s2"].ptr, node["s2"].R, self.dt)
             gx, acc = self.gacc(x)
-            self.bn_bwd(Bp, [g], [coef], [bn], [node["s2"]], x, gx, acc, cnt, masked=(relu and not node["fused"]))
+            self.bn_bwd(Bp, [g], [coef], [bn], [node["s2"]], x, gx, acc, cnt, masked=(relu and not node["fused"]), defer=defer)
         node["back"] = back
         return y, node
 
@@ -1119,12 +1126,21 @@ class Graph:
             F.add("rua_maxpool_derive", pooled[1].ptr, idxs[1].data_ptr(), pooled[2].ptr, idxs[2].data_ptr(), x.N, x.H // 2, x.W // 2, x.C, 2, self.dt)
             F.add("rua_maxpool_derive", pooled[2].ptr, idxs[2].data_ptr(), pooled[3].ptr, idxs[3].data_ptr(), x.N, x.H // 4, x.W // 4, x.C, 4, self.dt)
         # Keras creates the branch Conv2DN layers (conv, bn) in order, then the fuse Conv2DN
-        br = []
+        br, bds = [], []
+        group_bn = not self.dry and self.dt == L.RUA_BF16      # the branches' BatchNorms (equal channels, unequal pixel counts) as ONE launch
+        zs = []
         for k, p in zip(ks, pooled):
             z, lay = self.conv1x1_multi([(p, 0)], nf // 4, (p.H, p.W))
             bn = self.Lbn(nf // 4)
-            zb, node = self.bn_node(z, bn, False, count=z.M, bessel=z.M * k * k, stats=z.stats)
-            br.append((k, p, z, lay, zb, node))
+            zs.append((k, p, z, lay, bn))
+            if not group_bn:
+                zb, node = self.bn_node(z, bn, False, count=z.M, bessel=z.M * k * k, stats=z.stats)
+                br.append((k, p, z, lay, zb, node))
+        if group_bn:
+            for k, p, z, lay, bn in zs:
+                zb, node = self.bn_node(z, bn, False, count=z.M, bessel=z.M * k * k, stats=z.stats, defer=bds)
+                br.append((k, p, z, lay, zb, node))
+            self.issue_bn_fwd(F, bds)
         segs = [(b[4], int(math.log2(b[0]))) for b in br] + [(x, 0)]
         zf, layf = self.conv1x1_multi(segs, nf, (x.H, x.W))
         bnf = self.Lbn(nf)
@@ -1135,8 +1151,14 @@ class Graph:
                 nodef["back"]()                                    # out.grad -> zf.grad (unfused: several consumers)
                 targets = [self.fuse_target(b[5]) for b in br] + [None]
                 self.conv1x1_multi_back(Bp, segs, layf, zf, targets)
+                bbs = [] if (group_bn and all(b_[5]["fused"] for b_ in br)) else None
+                if bbs is not None:                                # every zb.grad is there: the four BatchNorm backwards as one launch
+                    for b_ in br:
+                        b_[5]["back"](defer=bbs)
+                    self.issue_bn_bwd(Bp, bbs)
                 for (k, p, z, lay, zb, node), idx in zip(br, idxs):
-                    node["back"]()                                 # zb.grad -> z.grad
+                    if bbs is None:
+                        node["back"]()                             # zb.grad -> z.grad
                     self.conv1x1_multi_back(Bp, [(p, 0)], lay, z, [None])   # -> p.grad (p is x for k == 1)
                     if k > 1 and not pyramid:
                         gx, acc = self.gacc(x)

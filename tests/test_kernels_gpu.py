@@ -1609,16 +1609,17 @@ def test_conv_dmap_issue_forms_are_bit_identical(N, H, W, Cs, Cout, dil):
             assert np.array_equal(res[form][k][1], res[0][k][1]), (form, k)
 
 
-@pytest.mark.parametrize("M,Cc,n", [(8 * 64 * 64, 128, 3), (2 * 128 * 128, 64, 4), (600, 32, 2)])
+@pytest.mark.parametrize("M,Cc,n", [(8 * 64 * 64, 128, 3), (2 * 128 * 128, 64, 4), (600, 32, 2), ((8 * 64 * 64, 8 * 32 * 32, 8 * 16 * 16, 8 * 8 * 8), 256, 4)])
 def test_bn_bwd_group_equals_separate_launches(M, Cc, n):
     """rua_bn_bwd_group: the one-branch BatchNorm backwards of a ResBlock's dilation branches (model2.py:21-22: one BatchNorm per branch
     behind its first conv) in ONE grid; outputs and dgamma / dbeta bit for bit those of n rua_bn_bwd calls."""
     dt = L.RUA_BF16
     lib = L.lib()
-    rng = np.random.default_rng(M + Cc)
+    Ms = list(M) if isinstance(M, tuple) else [M] * n              # unequal pixel counts: the branch BatchNorms of a PSPPooling (model2.py:56-66)
+    rng = np.random.default_rng(Ms[0] + Cc)
     f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
-    xs = [to_dev((rng.standard_normal((M, Cc)) * 1.3 + 0.2).astype(np.float32), dt) for _ in range(n)]
-    gs = [to_dev(rng.standard_normal((M, Cc)).astype(np.float32), dt) for _ in range(n)]
+    xs = [to_dev((rng.standard_normal((Ms[b], Cc)) * 1.3 + 0.2).astype(np.float32), dt) for b in range(n)]
+    gs = [to_dev(rng.standard_normal((Ms[b], Cc)).astype(np.float32), dt) for b in range(n)]
     gam = [f(rng.uniform(0.5, 1.5, Cc)) for _ in range(n)]
     coef = [torch.zeros(4, Cc, device=dev()) for _ in range(n)]
     for b in range(n):                                       # any consistent coefficients serve: scale, shift, mean, rstd
@@ -1629,15 +1630,15 @@ def test_bn_bwd_group_equals_separate_launches(M, Cc, n):
         coef[b][1] = 0.1 - mean * coef[b][0]
     st2 = [torch.zeros(4 * 2 * Cc, dtype=torch.float64, device=dev()) for _ in range(n)]
     for b in range(n):
-        lib.call("rua_col_stats2", gs[b].data_ptr(), xs[b].data_ptr(), coef[b][0].data_ptr(), coef[b][1].data_ptr(), 1, M, Cc, st2[b].data_ptr(), 4, dt, stream())
+        lib.call("rua_col_stats2", gs[b].data_ptr(), xs[b].data_ptr(), coef[b][0].data_ptr(), coef[b][1].data_ptr(), 1, Ms[b], Cc, st2[b].data_ptr(), 4, dt, stream())
     res = []
     for grouped in (False, True):
-        dxs = [torch.zeros((M, Cc), dtype=torch.bfloat16, device=dev()) for _ in range(n)]
+        dxs = [torch.zeros((Ms[b], Cc), dtype=torch.bfloat16, device=dev()) for b in range(n)]
         dg = [torch.zeros(Cc, device=dev()) for _ in range(n)]; db = [torch.zeros(Cc, device=dev()) for _ in range(n)]
         arr = (L.BnBwdDesc * n)()
         for b in range(n):
             e = arr[b]
-            e.x, e.dx, e.M, e.C, e.dtype, e.nb, e.masked, e.accumulate, e.count = xs[b].data_ptr(), dxs[b].data_ptr(), M, Cc, dt, 1, 1, 0, float(M)
+            e.x, e.dx, e.M, e.C, e.dtype, e.nb, e.masked, e.accumulate, e.count = xs[b].data_ptr(), dxs[b].data_ptr(), Ms[b], Cc, dt, 1, 1, 0, float(Ms[b])
             br = e.br[0]
             br.g, br.stats2, br.replicas, br.gamma = gs[b].data_ptr(), st2[b].data_ptr(), 4, gam[b].data_ptr()
             br.scale, br.shift, br.mean, br.rstd = [coef[b][i].data_ptr() for i in range(4)]
@@ -1656,29 +1657,30 @@ def test_bn_bwd_group_equals_separate_launches(M, Cc, n):
     assert float(res[1][0][0].float().abs().sum()) > 0
 
 
-@pytest.mark.parametrize("M,Cc,n,training", [(8 * 64 * 64, 128, 3, 1), (8 * 32 * 32, 256, 3, 0), (700, 32, 2, 1)])
+@pytest.mark.parametrize("M,Cc,n,training", [(8 * 64 * 64, 128, 3, 1), (8 * 32 * 32, 256, 3, 0), (700, 32, 2, 1), ((8 * 64 * 64, 8 * 32 * 32, 8 * 16 * 16, 8 * 8 * 8), 8, 4, 1)])
 def test_bn_fwd_group_equals_separate_launches(M, Cc, n, training):
     """rua_bn_fwd_group: the second BatchNorms of a ResBlock's dilation branches where they are materialised (model2.py:21: one per branch, own input,
     own statistics) in ONE grid; outputs, published coefficients and moving statistics bit for bit those of n rua_bn_fwd calls."""
     dt = L.RUA_BF16
     lib = L.lib()
-    rng = np.random.default_rng(M + Cc)
+    Ms = list(M) if isinstance(M, tuple) else [M] * n
+    rng = np.random.default_rng(Ms[0] + Cc)
     f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
-    xs = [to_dev((rng.standard_normal((M, Cc)) * 1.3 + 0.2).astype(np.float32), dt) for _ in range(n)]
+    xs = [to_dev((rng.standard_normal((Ms[b], Cc)) * 1.3 + 0.2).astype(np.float32), dt) for b in range(n)]
     gam = [f(rng.uniform(0.5, 1.5, Cc)) for _ in range(n)]; bet = [f(rng.standard_normal(Cc)) for _ in range(n)]
     sts = [torch.zeros(4 * 2 * Cc, dtype=torch.float64, device=dev()) for _ in range(n)]
     for b in range(n):
-        lib.call("rua_col_stats", xs[b].data_ptr(), M, Cc, sts[b].data_ptr(), 4, dt, stream())
+        lib.call("rua_col_stats", xs[b].data_ptr(), Ms[b], Cc, sts[b].data_ptr(), 4, dt, stream())
     res = []
     for grouped in (False, True):
-        outs = [torch.zeros((M, Cc), dtype=torch.bfloat16, device=dev()) for _ in range(n)]
+        outs = [torch.zeros((Ms[b], Cc), dtype=torch.bfloat16, device=dev()) for b in range(n)]
         co = [torch.zeros(4, Cc, device=dev()) for _ in range(n)]
         mm = [f(np.full(Cc, 0.25)) for _ in range(n)]; mv = [f(np.full(Cc, 2.0)) for _ in range(n)]
         arr = (L.BnFwdDesc * n)()
         for b in range(n):
             q = arr[b]
-            q.x, q.M, q.C, q.dtype, q.nb, q.relu, q.training = xs[b].data_ptr(), M, Cc, dt, 1, 1, training
-            q.stats, q.replicas, q.count, q.bessel_n, q.momentum, q.eps = sts[b].data_ptr(), 4, float(M), float(M), 0.99, 1e-3
+            q.x, q.M, q.C, q.dtype, q.nb, q.relu, q.training = xs[b].data_ptr(), Ms[b], Cc, dt, 1, 1, training
+            q.stats, q.replicas, q.count, q.bessel_n, q.momentum, q.eps = sts[b].data_ptr(), 4, float(Ms[b]), float(Ms[b]) * (b + 1), 0.99, 1e-3
             br = q.br[0]
             br.gamma, br.beta, br.moving_mean, br.moving_var = gam[b].data_ptr(), bet[b].data_ptr(), mm[b].data_ptr(), mv[b].data_ptr()
             br.scale, br.shift, br.mean, br.rstd, br.out = (co[b][0].data_ptr(), co[b][1].data_ptr(), co[b][2].data_ptr(), co[b][3].data_ptr(), outs[b].data_ptr())
