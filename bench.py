@@ -208,7 +208,7 @@ def profile_kernels(eng, g, dtype):
                 kid = lib.raw("rua_conv_kernel_id")(C.byref(d0))
                 bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d0)), lib.raw('rua_conv_tile_bn')(C.byref(d0))
                 # rocprofv3 names the grouped grids conv_igemm_g<...>, conv_dmap_g<...>, conv_strip32_g<...>
-                kn = (f"conv_igemm_g<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", dmap_name(bm_, bn_, True), f"conv_halo<{d0.Cout}>", "conv_pw", f"conv_strip_g<{d0.Cout}>")[kid]
+                kn = (f"conv_igemm_g<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", dmap_name(bm_, bn_, True), f"conv_halo<{d0.Cout}>", "conv_pw", f"conv_strip_g<{d0.Cout}>", "conv_small<2>")[kid]
                 grids = lib.raw("rua_conv_group_last_grids")()
                 nl = 1
                 if lib.raw("rua_conv_group_last_band")() == 1:   # C = 64: the members as ONE row-streaming launch
@@ -256,7 +256,7 @@ def profile_kernels(eng, g, dtype):
                 if name == "rua_conv_fwd":
                     bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d)), lib.raw('rua_conv_tile_bn')(C.byref(d))
                     two = fired
-                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", dmap_name(bm_, bn_, False), f"conv_halo<{d.Cout}>", "conv_pw", f"conv_strip<{d.Cout}>")[kid]
+                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", dmap_name(bm_, bn_, False), f"conv_halo<{d.Cout}>", "conv_pw", f"conv_strip<{d.Cout}>", "conv_small<2>")[kid]
                     kk = sum(d.seg[i].taps * d.seg[i].C for i in range(d.nseg))
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "") + (" splitk" if two else "")
                     fl, tag, second = conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags), f"conv_splitk_finish<{tname}>"

@@ -80,6 +80,7 @@ struct RuaTuning {
   // grouped launches of a ResBlock's dilation branches, one bit per kernel family (0: every member launches on its own)
   int conv_group = 15;                  // 1 conv_strip, 2 conv_igemm<bf16,256,64>, 4 conv_dmap<128,128>, 8 conv_dmap<64,128>
   int head_fwd2 = 1;                    // heads with Cin = 32: the register-weights kernel (0: the LDS-weights one)
+  int conv_small = 4096;                // conv_small serves 1x1 convolutions of at most this many output pixels (0: off)
   int bn_bwd_group = 1;                 // rua_bn_bwd_group: the one-branch BatchNorm backwards of a ResBlock in one grid
   int dmap_spread = 1;                  // conv_dmap: 0 the DMA instructions of a stage in one burst behind its barrier, 1 spread between the MFMAs (conv_dmap_s), 2 issued by waves of their own (conv_dmap_w; | 4: the 64-row tiles too).
                                         // Launch by launch 2 is the fastest (8 x 64 x 64 x 128: 18.5 - 20.2 us against 19.3 - 20.7 and 22 - 23; conv_dmap<128,128> 0.665 against 0.72 ms per step summed over

@@ -1793,6 +1793,113 @@ template <typename T> static int dispatch_conv(const ConvK& k, int bm, int bn, i
   return bn == 32 ? launch_conv<T, 128, 32>(k, nbm, st) : launch_conv<T, 128, 64>(k, nbm, st);
 }
 
+
+// =========================================================================================
+// conv_small: 1x1 convolutions over at most a few thousand output pixels, bf16 - the PSPPooling at the bottleneck (model2.py:41-79 at 8 x 8 x 1024:
+// four branch convs on 8 .. 512 pixels, the fuse conv over five concatenated sources), the upsampling / stride-2 convs of the two deepest
+// levels and the data gradients of all of them.  These are GEMMs of 0.03 - 2 GFLOP; on the tiled kernels they ran as 128 x 128 tiles with K split
+// 8 - 32 ways plus a finisher launch: 10 - 26 us each, almost all of it fixed cost (two launches, slab round trip, an LDS-DMA ring that never
+// fills).  Here a block owns 32 pixels x 64 output channels over the WHOLE K: no K split across blocks, no slabs, no finisher.  Its four
+// waves take a quarter of the K range each and read their MFMA fragments STRAIGHT from global memory into registers (both operands are
+// K-contiguous rows: a pixel's channels, an output channel's weights; 16-byte buffer loads, out-of-range rows read zeros), eight k-steps
+// = 24 loads per wave in flight, no LDS and no barrier in the loop; the four partial tiles meet in LDS and leave through the shared epilogue.
+// Concatenated sources (segments) follow one another in the K range; nearest-upsampled sources and stride 2 are address arithmetic.
+template <int BNT>
+__device__ __forceinline__ void conv_small_body(const ConvK& p) {
+  typedef bf16_t T;
+  constexpr int BM = 32, BN = 32 * BNT, CH = 8, CSTR = BN + 4;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* part = reinterpret_cast<float*>(smem);           // [4 waves][BM][CSTR]
+  float* sred = part + 4 * BM * CSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int bn_i = blockIdx.x % p.nbn, bm_i = blockIdx.x / p.nbn;
+  const long long m0 = (long long)bm_i * BM;
+  const int n0 = bn_i * BN;
+  const long long m = m0 + lr;
+  const bool av = m < p.M;
+  const int mm = av ? (int)m : 0, HW = p.H * p.W;
+  const int n = mm / HW, rem = mm - n * HW, h = rem / p.W, w = rem - h * p.W;
+  const int ah = h * p.stride, aw = w * p.stride;
+  int total = 0;
+  for (int s_ = 0; s_ < p.nseg; ++s_) total += p.seg[s_].C >> 4;
+  const int q = (total + 3) >> 2;
+  int ks = wid * q, ke = ks + q < total ? ks + q : total;
+  int seg = 0, kk = ks;
+  while (seg + 1 < p.nseg && kk >= (p.seg[seg].C >> 4)) { kk -= p.seg[seg].C >> 4; ++seg; }
+  f32x16 acc[BNT];
+#pragma unroll
+  for (int t = 0; t < BNT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  __amdgpu_buffer_rsrc_t rx = make_rsrc(p.seg[0].x, p.seg[0].xbytes), rw = make_rsrc(p.seg[0].w, p.seg[0].wbytes);
+  unsigned abase = OOB, bbase[BNT];
+  int nk = 1;
+  auto enter = [&]() {
+    const SegK sg = p.seg[seg];
+    rx = make_rsrc(sg.x, sg.xbytes); rw = make_rsrc(sg.w, sg.wbytes);
+    nk = sg.C >> 4;
+    abase = av ? (unsigned)((((n * sg.Hs + (ah >> sg.up)) * sg.Ws + (aw >> sg.up)) * sg.C + lh * 8) * 2) : OOB;
+#pragma unroll
+    for (int t = 0; t < BNT; ++t) bbase[t] = (n0 + t * 32 + lr) < p.Cout ? (unsigned)(((n0 + t * 32 + lr) * sg.C + lh * 8) * 2) : OOB;
+  };
+  if (ks < ke) enter();
+  while (ks < ke) {
+    int nstep = ke - ks;                                   // a chunk stays inside its segment
+    if (nstep > CH) nstep = CH;
+    if (nstep > nk - kk) nstep = nk - kk;
+    uint4 a[CH], b[BNT][CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (j < nstep) {
+        a[j] = bufload16(rx, abase + (unsigned)((kk + j) * 32));
+#pragma unroll
+        for (int t = 0; t < BNT; ++t) b[t][j] = bufload16(rw, bbase[t] + (unsigned)((kk + j) * 32));
+      }
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (j < nstep) {
+#pragma unroll
+        for (int t = 0; t < BNT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[t][j]), acc[t], 0, 0, 0);
+      }
+    ks += nstep; kk += nstep;
+    if (kk == nk && ks < ke) { ++seg; kk = 0; enter(); }
+  }
+  float* mine = part + wid * BM * CSTR;
+#pragma unroll
+  for (int t = 0; t < BNT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mine[((i & 3) + 8 * (i >> 2) + 4 * lh) * CSTR + t * 32 + lr] = acc[t][i];
+  __syncthreads();
+  for (int e = tid; e < BM * BN; e += 256) {                 // the four K quarters, in a fixed order
+    const int r = e / BN, c = e - r * BN, o = r * CSTR + c;
+    part[o] = ((part[o] + part[BM * CSTR + o]) + part[2 * BM * CSTR + o]) + part[3 * BM * CSTR + o];
+  }
+  __syncthreads();
+  conv_epilogue<T, BM, BN>(p, m0, n0, bm_i, part, CSTR, sred);
+}
+template <int BNT> __global__ __launch_bounds__(256) void conv_small(const ConvK p) { conv_small_body<BNT>(p); }
+
+// conv_small eligibility: bf16, every source 1x1 with a multiple of 16 channels, few pixels (the K-split regime of the tiled kernels)
+static bool pick_small(const rua_conv_desc* d) {
+  if (!g_tune.conv_small || d->dtype != RUA_BF16 || d->in_scale || d->in_fold) return false;
+  const long long M = (long long)d->N * d->H * d->W;
+  if (M > g_tune.conv_small || d->Cout < 32) return false;
+  for (int s_ = 0; s_ < d->nseg; ++s_)
+    if (d->seg[s_].taps != 1 || d->seg[s_].C % 16 != 0) return false;
+  return true;
+}
+static int launch_conv_small(ConvK& k, hipStream_t st) {
+  k.nbm = (int)((k.M + 31) / 32); k.nbn = (k.Cout + 63) / 64;
+  k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr; k.cnt = nullptr;
+  constexpr int smem = (4 * 32 * 68 + 4 * 8 * 16) * 4;
+  hipLaunchKernelGGL((conv_small<2>), dim3(k.nbm * k.nbn), dim3(256), smem, st, k);
+  RUA_LAUNCH_CHECK("conv_small");
+  return RUA_OK;
+}
+
 static thread_local int g_last_ksplit = 1;
 extern "C" int rua_conv_last_ksplit(void) { return g_last_ksplit; }    // K slices of this thread's latest rua_conv_fwd launch (1: no finisher ran)
 
@@ -1864,6 +1971,10 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     g_last_ksplit = 1;
     const int ks = pw_steps(d);
     return ks <= 2 ? launch_conv_pw<2>(k, d, st) : ks <= 4 ? launch_conv_pw<4>(k, d, st) : launch_conv_pw<6>(k, d, st);
+  }
+  if (pick_small(d)) {
+    g_last_ksplit = 1;
+    return launch_conv_small(k, st);
   }
   if (pick_dmap(d)) {
     // 128 x 128 tiles; split K until the grid covers the chip once (every level of the reference network then runs
@@ -3381,6 +3492,7 @@ extern "C" int rua_conv_kernel_id(const rua_conv_desc* d) {
   if (rua_pick_strip(d)) return 5;
   if (pick_halo(d)) return 3;
   if (pick_pw(d)) return 4;
+  if (pick_small(d)) return 6;
   if (pick_dmap(d)) return 2;
   return pick_dma(d, pick_bn(d, (long long)d->N * d->H * d->W)) ? 1 : 0;
 }

@@ -75,6 +75,12 @@ CONV_CASES = [
     (1, 256, 256, [(8, 0, 1, 1), (8, 1, 1, 1), (8, 2, 1, 1), (8, 3, 1, 1), (32, 0, 1, 1)], 32, 1),
     (2, 256, 128, [(32, 0, 1, 1)], 8, 1),
     (1, 320, 224, [(64, 0, 1, 1)], 24, 1),     # not a power of two: dense segments only
+    # bf16: conv_small (1x1 convs over <= 4096 pixels: a block = 32 pixels x 64 channels over the whole K, fragments straight from global memory)
+    (8, 8, 8, [(1024, 0, 1, 1)], 256, 1),
+    (8, 8, 8, [(256, 0, 1, 1), (256, 1, 1, 1), (256, 2, 1, 1), (256, 3, 1, 1), (1024, 0, 1, 1)], 1024, 1),      # the PSPPooling fuse conv at the bottleneck
+    (8, 8, 8, [(512, 0, 1, 1)], 1024, 2),      # stride 2 (model2.py:103-111)
+    (3, 5, 7, [(48, 0, 1, 1), (16, 0, 1, 1)], 40, 1),      # ragged: 105 pixels, 40 channels, K = 4 k-steps over two sources (a wave without work)
+    (8, 16, 16, [(256, 1, 1, 1), (512, 0, 1, 1)], 512, 1),  # upsampled + skip source (model2.py:81-94)
 ]
 
 
@@ -115,6 +121,8 @@ def test_conv_fwd(case, dt):
         assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 2 and lib.raw("rua_conv_tile_bm")(C.byref(d)) == 64
     if dt == L.RUA_BF16 and N * H * W >= 65536 and all(t == 1 for _, _, _, t in segs):
         assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 4
+    if dt == L.RUA_BF16 and N * H * W <= 4096 and Cout >= 32 and all(t == 1 and c % 16 == 0 for c, _, _, t in segs):
+        assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 6
     lib.call("rua_conv_fwd", C.byref(d), stream())
     torch.cuda.synchronize()
     exp = (exp + torch.from_numpy(bias).double() + rnd(dt, res).double()).numpy()
