@@ -1707,3 +1707,48 @@ def test_bn_fwd_group_equals_separate_launches(M, Cc, n, training):
     xr = xs[0].float()
     if training:
         assert np.allclose(res[1][2][0].cpu().numpy(), 0.25 * 0.99 + 0.01 * xr.mean(0).cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("aux_mode", [2, 3])
+def test_conv_small_data_gradient_epilogues(aux_mode):
+    """conv_small behind the data gradients of the bottleneck's 1x1 convolutions (model2.py:41-79 backward): ReLU mask from aux with scale / shift
+    (aux_mode 2) or aux as the second statistics operand only (aux_mode 3), statistics sum g / sum g * aux, 8 .. 512 pixels, two sources."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(aux_mode)
+    for N, H, W in ((8, 8, 8), (8, 1, 1)):
+        Cout = 320
+        segs = [(256, 0), (64, 0)]
+        M = N * H * W
+        d = L.ConvDesc()
+        d.nseg = len(segs)
+        keep, exp = [], 0
+        for i, (Cs, up) in enumerate(segs):
+            x = rng.standard_normal((N, H, W, Cs)).astype(np.float32)
+            w = (rng.standard_normal((1, Cout, Cs)) / np.sqrt(320)).astype(np.float32)
+            xd, wd = to_dev(x, dt), to_dev(w, dt)
+            keep += [xd, wd]
+            s = d.seg[i]
+            s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = xd.data_ptr(), wd.data_ptr(), Cs, H, W, up, 1, 1
+            exp = exp + ref_conv_nhwc(rnd(dt, x), rnd(dt, w), None, 1, 1).numpy()
+        aux = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+        ms, mt = rng.standard_normal(Cout).astype(np.float32), rng.standard_normal(Cout).astype(np.float32)
+        ad, msd, mtd = to_dev(aux, dt), torch.from_numpy(ms).to(dev()), torch.from_numpy(mt).to(dev())
+        y = torch.empty((N, H, W, Cout), dtype=torch.bfloat16, device=dev())
+        stats = torch.zeros(4 * 2 * Cout, dtype=torch.float64, device=dev())
+        d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cout, 1, dt
+        d.aux, d.aux_mode = ad.data_ptr(), aux_mode
+        if aux_mode == 2:
+            d.mscale, d.mshift = msd.data_ptr(), mtd.data_ptr()
+        d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+        d.stats, d.stats_mode, d.stats_replicas = stats.data_ptr(), 2, 4
+        assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 6
+        lib.call("rua_conv_fwd", C.byref(d), stream())
+        torch.cuda.synchronize()
+        a = rnd(dt, aux).numpy().astype(np.float64)
+        if aux_mode == 2:
+            exp = exp * ((np.float32(ms) * a.astype(np.float32) + np.float32(mt)) > 0)
+        assert rel_err(y.float().cpu().numpy(), exp) < tol(dt), (N, H, W)
+        st = stats.cpu().numpy().reshape(4, 2 * Cout).sum(0)
+        assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
+        assert rel_err(st[Cout:], (exp * a).sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
