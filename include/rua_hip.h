@@ -257,6 +257,9 @@ typedef struct rua_bn_branch {
                                                                                      (one block, nothing applied: the consumer
                                                                                      normalises on load, rua_conv_desc.in_scale) */
   const double* stats; int32_t replicas, pad;                                     /* this branch's own statistics (else the shared ones) */
+  double* out_stats;   /* optional [2][C] (training, relu == 0 only): per-channel sum / sum of squares of THIS BatchNorm's output, written by block 0 from the
+                          coefficients - sum = count * beta, sum of squares = count * (beta^2 + gamma^2 var / (var + eps)) exactly, so a BatchNorm that
+                          follows (the first BatchNorms of the next ResBlock: model2.py:17 behind model2.py:86) needs no statistics pass over the tensor */
 } rua_bn_branch;
 typedef struct rua_bn_fwd_desc {
   const void* x; int64_t M; int32_t C, dtype, nb, relu, training, replicas;

@@ -46,7 +46,7 @@ class WgradPending(C.Structure):
 
 class BnBranch(C.Structure):
     _fields_ = [("gamma", vp), ("beta", vp), ("moving_mean", vp), ("moving_var", vp), ("scale", vp), ("shift", vp),
-                ("mean", vp), ("rstd", vp), ("out", vp), ("stats", vp), ("replicas", i32), ("pad", i32)]
+                ("mean", vp), ("rstd", vp), ("out", vp), ("stats", vp), ("replicas", i32), ("pad", i32), ("out_stats", vp)]
 
 
 class BnFwdDesc(C.Structure):

@@ -393,6 +393,11 @@ __device__ __forceinline__ void bn_fwd_body(const rua_bn_fwd_desc& p, long long 
         br.scale[c] = (float)sc; br.shift[c] = (float)((double)br.beta[c] - m * sc);
         if (br.mean) br.mean[c] = (float)m;
         if (br.rstd) br.rstd[c] = (float)r;
+        if (p.training && br.out_stats) {               // statistics of the OUTPUT (no ReLU), from the coefficients: exact up to the output's rounding
+          const double be = (double)br.beta[c];
+          br.out_stats[c] = p.count * be;
+          br.out_stats[C + c] = p.count * (be * be + sc * sc * v);
+        }
         if (p.training && br.moving_mean) {
           const double unb = p.bessel_n > 1 ? v * (p.bessel_n / (p.bessel_n - 1)) : v;
           br.moving_mean[c] = (float)((double)br.moving_mean[c] * p.momentum + m * (1.0 - p.momentum));
@@ -474,7 +479,7 @@ extern "C" int rua_bn_fwd_group(const rua_bn_fwd_desc* d, int n, void* stream) {
     const rua_bn_branch& br = m.br[0];
     one = m.x && m.nb == 1 && m.M > 0 && m.C == d[0].C && m.dtype == d[0].dtype && m.training == d[0].training && m.relu == d[0].relu && br.out &&
           br.gamma && br.beta && br.scale && br.shift && (!m.training || (m.count > 0 && (br.stats ? br.replicas >= 1 : (m.stats && m.replicas >= 1)))) &&
-          (m.training || (br.moving_mean && br.moving_var));
+          (m.training || (br.moving_mean && br.moving_var)) && (br.out_stats == nullptr || (m.relu == 0 && m.training));
   }
   g_bn_fwd_group_last = n;
   if (!one) {                                            // same results member by member
@@ -511,6 +516,7 @@ extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream) {
     RUA_CHECK_ARG((br.out == nullptr) == coef_only, "rua_bn_fwd: either every branch has an output or none (coefficients only)");
     RUA_CHECK_ARG(!d->training || (br.stats ? br.replicas >= 1 : (d->stats && d->replicas >= 1)), "rua_bn_fwd: training needs statistics");
     RUA_CHECK_ARG(d->training || (br.moving_mean && br.moving_var), "rua_bn_fwd: inference needs moving statistics");
+    RUA_CHECK_ARG(br.out_stats == nullptr || (d->relu == 0 && d->training), "rua_bn_fwd: out_stats is the statistics of a training-mode BatchNorm WITHOUT ReLU");
   }
   const size_t smem = (size_t)(d->nb * 2 + 2) * d->C * 4;
   RUA_CHECK_ARG(smem <= 64 * 1024, "rua_bn_fwd: coefficient table too large");

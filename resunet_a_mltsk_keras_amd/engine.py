@@ -456,7 +456,8 @@ class Graph:
         plan.add("rua_bn_apply", x.ptr, len(coefs), sc, sh, 1 if relu else 0, ou, x.M, x.C, self.dt)
         return outs
 
-    def bn_fwd(self, plan: Plan, x: Ten, bns: List[dict], relu: bool, stats: Optional[Stat], count, bessel=None, defer: Optional[List] = None):
+    def bn_fwd(self, plan: Plan, x: Ten, bns: List[dict], relu: bool, stats: Optional[Stat], count, bessel=None, defer: Optional[List] = None,
+               out_stats: bool = False):
         """[relu](BN_b(x)) for every branch b in ONE launch: coefficients from the statistics in the kernel prologue,
         published to `Coef` buffers (block 0) for the ReLU masks / backward; moving statistics updated in training."""
         outs = [self.like(x) for _ in bns]
@@ -471,6 +472,11 @@ class Graph:
             b = d.br[i]
             b.gamma, b.beta, b.moving_mean, b.moving_var = self.P(bn["gamma"]), self.P(bn["beta"]), self.S(bn["mm"]), self.S(bn["mv"])
             b.scale, b.shift, b.mean, b.rstd, b.out = c.scale, c.shift, c.mean, c.rstd, o.ptr
+            if out_stats and self.training and not relu and not self.dry and self.e.bn_out_stats:
+                # the output's own statistics come out of the coefficients (sum = M beta, sum of squares = M (beta^2 + gamma^2 var / (var + eps))):
+                # the BatchNorms of the ResBlock this tensor feeds need no rua_col_stats pass over it
+                o.stats = Stat(self.salloc(2 * x.C), 1)
+                b.out_stats = o.stats.ptr
         plan.keep += coefs
         if defer is not None:                                # the caller issues several as one rua_bn_fwd_group
             defer.append(d)
@@ -1037,7 +1043,7 @@ class Graph:
         cnt = count or x.M
         if tr and stats is None:
             stats = x.stats if x.stats is not None else self.col_stats(F, x)
-        ys, coefs = self.bn_fwd(F, x, [bn], relu, stats, cnt, bessel, defer=defer)     # defer: the caller issues several as one group launch
+        ys, coefs = self.bn_fwd(F, x, [bn], relu, stats, cnt, bessel, defer=defer, out_stats=True)     # defer: the caller issues several as one group launch
         y, coef = ys[0], coefs[0]
         node = dict(x=x, y=y, coef=coef, bn=bn, relu=relu, cnt=cnt, s2=None, fused=False)
 
@@ -1453,6 +1459,7 @@ class Engine:
         self.dev = None
         self.fuse_bn = os.environ.get("RUA_FUSE_BN", "1") != "0"     # normalise-on-load ResBlocks where the library offers it
         self.fuse_head_loss = os.environ.get("RUA_FUSE_HEAD_LOSS", "1") != "0"   # Tanimoto moments / seg metrics in the heads' forward epilogue
+        self.bn_out_stats = os.environ.get("RUA_BN_OUT_STATS", "1") != "0"       # statistics of a ReLU-less BatchNorm's output from its coefficients
         self.pool_pyramid = os.environ.get("RUA_POOL_PYRAMID", "1") != "0"   # PSPPooling: the 2 / 4 / 8 poolings (and their adjoints) in single passes
         self.fold_bn = os.environ.get("RUA_FOLD_BN", "1") != "0"     # ... and their coefficient launches folded into the convs' prologues
         self.defer_reduce = os.environ.get("RUA_DEFER_REDUCE", "1") != "0"     # weight-gradient partials summed by batched launches

@@ -1752,3 +1752,37 @@ def test_conv_small_data_gradient_epilogues(aux_mode):
         st = stats.cpu().numpy().reshape(4, 2 * Cout).sum(0)
         assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
         assert rel_err(st[Cout:], (exp * a).sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+def test_bn_fwd_output_statistics_from_coefficients(dt):
+    """rua_bn_branch.out_stats: the per-channel sum / sum of squares of a training-mode BatchNorm's output WITHOUT ReLU, written from the coefficients
+    (sum = M beta, sum of squares = M (beta^2 + gamma^2 var / (var + eps))) - what a rua_col_stats pass over the output returns, up to the output's rounding
+    (fp32 storage: 1e-5; bf16: the rounding noise of the stored tensor, 1e-3) - so that the BatchNorms of the next ResBlock (model2.py:17 behind 86) skip that pass."""
+    rng = np.random.default_rng(21)
+    lib = L.lib()
+    M, Cc = 4096, 64
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+    x = to_dev((rng.standard_normal((M, Cc)) * 1.7 + 0.4).astype(np.float32), dt)
+    gam, bet = f(rng.uniform(0.5, 1.5, Cc)), f(rng.standard_normal(Cc))
+    st = torch.zeros(4 * 2 * Cc, dtype=torch.float64, device=dev())
+    lib.call("rua_col_stats", x.data_ptr(), M, Cc, st.data_ptr(), 4, dt, stream())
+    out = torch.zeros((M, Cc), dtype=tdt(dt), device=dev())
+    co = torch.zeros(4, Cc, device=dev()); mm, mv = f(np.zeros(Cc)), f(np.ones(Cc))
+    ost = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
+    q = L.BnFwdDesc()
+    q.x, q.M, q.C, q.dtype, q.nb, q.relu, q.training = x.data_ptr(), M, Cc, dt, 1, 0, 1
+    q.stats, q.replicas, q.count, q.bessel_n, q.momentum, q.eps = st.data_ptr(), 4, float(M), float(M), 0.99, 1e-3
+    br = q.br[0]
+    br.gamma, br.beta, br.moving_mean, br.moving_var = gam.data_ptr(), bet.data_ptr(), mm.data_ptr(), mv.data_ptr()
+    br.scale, br.shift, br.mean, br.rstd, br.out = (co[0].data_ptr(), co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), out.data_ptr())
+    br.out_stats = ost.data_ptr()
+    lib.call("rua_bn_fwd", C.byref(q), stream())
+    chk = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
+    lib.call("rua_col_stats", out.data_ptr(), M, Cc, chk.data_ptr(), 1, dt, stream())
+    torch.cuda.synchronize()
+    a, b = ost.cpu().numpy(), chk.cpu().numpy()
+    scale = np.abs(b).max()
+    assert np.abs(a - b).max() < (1e-5 if dt == L.RUA_F32 else 1e-3) * scale, np.abs(a - b).max() / scale
+    q.relu = 1                                                   # with a ReLU the output's statistics are not a function of the coefficients: refused
+    assert lib.raw("rua_bn_fwd")(C.byref(q), None) != 0
