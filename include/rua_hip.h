@@ -282,6 +282,8 @@ typedef struct rua_bn_bwd_desc {
   rua_bn_bwd_branch br[RUA_MAX_BRANCH];
   double* skip_stats;          /* optional [skip_replicas][2][C]: per-channel sum of dskip added into slot 0 (the bias gradient of */
   int32_t skip_replicas, pad2; /* the convs whose output the skip tensor is the gradient of: model2.py:27-31) - saves a pass over dskip */
+  double* dx_stats;            /* optional [dx_replicas][2][C]: per-channel sum of the values written to dx added into slot 0 - the bias gradient of the */
+  int32_t dx_replicas, pad3;   /* convolution that produced x (the stride-2 1x1 convs in front of the encoder ResBlocks: model2.py:103-111), without a pass over dx */
 } rua_bn_bwd_desc;
 int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream);
 /* n (<= RUA_MAX_BRANCH) independent one-branch BatchNorm backwards of equal channel count (any pixel counts) - the second BatchNorms of a

@@ -62,7 +62,7 @@ class BnBwdBranch(C.Structure):
 class BnBwdDesc(C.Structure):
     _fields_ = [("x", vp), ("dskip", vp), ("dx", vp), ("M", i64), ("C", i32), ("dtype", i32), ("nb", i32), ("masked", i32),
                 ("accumulate", i32), ("pad", i32), ("count", f64), ("br", BnBwdBranch * RUA_MAX_BRANCH),
-                ("skip_stats", vp), ("skip_replicas", i32), ("pad2", i32)]
+                ("skip_stats", vp), ("skip_replicas", i32), ("pad2", i32), ("dx_stats", vp), ("dx_replicas", i32), ("pad3", i32)]
 
 
 class WprepItem(C.Structure):

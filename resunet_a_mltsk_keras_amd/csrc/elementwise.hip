@@ -576,9 +576,9 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
   unsigned char* dx = (unsigned char*)p.dx;
   const long long stride = (long long)gridDim.x * 256;
   // per-channel sum of dskip (256 is a multiple of CG, so a thread stays on one channel group for the whole sweep)
-  float sk[VEC];
+  float sk[VEC], so[VEC];                              // so: per-channel sum of what this thread writes to dx (p.dx_stats)
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) sk[j] = 0.f;
+  for (int j = 0; j < VEC; ++j) { sk[j] = 0.f; so[j] = 0.f; }
   if constexpr (NB > 0) {
     // coefficients of this thread's channel group in registers for the whole sweep (see bn_fwd_kernel): no LDS reads in the loop
     const int c = (int)(threadIdx.x % CG) * VEC;
@@ -632,6 +632,8 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
           acc[j] = fmaf(cA[b][j], on ? gv[j] : 0.f, acc[j]);
         }
       }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) so[j] += acc[j];
       stg16(dx + i * 16, ET<T>::pack(acc));
     }
   } else {
@@ -662,6 +664,8 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
         acc[j] = fmaf(tab[(b * 3) * C + c + j], on ? gv[j] : 0.f, acc[j]);
       }
     }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) so[j] += acc[j];
     stg16(dx + i * 16, ET<T>::pack(acc));
   }
   }
@@ -677,6 +681,20 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
       float t = 0.f;
       for (int k = 0; k < per; ++k) t += red[(k * CG + cg) * VEC + j];
       unsafeAtomicAdd(&p.skip_stats[(size_t)(blockIdx.x & (p.skip_replicas - 1)) * 2 * C + ch], (double)t);
+    }
+  }
+  if (p.dx_stats) {                                      // uniform: the same fold for the sums of the output
+    __syncthreads();
+    float* red = tab;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = so[j];
+    __syncthreads();
+    const int per = 256 / CG;
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+      const int cg = ch / VEC, j = ch - cg * VEC;
+      float t = 0.f;
+      for (int k = 0; k < per; ++k) t += red[(k * CG + cg) * VEC + j];
+      unsafeAtomicAdd(&p.dx_stats[(size_t)(blockIdx.x & (p.dx_replicas - 1)) * 2 * C + ch], (double)t);
     }
   }
 }
@@ -699,7 +717,7 @@ extern "C" int rua_bn_bwd_group(const rua_bn_bwd_desc* d, int n, void* stream) {
   bool one = n > 1 && g_tune.bn_bwd_group && d[0].C % vec == 0 && d[0].C / vec <= 256 && 256 % (d[0].C / vec) == 0 && g_tune.bn_regs;
   for (int i = 0; i < n && one; ++i) {
     const rua_bn_bwd_desc& m = d[i];
-    one = m.x && m.dx && m.nb == 1 && m.M > 0 && m.C == d[0].C && m.dtype == d[0].dtype && m.masked == d[0].masked && !m.skip_stats && m.count > 0 &&
+    one = m.x && m.dx && m.nb == 1 && m.M > 0 && m.C == d[0].C && m.dtype == d[0].dtype && m.masked == d[0].masked && !m.skip_stats && !m.dx_stats && m.count > 0 &&
           m.br[0].g && m.br[0].stats2 && m.br[0].replicas >= 1 && m.br[0].gamma && m.br[0].mean && m.br[0].rstd &&
           (d[0].dtype == RUA_F32 || d[0].dtype == RUA_BF16);
   }
@@ -747,6 +765,11 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
   if (d->skip_stats) {
     RUA_CHECK_ARG(d->dskip && d->skip_replicas >= 1 && (d->skip_replicas & (d->skip_replicas - 1)) == 0 && CG <= 256 && 256 % CG == 0,
                   "rua_bn_bwd: skip_stats needs dskip, a power-of-two replica count and C / %d dividing 256", vec);
+    if (smem < (size_t)256 * vec * 4) smem = (size_t)256 * vec * 4;
+  }
+  if (d->dx_stats) {
+    RUA_CHECK_ARG(d->dx_replicas >= 1 && (d->dx_replicas & (d->dx_replicas - 1)) == 0 && CG <= 256 && 256 % CG == 0,
+                  "rua_bn_bwd: dx_stats needs a power-of-two replica count and C / %d dividing 256", vec);
     if (smem < (size_t)256 * vec * 4) smem = (size_t)256 * vec * 4;
   }
   const long long pieces = d->M * CG;

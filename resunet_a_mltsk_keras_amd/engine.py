@@ -168,7 +168,7 @@ class ParamStore:
 # ---------------------------------------------------------------------------------------
 class Ten:
     """A device activation tensor [N][H][W][C] (storage owned by a torch tensor)."""
-    __slots__ = ("N", "H", "W", "C", "t", "ptr", "grad", "gw", "stats", "f32", "relu_out", "masked_w", "plain_w")
+    __slots__ = ("N", "H", "W", "C", "t", "ptr", "grad", "gw", "stats", "f32", "relu_out", "masked_w", "plain_w", "bias_offs", "bias_done")
 
     def __init__(self, t: torch.Tensor, N, H, W, C, f32=False):
         self.t, self.N, self.H, self.W, self.C, self.f32 = t, N, H, W, C, f32
@@ -179,6 +179,8 @@ class Ten:
         self.relu_out = False      # output of a fused ReLU: gradient writers that know how apply the (t > 0) mask themselves
         self.masked_w = 0          # gradient writers that applied it / that did not
         self.plain_w = 0
+        self.bias_offs = None      # bias of the convolution that produced this tensor, if its gradient (the per-channel sum of this tensor's
+        self.bias_done = False     # gradient) may be taken by the kernel that writes the gradient: done = it was
 
     @property
     def M(self):
@@ -537,7 +539,8 @@ class Graph:
         return coefs
 
     def bn_bwd(self, plan: Plan, gs: List[Ten], coefs: List[Coef], bns: List[dict], stats2: List[Stat], x: Ten, out: Ten,
-               accumulate: int, count, dskip: Optional[Ten] = None, masked=False, skip_bias: Optional[List[int]] = None, defer: Optional[List] = None):
+               accumulate: int, count, dskip: Optional[Ten] = None, masked=False, skip_bias: Optional[List[int]] = None, defer: Optional[List] = None,
+               dx_bias: bool = False):
         """dx (=|+=) [dskip] + sum_b BN-backward_b(g_b) in ONE launch; dgamma/dbeta added by block 0.
         skip_bias: bias offsets whose gradient is the per-channel sum of dskip - accumulated by this launch while it reads
         dskip anyway (instead of a col_stats pass over the same tensor), converted by one rua_stats_to_f32."""
@@ -563,10 +566,20 @@ class Graph:
             assert st is None
             defer.append(d)
             return
+        sx = None
+        if (dx_bias and x.bias_offs and not accumulate and not self.dry and self.e.bn_dx_bias and cg <= 256 and 256 % cg == 0):
+            # x is the output of a convolution with a bias and `out` its complete gradient: the per-channel sums of what this launch
+            # writes ARE that bias gradient (no rua_col_stats pass over the gradient: the stride-2 convs in front of the encoder ResBlocks)
+            blocks = max(1, min(1024, x.M * (x.C // self.vec) // 256))
+            sx = self.stat(x.C, blocks, burst=True)
+            d.dx_stats, d.dx_replicas = sx.ptr, sx.R
+            x.bias_done = True
         plan.keep.append(d)
         plan.add("rua_bn_bwd", C.byref(d))
         if st is not None:
             self.stats_to_grads(plan, st, x.C, skip_bias)
+        if sx is not None:
+            self.stats_to_grads(plan, sx, x.C, x.bias_offs)
 
     def bn_bwd_group(self, plan: Plan, items: List[tuple]):
         """The one-branch BatchNorm backwards of a ResBlock's dilation branches (their second BatchNorms: own gradient, own input, own
@@ -883,7 +896,7 @@ class Graph:
                                  for d, l, dy1, c1, g1, s1 in zip(dils, lay, dy1s, coef1, g1s, s1s)])
             gx, acc = self.gacc(x)
             self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None,
-                        skip_bias=[l[3]["bias"] for l in lay] if v2 else None)
+                        skip_bias=[l[3]["bias"] for l in lay] if v2 else None, dx_bias=True)
             Bp.scope = None
         self.back_steps.append(back)
         return out
@@ -1010,7 +1023,7 @@ class Graph:
                                  for d, l, dy1, c1, g1, s1 in zip(dils, lay, dy1s, coef1, g1s, s1s)])
             gx, acc = self.gacc(x)
             self.bn_bwd(Bp, g1s, coef1, [l[0] for l in lay], s1s, x, gx, acc, cnt, dskip=dO if v2 else None,
-                        skip_bias=[l[3]["bias"] for l in lay] if v2 else None)
+                        skip_bias=[l[3]["bias"] for l in lay] if v2 else None, dx_bias=True)
             Bp.scope = None
         self.back_steps.append(back)
         return out
@@ -1023,11 +1036,13 @@ class Graph:
         st = self.stat(nf, (y.M + 127) // 128) if tr else None
         self.conv(F, [(x, 0, 1, 1)], lay["segs"], nf, self.P(lay["bias"]), y, stride=2, stats=st)
         y.stats = st
+        y.bias_offs = [lay["bias"]]                          # the ResBlock behind it writes y's whole gradient: it may take the bias gradient on the way
         if tr:
             def back():
                 Bp = self.bwd
                 dy = y.grad
-                self.bias_grad(Bp, dy, [lay["bias"]])
+                if not y.bias_done:
+                    self.bias_grad(Bp, dy, [lay["bias"]])
                 self.wgrad(Bp, x, dy, lay["segs"][0]["off"], 2, 1, 1)
                 gx, acc = self.gacc(x)
                 if not acc:
@@ -1460,6 +1475,7 @@ class Engine:
         self.fuse_bn = os.environ.get("RUA_FUSE_BN", "1") != "0"     # normalise-on-load ResBlocks where the library offers it
         self.fuse_head_loss = os.environ.get("RUA_FUSE_HEAD_LOSS", "1") != "0"   # Tanimoto moments / seg metrics in the heads' forward epilogue
         self.bn_out_stats = os.environ.get("RUA_BN_OUT_STATS", "1") != "0"       # statistics of a ReLU-less BatchNorm's output from its coefficients
+        self.bn_dx_bias = os.environ.get("RUA_BN_DX_BIAS", "1") != "0"           # bias gradients of the stride-2 convs from the sums of the BatchNorm backward that writes their output's gradient
         self.pool_pyramid = os.environ.get("RUA_POOL_PYRAMID", "1") != "0"   # PSPPooling: the 2 / 4 / 8 poolings (and their adjoints) in single passes
         self.fold_bn = os.environ.get("RUA_FOLD_BN", "1") != "0"     # ... and their coefficient launches folded into the convs' prologues
         self.defer_reduce = os.environ.get("RUA_DEFER_REDUCE", "1") != "0"     # weight-gradient partials summed by batched launches

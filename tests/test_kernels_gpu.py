@@ -1786,3 +1786,46 @@ def test_bn_fwd_output_statistics_from_coefficients(dt):
     assert np.abs(a - b).max() < (1e-5 if dt == L.RUA_F32 else 1e-3) * scale, np.abs(a - b).max() / scale
     q.relu = 1                                                   # with a ReLU the output's statistics are not a function of the coefficients: refused
     assert lib.raw("rua_bn_fwd")(C.byref(q), None) != 0
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+def test_bn_bwd_output_sums_are_the_bias_gradient(dt):
+    """rua_bn_bwd_desc.dx_stats: the per-channel sums of what the launch writes to dx - the bias gradient of the convolution that produced x (the stride-2
+    convs in front of the encoder ResBlocks, model2.py:103-111) - against a rua_col_stats pass over dx (taken before rounding: tolerance of the storage type)."""
+    rng = np.random.default_rng(33)
+    lib = L.lib()
+    M, Cc, R = 5000, 64, 2
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+    x = to_dev((rng.standard_normal((M, Cc)) * 1.4 + 0.3).astype(np.float32), dt)
+    skip = to_dev(rng.standard_normal((M, Cc)).astype(np.float32), dt)
+    gs = [to_dev(rng.standard_normal((M, Cc)).astype(np.float32), dt) for _ in range(3)]
+    gam = [f(rng.uniform(0.5, 1.5, Cc)) for _ in range(3)]
+    coef = [torch.zeros(4, Cc, device=dev()) for _ in range(3)]
+    xm = x.float()
+    mean, var = xm.mean(0), xm.var(0, unbiased=False)
+    for b in range(3):
+        coef[b][2], coef[b][3] = mean, torch.rsqrt(var + 1e-3)
+        coef[b][0] = gam[b] * coef[b][3]
+        coef[b][1] = 0.2 * b - mean * coef[b][0]
+    st2 = [torch.zeros(R * 2 * Cc, dtype=torch.float64, device=dev()) for _ in range(3)]
+    for b in range(3):
+        lib.call("rua_col_stats2", gs[b].data_ptr(), x.data_ptr(), coef[b][0].data_ptr(), coef[b][1].data_ptr(), 1, M, Cc, st2[b].data_ptr(), R, dt, stream())
+    dx = torch.zeros((M, Cc), dtype=tdt(dt), device=dev())
+    dg = [torch.zeros(Cc, device=dev()) for _ in range(3)]; db = [torch.zeros(Cc, device=dev()) for _ in range(3)]
+    sums = torch.zeros(8 * 2 * Cc, dtype=torch.float64, device=dev())
+    e = L.BnBwdDesc()
+    e.x, e.dskip, e.dx, e.M, e.C, e.dtype, e.nb, e.masked, e.accumulate, e.count = x.data_ptr(), skip.data_ptr(), dx.data_ptr(), M, Cc, dt, 3, 1, 0, float(M)
+    for b in range(3):
+        br = e.br[b]
+        br.g, br.stats2, br.replicas, br.gamma = gs[b].data_ptr(), st2[b].data_ptr(), R, gam[b].data_ptr()
+        br.scale, br.shift, br.mean, br.rstd = [coef[b][i].data_ptr() for i in range(4)]
+        br.dgamma, br.dbeta = dg[b].data_ptr(), db[b].data_ptr()
+    e.dx_stats, e.dx_replicas = sums.data_ptr(), 8
+    lib.call("rua_bn_bwd", C.byref(e), stream())
+    chk = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
+    lib.call("rua_col_stats", dx.data_ptr(), M, Cc, chk.data_ptr(), 1, dt, stream())
+    torch.cuda.synchronize()
+    got = sums.cpu().numpy().reshape(8, 2 * Cc).sum(0)[:Cc]
+    exp = chk.cpu().numpy()[:Cc]
+    assert np.abs(got - exp).max() < (1e-4 if dt == L.RUA_F32 else 2e-2) * max(1.0, np.abs(exp).max()), np.abs(got - exp).max()
+    assert float(np.abs(exp).max()) > 1.0
