@@ -220,6 +220,10 @@ int rua_head_fwd_loss(const void* x, const float* w, const float* b, float* z, f
  * backward is applied here instead of in a pass of its own */
 int rua_head_bwd(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db,
                  float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, int mask_dx, void* stream);
+/* the same with dxsum (fp32 [Cin], +=, optional): the per-channel sums of the values written to dx - the bias gradient of the convolution that produced x
+ * where dx is its output's complete gradient (the 3x3 + ReLU convs in front of the heads: model2.py:153-171) - taken in the same pass */
+int rua_head_bwd_sums(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db, float* dxsum,
+                      float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, int mask_dx, void* stream);
 
 /* ---- BatchNormalization (model2.py:17,21,38,86,93; Keras eps 1e-3, momentum .99) -------- */
 /* per-channel sum / sum of squares over all rows of x [M][C] -> stats[R][2][C] (fp64, accumulated over R replicas) */

@@ -109,6 +109,7 @@ _SIGS = {
     "rua_head_fwd": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp], i32),
     "rua_head_fwd_loss": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp], i32),
     "rua_head_bwd": ([vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp], i32),
+    "rua_head_bwd_sums": ([vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp], i32),
     "rua_col_stats": ([vp, i64, i32, vp, i32, i32, vp], i32),
     "rua_col_stats2": ([vp, vp, vp, vp, i32, i64, i32, vp, i32, i32, vp], i32),
     "rua_stats_replicas": ([i64], i32),

@@ -446,14 +446,16 @@ __global__ __launch_bounds__(256) void head_fwd_loss_kernel(const unsigned char*
 template <typename T, int CO>      // CO: output channels held in registers (exact for the reference's 6 classes / 3 colour bands, else 8)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, const float* __restrict__ dz, const float* __restrict__ w,
                                                         unsigned char* dx, int accumulate_dx, float* dw, float* db, float* partial,
-                                                        long long M, int Cin, int Cout, int rows_per_block, int mask_dx) {
+                                                        long long M, int Cin, int Cout, int rows_per_block, int mask_dx, float* dxsum) {
   constexpr int VEC = ET<T>::VEC;
-  extern __shared__ float red[];                      // [4 waves][Cout*Cin + Cout]
-  const int NE = Cout * Cin + Cout;
+  extern __shared__ float red[];                      // [4 waves][Cout*Cin + Cout (+ Cin: per-channel sums of dx)]
+  const int NE = Cout * Cin + Cout + (dxsum ? Cin : 0);
   const int CGI = Cin / VEC;
   const int cp = threadIdx.x % CGI, pl = threadIdx.x / CGI, PL = 256 / CGI;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  float wr[CO][VEC], acc[CO][VEC], bs[CO];
+  float wr[CO][VEC], acc[CO][VEC], bs[CO], so[VEC];   // so: sums of the dx values this thread writes (dxsum: the bias gradient of the conv that produced x)
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) so[j] = 0.f;
 #pragma unroll
   for (int co = 0; co < CO; ++co) { bs[co] = 0.f;
 #pragma unroll
@@ -476,6 +478,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o[j] = xv[j] > 0.f ? o[j] : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) so[j] += o[j];
     if (dx) stg16(dx + ((size_t)rr * CGI + cp) * 16, ET<T>::pack(o));
   };
   // two rows per iteration, every load of both issued before the first use
@@ -507,6 +511,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
       for (int o = CGI; o < 64; o <<= 1) acc[co][j] += __shfl_xor(acc[co][j], o, 64);
     for (int o = CGI; o < 64; o <<= 1) bs[co] += __shfl_xor(bs[co], o, 64);
   }
+  if (dxsum) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      for (int o = CGI; o < 64; o <<= 1) so[j] += __shfl_xor(so[j], o, 64);
+  }
   if (lane < CGI) {
 #pragma unroll
     for (int co = 0; co < CO; ++co) {
@@ -516,19 +525,25 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
         if (lane == 0) red[wid * NE + Cout * Cin + co] = bs[co];
       }
     }
+    if (dxsum) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) red[wid * NE + Cout * Cin + Cout + lane * VEC + j] = so[j];
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NE; i += 256) {
     const float v = red[i] + red[NE + i] + red[2 * NE + i] + red[3 * NE + i];
     if (partial) partial[(size_t)blockIdx.x * NE + i] = v;                       // deterministic two-stage path
     else if (i < Cout * Cin) unsafeAtomicAdd(&dw[i], v);
-    else if (db) unsafeAtomicAdd(&db[i - Cout * Cin], v);
+    else if (i < Cout * Cin + Cout) { if (db) unsafeAtomicAdd(&db[i - Cout * Cin], v); }
+    else unsafeAtomicAdd(&dxsum[i - Cout * Cin - Cout], v);
   }
 }
 
 // dst[e] += sum_b partial[b][e]; 4 elements x 64 slices per block (a thread's loads are independent: unrolled by 8), slices
 // folded in a fixed order
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int ne, int nparts, float* dw, int ndw, float* db) {
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int ne, int nparts, float* dw, int ndw, float* db,
+                                                             int ndb = 1 << 30, float* dsum = nullptr) {
   __shared__ float sh[256];
   const int el = threadIdx.x & 3, sl = threadIdx.x >> 2;
   const int e = blockIdx.x * 4 + el;
@@ -550,7 +565,9 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __rest
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 64; ++k) t += sh[k * 4 + el];
-    if (e < ndw) dw[e] += t; else if (db) db[e - ndw] += t;
+    if (e < ndw) dw[e] += t;
+    else if (e < ndw + ndb) { if (db) db[e - ndw] += t; }
+    else if (dsum) dsum[e - ndw - ndb] += t;
   }
 }
 
@@ -600,8 +617,8 @@ extern "C" int rua_head_fwd_loss(const void* x, const float* w, const float* b, 
   return RUA_OK;
 }
 
-extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db,
-                            float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, int mask_dx, void* stream) {
+extern "C" int rua_head_bwd_sums(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db, float* dxsum,
+                                 float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, int mask_dx, void* stream) {
   RUA_CHECK_ARG(x && dz && w && dw && M > 0, "rua_head_bwd: bad arguments");
   const int vec = dtype == RUA_BF16 ? 8 : 4;
   RUA_CHECK_ARG(Cin % vec == 0 && Cin <= 256 && 256 % (Cin / vec) == 0, "rua_head_bwd: unsupported Cin=%d", Cin);
@@ -611,19 +628,27 @@ extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void
   // 640: 52, 1024: 51, 2048: 85 (kernel + partial reduce, 256x256x32 -> 6)
   int64_t blocks = blocks_env > 0 ? blocks_env : 2 * rua_cu_count(); int64_t rpb = (M + blocks - 1) / blocks; if (rpb < 64) rpb = 64;
   const int g = (int)((M + rpb - 1) / rpb);
-  const int ne = Cout * Cin + Cout;
+  RUA_CHECK_ARG(!dxsum || dx, "rua_head_bwd_sums: the sums are those of dx");
+  const int ne = Cout * Cin + Cout + (dxsum ? Cin : 0);
   const size_t smem = (size_t)4 * ne * 4;
   float* partial = (scratch && scratch_bytes >= (int64_t)g * ne * 4) ? scratch : nullptr;   // else: fp32 atomics
   hipStream_t st = (hipStream_t)stream;
 #define RUA_HEAD_BWD(TT, CO_) hipLaunchKernelGGL((head_bwd_kernel<TT, CO_>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, \
-    (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb, mask_dx)
+    (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb, mask_dx, dxsum)
   if (dtype == RUA_BF16) { if (Cout == 6) RUA_HEAD_BWD(bf16_t, 6); else if (Cout == 3) RUA_HEAD_BWD(bf16_t, 3); else RUA_HEAD_BWD(bf16_t, 8); }
   else { if (Cout == 6) RUA_HEAD_BWD(float, 6); else if (Cout == 3) RUA_HEAD_BWD(float, 3); else RUA_HEAD_BWD(float, 8); }
 #undef RUA_HEAD_BWD
   RUA_LAUNCH_CHECK("rua_head_bwd");
   if (partial) {
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((ne + 3) / 4), dim3(256), 0, st, (const float*)partial, ne, g, dw, Cout * Cin, db);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((ne + 3) / 4), dim3(256), 0, st, (const float*)partial, ne, g, dw, Cout * Cin, db, Cout, dxsum);
     RUA_LAUNCH_CHECK("partial_reduce_kernel");
   }
   return RUA_OK;
+}
+
+// dxsum (optional, fp32 [Cin], +=): the per-channel sums of the values written to dx - the bias gradient of the convolution that produced x when dx is
+// its output's complete gradient (the 3x3 + ReLU convs in front of the heads, model2.py:153-171) - taken in the same pass
+extern "C" int rua_head_bwd(const void* x, const float* dz, const float* w, void* dx, int accumulate_dx, float* dw, float* db,
+                            float* scratch, int64_t scratch_bytes, int64_t M, int Cin, int Cout, int dtype, int mask_dx, void* stream) {
+  return rua_head_bwd_sums(x, dz, w, dx, accumulate_dx, dw, db, nullptr, scratch, scratch_bytes, M, Cin, Cout, dtype, mask_dx, stream);
 }

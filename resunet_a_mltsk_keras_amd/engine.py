@@ -405,6 +405,7 @@ class Graph:
     def gacc(self, x: Ten, masked: bool = False) -> Tuple[Ten, int]:
         """Gradient buffer of x and whether the next writer must accumulate.  masked: this writer applies x's ReLU mask to
         what it writes (the mask is idempotent on a masked sum, so it commutes with accumulation)."""
+        assert not x.bias_done, "a gradient whose per-channel sums were already taken (bias gradient) gets another writer"
         if x.grad is None:
             x.grad = self.like(x)
         acc = 1 if x.gw else 0
@@ -1300,17 +1301,28 @@ class Graph:
         y = self.new(x.N, x.H, x.W, nf)
         y.relu_out = True
         self.conv(F, [(x, 0, 1, 9)], lay["segs"], nf, self.P(lay["bias"]), y, out_relu=True)
+        y.bias_offs = [lay["bias"]]                          # the single consumer writes y's whole (masked) gradient: it may take the bias gradient on the way
         if tr:
             def back():
                 Bp = self.bwd
                 dy = y.grad
                 assert not (y.masked_w and y.plain_w), "mixed masked / unmasked writers of a ReLU output's gradient"
                 if y.plain_w:
+                    assert not y.bias_done
                     Bp.add("rua_relu_mask", dy.ptr, y.ptr, y.t.numel(), self.dt)
-                self.bias_grad(Bp, dy, [lay["bias"]])
+                if not y.bias_done:
+                    self.bias_grad(Bp, dy, [lay["bias"]])
                 self.wgrad(Bp, x, dy, lay["segs"][0]["off"], 1, 1, 9)
                 gx, acc = self.gacc(x, masked=x.relu_out)
-                self.dgrad(Bp, dy, self.Wd(lay["segs"][0]["dst"]), x.C, 1, 9, gx, acc, mask=(x, None, None) if x.relu_out else None)
+                sx = None
+                if x.bias_offs and x.relu_out and not acc and not self.dry and self.e.bn_dx_bias:
+                    # x is the ReLU'ed output of a conv with a bias and this data gradient its only consumer: the epilogue's per-channel sums of the
+                    # masked gradient are that bias gradient (no rua_col_stats pass)
+                    sx = self.stat(x.C, (x.M + 127) // 128)
+                self.dgrad(Bp, dy, self.Wd(lay["segs"][0]["dst"]), x.C, 1, 9, gx, acc, mask=(x, None, None) if x.relu_out else None, stats2=sx)
+                if sx is not None:
+                    self.stats_to_grads(Bp, sx, x.C, x.bias_offs)
+                    x.bias_done = True
             self.back_steps.append(back)
         return y
 
@@ -1369,8 +1381,12 @@ class Graph:
             hx = h["x"]
             gx, acc = self.gacc(hx, masked=hx.relu_out)
             lay = h["lay"]
-            Bp.add("rua_head_bwd", hx.ptr, dz.ptr, self.P(lay["segs"][0]["off"]), gx.ptr, acc, self.G(lay["segs"][0]["off"]),
-                   self.G(lay["bias"]), self.e.scratch.data_ptr(), self.e.scratch.numel() * 4, M, hx.C, Cc, self.dt,
+            dxsum = None
+            if hx.bias_offs and hx.relu_out and not acc and not self.dry and self.e.bn_dx_bias:
+                dxsum = self.G(hx.bias_offs[0])            # the head's backward sums the masked gradient it writes: the bias gradient of the conv behind hx
+                hx.bias_done = True
+            Bp.add("rua_head_bwd_sums", hx.ptr, dz.ptr, self.P(lay["segs"][0]["off"]), gx.ptr, acc, self.G(lay["segs"][0]["off"]),
+                   self.G(lay["bias"]), dxsum, self.e.scratch.data_ptr(), self.e.scratch.numel() * 4, M, hx.C, Cc, self.dt,
                    1 if hx.relu_out else 0)
         self.back_steps.append(back)
 

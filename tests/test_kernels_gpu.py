@@ -1829,3 +1829,37 @@ def test_bn_bwd_output_sums_are_the_bias_gradient(dt):
     exp = chk.cpu().numpy()[:Cc]
     assert np.abs(got - exp).max() < (1e-4 if dt == L.RUA_F32 else 2e-2) * max(1.0, np.abs(exp).max()), np.abs(got - exp).max()
     assert float(np.abs(exp).max()) > 1.0
+
+
+@pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
+@pytest.mark.parametrize("Cc,use_scratch", [(6, True), (3, False)])
+def test_head_bwd_sums_of_dx(dt, Cc, use_scratch):
+    """rua_head_bwd_sums: dx, dW, db as rua_head_bwd (bit for bit) plus the per-channel sums of the masked dx it writes - the bias gradient of the 3x3 + ReLU
+    conv in front of the head (model2.py:153-171) - on both reduction paths (per-block partials + fixed-order reduce, fp32 atomics)."""
+    lib = L.lib()
+    rng = np.random.default_rng(Cc)
+    M, Cin = 3 * 40 * 24, 32
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+    x = to_dev(np.maximum(rng.standard_normal((M, Cin)), 0).astype(np.float32), dt)
+    dz, w = f(rng.standard_normal((M, Cc))), f(rng.standard_normal((Cc, Cin)) / 6)
+    scratch = torch.zeros(1 << 20, device=dev())
+    res = []
+    for sums in (False, True):
+        dx = torch.zeros((M, Cin), dtype=tdt(dt), device=dev())
+        dw, db, ds = torch.zeros((Cc, Cin), device=dev()), torch.zeros(Cc, device=dev()), torch.full((Cin,), 0.5, device=dev())
+        sp, sb = (scratch.data_ptr(), scratch.numel() * 4) if use_scratch else (None, 0)
+        if sums:
+            lib.call("rua_head_bwd_sums", x.data_ptr(), dz.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), db.data_ptr(), ds.data_ptr(), sp, sb,
+                     M, Cin, Cc, dt, 1, stream())
+        else:
+            lib.call("rua_head_bwd", x.data_ptr(), dz.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), db.data_ptr(), sp, sb, M, Cin, Cc, dt, 1, stream())
+        torch.cuda.synchronize()
+        res.append((dx, dw, db, ds))
+    assert torch.equal(res[0][0], res[1][0])
+    if use_scratch:                                            # (the atomic path adds in arrival order)
+        assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    else:
+        assert torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-4)
+    exp = (dz.double() @ w.double()) * (x.double() > 0)
+    got = res[1][3].cpu().numpy() - 0.5                          # += semantics
+    assert np.abs(got - exp.sum(0).cpu().numpy()).max() < (1e-3 if dt == L.RUA_F32 else 2e-2) * max(1.0, float(exp.sum(0).abs().max()))
