@@ -277,7 +277,9 @@ int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream);
 int rua_bn_fwd_group(const rua_bn_fwd_desc* d, int n, void* stream);
 int rua_bn_fwd_group_last_grids(void);
 typedef struct rua_bn_bwd_branch {
-  const void* g; const double* stats2; int32_t replicas, pad;
+  const void* g; const double* stats2; int32_t replicas;
+  int32_t stats2_out;   /* 1: slot 1 of stats2 is sum g * OUT (this BatchNorm's output, no ReLU: what rua_bn_bwd_desc.dx_stats of the launch that wrote g
+                           provides) instead of sum g * x; the kernel converts with x = (out - shift) / scale (scale, shift must be set) */
   const float* gamma; const float* mean; const float* rstd; const float* scale; const float* shift;
   float* dgamma; float* dbeta;
 } rua_bn_bwd_branch;
@@ -287,7 +289,8 @@ typedef struct rua_bn_bwd_desc {
   double* skip_stats;          /* optional [skip_replicas][2][C]: per-channel sum of dskip added into slot 0 (the bias gradient of */
   int32_t skip_replicas, pad2; /* the convs whose output the skip tensor is the gradient of: model2.py:27-31) - saves a pass over dskip */
   double* dx_stats;            /* optional [dx_replicas][2][C]: per-channel sum of the values written to dx added into slot 0 - the bias gradient of the */
-  int32_t dx_replicas, pad3;   /* convolution that produced x (the stride-2 1x1 convs in front of the encoder ResBlocks: model2.py:103-111), without a pass over dx */
+  int32_t dx_replicas, pad3;   /* convolution that produced x (the stride-2 1x1 convs in front of the encoder ResBlocks: model2.py:103-111), without a pass over dx;
+                                  slot 1 += sum dx * x: with stats2_out the statistics of the BatchNorm backward of the BatchNorm that produced x (model2.py:86) */
 } rua_bn_bwd_desc;
 int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream);
 /* n (<= RUA_MAX_BRANCH) independent one-branch BatchNorm backwards of equal channel count (any pixel counts) - the second BatchNorms of a

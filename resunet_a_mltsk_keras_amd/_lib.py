@@ -55,7 +55,7 @@ class BnFwdDesc(C.Structure):
 
 
 class BnBwdBranch(C.Structure):
-    _fields_ = [("g", vp), ("stats2", vp), ("replicas", i32), ("pad", i32), ("gamma", vp), ("mean", vp), ("rstd", vp),
+    _fields_ = [("g", vp), ("stats2", vp), ("replicas", i32), ("stats2_out", i32), ("gamma", vp), ("mean", vp), ("rstd", vp),
                 ("scale", vp), ("shift", vp), ("dgamma", vp), ("dbeta", vp)]
 
 

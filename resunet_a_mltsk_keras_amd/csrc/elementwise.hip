@@ -556,6 +556,10 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
       double sg, sgx;
       replica_sum(br.stats2, br.replicas, C, c, sg, sgx);
       const double mu = br.mean[c], r = br.rstd[c], gm = br.gamma[c];
+      if (br.stats2_out) {                             // slot 1 holds sum g * (scale x + shift): back to sum g * x
+        const double sc = br.scale[c], sh = br.shift[c];
+        sgx = sc != 0.0 ? (sgx - sh * sg) / sc : mu * sg;
+      }
       const double dga = r * (sgx - mu * sg);
       const double s = gm * r;
       tab[(b * 3) * C + c] = (float)s;
@@ -576,9 +580,9 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
   unsigned char* dx = (unsigned char*)p.dx;
   const long long stride = (long long)gridDim.x * 256;
   // per-channel sum of dskip (256 is a multiple of CG, so a thread stays on one channel group for the whole sweep)
-  float sk[VEC], so[VEC];                              // so: per-channel sum of what this thread writes to dx (p.dx_stats)
+  float sk[VEC], so[VEC], so2[VEC];                    // so / so2: per-channel sums of dx and of dx * x over what this thread writes (p.dx_stats)
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) { sk[j] = 0.f; so[j] = 0.f; }
+  for (int j = 0; j < VEC; ++j) { sk[j] = 0.f; so[j] = 0.f; so2[j] = 0.f; }
   if constexpr (NB > 0) {
     // coefficients of this thread's channel group in registers for the whole sweep (see bn_fwd_kernel): no LDS reads in the loop
     const int c = (int)(threadIdx.x % CG) * VEC;
@@ -633,7 +637,7 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
         }
       }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) so[j] += acc[j];
+      for (int j = 0; j < VEC; ++j) { so[j] += acc[j]; so2[j] = fmaf(acc[j], xv[j], so2[j]); }
       stg16(dx + i * 16, ET<T>::pack(acc));
     }
   } else {
@@ -665,7 +669,7 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
       }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) so[j] += acc[j];
+    for (int j = 0; j < VEC; ++j) { so[j] += acc[j]; so2[j] = fmaf(acc[j], xv[j], so2[j]); }
     stg16(dx + i * 16, ET<T>::pack(acc));
   }
   }
@@ -695,6 +699,16 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
       float t = 0.f;
       for (int k = 0; k < per; ++k) t += red[(k * CG + cg) * VEC + j];
       unsafeAtomicAdd(&p.dx_stats[(size_t)(blockIdx.x & (p.dx_replicas - 1)) * 2 * C + ch], (double)t);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = so2[j];
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+      const int cg = ch / VEC, j = ch - cg * VEC;
+      float t = 0.f;
+      for (int k = 0; k < per; ++k) t += red[(k * CG + cg) * VEC + j];
+      unsafeAtomicAdd(&p.dx_stats[(size_t)(blockIdx.x & (p.dx_replicas - 1)) * 2 * C + C + ch], (double)t);
     }
   }
 }

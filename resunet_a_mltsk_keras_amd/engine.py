@@ -168,7 +168,7 @@ class ParamStore:
 # ---------------------------------------------------------------------------------------
 class Ten:
     """A device activation tensor [N][H][W][C] (storage owned by a torch tensor)."""
-    __slots__ = ("N", "H", "W", "C", "t", "ptr", "grad", "gw", "stats", "f32", "relu_out", "masked_w", "plain_w", "bias_offs", "bias_done")
+    __slots__ = ("N", "H", "W", "C", "t", "ptr", "grad", "gw", "stats", "f32", "relu_out", "masked_w", "plain_w", "bias_offs", "bias_done", "bn_src")
 
     def __init__(self, t: torch.Tensor, N, H, W, C, f32=False):
         self.t, self.N, self.H, self.W, self.C, self.f32 = t, N, H, W, C, f32
@@ -181,6 +181,8 @@ class Ten:
         self.plain_w = 0
         self.bias_offs = None      # bias of the convolution that produced this tensor, if its gradient (the per-channel sum of this tensor's
         self.bias_done = False     # gradient) may be taken by the kernel that writes the gradient: done = it was
+        self.bn_src = None         # bn_node record of the ReLU-less BatchNorm that produced this tensor: the kernel that writes its whole gradient may take the
+                                   # BatchNorm backward's statistics (sum g, sum g * this tensor) on the way
 
     @property
     def M(self):
@@ -541,7 +543,7 @@ class Graph:
 
     def bn_bwd(self, plan: Plan, gs: List[Ten], coefs: List[Coef], bns: List[dict], stats2: List[Stat], x: Ten, out: Ten,
                accumulate: int, count, dskip: Optional[Ten] = None, masked=False, skip_bias: Optional[List[int]] = None, defer: Optional[List] = None,
-               dx_bias: bool = False):
+               dx_bias: bool = False, stats2_out: Optional[List[bool]] = None):
         """dx (=|+=) [dskip] + sum_b BN-backward_b(g_b) in ONE launch; dgamma/dbeta added by block 0.
         skip_bias: bias offsets whose gradient is the per-channel sum of dskip - accumulated by this launch while it reads
         dskip anyway (instead of a col_stats pass over the same tensor), converted by one rua_stats_to_f32."""
@@ -552,6 +554,7 @@ class Graph:
         for i, (g, c, bn, s2) in enumerate(zip(gs, coefs, bns, stats2)):
             b = d.br[i]
             b.g, b.stats2, b.replicas = g.ptr, s2.ptr, s2.R
+            b.stats2_out = 1 if (stats2_out and stats2_out[i]) else 0
             b.gamma, b.mean, b.rstd, b.scale, b.shift = self.P(bn["gamma"]), c.mean, c.rstd, c.scale, c.shift
             b.dgamma, b.dbeta = self.G(bn["gamma"]), self.G(bn["beta"])
         st = None
@@ -568,7 +571,15 @@ class Graph:
             defer.append(d)
             return
         sx = None
-        if (dx_bias and x.bias_offs and not accumulate and not self.dry and self.e.bn_dx_bias and cg <= 256 and 256 % cg == 0):
+        if (dx_bias and x.bn_src is not None and not x.bn_src["fused"] and not accumulate and not self.dry and self.e.bn_dx_bias and cg <= 256 and 256 % cg == 0):
+            # x is the output of a ReLU-less BatchNorm (the combine BatchNorm in front of a decoder ResBlock, model2.py:86) and `out` its complete gradient g:
+            # the sums of g and of g * x taken here are the statistics that BatchNorm's backward needs (it converts x back to its own input): no rua_col_stats2 pass
+            blocks = max(1, min(1024, x.M * (x.C // self.vec) // 256))
+            s2 = self.stat(x.C, blocks, burst=True)
+            d.dx_stats, d.dx_replicas = s2.ptr, s2.R
+            x.bn_src["s2"], x.bn_src["s2_out"] = s2, True
+            x.bias_done = True                               # (no further writer of this gradient)
+        elif (dx_bias and x.bias_offs and not accumulate and not self.dry and self.e.bn_dx_bias and cg <= 256 and 256 % cg == 0):
             # x is the output of a convolution with a bias and `out` its complete gradient: the per-channel sums of what this launch
             # writes ARE that bias gradient (no rua_col_stats pass over the gradient: the stride-2 convs in front of the encoder ResBlocks)
             blocks = max(1, min(1024, x.M * (x.C // self.vec) // 256))
@@ -1061,16 +1072,19 @@ class Graph:
             stats = x.stats if x.stats is not None else self.col_stats(F, x)
         ys, coefs = self.bn_fwd(F, x, [bn], relu, stats, cnt, bessel, defer=defer, out_stats=True)     # defer: the caller issues several as one group launch
         y, coef = ys[0], coefs[0]
-        node = dict(x=x, y=y, coef=coef, bn=bn, relu=relu, cnt=cnt, s2=None, fused=False)
+        node = dict(x=x, y=y, coef=coef, bn=bn, relu=relu, cnt=cnt, s2=None, fused=False, s2_out=False)
+        if not relu and tr:
+            y.bn_src = node
 
         def back(defer=None):
             Bp = self.bwd
             g = y.grad
-            if not node["fused"]:
+            if not node["fused"] and not node["s2_out"]:
                 node["s2"] = self.stat(x.C, self.stat_blocks(x), burst=True)
                 Bp.add("rua_col_stats2", g.ptr, x.ptr, coef.scale, coef.shift, 1 if relu else 0, x.M, x.C, node["s2"].ptr, node["s2"].R, self.dt)
             gx, acc = self.gacc(x)
-            self.bn_bwd(Bp, [g], [coef], [bn], [node["s2"]], x, gx, acc, cnt, masked=(relu and not node["fused"]), defer=defer)
+            self.bn_bwd(Bp, [g], [coef], [bn], [node["s2"]], x, gx, acc, cnt, masked=(relu and not node["fused"]), defer=defer,
+                        stats2_out=[node["s2_out"]])
         node["back"] = back
         return y, node
 

@@ -1863,3 +1863,61 @@ def test_head_bwd_sums_of_dx(dt, Cc, use_scratch):
     exp = (dz.double() @ w.double()) * (x.double() > 0)
     got = res[1][3].cpu().numpy() - 0.5                          # += semantics
     assert np.abs(got - exp.sum(0).cpu().numpy()).max() < (1e-3 if dt == L.RUA_F32 else 2e-2) * max(1.0, float(exp.sum(0).abs().max()))
+
+
+def test_bn_bwd_statistics_in_terms_of_the_output():
+    """rua_bn_bwd_branch.stats2_out: the BatchNorm backward of a ReLU-less BatchNorm fed with (sum g, sum g * OUT) - what the launch that wrote g takes
+    through rua_bn_bwd_desc.dx_stats (slot 1 = sum dx * x) - instead of (sum g, sum g * x) from a rua_col_stats2 pass: same dx, dgamma, dbeta (fp32)."""
+    dt = L.RUA_F32
+    lib = L.lib()
+    rng = np.random.default_rng(44)
+    M, Cc, R = 3000, 32, 2
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
+    x = f(rng.standard_normal((M, Cc)) * 1.4 + 0.3)
+    g = f(rng.standard_normal((M, Cc)))
+    gam, bet = f(rng.uniform(0.5, 1.5, Cc)), f(rng.standard_normal(Cc))
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-3)
+    scale = gam * rstd
+    shift = bet - mean * scale
+    out = x * scale + shift                                    # the BatchNorm's output (no ReLU): the tensor the next ResBlock reads
+    # (1) the writer of g: a one-branch BatchNorm backward over `out` (any coefficients) that also takes sum dx and sum dx * out
+    co2 = torch.stack([torch.ones(Cc, device=dev()), torch.zeros(Cc, device=dev()), out.mean(0), torch.rsqrt(out.var(0, unbiased=False) + 1e-3)])
+    gg = f(rng.standard_normal((M, Cc)))
+    s_in = torch.zeros(R * 2 * Cc, dtype=torch.float64, device=dev())
+    lib.call("rua_col_stats2", gg.data_ptr(), out.data_ptr(), co2[0].data_ptr(), co2[1].data_ptr(), 0, M, Cc, s_in.data_ptr(), R, dt, stream())
+    gdx = torch.zeros((M, Cc), device=dev())
+    sums = torch.zeros(4 * 2 * Cc, dtype=torch.float64, device=dev())
+    e = L.BnBwdDesc()
+    e.x, e.dx, e.M, e.C, e.dtype, e.nb, e.masked, e.accumulate, e.count = out.data_ptr(), gdx.data_ptr(), M, Cc, dt, 1, 0, 0, float(M)
+    br = e.br[0]
+    g1 = torch.ones(Cc, device=dev())
+    br.g, br.stats2, br.replicas, br.gamma = gg.data_ptr(), s_in.data_ptr(), R, g1.data_ptr()
+    br.scale, br.shift, br.mean, br.rstd = [co2[i].data_ptr() for i in range(4)]
+    e.dx_stats, e.dx_replicas = sums.data_ptr(), 4
+    lib.call("rua_bn_bwd", C.byref(e), stream())
+    torch.cuda.synchronize()
+    s = sums.cpu().numpy().reshape(4, 2 * Cc).sum(0)
+    gd = gdx.double()
+    assert np.allclose(s[:Cc], gd.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    assert np.allclose(s[Cc:], (gd * out.double()).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    # (2) the consumer: the backward of the BatchNorm that produced `out`, its gradient being gdx
+    res = []
+    for mode in (0, 1):
+        st = torch.zeros(4 * 2 * Cc, dtype=torch.float64, device=dev())
+        if mode == 0:
+            lib.call("rua_col_stats2", gdx.data_ptr(), x.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, M, Cc, st.data_ptr(), 4, dt, stream())
+        else:
+            st.copy_(sums)
+        dx = torch.zeros((M, Cc), device=dev()); dgm, dbt = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
+        q = L.BnBwdDesc()
+        q.x, q.dx, q.M, q.C, q.dtype, q.nb, q.masked, q.accumulate, q.count = x.data_ptr(), dx.data_ptr(), M, Cc, dt, 1, 0, 0, float(M)
+        b = q.br[0]
+        b.g, b.stats2, b.replicas, b.gamma, b.stats2_out = gdx.data_ptr(), st.data_ptr(), 4, gam.data_ptr(), mode
+        b.scale, b.shift, b.mean, b.rstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        b.dgamma, b.dbeta = dgm.data_ptr(), dbt.data_ptr()
+        lib.call("rua_bn_bwd", C.byref(q), stream())
+        torch.cuda.synchronize()
+        res.append((dx.cpu().numpy(), dgm.cpu().numpy(), dbt.cpu().numpy()))
+    for a, b_ in zip(res[0], res[1]):
+        assert np.abs(a - b_).max() < 2e-4 * max(1.0, np.abs(a).max()), np.abs(a - b_).max()
