@@ -673,44 +673,41 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
     stg16(dx + i * 16, ET<T>::pack(acc));
   }
   }
-  if (p.skip_stats && dskip) {                           // uniform: fold the block's partial sums through LDS, one fp64 add per channel
-    __syncthreads();                                     // the coefficient table is dead
-    float* red = tab;                                    // [256][VEC] (the launcher sized the dynamic LDS for it)
+  // Per-channel sums of the block (sums of dskip, of dx, of dx * x): every thread holds VEC channels of ONE channel group (256 % CG == 0), so the lanes of a wave
+  // that share a group are folded with shuffles first (CG <= 32: 64 / CG lanes each), the four waves through [4][CG][VEC] floats of LDS, one fp64 add per channel
+  // and block.  (The first form staged all 256 x VEC partials in LDS and let C threads walk 256 / CG of them each: +9 us on the 256 x 256 x 32 launch.)
+  auto fold = [&](float* v, double* dst, int replicas, int slot) {
+    float* red = tab;                                    // the coefficient table is dead
+    __syncthreads();
+    if (CG <= 32) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = sk[j];
-    __syncthreads();
-    const int per = 256 / CG;                            // threads per channel group
-    for (int ch = threadIdx.x; ch < C; ch += 256) {
-      const int cg = ch / VEC, j = ch - cg * VEC;
-      float t = 0.f;
-      for (int k = 0; k < per; ++k) t += red[(k * CG + cg) * VEC + j];
-      unsafeAtomicAdd(&p.skip_stats[(size_t)(blockIdx.x & (p.skip_replicas - 1)) * 2 * C + ch], (double)t);
-    }
-  }
-  if (p.dx_stats) {                                      // uniform: the same fold for the sums of the output
-    __syncthreads();
-    float* red = tab;
+      for (int j = 0; j < VEC; ++j)
+        for (int o = CG; o < 64; o <<= 1) v[j] += __shfl_xor(v[j], o, 64);
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      if (lane < CG) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = so[j];
-    __syncthreads();
-    const int per = 256 / CG;
-    for (int ch = threadIdx.x; ch < C; ch += 256) {
-      const int cg = ch / VEC, j = ch - cg * VEC;
-      float t = 0.f;
-      for (int k = 0; k < per; ++k) t += red[(k * CG + cg) * VEC + j];
-      unsafeAtomicAdd(&p.dx_stats[(size_t)(blockIdx.x & (p.dx_replicas - 1)) * 2 * C + ch], (double)t);
-    }
-    __syncthreads();
+        for (int j = 0; j < VEC; ++j) red[(wv * CG + lane) * VEC + j] = v[j];
+      }
+      __syncthreads();
+      for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const float t = (red[ch] + red[C + ch]) + (red[2 * C + ch] + red[3 * C + ch]);       // [wave][CG][VEC] = [wave][C]
+        unsafeAtomicAdd(&dst[(size_t)(blockIdx.x & (replicas - 1)) * 2 * C + slot * C + ch], (double)t);
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = so2[j];
-    __syncthreads();
-    for (int ch = threadIdx.x; ch < C; ch += 256) {
-      const int cg = ch / VEC, j = ch - cg * VEC;
-      float t = 0.f;
-      for (int k = 0; k < per; ++k) t += red[(k * CG + cg) * VEC + j];
-      unsafeAtomicAdd(&p.dx_stats[(size_t)(blockIdx.x & (p.dx_replicas - 1)) * 2 * C + C + ch], (double)t);
+      for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = v[j];
+      __syncthreads();
+      const int per = 256 / CG;                          // threads per channel group (2 or 4)
+      for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const int cg = ch / VEC, j = ch - cg * VEC;
+        float t = 0.f;
+        for (int k = 0; k < per; ++k) t += red[(k * CG + cg) * VEC + j];
+        unsafeAtomicAdd(&dst[(size_t)(blockIdx.x & (replicas - 1)) * 2 * C + slot * C + ch], (double)t);
+      }
     }
-  }
+  };
+  if (p.skip_stats && dskip) fold(sk, p.skip_stats, p.skip_replicas, 0);      // (uniform branches)
+  if (p.dx_stats) { fold(so, p.dx_stats, p.dx_replicas, 0); fold(so2, p.dx_stats, p.dx_replicas, 1); }
 }
 
 template <typename T, int NB, bool MASKED>
