@@ -43,18 +43,21 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-def exact_grads(trainer, x, y):
-    """The same oracle step in float64 (call BEFORE the fp32 oracle step, it clones the current weights), and - key
+def exact_grads(trainer, x, y, second_order=False):
+    """The same oracle step in float64 (call BEFORE the fp32 oracle step, it clones the current weights).  second_order: also - key
     "_spread" - the gradient of a second float32 evaluation ORDER of the oracle (same batch, samples reversed): the fp32
-    oracle's own distance to the exact gradient depends on the order it sums in (oracle/conditioning.py)."""
+    oracle's own distance to the exact gradient depends on the order it sums in (oracle/conditioning.py).  That third oracle
+    step (8 - 20 s of host time on a 42 M-parameter graph) is taken where the bound is meant to be tight - the full-size gradient
+    test, the Tanimoto / Adam step of the small graph; elsewhere check_step uses the documented upper range of that spread."""
     f64 = lambda a: a.astype(np.float64)
     rev = lambda a: np.ascontiguousarray(a[::-1])
     t64 = ref.RefTrainer(trainer.cfg, {k: v.detach().double() for k, v in trainer.params.items()}, trainer.order, trainer.spec)
     t64.train_on_batch(f64(x), {k: f64(v) for k, v in y.items()} if isinstance(y, dict) else f64(y))
     out = {k: t64.last_grads[k].numpy() for k in trainer.order}
-    t32 = ref.RefTrainer(trainer.cfg, {k: v.detach().clone() for k, v in trainer.params.items()}, trainer.order, trainer.spec)
-    t32.train_on_batch(rev(x), {k: rev(v) for k, v in y.items()} if isinstance(y, dict) else rev(y))
-    out["_spread"] = {k: t32.last_grads[k].numpy() for k in trainer.order}
+    if second_order:
+        t32 = ref.RefTrainer(trainer.cfg, {k: v.detach().clone() for k, v in trainer.params.items()}, trainer.order, trainer.spec)
+        t32.train_on_batch(rev(x), {k: rev(v) for k, v in y.items()} if isinstance(y, dict) else rev(y))
+        out["_spread"] = {k: t32.last_grads[k].numpy() for k in trainer.order}
     return out
 
 
@@ -101,8 +104,11 @@ def check_step(trainer, eng, x, y, mt, tol_loss, tol_logit, tol_grad, tol_w, che
                 continue
             r_hip.append(float(np.abs(grads[k] - e).max() / np.abs(e).max()))
             r_ref.append(float(np.abs(trainer.last_grads[k].numpy() - e).max() / np.abs(e).max()))
-            r_alt.append(float(np.abs(exact["_spread"][k] - e).max() / np.abs(e).max()))
-        r_hip, r_ref, r_alt = np.array(r_hip), np.array(r_ref), np.array(r_alt)
+            if "_spread" in exact:
+                r_alt.append(float(np.abs(exact["_spread"][k] - e).max() / np.abs(e).max()))
+        r_hip, r_ref = np.array(r_hip), np.array(r_ref)
+        # without the second fp32 order of the oracle: the upper range of the spread measured over sizes and seeds (oracle/conditioning.py: 1e-6 .. 2e-3)
+        r_alt = np.array(r_alt) if r_alt else np.array([2e-3])
         spread = max(float(np.median(r_ref)), float(np.median(r_alt)))
         print("gradient distance to float64 (median / max): HIP %.2e / %.2e, oracle fp32 %.2e / %.2e, oracle fp32 reversed batch %.2e / %.2e"
               % (np.median(r_hip), r_hip.max(), np.median(r_ref), r_ref.max(), np.median(r_alt), r_alt.max()))
@@ -135,7 +141,7 @@ def test_tiny_multitask_fp32_two_steps(loss, opt):
     trainer, eng = make_pair(shape, C, True, 32, loss, opt, cw=cw, depth=6 if loss == "tanimoto" else 4)
     for step in range(2):
         x, y = make_batch(2, 64, 3, C, True, seed=11 + step, block=16)
-        ex = exact_grads(trainer, x, y) if step == 0 else None
+        ex = exact_grads(trainer, x, y, second_order=(loss == "tanimoto")) if step == 0 else None
         check_step(trainer, eng, x, y, True, 1e-3, 1e-3, 5e-3, 2e-3, check_grads=(step == 0), exact=ex)
         # the second step starts from the oracle's weights: after a ReLU flip (see check_step) Adam moves the affected
         # elements by +-lr the other way, and the 8-sample BatchNorms turn that into ~3e-3 on the logits
@@ -455,7 +461,7 @@ def test_cfg3_full_size_gradients_fp32_vs_float64_oracle_and_bf16_at_batch8():
     lw = {"seg": 1.0, "bound": 1.0, "dist": 1.0, "color": 1.0}
     trainer, eng = make_pair((256, 256, 6), 6, True, 32, "tanimoto", lw=lw, split_k=True)
     x, y = make_batch(2, 256, 6, 6, True, seed=1234)
-    check_step(trainer, eng, x, y, True, 1e-3, 1e-3, 0.0, 2e-3, exact=exact_grads(trainer, x, y))
+    check_step(trainer, eng, x, y, True, 1e-3, 1e-3, 0.0, 2e-3, exact=exact_grads(trainer, x, y, second_order=True))
     weights = {k: v.detach().numpy().copy() for k, v in trainer.params.items()}
     del trainer, eng
     torch.cuda.empty_cache()
