@@ -543,7 +543,9 @@ extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream) {
 
 // (Measured and rejected, same-box A/B: issuing the sweep's first loads before the coefficient prologue and double-buffering the
 // sweep in registers - 9.70 vs 9.68 ms per step; the blocks of one launch already overlap each other's prologue.)
-template <typename T, int NB, bool MASKED>
+// DXS: the launch also takes the per-channel sums of dx and of dx * x (rua_bn_bwd_desc.dx_stats).  A template flag: the 16 accumulators take the
+// four-branch form from 124 to 144 registers (four waves per SIMD -> three: 42 -> 55 us on the 256 x 256 x 32 launch), which only the launches that ask pay.
+template <typename T, int NB, bool MASKED, bool DXS = false>
 __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long pieces, int CG) {
   constexpr int VEC = ET<T>::VEC;
   extern __shared__ float tab[];                       // [nb][3][C] : A, ms, mt ; then [2][C] : sumB, sumC
@@ -637,7 +639,7 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
         }
       }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { so[j] += acc[j]; so2[j] = fmaf(acc[j], xv[j], so2[j]); }
+      for (int j = 0; j < VEC; ++j) if constexpr (DXS) { so[j] += acc[j]; so2[j] = fmaf(acc[j], xv[j], so2[j]); }
       stg16(dx + i * 16, ET<T>::pack(acc));
     }
   } else {
@@ -669,7 +671,7 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
       }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { so[j] += acc[j]; so2[j] = fmaf(acc[j], xv[j], so2[j]); }
+    for (int j = 0; j < VEC; ++j) if constexpr (DXS) { so[j] += acc[j]; so2[j] = fmaf(acc[j], xv[j], so2[j]); }
     stg16(dx + i * 16, ET<T>::pack(acc));
   }
   }
@@ -707,11 +709,11 @@ __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long 
     }
   };
   if (p.skip_stats && dskip) fold(sk, p.skip_stats, p.skip_replicas, 0);      // (uniform branches)
-  if (p.dx_stats) { fold(so, p.dx_stats, p.dx_replicas, 0); fold(so2, p.dx_stats, p.dx_replicas, 1); }
+  if constexpr (DXS) { fold(so, p.dx_stats, p.dx_replicas, 0); fold(so2, p.dx_stats, p.dx_replicas, 1); }
 }
 
-template <typename T, int NB, bool MASKED>
-__global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, long long pieces, int CG) { bn_bwd_body<T, NB, MASKED>(p, pieces, CG); }
+template <typename T, int NB, bool MASKED, bool DXS = false>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const rua_bn_bwd_desc p, long long pieces, int CG) { bn_bwd_body<T, NB, MASKED, DXS>(p, pieces, CG); }
 // rua_bn_bwd_group: independent one-branch BatchNorm backwards of equal shape (the second BatchNorms of a ResBlock's dilation branches:
 // model2.py:21-22, one per branch, each with its own gradient, input and output) as ONE grid - blockIdx.y picks the member
 struct BnBwdG { rua_bn_bwd_desc k[RUA_MAX_BRANCH]; long long pieces[RUA_MAX_BRANCH]; };     // members of unequal pixel counts (the PSPPooling branches) sweep their own range
@@ -792,7 +794,8 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int nbk = (CG <= 256 && 256 % CG == 0 && g_tune.bn_regs) ? d->nb : 0;
   const bool mk = d->masked != 0;
-#define RUA_BN_BWD_GO(T_, NB_, MK_) hipLaunchKernelGGL((bn_bwd_kernel<T_, NB_, MK_>), dim3(g), dim3(256), smem, st, *d, pieces, CG)
+#define RUA_BN_BWD_GO(T_, NB_, MK_) do { if (d->dx_stats) hipLaunchKernelGGL((bn_bwd_kernel<T_, NB_, MK_, true>), dim3(g), dim3(256), smem, st, *d, pieces, CG); \
+                                         else hipLaunchKernelGGL((bn_bwd_kernel<T_, NB_, MK_, false>), dim3(g), dim3(256), smem, st, *d, pieces, CG); } while (0)
 #define RUA_BN_BWD_SW(T_) switch (nbk * 2 + (mk ? 1 : 0)) { \
     case 2: RUA_BN_BWD_GO(T_, 1, false); break; case 3: RUA_BN_BWD_GO(T_, 1, true); break; \
     case 4: RUA_BN_BWD_GO(T_, 2, false); break; case 5: RUA_BN_BWD_GO(T_, 2, true); break; \
