@@ -98,6 +98,8 @@ struct RuaTuning {
   int conv_band64 = 1;                  // ... and of a C = 64 ResBlock (conv_band64)
   int conv_band = 1;                    // rua_conv_fwd_sum: the branches' second convs of a C = 32 ResBlock as ONE launch with the sum kept on chip (conv_band32)
   int wgd_ks_slow = 1;                  // wgrad_dmap block order: K slice slowest (blocks that read the same pixels share an XCD's L2)
+  int strip_seglen = 0;                 // experiments (tools/bench_conv3x3.py): rows per block of conv_strip, 0 = one round of blocks
+  int strip_stag = 1;                   // conv_strip32s: full-width strips with the two halves of a block half a stage apart (0: conv_strip32 everywhere)
   int wgrad_group = 7;                  // 1 wgrad_kernel, 2 wgrad_taps<32>, 4 wgrad_taps<64>, 8 wgrad_dmap (off: three members at once thrash the L2, 27.6 vs 24.6 us each)
 };
 extern RuaTuning g_tune;

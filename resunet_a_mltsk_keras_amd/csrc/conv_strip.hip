@@ -26,6 +26,7 @@
 // (waves w / w + 4 of a SIMD alternate MFMA phase and epilogue, exact per-interval wait counts) overlapped the two phases as
 // designed and was no faster (24.4 us plain, step 9.88 vs 9.78 ms): the rows arrive no sooner.
 #include "common.h"
+#include <type_traits>
 
 struct StripK {
   ConvK c;
@@ -33,6 +34,7 @@ struct StripK {
   unsigned epbytes;
   int d, strips, spc, seglen, njobs, nchains;
   int slot_bytes, SWH;                    // bytes of one x-ring slot (multiple of 1024), pixels per slot row (SW + 2 d)
+  int dbg;                                // experiments (tuning key band_dbg; conv_strip32s): 1 no stages (prologue + tail only), 2 no row DMAs in the prologue
   int has_fold; rua_bn_fold f;            // BatchNorm coefficients derived in the prologue from the input's statistics (in_fold)
 };
 
@@ -387,6 +389,8 @@ template <int NW, bool HAS_EP, int R> __global__ __launch_bounds__(NW * 64) void
 // grouped launch (rua_conv_fwd_group): the four dilation branches of the d6 block in one grid, blockIdx.y = branch
 template <int NW, bool HAS_EP, int R> __global__ __launch_bounds__(NW * 64) void conv_strip32_g(const StripKG g) { conv_strip32_body<NW, HAS_EP, R>(g.k[blockIdx.y]); }
 
+#include "conv_strip2.inc"
+
 // ---- host side ---------------------------------------------------------------------------------------------------------
 // strip width: 256 pixels (8 waves) where the row allows it; tuning key strip_narrow_maxd: dilations up to it take 128-pixel
 // strips instead (twice the chains, half the window-fill overhead, four waves per block)
@@ -426,7 +430,54 @@ template <int NW, bool HAS_EP, int R> static int launch_strip_members(const Stri
   RUA_LAUNCH_CHECK("conv_strip32");
   return RUA_OK;
 }
+// conv_strip32s: always the grouped kernel (a lone convolution is a group of one)
+template <int NW, int IN, int EP, int ST, int ORELU, int R> static int launch_strip_s(const StripK* ks, const int* smems, int m, hipStream_t st) {
+  static thread_local bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32s_g<NW, IN, EP, ST, ORELU, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  StripKG g;
+  int grid = 0, smem = 0;
+  for (int i = 0; i < m; ++i) { g.k[i] = ks[i]; if (ks[i].njobs > grid) grid = ks[i].njobs; if (smems[i] > smem) smem = smems[i]; }
+  hipLaunchKernelGGL((conv_strip32s_g<NW, IN, EP, ST, ORELU, R>), dim3((grid + 7) / 8 * 8, m), dim3(NW * 64), smem, st, g);
+  RUA_LAUNCH_CHECK("conv_strip32s");
+  return RUA_OK;
+}
+// the (IN, EP, ST, ORELU) forms the step uses; everything else stays on conv_strip32
+struct StripSForm { int in, ep, st, orelu, R; };
+static const StripSForm kStripS[] = {
+  {1, 0, 1, 0, 6},   // first convs of a ResBlock: BatchNorm + ReLU on load, statistics of the output
+  {1, 0, 0, 0, 6},   // ... in evaluation mode
+  {0, 2, 2, 0, 5},   // data gradients: ReLU mask from aux, sums of g and g * aux
+  {0, 2, 0, 0, 5},   // ... mask only
+  {0, 0, 0, 1, 6},   // 3x3 + ReLU of the heads
+  {0, 0, 0, 0, 6},   // plain
+  {1, 1, 0, 0, 5},   // BatchNorm on load, accumulating / residual (second convs member by member)
+  {0, 1, 0, 0, 5},   // accumulating data gradient
+};
+static int strip_s_form(const rua_conv_desc* d) {
+  const int in = (d->in_scale || d->in_fold) ? 1 : 0;
+  if (in && !d->in_relu) return -1;
+  const int ep = d->aux_mode == 2 ? 2 : ((d->aux_mode == 1 || d->accumulate) ? 1 : 0);
+  for (int i = 0; i < (int)(sizeof(kStripS) / sizeof(kStripS[0])); ++i)
+    if (kStripS[i].in == in && kStripS[i].ep == ep && kStripS[i].st == d->stats_mode && kStripS[i].orelu == (d->out_relu ? 1 : 0)) return i;
+  return -1;
+}
 static int launch_strip_variant(int variant, const StripK* ks, const int* smems, int m, hipStream_t st) {
+  if (variant >= 16) {
+    const int form = (variant - 16) >> 1;
+    const bool w4 = (variant & 1) != 0;
+#define RUA_STRIP_S(F_, IN_, EP_, ST_, OR_, R_) case F_: return w4 ? launch_strip_s<4, IN_, EP_, ST_, OR_, R_>(ks, smems, m, st) : launch_strip_s<8, IN_, EP_, ST_, OR_, R_>(ks, smems, m, st)
+    switch (form) {
+      RUA_STRIP_S(0, 1, 0, 1, 0, 6);
+      RUA_STRIP_S(1, 1, 0, 0, 0, 6);
+      RUA_STRIP_S(2, 0, 2, 2, 0, 5);
+      RUA_STRIP_S(3, 0, 2, 0, 0, 5);
+      RUA_STRIP_S(4, 0, 0, 0, 1, 6);
+      RUA_STRIP_S(5, 0, 0, 0, 0, 6);
+      RUA_STRIP_S(6, 1, 1, 0, 0, 5);
+      default: RUA_STRIP_S(7, 0, 1, 0, 0, 5);
+    }
+#undef RUA_STRIP_S
+  }
   switch (variant) {
     case 0: return launch_strip_members<8, true, 5>(ks, smems, m, st);
     case 1: return launch_strip_members<8, false, 7>(ks, smems, m, st);
@@ -463,6 +514,7 @@ int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st
   q.ep = has_ep ? (d->aux_mode != 0 ? (const unsigned char*)d->aux : (const unsigned char*)d->y) : nullptr;
   q.epbytes = (unsigned)((size_t)k.M * 32 * 2);
   q.d = dil;
+  q.dbg = g_tune.band_dbg;
   q.strips = d->W / sw;
   q.SWH = sw + 2 * dil;
   q.slot_bytes = (q.SWH * 64 + 1023) / 1024 * 1024;
@@ -478,10 +530,14 @@ int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st
   if (spc > (ny + 3) / 4) spc = (ny + 3) / 4;          // >= 4 rows per segment (a segment re-reads two window rows)
   if (spc < 1) spc = 1;
   q.seglen = (ny + spc - 1) / spc;
+  if (g_tune.strip_seglen > 0) q.seglen = g_tune.strip_seglen;
   q.spc = (ny + q.seglen - 1) / q.seglen;
   q.njobs = q.nchains * q.spc;
-  const int R = has_ep ? 5 : 7;
-  const int smem = R * q.slot_bytes + (has_ep ? 3 * sw * 64 : 0) + nw * 1024 + 5 * 32 * 4;
+  // full-width strips: conv_strip32s (the two halves of a block half a stage apart, fragments kept in registers)
+  const int sform = (g_tune.strip_stag && q.strips == 1 && (size_t)k.M * 64 < 0x80000000ull) ? strip_s_form(d) : -1;
+  const int R = sform >= 0 ? kStripS[sform].R : (has_ep ? 5 : 7);
+  const int smem = sform >= 0 ? R * (sw + 64) * 64 + (has_ep ? 3 * sw * 64 : 0) + 7 * 32 * 4
+                              : R * q.slot_bytes + (has_ep ? 3 * sw * 64 : 0) + nw * 1024 + 5 * 32 * 4;
   RUA_CHECK_ARG(smem >= nw * (64 * 33 + 64) * 4, "conv_strip: no room for the statistics fold");
   q.has_fold = d->in_fold ? 1 : 0;
   if (d->in_fold) {
@@ -492,7 +548,7 @@ int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st
     RUA_CHECK_ARG(nw * 2 * 2 * 32 * 8 <= R * q.slot_bytes, "conv_strip: no room for the in_fold scratch");
   } else memset(&q.f, 0, sizeof(q.f));
   RUA_CHECK_ARG(smem <= 160 * 1024, "conv_strip: %d bytes of LDS", smem);
-  const int variant = (nw == 8 ? 0 : 2) + (has_ep ? 0 : 1);
+  const int variant = sform >= 0 ? 16 + sform * 2 + (nw == 4 ? 1 : 0) : (nw == 8 ? 0 : 2) + (has_ep ? 0 : 1);
   if (g_conv_group && (g_tune.conv_group & 1)) {        // capture mode: issued by rua_strip_group_flush, grouped with its siblings
     StripCapture& c = g_strip_cap;
     RUA_CHECK_ARG(c.n < RUA_MAX_BRANCH, "conv_strip: group capture overflow");

@@ -1003,10 +1003,10 @@ def test_conv_group_equals_separate_launches(shape):
     for i, d in enumerate(descs):
         C.memmove(C.byref(arr, i * C.sizeof(L.ConvDesc)), C.byref(d), C.sizeof(L.ConvDesc))
     lib.call("rua_conv_fwd_group", arr, len(descs), stream())
-    # 16x16x512: split-K members launch one by one; 128-pixel strips (W = 128): d = 31 needs more LDS than two blocks per CU allow,
-    # so it does not share a grid with d = 1, 3, 15 (which run two per CU); members of unequal job counts are renumbered each over
-    # their own jobs
-    assert lib.raw("rua_conv_group_last_grids")() == (len(dils) if split else 2 if (Cs == 32 and W == 128) else 1)
+    # 16x16x512: split-K members launch one by one; members of unequal job counts are renumbered each over their own jobs.  (128-pixel
+    # strips, W = 128, on conv_strip32: d = 31 needs more LDS than two blocks per CU allow and did not share a grid with d = 1, 3, 15;
+    # conv_strip32s lays its slots out for the largest dilation, so full-width strips of every dilation share ONE grid)
+    assert lib.raw("rua_conv_group_last_grids")() == (len(dils) if split else 1)
     torch.cuda.synchronize()
     assert lib.raw("rua_conv_group_last_chain")() == 0
     band = lib.raw("rua_conv_group_last_band")() == 1          # 128x128x64: the group is ONE conv_band64m launch - another kernel than the

@@ -59,7 +59,7 @@ def main():
                     d.accumulate = 1
                     if strip:
                         d.in_scale, d.in_shift, d.in_relu = sc.data_ptr(), sh.data_ptr(), 1
-                lib.set_tuning(conv_strip=strip, strip_narrow_maxd=int(os.environ.get("B3_NARROW", "0")))
+                lib.set_tuning(conv_strip=strip, strip_narrow_maxd=int(os.environ.get("B3_NARROW", "0")), strip_seglen=int(os.environ.get("B3_SEGLEN", "0")), strip_stag=int(os.environ.get("B3_STAG", "1")), band_dbg=int(os.environ.get("B3_DBG", "0")))
                 kid = lib.raw("rua_conv_kernel_id")(C.byref(d))
                 for _ in range(5):
                     lib.call("rua_conv_fwd", C.byref(d), s)
