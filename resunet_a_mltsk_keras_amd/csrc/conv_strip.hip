@@ -430,14 +430,37 @@ template <int NW, bool HAS_EP, int R> static int launch_strip_members(const Stri
   RUA_LAUNCH_CHECK("conv_strip32");
   return RUA_OK;
 }
-// conv_strip32s: always the grouped kernel (a lone convolution is a group of one)
+// conv_strip32s: ONE grid for all members (a lone convolution is a group of one); the members' row stages form one line of cost units
+// that the blocks - one per CU - cut into equal pieces (conv_strip2.inc)
 template <int NW, int IN, int EP, int ST, int ORELU, int R> static int launch_strip_s(const StripK* ks, const int* smems, int m, hipStream_t st) {
   static thread_local bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32s_g<NW, IN, EP, ST, ORELU, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  StripKG g;
-  int grid = 0, smem = 0;
-  for (int i = 0; i < m; ++i) { g.k[i] = ks[i]; if (ks[i].njobs > grid) grid = ks[i].njobs; if (smems[i] > smem) smem = smems[i]; }
-  hipLaunchKernelGGL((conv_strip32s_g<NW, IN, EP, ST, ORELU, R>), dim3((grid + 7) / 8 * 8, m), dim3(NW * 64), smem, st, g);
+  StripSG g;
+  memset(&g, 0, sizeof(g));
+  int smem = 0;
+  g.nmem = m; g.N = ks[0].c.N; g.H = ks[0].c.H; g.dbg = ks[0].dbg;
+  g.c0 = 3;                                             // a restart: three rows of DMA latency, their BatchNorm, two barriers - about three row stages
+  g.tbytes = (unsigned)((size_t)ks[0].c.M * 64);
+  int units = 0;
+  for (int i = 0; i < m; ++i) {
+    const StripK& k = ks[i];
+    RUA_CHECK_ARG(k.c.N == g.N && k.c.H == g.H && k.c.M == ks[0].c.M, "conv_strip32s: the members of a group differ in shape");
+    StripSM& M = g.m[i];
+    M.x = k.c.seg[0].x; M.w = k.c.seg[0].w; M.y = k.c.y; M.ep = k.ep;
+    M.bias = k.c.bias; for (int r = 0; r < 3; ++r) M.bias_more[r] = k.c.bias_more[r];
+    M.mscale = k.c.mscale; M.mshift = k.c.mshift; M.in_scale = k.c.in_scale; M.in_shift = k.c.in_shift;
+    M.stats = k.c.stats; M.stats_R = k.c.stats_R > 0 ? k.c.stats_R : 1; M.d = k.d; M.has_fold = k.has_fold; M.f = k.f;
+    g.ustart[i] = units;
+    units += g.H + k.d * g.c0;
+    if (smems[i] > smem) smem = smems[i];
+  }
+  g.ustart[m] = units;                                  // the units of one image
+  units *= g.N;
+  int nb = units / (g.c0 + 5);                          // a piece is worth a block's setup from about five row stages on
+  if (nb > rua_cu_count()) nb = rua_cu_count();
+  if (nb < 1) nb = 1;
+  g.nblocks = nb;
+  hipLaunchKernelGGL((conv_strip32s_g<NW, IN, EP, ST, ORELU, R>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), smem, st, g);
   RUA_LAUNCH_CHECK("conv_strip32s");
   return RUA_OK;
 }
@@ -536,7 +559,7 @@ int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st
   // full-width strips: conv_strip32s (the two halves of a block half a stage apart, fragments kept in registers)
   const int sform = (g_tune.strip_stag && q.strips == 1 && (size_t)k.M * 64 < 0x80000000ull) ? strip_s_form(d) : -1;
   const int R = sform >= 0 ? kStripS[sform].R : (has_ep ? 5 : 7);
-  const int smem = sform >= 0 ? R * (sw + 64) * 64 + (has_ep ? 3 * sw * 64 : 0) + 7 * 32 * 4
+  const int smem = sform >= 0 ? R * (sw + 64) * 64 + (has_ep ? 3 * sw * 64 : 0) + RUA_MAX_BRANCH * 7 * 32 * 4
                               : R * q.slot_bytes + (has_ep ? 3 * sw * 64 : 0) + nw * 1024 + 5 * 32 * 4;
   RUA_CHECK_ARG(smem >= nw * (64 * 33 + 64) * 4, "conv_strip: no room for the statistics fold");
   q.has_fold = d->in_fold ? 1 : 0;

@@ -86,7 +86,10 @@ def main():
 
     print(f"{N}x{H}x{W}x{Cc}, dilations {dils}: {flops / 1e9:.1f} GFLOP per stage, {mb:.1f} MB per tensor")
     if only in (None, "first") and Cc == 32:
-        timed("first convs, grouped (conv_strip32_g)", lambda: lib.call("rua_conv_fwd_group", first, nb, s), 2 * nb)
+        for dbg in [int(v) for v in os.environ.get("BB_DBG", "0").split(",")]:
+            lib.set_tuning(band_dbg=dbg)                  # conv_strip32s ablations: 4 no row DMAs in the loop, 8 no stores, 16 no MFMAs
+            timed(f"first convs, grouped (conv_strip32s_g) dbg={dbg}", lambda: lib.call("rua_conv_fwd_group", first, nb, s), 2 * nb)
+        lib.set_tuning(band_dbg=0)
     if only in (None, "sum"):
         lib.set_tuning(conv_band=1)
         for dbg in [int(v) for v in os.environ.get("BB_DBG", "0").split(",")]:
