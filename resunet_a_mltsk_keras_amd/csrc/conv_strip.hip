@@ -432,9 +432,9 @@ template <int NW, bool HAS_EP, int R> static int launch_strip_members(const Stri
 }
 // conv_strip32s: ONE grid for all members (a lone convolution is a group of one); the members' row stages form one line of cost units
 // that the blocks - one per CU - cut into equal pieces (conv_strip2.inc)
-template <int NW, int IN, int EP, int ST, int ORELU, int R> static int launch_strip_s(const StripK* ks, const int* smems, int m, hipStream_t st) {
+template <int NW, int IN, int EP, int ST, int ORELU, int R, int BIAS> static int launch_strip_s(const StripK* ks, const int* smems, int m, hipStream_t st) {
   static thread_local bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32s_g<NW, IN, EP, ST, ORELU, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32s_g<NW, IN, EP, ST, ORELU, R, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   StripSG g;
   memset(&g, 0, sizeof(g));
   int smem = 0;
@@ -460,44 +460,46 @@ template <int NW, int IN, int EP, int ST, int ORELU, int R> static int launch_st
   if (nb > rua_cu_count()) nb = rua_cu_count();
   if (nb < 1) nb = 1;
   g.nblocks = nb;
-  hipLaunchKernelGGL((conv_strip32s_g<NW, IN, EP, ST, ORELU, R>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), smem, st, g);
+  hipLaunchKernelGGL((conv_strip32s_g<NW, IN, EP, ST, ORELU, R, BIAS>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), smem, st, g);
   RUA_LAUNCH_CHECK("conv_strip32s");
   return RUA_OK;
 }
 // the (IN, EP, ST, ORELU) forms the step uses; everything else stays on conv_strip32
-struct StripSForm { int in, ep, st, orelu, R; };
+struct StripSForm { int in, ep, st, orelu, R, bias; };
 static const StripSForm kStripS[] = {
-  {1, 0, 1, 0, 6},   // first convs of a ResBlock: BatchNorm + ReLU on load, statistics of the output
-  {1, 0, 0, 0, 6},   // ... in evaluation mode
-  {0, 2, 2, 0, 5},   // data gradients: ReLU mask from aux, sums of g and g * aux
-  {0, 2, 0, 0, 5},   // ... mask only
-  {0, 0, 0, 1, 6},   // 3x3 + ReLU of the heads
-  {0, 0, 0, 0, 6},   // plain
-  {1, 1, 0, 0, 5},   // BatchNorm on load, accumulating / residual (second convs member by member)
-  {0, 1, 0, 0, 5},   // accumulating data gradient
+  {1, 0, 1, 0, 6, 1},   // first convs of a ResBlock: BatchNorm + ReLU on load, statistics of the output
+  {1, 0, 0, 0, 6, 1},   // ... in evaluation mode
+  {0, 2, 2, 0, 5, 0},   // data gradients (no bias): ReLU mask from aux, sums of g and g * aux
+  {0, 2, 0, 0, 5, 0},   // ... mask only
+  {0, 0, 0, 1, 6, 1},   // 3x3 + ReLU of the heads
+  {0, 0, 0, 0, 6, 1},   // plain
+  {1, 1, 0, 0, 5, 1},   // BatchNorm on load, accumulating / residual (second convs member by member)
+  {0, 1, 0, 0, 5, 0},   // accumulating data gradient
 };
 static int strip_s_form(const rua_conv_desc* d) {
   const int in = (d->in_scale || d->in_fold) ? 1 : 0;
   if (in && !d->in_relu) return -1;
   const int ep = d->aux_mode == 2 ? 2 : ((d->aux_mode == 1 || d->accumulate) ? 1 : 0);
+  const bool has_bias = d->bias || d->bias_more[0] || d->bias_more[1] || d->bias_more[2];
   for (int i = 0; i < (int)(sizeof(kStripS) / sizeof(kStripS[0])); ++i)
-    if (kStripS[i].in == in && kStripS[i].ep == ep && kStripS[i].st == d->stats_mode && kStripS[i].orelu == (d->out_relu ? 1 : 0)) return i;
+    if (kStripS[i].in == in && kStripS[i].ep == ep && kStripS[i].st == d->stats_mode && kStripS[i].orelu == (d->out_relu ? 1 : 0) &&
+        (kStripS[i].bias || !has_bias)) return i;
   return -1;
 }
 static int launch_strip_variant(int variant, const StripK* ks, const int* smems, int m, hipStream_t st) {
   if (variant >= 16) {
     const int form = (variant - 16) >> 1;
     const bool w4 = (variant & 1) != 0;
-#define RUA_STRIP_S(F_, IN_, EP_, ST_, OR_, R_) case F_: return w4 ? launch_strip_s<4, IN_, EP_, ST_, OR_, R_>(ks, smems, m, st) : launch_strip_s<8, IN_, EP_, ST_, OR_, R_>(ks, smems, m, st)
+#define RUA_STRIP_S(F_, IN_, EP_, ST_, OR_, R_, B_) case F_: return w4 ? launch_strip_s<4, IN_, EP_, ST_, OR_, R_, B_>(ks, smems, m, st) : launch_strip_s<8, IN_, EP_, ST_, OR_, R_, B_>(ks, smems, m, st)
     switch (form) {
-      RUA_STRIP_S(0, 1, 0, 1, 0, 6);
-      RUA_STRIP_S(1, 1, 0, 0, 0, 6);
-      RUA_STRIP_S(2, 0, 2, 2, 0, 5);
-      RUA_STRIP_S(3, 0, 2, 0, 0, 5);
-      RUA_STRIP_S(4, 0, 0, 0, 1, 6);
-      RUA_STRIP_S(5, 0, 0, 0, 0, 6);
-      RUA_STRIP_S(6, 1, 1, 0, 0, 5);
-      default: RUA_STRIP_S(7, 0, 1, 0, 0, 5);
+      RUA_STRIP_S(0, 1, 0, 1, 0, 6, 1);
+      RUA_STRIP_S(1, 1, 0, 0, 0, 6, 1);
+      RUA_STRIP_S(2, 0, 2, 2, 0, 5, 0);
+      RUA_STRIP_S(3, 0, 2, 0, 0, 5, 0);
+      RUA_STRIP_S(4, 0, 0, 0, 1, 6, 1);
+      RUA_STRIP_S(5, 0, 0, 0, 0, 6, 1);
+      RUA_STRIP_S(6, 1, 1, 0, 0, 5, 1);
+      default: RUA_STRIP_S(7, 0, 1, 0, 0, 5, 0);
     }
 #undef RUA_STRIP_S
   }

@@ -985,7 +985,8 @@ def test_conv_group_equals_separate_launches(shape):
         s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = x.data_ptr(), w.data_ptr(), Cs, H, W, 0, dil, 9
         d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cs, 1, dt
         d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
-        d.bias = bias.data_ptr()
+        if Cs != 32:                                        # (C = 32: the form the engine issues - a data gradient has no bias - and conv_strip32s serves)
+            d.bias = bias.data_ptr()
         d.aux, d.aux_mode, d.mscale, d.mshift = aux.data_ptr(), 2, sc.data_ptr(), sh.data_ptr()
         d.stats, d.stats_mode, d.stats_replicas = stats.data_ptr(), 2, 32
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -1020,7 +1021,9 @@ def test_conv_group_equals_separate_launches(shape):
         # (outputs bit-identical; the statistics are fp32 per-lane partial sums over a block's rows folded in fp64: the members of a
         # grouped conv_strip launch share one round of blocks - longer chain segments than a launch on its own - so the partial sums
         # are taken over other row sets and differ in their last fp32 bits)
-        assert np.allclose(keep[4 * i + 3].cpu().numpy().reshape(32, -1).sum(0), sep[i][1].cpu().numpy().reshape(32, -1).sum(0), rtol=2e-6)
+        # conv_strip32s: a block's piece of the group's rows is four times a lone launch's: bound = 2e-7 of the sum of the terms' magnitudes
+        assert np.allclose(keep[4 * i + 3].cpu().numpy().reshape(32, -1).sum(0), sep[i][1].cpu().numpy().reshape(32, -1).sum(0), rtol=2e-6,
+                           atol=2e-7 * N * H * W)
     if Cs >= 128 and not split:
         # tuning key dmap_chain (off by default: measured no gain): conv_dmap members with the same tiles walk back to back through ONE
         # grid, a block running every member over its pixel tile with the DMA ring kept alive across the epilogues - bit-identical

@@ -48,7 +48,8 @@ def main():
                 d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cc, 1, L.RUA_BF16
                 d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
                 d.stats, d.stats_replicas = stats.data_ptr(), 32        # what the engine passes for 4096 row tiles
-                d.bias = bias.data_ptr()
+                if mode != "dgrad_mask_stats2":                  # (a data gradient has no bias)
+                    d.bias = bias.data_ptr()
                 if mode in ("fwd_bn_stats", "fwd_bn"):
                     d.stats_mode = 1 if mode == "fwd_bn_stats" else 0
                     if strip:
