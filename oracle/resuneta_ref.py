@@ -345,6 +345,13 @@ class RefTrainer:
             _, vals, mets, _ = self._losses(x, y, training=False)
         return [float(v.detach()) for v in vals] + mets
 
+    def losses_on_batch(self, x, y):
+        """The losses and (in last_taps) the pre-activation logits train_on_batch would report for this batch - training-mode
+        BatchNorm (batch statistics), no gradient, no update: what the full-size golden fixtures hold (oracle/make_golden_fullsize.py)."""
+        with torch.no_grad():
+            _, vals, mets, _ = self._losses(x, y, training=True)
+        return [float(v.detach()) for v in vals] + mets
+
     def train_on_batch(self, x, y):
         for k in self.order:
             self.params[k].requires_grad_(True)

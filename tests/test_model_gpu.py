@@ -200,6 +200,25 @@ def oracle_step(name, shape, C, mt, loss, B, seed, cw=None, depth=6):
     return _ORACLE_CACHE[name]
 
 
+def golden_step(name):
+    """The same step from the committed fixture tests/golden/fullsize_<name>.npz (oracle/make_golden_fullsize.py: one training-mode
+    forward of the CPU oracle at the configuration's own size and batch; the CPU suite re-derives fixtures live,
+    tests/test_oracle_kat.py::test_fullsize_goldens_match_the_live_oracle): losses, and per head a strided sample of the logits with
+    their scale and two checksums.  Weights and batch are regenerated from their seeds (cheap); the oracle itself - 20-60 s per
+    configuration with its backward pass on the GPU box's host cores, 150 s of the round-3 GPU suite - does not run."""
+    import os
+    from oracle import make_golden_fullsize as mg
+    if ("g", name) not in _ORACLE_CACHE:
+        shape, C, mt, loss, B, seed, cw, depth = mg.CONFIGS[name]
+        rcfg = ref.RefConfig(input_shape=shape, num_classes=C, multitasking=mt, depth=depth)
+        params, _ = ref.init_params(rcfg, mg.PARAM_SEED)
+        x, y = make_batch(B, shape[0], shape[2], C, mt, seed=seed)
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_%s.npz" % name))
+        _ORACLE_CACHE[("g", name)] = dict(params={k: v.numpy().copy() for k, v in params.items()}, x=x, y=y, exp=list(z["losses"]),
+                                          digest={k: z[k] for k in z.files}, cfg=mg.CONFIGS[name])
+    return _ORACLE_CACHE[("g", name)]
+
+
 def hip_engine(shape, C, mt, loss, dtype, weights, cw=None, depth=6):
     eng = Engine(ModelConfig(input_shape=shape, num_classes=C, multitasking=mt, depth=depth), dtype=dtype, seed=0, split_k=True)
     heads = ref.HEADS if mt else ["seg"]
@@ -221,7 +240,16 @@ def compare_full_size(o, eng, mt, tol_loss, tol_logit):
         worst["loss%d" % i] = abs(got[i] - exp[i]) / max(1.0, abs(exp[i]))
         assert worst["loss%d" % i] <= tol_loss, (i, got[i], exp[i])
     for h, z in eng.logits(True, o["x"].shape[0]).items():
-        worst[h] = rel(z, o["taps"][(h + "_logits") if mt else "logits"])
+        key = (h + "_logits") if mt else "logits"
+        if "taps" in o:
+            worst[h] = rel(z, o["taps"][key])
+        else:                                                # fixture: the strided sample against the logits' scale, and the sum as a checksum of the rest
+            dg = o["digest"]
+            flat = np.ascontiguousarray(z, np.float32).ravel()
+            assert flat.size == int(dg[key + "_n"]), (h, flat.size)
+            worst[h] = float(np.abs(flat[::int(dg[key + "_stride"])] - dg[key + "_sample"]).max() / float(dg[key + "_maxabs"]))
+            csum = abs(float(flat.astype(np.float64).sum()) - float(dg[key + "_sum"])) / float(dg[key + "_sumabs"])
+            assert csum < tol_logit * 0.1, (h, "checksum", csum)
         assert worst[h] < tol_logit, (h, worst[h])
     print("full-size parity (%s):" % eng.dtype, {k: float("%.3g" % v) for k, v in worst.items()})
     return got
@@ -245,7 +273,7 @@ def test_cfg3_full_size_bf16_bound_and_trajectory():
     2e-3, per-head logits within 5e-2 of their scale (measured: 2.4e-5 and 2.8e-2).  (b) batch 8 (the bench's), ten Adam steps from the same weights,
     bf16 against fp32 storage on the HIP path: the loss trajectories stay within 2e-3 of each other at every step
     (measured: 1.3e-4) and both fall."""
-    o = oracle_step(*CFG3)
+    o = golden_step("cfg3")
     eng = hip_engine((256, 256, 6), 6, True, "tanimoto", "bf16", o["params"])
     compare_full_size(o, eng, True, 2e-3, 5e-2)
     x, y = make_batch(8, 256, 6, 6, True, seed=1234)
@@ -266,7 +294,7 @@ def test_cfg2_full_size_single_task_fp32_and_bf16():
     """BASELINE config 2: ResUnet-a d6 single-task segmentation head (model2.py:144-147), 256x256x6, 6 classes: loss and
     logits within 1e-3 of the oracle in fp32 storage, within the bf16 bounds of the cfg3 test in bf16 (the configuration's
     own dtype)."""
-    o = oracle_step("cfg2", (256, 256, 6), 6, False, "tanimoto", 2, 4321)
+    o = golden_step("cfg2")
     eng = hip_engine((256, 256, 6), 6, False, "tanimoto", "f32", o["params"])
     compare_full_size(o, eng, False, 1e-3, 1e-3)
     assert eng.count_params() == 42690134
@@ -278,7 +306,7 @@ def test_cfg1_hip_fp32_vs_the_cpu_baseline_step():
     """BASELINE config 1 (256x256x3, 6 classes, single task, bs 4, weighted CE with unit weights, Adam 1e-3) - the very
     step bench.py's cpu_baseline leg times on the host cores ("parity check on the same run") - on the HIP fp32
     path: loss and logits within 1e-3, and the metrics the reference prints (train_ISPRS.py:458-461)."""
-    o = oracle_step("cfg1", (256, 256, 3), 6, False, "weighted_cross_entropy", 4, 1234, cw=[1.0] * 6)
+    o = golden_step("cfg1")
     eng = hip_engine((256, 256, 3), 6, False, "weighted_cross_entropy", "f32", o["params"], cw=[1.0] * 6)
     got = compare_full_size(o, eng, False, 1e-3, 1e-3)
     exp = o["exp"]
@@ -426,7 +454,7 @@ def test_cfg5_own_form_bf16_batch32():
     128x128x7 patches, 2 classes, bf16 storage, batch 32 - 128-pixel strips, the 3-branch PSPPooling (model2.py:49-52) and the 4x4
     bottleneck, none of which cfg3 reaches.  Loss and logits against the CPU oracle on the same step, same bounds as cfg3's bf16
     test (loss 2e-3, logits 5e-2 of their scale)."""
-    o = oracle_step("cfg5", (128, 128, 7), 2, False, "tanimoto", 32, 555)
+    o = golden_step("cfg5")
     eng = hip_engine((128, 128, 7), 2, False, "tanimoto", "bf16", o["params"])
     compare_full_size(o, eng, False, 2e-3, 5e-2)
     assert eng.count_params() == 42163914
@@ -435,12 +463,12 @@ def test_cfg5_own_form_bf16_batch32():
     compare_full_size(o, hip_engine((128, 128, 7), 2, False, "tanimoto", "f32", o["params"]), False, 1e-3, 1e-3)
 
 
-def test_cfg4_d7_512_bf16_batch2():
-    """BASELINE config 4 (the d7 extrapolation, SURVEY A15: not in the reference, restatement-vs-kernel) in its own storage type:
-    512x512x6, multitask, bf16.  Batch 2 of the configuration's 4: the float32 oracle step holds ~12 GB of autograd state at batch 2
-    (measured here) and the GPU box's host memory is not ours to fill; the kernels' grids scale with the batch, their tiling does not
-    change between 2 and 4.  Same bf16 bounds as cfg3 (loss 2e-3, logits 5e-2)."""
-    o = oracle_step("cfg4", (512, 512, 6), 6, True, "tanimoto", 2, 777, depth=7)
+def test_cfg4_d7_512_bf16_and_fp32_at_its_own_batch4():
+    """BASELINE config 4 (the d7 extrapolation, SURVEY A15: not in the reference, restatement-vs-kernel) in its own storage type and at
+    its OWN batch: 512x512x6, multitask, bf16, batch 4 per GPU.  (Round 3 ran batch 2: the float32 oracle step held ~12 GB of autograd
+    state there.  Loss and logits need no autograd: the fixture is a training-mode forward of the oracle under torch.no_grad at batch 4,
+    oracle/make_golden_fullsize.py.)  Same bf16 bounds as cfg3 (loss 2e-3, logits 5e-2), fp32 storage within 1e-3."""
+    o = golden_step("cfg4")
     eng = hip_engine((512, 512, 6), 6, True, "tanimoto", "bf16", o["params"], depth=7)
     compare_full_size(o, eng, True, 2e-3, 5e-2)
     assert eng.count_params() > 150e6
@@ -481,8 +509,40 @@ def test_cfg3_full_size_gradients_fp32_vs_float64_oracle_and_bf16_at_batch8():
     cos = np.array([float((gb[k].ravel() @ gf[k].ravel()) / (np.linalg.norm(gb[k]) * np.linalg.norm(gf[k]) + 1e-30)) for k in keys])
     print("cfg3 B=8 bf16 vs fp32 gradient: distance median %.3f / p90 %.3f / max %.3f of the tensor's scale; cosine median %.4f / min %.4f"
           % (np.median(dist), np.quantile(dist, 0.9), dist.max(), np.median(cos), cos.min()))
+    for i in np.argsort(-dist)[:6]:
+        print("   farthest: %-28s distance %.3f cosine %.4f |g| max %.3g (largest of the model %.3g)" % (keys[i], dist[i], cos[i], np.abs(gf[keys[i]]).max(), gmax))
+    for i in np.argsort(cos)[:6]:
+        print("   least aligned: %-28s cosine %.4f distance %.3f |g| max %.3g" % (keys[i], cos[i], dist[i], np.abs(gf[keys[i]]).max()))
     assert all(np.isfinite(gb[k]).all() for k in gb)
-    assert np.median(dist) < BF16_GRAD_MEDIAN_B8 and dist.max() < BF16_GRAD_MAX_B8 and np.median(cos) > BF16_GRAD_COS_B8
+    assert np.median(dist) < BF16_GRAD_MEDIAN_B8 and dist.max() < BF16_GRAD_MAX_B8 and np.median(cos) > BF16_GRAD_COS_B8 and cos.min() > BF16_GRAD_COSMIN_B8
 
 
+BF16_GRAD_COSMIN_B8 = 0.81                                                      # 1 - cosine within twice the measured 0.094 of the least aligned tensor
 BF16_GRAD_MEDIAN_B8, BF16_GRAD_MAX_B8, BF16_GRAD_COS_B8 = 0.10, 0.6, 0.95     # measured: median 0.053 / p90 0.198 / max 0.321 of a tensor's scale, cosine median 0.976 / min 0.906 (batch 1: median 0.17)
+
+
+def test_cfg3_bf16_training_tracks_fp32_over_200_steps_on_varying_batches():
+    """Training quality of the BENCHMARKED storage type: 200 Adam steps of cfg3 (256x256x6 multitask, Tanimoto-dual on
+    all heads, batch 8, lr 1e-3) over eight DIFFERENT synthetic batches in rotation, bf16 storage against fp32 storage on the HIP path from
+    the same initial weights.  Both runs must fall, and the bf16 run must end where the fp32 run ends: the mean total loss of the last 20
+    steps within BF16_TRAIN_GAP (relative; twice the measured gap), no step of the bf16 run further than BF16_TRAIN_STEP_GAP from the
+    fp32 run's step (the two runs see the same batches in the same order, so their losses are comparable step by step)."""
+    batches = [make_batch(8, 256, 6, 6, True, seed=9000 + i) for i in range(8)]
+    o = golden_step("cfg3")
+    traj = {}
+    for dtype in ("f32", "bf16"):
+        e = hip_engine((256, 256, 6), 6, True, "tanimoto", dtype, o["params"])
+        traj[dtype] = np.array([e.train_step(*batches[i % len(batches)])[:5] for i in range(200)])
+        del e
+        torch.cuda.empty_cache()
+    a, b = traj["f32"][:, 0], traj["bf16"][:, 0]
+    gap_end = abs(b[-20:].mean() - a[-20:].mean()) / a[-20:].mean()
+    gap_step = float(np.max(np.abs(b - a) / a))
+    print("cfg3 B=8, 200 steps on 8 rotating batches: total loss f32 %.4f -> %.4f, bf16 %.4f -> %.4f; mean of the last 20 steps: f32 %.4f bf16 %.4f "
+          "(relative gap %.2e); largest per-step gap %.2e" % (a[0], a[-1], b[0], b[-1], a[-20:].mean(), b[-20:].mean(), gap_end, gap_step))
+    assert np.all(np.isfinite(traj["bf16"])) and np.all(np.isfinite(traj["f32"]))
+    assert a[-20:].mean() < 0.8 * a[:8].mean() and b[-20:].mean() < 0.8 * b[:8].mean()       # both fall (measured: to about half)
+    assert gap_end < BF16_TRAIN_GAP and gap_step < BF16_TRAIN_STEP_GAP, (gap_end, gap_step)
+
+
+BF16_TRAIN_GAP, BF16_TRAIN_STEP_GAP = 0.10, 0.21     # measured (round 4): 4.6e-2 at the end (f32 1.1505, bf16 1.2035 over the last 20 steps), 1.05e-1 at the worst step; both runs fall 1.903 -> ~1.15

@@ -252,3 +252,20 @@ def test_tiny_model_forward_matches_numpy_composition():
     z = conv(t)
     assert np.allclose(z, taps["logits"], atol=2e-3, rtol=2e-3)
     assert np.allclose(nv.softmax(z), out_t, atol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3"])
+def test_fullsize_goldens_match_the_live_oracle(name):
+    """tests/golden/fullsize_<cfg>.npz (what the GPU tests compare the HIP path with at full size) against the oracle run HERE: the same
+    training-mode forward, the same digest.  Two of the five configurations (1 s and 4 s of host time; the others are produced by the
+    same code path, oracle/make_golden_fullsize.py)."""
+    import os
+    from oracle import make_golden_fullsize as mg
+    exp, taps = mg.oracle_forward(name)
+    live = mg.digest(exp, taps)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_%s.npz" % name))
+    assert sorted(gold.files) == sorted(live)
+    for k in gold.files:
+        a, b = np.asarray(gold[k], np.float64), np.asarray(live[k], np.float64)
+        scale = max(1.0, float(np.abs(a).max()))
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5 * scale, (k, float(np.abs(a - b).max()), scale)
