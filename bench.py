@@ -541,7 +541,10 @@ def main():
 
     # SURVEY 8d protocol: 10 warm-up steps, then 3 timed blocks of >= 50 steps, each bracketed by barrier + device
     # synchronise on both sides and taken as the MAX over ranks; the MEDIAN block is the reported one.
+    if eng.dist is not None:
+        eng.dist.reducer.measure = True                         # event pairs around the wait for the buckets (dp.allreduce_exposed_ms)
     block_dt = []
+    own_dt = []                                                 # this rank's own block times (dp.ms_per_step_per_rank)
     host_issue = 0.0                                            # host time spent INSIDE train_step (issue only: nothing in it waits for the GPU)
     for _ in range(max(args.blocks, 1)):
         fence()
@@ -551,6 +554,7 @@ def main():
         host_issue += time.perf_counter() - t0
         fence()
         dt = time.perf_counter() - t0
+        own_dt.append(dt)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -580,6 +584,13 @@ def main():
         "step_path": ("hip-graph (whole step)" if (eng.use_graph and eng.dist is None) else
                       ("hip-graph pieces + eager collectives" if (eng.use_graph and eng.dp_graph) else "eager launches + bucketed all-reduce overlapped with backward")),
     }
+    if eng.dist is not None:
+        # data-parallel diagnostics, so that the first multi-GPU record explains itself: ranks counted BY the communicator, bucket
+        # sizes, the all-reduce time the backward did not hide (events around the launch stream's wait), every rank's own step time
+        from resunet_a_mltsk_keras_amd.dist import dp_report
+        torch.cuda.synchronize()
+        eng.dist.reducer.measure = False
+        out["dp"] = dp_report(eng.dist, 1e3 * sorted(own_dt)[len(own_dt) // 2] / args.steps, torch.device("cuda", torch.cuda.current_device()))
     # every rank runs the instrumented pass (its keep-busy steps contain the gradient all-reduces); rank 0 reports
     prof = profile_kernels(eng, eng.graph(B, True), args.dtype)
     if rank == 0:

@@ -364,16 +364,10 @@ int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float l
 int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, const float* lr_dev, float momentum, float grad_scale,
                  int zero_grad, void* stream);
 
-/* ---- data parallel: gradient all-reduce over RCCL / xGMI (train_ISPRS.py:347,432: the implicit NCCL all-reduce of
- * tf.distribute.MirroredStrategy).  One process per GPU.  rua_comm_unique_id() on rank 0 -> ship the 128 bytes to the
- * other ranks by any host channel -> rua_comm_init() on every rank (collective) -> rua_allreduce_bucket() per contiguous
- * slice of the flat fp32 gradient buffer, in place, sum, asynchronous on `stream` (issue it on a side stream as soon as
- * the backward has produced the slice; it may be captured into a HIP graph) -> rua_comm_destroy().  RCCL is bound with
- * dlopen at first use: hosts that never call these need no RCCL. */
-int rua_comm_unique_id(void* id128);
-int rua_comm_init(void** comm, int world, int rank, const void* id128);
-int rua_comm_destroy(void* comm);
-int rua_allreduce_bucket(void* comm, float* grads, int64_t count, void* stream);
+/* ---- data parallel (train_ISPRS.py:347,432: the implicit NCCL all-reduce of tf.distribute.MirroredStrategy).  The library exports
+ * no collective: gradients live in ONE flat fp32 buffer in parameter order, so the all-reduce is ncclAllReduce (RCCL) on contiguous
+ * slices of it, issued by the host as the backward completes them (the Python engine: torch.distributed, dist.py; a C embedder:
+ * INTEGRATION.md section 2).  rua_adam_step / rua_sgd_step take grad_scale = 1 / replicas. */
 
 /* ---- tuning switches (experiments, A/B runs).  The launchers never read the environment and keep no other global
  * state: a heuristic changes only through this call.  Keys: rua_tuning_key(0..) until NULL.  Grid-size keys

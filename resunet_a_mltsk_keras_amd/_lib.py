@@ -146,10 +146,6 @@ _SIGS = {
     "rua_lr_step": ([vp, vp, i32, f64, f64, vp], i32),
     "rua_adam_step": ([vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, i32, vp], i32),
     "rua_sgd_step": ([vp, vp, vp, i64, f32, vp, f32, f32, i32, vp], i32),
-    "rua_comm_unique_id": ([vp], i32),
-    "rua_comm_init": ([C.POINTER(vp), i32, i32, vp], i32),
-    "rua_comm_destroy": ([vp], i32),
-    "rua_allreduce_bucket": ([vp, vp, i64, vp], i32),
     "rua_set_tuning": ([C.c_char_p, i64], i32),
     "rua_get_tuning": ([C.c_char_p, C.POINTER(i64)], i32),
     "rua_tuning_key": ([i32], C.c_char_p),

@@ -98,12 +98,17 @@ struct RuaTuning {
   int conv_band64 = 1;                  // ... and of a C = 64 ResBlock (conv_band64)
   int conv_band = 1;                    // rua_conv_fwd_sum: the branches' second convs of a C = 32 ResBlock as ONE launch with the sum kept on chip (conv_band32)
   int wgd_ks_slow = 1;                  // wgrad_dmap block order: K slice slowest (blocks that read the same pixels share an XCD's L2)
+  int cu_reserve = 0;                   // CUs the one-round grids leave free (rua_cu_count() = CUs - cu_reserve): room for RCCL's kernels under data parallel
   int strip_seglen = 0;                 // experiments (tools/bench_conv3x3.py): rows per block of conv_strip, 0 = one round of blocks
   int strip_stag = 1;                   // conv_strip32s: full-width strips with the two halves of a block half a stage apart (0: conv_strip32 everywhere)
   int wgrad_group = 7;                  // 1 wgrad_kernel, 2 wgrad_taps<32>, 4 wgrad_taps<64>, 8 wgrad_dmap (off: three members at once thrash the L2, 27.6 vs 24.6 us each)
 };
 extern RuaTuning g_tune;
 int rua_cu_count();          // compute units of the current device (queried once per device, cached)
+int rua_device_index();      // the calling thread's current HIP device
+// "done once" flags of the launchers (hipFuncSetAttribute is per device): one flag per device, not per process - a process that drives
+// several devices (not this package's model: one process per GPU) would otherwise configure a kernel on the first device only
+struct RuaPerDevFlag { bool f[64] = {}; bool& get() { return f[rua_device_index() & 63]; } };
 
 // Sum of the R replicas of stats[.][2][C] for channel c: the R loads are issued together (independent
 // addresses, unrolled) instead of a dependent chain, so a finalize launch costs one memory round trip.

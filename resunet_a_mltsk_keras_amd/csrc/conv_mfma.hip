@@ -1322,7 +1322,8 @@ void conv_halo(const HaloK q) {
 template <typename T, int BM, int BN> static constexpr int conv_smem() { return conv_smem_base<T, BM, BN>() + RUA_MAX_UNITS * 16; }
 
 template <typename T, int BM, int BN> static int launch_conv(const ConvK& k, int nbm, hipStream_t st) {
-  static bool attr_set = false;
+  static RuaPerDevFlag attr_set_;
+  bool& attr_set = attr_set_.get();
   constexpr int smem = conv_smem<T, BM, BN>();
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1396,7 +1397,8 @@ extern "C" int rua_conv_smem_bytes(const rua_conv_desc* d) {
 }
 
 template <int BM, int BN> static int launch_conv_dma(const ConvK& k, int nbm, hipStream_t st) {
-  static bool attr_set = false;
+  static RuaPerDevFlag attr_set_;
+  bool& attr_set = attr_set_.get();
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               conv_dma_base<BM, BN>());
@@ -1413,7 +1415,8 @@ template <int BM, int BN> static int launch_conv_dma(const ConvK& k, int nbm, hi
 }
 
 template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, hipStream_t st) {
-  static bool attr_set = false;
+  static RuaPerDevFlag attr_set_;
+  bool& attr_set = attr_set_.get();
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dmap<BM, BN, ROWB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               conv_dmap_smem<BM, BN>());
@@ -1752,7 +1755,8 @@ static int launch_conv_halo(const ConvK& k, int dil, hipStream_t st) {
   const int area = epi_bytes > halo_bytes ? epi_bytes : halo_bytes;
   const int smem = area + (Cc == 64 ? 9 * 32 * 128 : 0) + q.rows * 4 + 4 * 12 * 4 + 4 * 4 * 16 * 4;
   const int blocks = (int)((total + q.NS - 1) / q.NS);
-  static bool attr2 = false, attr3 = false, attr642 = false, attr643 = false;
+  static RuaPerDevFlag attr2_, attr3_, attr642_, attr643_;
+  bool &attr2 = attr2_.get(), &attr3 = attr3_.get(), &attr642 = attr642_.get(), &attr643 = attr643_.get();
   if (Cc == 64) {
     if (q.rows <= 256) {
       if (!attr642) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr642 = true; }
@@ -3138,7 +3142,8 @@ static int launch_wgrad_pw(const rua_wgrad_desc* d, hipStream_t st) {
   }
   const unsigned grid = (unsigned)((k.M + ppw * 16 - 1) / (ppw * 16));
   constexpr int s11 = wgrad_pw_smem<1, 1>(), s21 = wgrad_pw_smem<2, 1>(), s12 = wgrad_pw_smem<1, 2>(), s22 = wgrad_pw_smem<2, 2>();
-  static bool attr = false;
+  static RuaPerDevFlag attr_;
+  bool& attr = attr_.get();
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pw<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, s21);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pw<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, s12);
@@ -3200,7 +3205,8 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
     c.post[i] = (k.slabs && !d->defer) ? 2 : 0; c.part[i] = k.slabs; c.dw[i] = d->dw; c.ndw[i] = ndw; c.parts[i] = k.ksplit; c.CC[i] = 0; c.rblocks[i] = 0;
     return RUA_OK;
   }
-  static bool attr = false;
+  static RuaPerDevFlag attr_;
+  bool& attr = attr_.get();
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
   hipLaunchKernelGGL(wgrad_dmap, dim3((unsigned)(tiles * k.ksplit)), dim3(256), 96 * 1024, st, k);
   RUA_LAUNCH_CHECK("wgrad_dmap");

@@ -416,7 +416,8 @@ struct StripCapture { int n; int variant[RUA_MAX_BRANCH]; int smem[RUA_MAX_BRANC
 static thread_local StripCapture g_strip_cap = {0, {0}, {0}, {}};
 
 template <int NW, bool HAS_EP, int R> static int launch_strip_members(const StripK* ks, const int* smems, int m, hipStream_t st) {
-  static bool attr = false, attr_g = false;
+  static RuaPerDevFlag attr_, attr_g_;
+  bool &attr = attr_.get(), &attr_g = attr_g_.get();
   if (m == 1) {
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32<NW, HAS_EP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL((conv_strip32<NW, HAS_EP, R>), dim3(ks[0].njobs), dim3(NW * 64), smems[0], st, ks[0]);

@@ -51,6 +51,17 @@ class GradReducer:
         self.side = torch.cuda.Stream(device=flat.device) if (self.cuda and use_side_stream and not host_staged) else None
         self.works: List = []
         self.fired = [False] * len(buckets)
+        self.measure = False                     # bench.py: bracket the wait for the collectives with events on the launch stream
+        self._exposed: List[Tuple[object, object]] = []
+
+    def exposed_ms(self) -> Optional[float]:
+        """Mean time per step the LAUNCH stream stood waiting for gradient all-reduces (what the backward did not hide), from the
+        event pairs recorded while `measure` was set; None if nothing was measured.  Call after a device synchronise."""
+        if not self._exposed:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return float(sum(ms) / len(ms))
 
     def begin(self):
         self.works = []
@@ -81,10 +92,17 @@ class GradReducer:
         """Every bucket reduced and visible to the current stream."""
         for i in range(len(self.buckets)):
             self.ready(i)
+        ev = None
+        if self.measure and self.cuda and not self.host_staged:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(self.flat.device))
         for w in self.works:
             w.wait()
         if self.side is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(self.flat.device))
+            self._exposed.append(ev)
         self.works = []
 
 
@@ -110,6 +128,13 @@ class DataParallel:
         self.reducer = GradReducer(eng.G[:eng.params.n], self.buckets, group, use_side_stream=overlap and side, host_staged=self.host_staged)
         self._bcast(eng.P); self._bcast(eng.S)
         eng.weights_dirty = True
+        # Room for RCCL's kernels: several launchers size their grid at exactly one block per CU; with a bucket's all-reduce in flight
+        # its workgroups hold some CUs and the last blocks of such a grid would wait for a second round.  Measured COST on one GPU
+        # (nothing to make room for there): 8 CUs +0.3 %, 16 +1.2 %, 32 +2.0 % of the step; the benefit needs N > 1 to show.
+        self.cu_reserve = int(os.environ.get("RUA_DP_CU_RESERVE", "8")) if (self.world > 1 and eng.P.is_cuda) else 0
+        if eng.P.is_cuda:
+            from . import _lib as L
+            L.lib().set_tuning(cu_reserve=self.cu_reserve)
 
     def _bcast(self, t):
         if self.host_staged:
@@ -176,3 +201,38 @@ class DataParallel:
         else:
             dist.all_reduce(S, group=self.group)
             S.div_(self.world)
+
+
+def comm_ranks(group=None, device=None) -> int:
+    """How many ranks really take part in the group's collectives - counted BY a collective (a sum of ones), not read from the
+    environment: the first line a multi-GPU bench record should be able to show."""
+    t = torch.ones(1, dtype=torch.float32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, group=group)
+    return int(round(float(t.item())))
+
+
+def gather_floats(v: float, group=None, device=None) -> List[float]:
+    """v of every rank, in rank order (all_gather)."""
+    world = dist.get_world_size(group)
+    t = torch.tensor([float(v)], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return [float(o.item()) for o in out]
+
+
+def dp_report(dp: "DataParallel", ms_per_step: float, device=None) -> dict:
+    """The data-parallel block of bench.py's JSON line (collective: every rank calls it): ranks counted by the communicator,
+    bucket sizes, the exposed all-reduce time, the ranks' own step times."""
+    per_rank = gather_floats(ms_per_step, dp.group, device)
+    exposed = dp.reducer.exposed_ms()
+    exp_all = gather_floats(-1.0 if exposed is None else exposed, dp.group, device)
+    return {
+        "rccl_ranks": comm_ranks(dp.group, device),
+        "backend": dist.get_backend(dp.group),
+        "bucket_mb": [round((b - a) * 4 / 2**20, 2) for a, b in dp.buckets],
+        "allreduce_exposed_ms": None if exposed is None else round(max(exp_all), 3),
+        "allreduce_exposed_ms_per_rank": None if exposed is None else [round(v, 3) for v in exp_all],
+        "ms_per_step_min": round(min(per_rank), 3), "ms_per_step_max": round(max(per_rank), 3),
+        "ms_per_step_per_rank": [round(v, 3) for v in per_rank],
+        "cu_reserve": dp.cu_reserve, "overlap": bool(dp.overlap),
+    }

@@ -81,38 +81,6 @@ def test_standalone_tanimoto_loss_matches_reference_definition():
     assert np.allclose(Tanimoto_dual_loss()(y, p), dual, rtol=1e-5, atol=1e-6)
 
 
-def test_c_abi_allreduce_bucket_one_rank_and_graph_capture():
-    """rua_comm_* / rua_allreduce_bucket: a C embedder's whole data-parallel surface.  One rank on the test box:
-    the sum over one replica is the identity, issued eagerly and from inside a captured HIP graph (how a whole-step graph
-    would carry it)."""
-    import ctypes
-    from resunet_a_mltsk_keras_amd import _lib as L
-    lib = L.lib()
-    uid = ctypes.create_string_buffer(128)
-    lib.call("rua_comm_unique_id", uid)
-    comm = ctypes.c_void_p()
-    lib.call("rua_comm_init", ctypes.byref(comm), 1, 0, uid)
-    try:
-        g = torch.randn(1 << 20, device="cuda")
-        ref = g.clone()
-        st = torch.cuda.Stream()
-        st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st):
-            lib.call("rua_allreduce_bucket", comm, g.data_ptr(), g.numel(), ctypes.c_void_p(st.cuda_stream))
-        st.synchronize()
-        assert torch.equal(g, ref)
-        cap = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cap):
-            s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            g.mul_(2.0)
-            lib.call("rua_allreduce_bucket", comm, g.data_ptr(), g.numel(), s)
-        cap.replay(); cap.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(g, ref * 4.0)
-    finally:
-        lib.call("rua_comm_destroy", comm)
-
-
 class Args:
     multitasking = True
     gpu_parallel = False
