@@ -2758,6 +2758,214 @@ template <int CC> __global__ __launch_bounds__(768) void wgrad_taps_kernel_g(con
   wgrad_taps_body<CC>(p);
 }
 
+// wgrad_rows32<NPG, BN> (round 4): the all-taps weight gradient at C = Cout = 32 for rows that are exactly 64 * NPG pixels wide (the
+// d6 residual atrous block at 256 x 256: NPG = 4; 128 x 128: NPG = 2), rebuilt like conv_strip32s around what the round-3 census of
+// wgrad_taps_kernel<32> showed - 190 - 300 instructions per wave and 64-pixel stage around its 12 MFMAs, three waves per SIMD:
+//   * the block works on WHOLE rows: its NPG pixel groups (3 waves each: kernel rows) share one ring of full-width input rows
+//     instead of walking NPG chains with private rings - a halo row is loaded once, not per 64-pixel strip with 2 d halo pixels;
+//   * rows enter LDS by LDS-DMA (no registers: wgrad_taps_kernel staged every row through VGPRs and C++ LDS stores), waited for
+//     with counted vmcnt; the BatchNorm + ReLU of the conv input is applied in place ONE row ahead of its first use, each wave on
+//     its own DMA pieces, coefficients read with the pieces, a row outside the image normalised with zeros (no branch);
+//   * ONE barrier per stage (wgrad_taps_kernel: two); the slot layout [row | 32 zero pixels] makes the zero padding of a row's
+//     left edge the pad of the slot before it: 18 KB per slot, six slots + three dy slots in 160 KB;
+//   * fragments by raw ds_read_b64_tr_b16 (hipcc drains the DMA ring in front of the builtin), the reads of k-step k + 1 issued
+//     under the MFMAs of k-step k.
+// Same jobs (chain segments, several per block), same block partial and deterministic reduction as wgrad_taps_kernel.
+// vmcnt: every wave issues exactly KDMA vector-memory operations per stage (row pieces, dy pieces, dummy stores).
+template <int NPG, bool BN>
+__device__ __forceinline__ void wgrad_rows32_body(const WgtK& p) {
+  constexpr int C = 32, NW = 3 * NPG, NT = NW * 64, SW = 64 * NPG, PADPX = 32;
+  constexpr int SLOT = (SW + PADPX) * 64, DSLOT = SW * 64, R = 6, RD = 3;
+  constexpr int NPS = SW / 16;                          // 1-KiB DMA pieces per row
+  constexpr int KDMA = (2 * NPS + NW - 1) / NW;         // operations per wave and stage
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sX = smem + PADPX * 64;                // slot 0 (the 2 KiB in front of it: the zero pad of row pixels < 0)
+  unsigned char* sDy = sX + R * SLOT;
+  float* tab = reinterpret_cast<float*>(sDy + RD * DSLOT);            // [32] scale, [32] shift, [64] zeros
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pgx = wv / 3, ty = wv - 3 * pgx;
+  const int H = p.H, d = p.dil;
+  const unsigned rowbytes = (unsigned)(SW * C * 2);
+
+  if (tid < 32) {
+    tab[tid] = BN ? p.in_scale[tid] : 1.f; tab[32 + tid] = (BN && p.in_shift) ? p.in_shift[tid] : 0.f;
+    tab[64 + tid] = 0.f; tab[96 + tid] = 0.f;
+  }
+  // zero pads: the front pad and the 32 pixels behind every row slot (never written again: the row DMAs cover the SW row pixels only)
+  for (int i = tid; i < (R + 1) * (PADPX * 64 / 16); i += NT) {
+    const int sl = i / (PADPX * 4), k = i - sl * (PADPX * 4);
+    unsigned char* z = (sl == 0 ? smem : sX + (sl - 1) * SLOT + SW * 64) + k * 16;
+    *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.a, p.abytes), rd = make_rsrc(p.dy, p.dybytes);
+  const unsigned sx_a = (unsigned)(size_t)(lds_void_p)sX, sd_a = (unsigned)(size_t)(lds_void_p)sDy;
+  const unsigned tab_a = (unsigned)(size_t)(lds_void_p)tab;
+  const unsigned lrel = (unsigned)(lane * 16);
+  // transposing-read lane geometry (wgrad_kernel): a 32-channel x 16-pixel fragment = two ds_read_b64_tr_b16, 4 pixel rows apart
+  const int li = lane & 15, g = lane >> 4;
+  const int q4 = li >> 2, pp = li & 3;
+  const int chan = 16 * (g & 1) + 4 * pp;
+  const int hrow = 8 * (g >> 1) + q4;
+  const unsigned fbase = (unsigned)((64 * pgx + hrow) * 64 + chan * 2);       // pixel 64 pgx + hrow of a slot row, channel chan
+  const int tapoff = d * 64;                            // one tap column = d pixels
+
+  int n_ = 0, r_ = 0, i0 = 0, nit = 0;
+  auto enter_job = [&](int job) {
+    n_ = 0; r_ = 0; i0 = 0; nit = 0;
+    if (job < p.njobs) {
+      const int chain = job / p.spc, seg = job - chain * p.spc;
+      r_ = chain % d; n_ = chain / d;
+      const int ny = (H - r_ + d - 1) / d;
+      i0 = seg * p.seglen;
+      int i1 = i0 + p.seglen; if (i1 > ny) i1 = ny;
+      nit = i1 > i0 ? i1 - i0 : 0;
+    }
+  };
+  auto xrow_ok = [&](int rho) { const int h = r_ + (i0 + rho) * d; return nit > 0 && rho <= nit && h >= 0 && h < H; };
+  auto xslot = [&](int rho) { return (unsigned)(((rho + 1 + R) % R) * SLOT); };
+  auto dslot = [&](int j) { return (unsigned)(((j + RD) % RD) * DSLOT); };
+  // the stage's DMA operations of this wave: piece pi = k NW + wv: < NPS a piece of input row xr, < 2 NPS a piece of dy row dr, else a dummy
+  auto issue = [&](int xr, int dr) {
+    const unsigned xbase = xrow_ok(xr) ? (unsigned)(n_ * H + r_ + (i0 + xr) * d) * rowbytes : OOB;
+    const unsigned dbase = (dr >= 0 && dr < nit) ? (unsigned)(n_ * H + r_ + (i0 + dr) * d) * rowbytes : OOB;
+    const unsigned xs = xslot(xr), ds = dslot(dr);
+#pragma unroll
+    for (int k = 0; k < KDMA; ++k) {
+      const int pi = k * NW + wv;
+      if (pi < NPS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sX + xs + pi * 1024), 16, (xbase + (unsigned)(pi * 1024)) + lrel, 0, 0, 0);
+      else if (pi < 2 * NPS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_p)(sDy + ds + (pi - NPS) * 1024), 16, (dbase + (unsigned)((pi - NPS) * 1024)) + lrel, 0, 0, 0);
+      else { const unsigned z = 0u, off = OOB; asm volatile("buffer_store_dword %0, %1, %2, 0 offen" :: "v"(z), "v"(off), "s"(rd) : "memory"); }
+    }
+  };
+  // BatchNorm + ReLU of input row rho in place, on this wave's own pieces of it (piece pi = k NW + wv < NPS)
+  auto transform = [&](int rho) {
+    if constexpr (BN) {
+      const unsigned ca = (tab_a + (xrow_ok(rho) ? 0u : 64u * 4u)) + (unsigned)((lane & 3) * 32);
+      const unsigned xs = sx_a + xslot(rho) + lrel;
+#pragma unroll
+      for (int k = 0; k < KDMA; ++k) {
+        const int pi = k * NW + wv;
+        if (pi < NPS) {                                 // wave-uniform
+          u32x4_t rw; f32x4 sa, sb, ha, hb;
+          const unsigned a = xs + (unsigned)(pi * 1024);
+          asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\tds_read_b128 %3, %6 offset:128\n\tds_read_b128 %4, %6 offset:144\n\t"
+                       "s_waitcnt lgkmcnt(0)" : "=&v"(rw), "=&v"(sa), "=&v"(sb), "=&v"(ha), "=&v"(hb) : "v"(a), "v"(ca) : "memory");
+          float f[8];
+          ET<bf16_t>::unpack(make_uint4(rw[0], rw[1], rw[2], rw[3]), f);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { f[j] = fmaf(sa[j], f[j], ha[j]); f[4 + j] = fmaf(sb[j], f[4 + j], hb[j]); }
+          typedef __attribute__((ext_vector_type(2))) short s16x2;
+          typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+          const s16x2 z = {0, 0};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x2_t p2 = {f[2 * j], f[2 * j + 1]};
+            const bf16x2_t b2 = __builtin_convertvector(p2, bf16x2_t);
+            rw[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, b2), z));
+          }
+          asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(rw) : "memory");
+        }
+      }
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  // fragments of k-step ks of the stage (16 pixels): dy (the a-operand) and the three tap columns of input row `it + ty - 1`
+  struct Frags { s16x4 d0, d1, x0[3], x1[3]; };
+  auto read_frags = [&](unsigned da, unsigned xa, int ks, Frags& f) {
+    const unsigned dk = da + (unsigned)(ks * 1024), xk = xa + (unsigned)(ks * 1024);
+    const unsigned xl = xk - (unsigned)tapoff, xr_ = xk + (unsigned)tapoff;
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:256\n\t"
+                 "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:256\n\t"
+                 "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:256\n\t"
+                 "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:256"
+                 : "=&v"(f.d0), "=&v"(f.d1), "=&v"(f.x0[0]), "=&v"(f.x1[0]), "=&v"(f.x0[1]), "=&v"(f.x1[1]), "=&v"(f.x0[2]), "=&v"(f.x1[2])
+                 : "v"(dk), "v"(xl), "v"(xk), "v"(xr_) : "memory");
+  };
+  auto wait_frags = [&](Frags& f, int pending) {
+    if (pending) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f.d0), "+v"(f.d1), "+v"(f.x0[0]), "+v"(f.x1[0]), "+v"(f.x0[1]), "+v"(f.x1[1]), "+v"(f.x0[2]), "+v"(f.x1[2]) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.d0), "+v"(f.d1), "+v"(f.x0[0]), "+v"(f.x1[0]), "+v"(f.x0[1]), "+v"(f.x1[1]), "+v"(f.x0[2]), "+v"(f.x1[2]) :: "memory");
+  };
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto mfma3 = [&](const Frags& f) {
+    const s16x8 fd = {f.d0[0], f.d0[1], f.d0[2], f.d0[3], f.d1[0], f.d1[1], f.d1[2], f.d1[3]};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const s16x8 fx = {f.x0[j][0], f.x0[j][1], f.x0[j][2], f.x0[j][3], f.x1[j][0], f.x1[j][1], f.x1[j][2], f.x1[j][3]};
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc[j], 0, 0, 0);
+    }
+  };
+
+  for (int jb = 0; jb < p.jpw; ++jb) {
+    enter_job((int)blockIdx.x + jb * p.gx);
+    // ---- window fill: input rows -1 .. 3 and dy rows 0, 1 in flight, all landed; rows -1, 0, 1 normalised -------------------------
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // the previous job's last stage is done with the rings
+    issue(-1, -1); issue(0, 0); issue(1, 1); issue(2, -1); issue(3, -1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    transform(-1); transform(0); transform(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = 0; it < nit; ++it) {
+      __builtin_amdgcn_s_barrier();                     // input row it + 1 is normalised and dy row it has landed, for everyone
+      issue(it + 4, it + 2);                            // input row it + 4 into the slot of row it - 2, dy row it + 2 into the slot of dy row it - 1
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * KDMA) : "memory");      // the operations of stage it - 2 (input row it + 2) are done
+      const unsigned da = sd_a + dslot(it) + fbase;
+      const unsigned xa = sx_a + xslot(it + ty - 1) + fbase;
+      Frags fa, fb;
+      read_frags(da, xa, 0, fa);
+      read_frags(da, xa, 1, fb);
+      wait_frags(fa, 1); mfma3(fa);
+      read_frags(da, xa, 2, fa);
+      wait_frags(fb, 1); mfma3(fb);
+      read_frags(da, xa, 3, fb);
+      wait_frags(fa, 1); mfma3(fa);
+      wait_frags(fb, 0); mfma3(fb);
+      transform(it + 2);
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" :: "n"(KDMA) : "memory");   // stage it - 1's operations (dy row it + 1) are done; this wave's LDS writes too
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  // ---- reduce the pixel groups through LDS, then one partial per block (wgrad_taps_kernel's layout) -------------------------------
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+  const int lane_ = lane;
+  if (pgx > 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[((((pgx - 1) * 3 + ty) * 3 + j) * 16 + i) * 64 + lane_] = acc[j][i];
+  }
+  __syncthreads();
+  if (pgx == 0) {
+    float* part = p.scratch + (size_t)blockIdx.x * 9 * 32 * C;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = acc[j][i];
+        for (int gg = 1; gg < NPG; ++gg) v += red[((((gg - 1) * 3 + ty) * 3 + j) * 16 + i) * 64 + lane_];
+        const int co = (i & 3) + 8 * (i >> 2) + 4 * (lane_ >> 5);
+        part[((ty * 3 + j) * 32 + co) * C + (lane_ & 31)] = v;
+      }
+  }
+}
+template <int NPG, bool BN> __global__ __launch_bounds__(NPG * 192) void wgrad_rows32(const WgtK p) { wgrad_rows32_body<NPG, BN>(p); }
+template <int NPG, bool BN> __global__ __launch_bounds__(NPG * 192) void wgrad_rows32_g(const WgtKG g) {       // blockIdx.z = member
+  const WgtK& p = g.k[blockIdx.z];
+  if ((int)blockIdx.x >= p.gx) return;
+  wgrad_rows32_body<NPG, BN>(p);
+}
+
 // dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 64 float4 columns x 4 slice lanes: a wave
 // reads 1 KiB runs of a partial, eight loads in flight per thread, the four lanes are folded through LDS in a fixed order
 // (deterministic).  (Before: 16 columns x 16 lanes - 256-byte runs, four loads in flight, 4x the blocks.)
@@ -2812,6 +3020,24 @@ struct WgGroupCapture {
 };
 static thread_local WgGroupCapture* g_wg_group = nullptr;
 
+// wgrad_rows32 variants: kind 4 + 2 * (NPG == 2) + (no BatchNorm on load)
+static void launch_rows32(int kind, bool grouped, dim3 grid, int smem, hipStream_t st, const WgtK* one, const WgtKG* many) {
+  static RuaPerDevFlag attr_[8];
+  bool& attr = attr_[(kind - 4) * 2 + (grouped ? 1 : 0)].get();
+#define RUA_ROWS_GO(NPG_, BN_) do { \
+    if (grouped) { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows32_g<NPG_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+                   hipLaunchKernelGGL((wgrad_rows32_g<NPG_, BN_>), grid, dim3(NPG_ * 192), smem, st, *many); } \
+    else { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows32<NPG_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+           hipLaunchKernelGGL((wgrad_rows32<NPG_, BN_>), grid, dim3(NPG_ * 192), smem, st, *one); } } while (0)
+  switch (kind) {
+    case 4: RUA_ROWS_GO(4, true); break;
+    case 5: RUA_ROWS_GO(4, false); break;
+    case 6: RUA_ROWS_GO(2, true); break;
+    default: RUA_ROWS_GO(2, false); break;
+  }
+#undef RUA_ROWS_GO
+}
+
 static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   const int CC = d->C;
   WgtK k;
@@ -2848,17 +3074,40 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   size_t smem = (size_t)k.group_bytes * k.NPG;
   const size_t red = (size_t)(k.NPG - 1) * 3 * (CC / 32) * 3 * 16 * 64 * 4;
   if (red > smem) smem = red;
+  // full-width rows at C = 32: wgrad_rows32 (tuning key wgrad_rows) - the block's pixel groups share ONE ring of whole rows; a worker is a block
+  int rows_kind = 0;
+  if (g_tune.wgrad_rows && CC == 32 && (d->W == 256 || d->W == 128) && d->dil <= 31 && (!d->in_scale || d->in_relu) && (size_t)M * CC * 2 < 0x80000000ull) {
+    const int npg = d->W / 64;
+    rows_kind = 4 + (npg == 2 ? 2 : 0) + (d->in_scale ? 0 : 1);
+    k.NPG = npg; k.strips = 1;
+    k.nchains = d->N * d->dil;
+    const int blocks = ncu / share > 0 ? ncu / share : 1;
+    int spc2 = blocks / k.nchains;
+    if (spc2 < 1) spc2 = 1;
+    if (spc2 > (ny + 3) / 4) spc2 = (ny + 3) / 4;       // >= 4 rows per segment (a segment re-reads two window rows)
+    if (spc2 < 1) spc2 = 1;
+    k.seglen = (ny + spc2 - 1) / spc2;
+    k.spc = (ny + k.seglen - 1) / k.seglen;
+    k.njobs = k.nchains * k.spc;
+    gx = k.njobs < blocks ? k.njobs : blocks;
+    k.gx = gx; k.nworkers = gx;
+    k.jpw = (k.njobs + gx - 1) / gx;
+    smem = (size_t)32 * 64 + 6 * (size_t)(d->W + 32) * 64 + 3 * (size_t)d->W * 64 + 128 * 4;
+    const size_t red2 = (size_t)(npg - 1) * 3 * 3 * 16 * 64 * 4;
+    if (red2 > smem) smem = red2;
+  }
   const int rblocks = rua_div_up(9 * CC * CC / 4, TAPS_RED_COLS);
   note_pending(1, gx, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks);
   if (g_wgrad_dry) return RUA_OK;
   if (g_wg_group && (g_tune.wgrad_group & (CC == 32 ? 2 : 4)) && g_wg_group->n < RUA_MAX_BRANCH) {
     WgGroupCapture& c = *g_wg_group; const int i = c.n++;
-    c.kind[i] = CC == 32 ? 1 : 2; c.gx[i] = gx; c.smem[i] = (int)smem; c.t[i] = k;
+    c.kind[i] = rows_kind ? rows_kind : (CC == 32 ? 1 : 2); c.gx[i] = gx; c.smem[i] = (int)smem; c.t[i] = k;
     c.post[i] = d->defer ? 0 : 1; c.part[i] = k.scratch; c.dw[i] = d->dw; c.CC[i] = CC; c.parts[i] = gx; c.rblocks[i] = rblocks; c.ndw[i] = 0;
     return RUA_OK;
   }
   static thread_local bool attr32 = false, attr64 = false;
-  if (CC == 32) {
+  if (rows_kind) launch_rows32(rows_kind, false, dim3(gx), (int)smem, st, &k, nullptr);
+  else if (CC == 32) {
     if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr32 = true; }
     hipLaunchKernelGGL((wgrad_taps_kernel<32>), dim3(gx, gy), dim3(768), smem, st, k);
   } else {
@@ -3342,6 +3591,10 @@ extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream
       }
       if (m == 1) hipLaunchKernelGGL(wgrad_dmap, dim3(gx), dim3(256), smem, st, cap.d[idx[0]]);
       else { WgdKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.d[idx[q]]; hipLaunchKernelGGL(wgrad_dmap_g, dim3((gx + 7) / 8 * 8, m), dim3(256), smem, st, g); }
+    } else if (kd >= 4) {
+      WgtKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.t[idx[q]];
+      if (m == 1) launch_rows32(kd, false, dim3(gx), smem, st, &g.k[0], nullptr);
+      else launch_rows32(kd, true, dim3(gx, 1, m), smem, st, nullptr, &g);
     } else {
       const int gy = kd == 1 ? 1 : 2;
       if (!attr[kd]) {
