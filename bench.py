@@ -64,16 +64,26 @@ def measured_traffic(kernel, args):
     k = t["kernels"].get(name)
     if k:
         return k["bytes_per_launch"]
-    # template instantiations the bench name folds together (conv_halo<32> = conv_halo<32,2> + conv_halo<32,3>, ...;
-    # conv_strip<32> = conv_strip32<8,true,5> + conv_strip32<8,false,7>)
-    pref = name[:-1] + ","
-    if name.startswith("conv_strip<"):
-        pref = "conv_strip" + name[len("conv_strip<"):-1] + "<"
-    elif name.startswith("conv_strip_g<"):
-        pref = "conv_strip" + name[len("conv_strip_g<"):-1] + "_g<"
-    fam = [v for kk, v in t["kernels"].items() if kk.startswith(pref)]
+    fam = [v for kk, v in t["kernels"].items() if kk.startswith(rocprof_prefixes(name))]
     n = sum(v["launches_seen"] for v in fam)
     return round(sum(v["bytes_per_launch"] * v["launches_seen"] for v in fam) / n) if n else None
+
+
+def rocprof_prefixes(name):
+    """rocprofv3 kernel-name prefixes of the template instantiations a bench kernel name folds together (conv_halo<32> =
+    conv_halo<32,2> + conv_halo<32,3>, ...; conv_strip<32> = conv_strip32<8,true,5> + conv_strip32<8,false,7> + the round-4
+    conv_strip32s<8,...> forms; wgrad_taps_kernel<32> = wgrad_taps_kernel<32> + wgrad_rows32<4,...>)."""
+    if name.startswith("conv_strip<"):
+        c = name[len("conv_strip<"):-1]
+        return ("conv_strip" + c + "<", "conv_strip" + c + "s<")
+    if name.startswith("conv_strip_g<"):
+        c = name[len("conv_strip_g<"):-1]
+        return ("conv_strip" + c + "_g<", "conv_strip" + c + "s_g<")
+    if name == "wgrad_taps_kernel<32>":
+        return (name, "wgrad_rows32<")
+    if name == "wgrad_taps_kernel_g<32>":
+        return (name, "wgrad_rows32_g<")
+    return (name[:-1] + ",",)
 
 
 def committed_rocprof_avg(kernel, args):

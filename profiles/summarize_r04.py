@@ -92,12 +92,22 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes),
 names = bench["roofline"]["all_mfma_kernels"]
 
 
-def fam_avg(name):
-    strip = "conv_strip" + name[len("conv_strip<"):-1] + "<" if name.startswith("conv_strip<") else None
+def rocprof_prefixes(name):            # bench.py::rocprof_prefixes (kept in step by hand: this script must not import bench.py's torch)
+    if name.startswith("conv_strip<"):
+        c = name[len("conv_strip<"):-1]
+        return ("conv_strip" + c + "<", "conv_strip" + c + "s<")
     if name.startswith("conv_strip_g<"):
-        strip = "conv_strip" + name[len("conv_strip_g<"):-1] + "_g<"
-    fam = [(c, t) for nm, (c, _, t) in stat.items() if nm == name or nm.startswith(name[:-1] + ",") or (name in ("conv_pw", "wgrad_pw") and nm.startswith(name + "<"))
-           or (strip and nm.startswith(strip))]
+        c = name[len("conv_strip_g<"):-1]
+        return ("conv_strip" + c + "_g<", "conv_strip" + c + "s_g<")
+    if name == "wgrad_taps_kernel<32>":
+        return (name, "wgrad_rows32<")
+    if name == "wgrad_taps_kernel_g<32>":
+        return (name, "wgrad_rows32_g<")
+    return (name[:-1] + ",",)
+
+
+def fam_avg(name):
+    fam = [(c, t) for nm, (c, _, t) in stat.items() if nm == name or nm.startswith(rocprof_prefixes(name)) or (name in ("conv_pw", "wgrad_pw") and nm.startswith(name + "<"))]
     return round(1e3 * sum(t for _, t in fam) / sum(c for c, _ in fam), 2) if fam else None
 
 

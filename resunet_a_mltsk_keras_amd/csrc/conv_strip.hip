@@ -434,8 +434,13 @@ template <int NW, bool HAS_EP, int R> static int launch_strip_members(const Stri
 // conv_strip32s: ONE grid for all members (a lone convolution is a group of one); the members' row stages form one line of cost units
 // that the blocks - one per CU - cut into equal pieces (conv_strip2.inc)
 template <int NW, int IN, int EP, int ST, int ORELU, int R, int BIAS> static int launch_strip_s(const StripK* ks, const int* smems, int m, hipStream_t st) {
-  static thread_local bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32s_g<NW, IN, EP, ST, ORELU, R, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static RuaPerDevFlag attr_;
+  bool& attr = attr_.get();
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32s_g<NW, IN, EP, ST, ORELU, R, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip32s<NW, IN, EP, ST, ORELU, R, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
   StripSG g;
   memset(&g, 0, sizeof(g));
   int smem = 0;
@@ -461,7 +466,8 @@ template <int NW, int IN, int EP, int ST, int ORELU, int R, int BIAS> static int
   if (nb > rua_cu_count()) nb = rua_cu_count();
   if (nb < 1) nb = 1;
   g.nblocks = nb;
-  hipLaunchKernelGGL((conv_strip32s_g<NW, IN, EP, ST, ORELU, R, BIAS>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), smem, st, g);
+  if (m == 1) hipLaunchKernelGGL((conv_strip32s<NW, IN, EP, ST, ORELU, R, BIAS>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), smem, st, g);
+  else hipLaunchKernelGGL((conv_strip32s_g<NW, IN, EP, ST, ORELU, R, BIAS>), dim3((nb + 7) / 8 * 8), dim3(NW * 64), smem, st, g);
   RUA_LAUNCH_CHECK("conv_strip32s");
   return RUA_OK;
 }
