@@ -206,6 +206,9 @@ int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, const rua_w
 /* ---- few-channel 1x1 convolutions (VALU; the stem and the heads) -------------------------
  * stem: KL.Conv2D(32,(1,1)) on the 3/6/7-band input (model2.py:101).  x fp32 [M][Cin<=16]. */
 int rua_stem_fwd(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, void* stream);
+/* rua_stem_fwd with the per-channel statistics of its output in the epilogue: stats [replicas][2][Cout] fp64 (sum, sum of squares of y as stored;
+ * zeroed by the caller) - what rua_col_stats would compute from y in a pass of its own (the first BatchNorm of the encoder, model2.py:102-103). */
+int rua_stem_fwd_stats(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, double* stats, int replicas, void* stream);
 int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db, int64_t M, int Cin, int Cout, int dtype, void* stream);
 /* heads: Conv2D(num_classes,(1,1)) + softmax / sigmoid (model2.py:145-146,160-162,169-171,181-183,186-188).
  * act: 0 none, 1 softmax over channels, 2 sigmoid.  z (logits) and p are fp32 [M][Cout<=8]. */

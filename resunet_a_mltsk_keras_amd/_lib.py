@@ -105,6 +105,7 @@ _SIGS = {
     "rua_wgrad_reduce_batch": ([vp, i32, i32, vp], i32),
     "rua_weight_prep": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "rua_stem_fwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
+    "rua_stem_fwd_stats": ([vp, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp], i32),
     "rua_stem_bwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "rua_head_fwd": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp], i32),
     "rua_head_fwd_loss": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp], i32),

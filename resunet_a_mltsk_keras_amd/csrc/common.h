@@ -101,6 +101,7 @@ struct RuaTuning {
   int wgrad_rows = 1;                   // wgrad_rows32: the all-taps weight gradient at C = 32 on whole rows (W = 256 / 128) with one shared LDS-DMA ring (0: wgrad_taps_kernel<32>)
   int cu_reserve = 0;                   // CUs the one-round grids leave free (rua_cu_count() = CUs - cu_reserve): room for RCCL's kernels under data parallel
   int strip_seglen = 0;                 // experiments (tools/bench_conv3x3.py): rows per block of conv_strip, 0 = one round of blocks
+  int band_stag = 1;                    // conv_band32s (staggered halves) for full-width BatchNorm + ReLU sums (0: conv_band32; >= 4: that many ring slots)
   int strip_stag = 1;                   // conv_strip32s: full-width strips with the two halves of a block half a stage apart (0: conv_strip32 everywhere)
   int wgrad_group = 7;                  // 1 wgrad_kernel, 2 wgrad_taps<32>, 4 wgrad_taps<64>, 8 wgrad_dmap (off: three members at once thrash the L2, 27.6 vs 24.6 us each)
 };
@@ -132,6 +133,78 @@ __device__ __forceinline__ void replica_sum(const double* __restrict__ stats, in
   }
   for (; r < R; ++r) { a1 += stats[(size_t)r * 2 * C + c]; a2 += stats[(size_t)r * 2 * C + C + c]; }
   s1 = a1 + b1; s2 = a2 + b2;
+}
+
+// p[c], or 0 for a null pointer, without a branch: a buffer load whose range is empty for a null pointer.  Several of these are in flight at once;
+// behind `if (p)` every load waits for the one before it (a prologue of four dependent round trips instead of one).  p must be wave-uniform.
+__device__ __forceinline__ float ld_f32_or_zero(const float* p, int c, int n) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p, p ? (unsigned)(n * 4) : 0u), (unsigned)(c * 4), 0, 0));
+}
+
+// in_fold of up to RUA_MAX_BRANCH members at once - the prologue of the row-streaming kernels (conv_strip32s, conv_band32s, conv_band64): every
+// block derives scale / shift of each member's BatchNorm from the replicated fp64 statistics of its input.  The NT / CH thread groups are dealt to
+// the members (gpm groups each); a thread sums the replicas gi, gi + gpm, ... of its channel with ALL its loads in flight at once - buffer loads
+// whose range ends at the replica count, so a replica beyond it reads zeros and there is no loop to put a memory round trip behind every pair
+// of loads (in-kernel stamps, tools/band_phases.py: the four members of a conv_band32 launch one after the other, two block barriers and a
+// dependent load loop each, were 6.5 - 7.7 us of an 83 us launch) -, gamma / beta of the finishing thread are fetched beside them; the first
+// group of a member adds the groups' shares in a fixed order, finishes mean / variance -> scale / shift and hands them to store(m, c, scale,
+// shift); `publish` (one block of the grid) also writes the coefficients out and updates the moving statistics.  red: LDS scratch of
+// NT / CH * 2 * CH doubles.  Ends with a block barrier.
+// getf(m): the member's rua_bn_fold by reference (a kernel argument: no pointer to it may escape, or hipcc copies the argument block to scratch and
+// every descriptor in it turns into a vector value); has(m): false for a member whose coefficients were given.
+template <int NT, int CH, typename GetF, typename Has, typename Store>
+__device__ __forceinline__ void rua_fold_members(GetF&& getf, Has&& has, int nmem, bool publish, double* red, int tid, Store&& store) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+  constexpr int NG = NT / CH, gpm = NG / RUA_MAX_BRANCH;
+  static_assert(gpm >= 1, "thread groups per member");
+  constexpr int KMAX = (32 + gpm - 1) / gpm;            // rua_stats_replicas() hands out at most 32
+  constexpr int GPW = 64 / CH;                          // thread groups per wave: a wave's groups belong to ONE member (its descriptor stays in SGPRs)
+  static_assert(CH <= 64 && gpm % GPW == 0, "a wave must not straddle two members");
+  const int c = tid % CH, grp = tid / CH;
+  const int m = __builtin_amdgcn_readfirstlane(tid >> 6) / (gpm / GPW), gi = grp - m * gpm;
+  const int mc = m < nmem ? m : 0;
+  const bool act = m < nmem && has(mc);
+  const rua_bn_fold& f = getf(mc);
+  float gam = 0.f, bet = 0.f;
+  if (act) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(f.stats, (unsigned)(f.replicas * 2 * CH * 8));
+    u32x2_t x[KMAX], y[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const unsigned off = (unsigned)(((gi + k * gpm) * 2 * CH + c) * 8);
+      x[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+      y[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, off + (unsigned)(CH * 8), 0, 0);
+    }
+    if (gi == 0) { gam = f.gamma[c]; bet = f.beta[c]; }
+    double a1 = 0, a2 = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { a1 += __builtin_bit_cast(double, x[k]); a2 += __builtin_bit_cast(double, y[k]); }
+    for (int r = gi + KMAX * gpm; r < f.replicas; r += gpm) { a1 += f.stats[(size_t)r * 2 * CH + c]; a2 += f.stats[(size_t)r * 2 * CH + CH + c]; }
+    red[(grp * 2) * CH + c] = a1; red[(grp * 2 + 1) * CH + c] = a2;
+  }
+  __syncthreads();
+  if (act && gi == 0) {
+    double s1 = 0, s2 = 0;
+    for (int g = 0; g < gpm; ++g) { s1 += red[((grp + g) * 2) * CH + c]; s2 += red[((grp + g) * 2 + 1) * CH + c]; }
+    const double mean = s1 / f.count;
+    double v = s2 / f.count - mean * mean;
+    if (v < 0) v = 0;
+    const double r = 1.0 / sqrt(v + (double)f.eps);
+    const double sc = (double)gam * r;
+    const float scf = (float)sc, shf = (float)((double)bet - mean * sc);
+    store(m, c, scf, shf);
+    if (publish) {
+      f.scale[c] = scf; f.shift[c] = shf;
+      if (f.mean) f.mean[c] = (float)mean;
+      if (f.rstd) f.rstd[c] = (float)r;
+      if (f.moving_mean) {
+        const double unb = f.bessel_n > 1 ? v * (f.bessel_n / (f.bessel_n - 1)) : v;
+        f.moving_mean[c] = (float)((double)f.moving_mean[c] * f.momentum + mean * (1.0 - f.momentum));
+        f.moving_var[c] = (float)((double)f.moving_var[c] * f.momentum + unb * (1.0 - f.momentum));
+      }
+    }
+  }
+  __syncthreads();
 }
 
 // ---- kernel-side view of a rua_conv_desc (filled by rua_conv_fwd, shared by the conv kernels of conv_mfma.hip / conv_strip.hip)

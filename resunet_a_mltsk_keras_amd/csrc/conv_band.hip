@@ -23,6 +23,7 @@
 // addressing and the in-place transform do not depend on the branch; columns outside the image are out-of-range DMA lanes (zeros,
 // no memory traffic): for full-width strips the halo costs nothing.
 #include "common.h"
+#include <type_traits>
 
 struct BandK {
   const unsigned char* x[RUA_MAX_BRANCH];
@@ -40,6 +41,17 @@ struct BandK {
   int dbg;
 };
 static_assert(sizeof(BandK) <= 4096, "kernel arguments are limited to 4 KiB");
+
+#ifdef RUA_BAND_TS                                    // (debug build: 100 MHz wall-clock stamps of three blocks, read by rua_band_debug_ts; tools/band_phases.py)
+__device__ unsigned long long g_band_ts[3 * 32 + 32];
+#define RUA_BST(i) do { if (r == 3) st_[i] = clock64(); } while (0)
+#define RUA_BTS(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == gridDim.x - 1)) \
+    g_band_ts[(blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : 2)) * 32 + (i)] = wall_clock64(); } while (0)
+extern "C" int rua_band_debug_ts(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_band_ts), sizeof(g_band_ts)); }
+#else
+#define RUA_BTS(i) do { } while (0)
+#define RUA_BST(i) do { } while (0)
+#endif
 
 // FULLW: the strip is the whole image row (W == SW).  The 32 halo pixels either side of a slot row are then zero padding for every
 // branch: they are zeroed ONCE and the row DMAs cover the interior only - 2 instead of 3 DMA instructions and transformed pieces
@@ -72,6 +84,7 @@ __device__ __forceinline__ void conv_band32_body(const BandK& q) {
 
   const int nwg = q.njobs, bid = blockIdx.x;
   if (bid >= nwg) return;
+  RUA_BTS(0);
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int job = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // consecutive jobs share an XCD's L2
   const int band = job % q.bands, tq = job / q.bands;
@@ -127,6 +140,7 @@ __device__ __forceinline__ void conv_band32_body(const BandK& q) {
     }
   }
   __syncthreads();
+  RUA_BTS(1);
   const bool bn = q.has_bn != 0 && !(q.dbg & 2);
   const int d0 = q.d[0], d1 = q.d[1], d2 = q.d[2], d3 = q.d[3];
   auto dil_of = [&](int b) { return b == 0 ? d0 : (b == 1 ? d1 : (b == 2 ? d2 : d3)); };
@@ -263,6 +277,7 @@ __device__ __forceinline__ void conv_band32_body(const BandK& q) {
     tr_read(cur, 0u, sa, sb, ha, hb, rw); tr_math(sa, sb, ha, hb, rw); tr_write(0u, rw);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  RUA_BTS(2);
 
   // slot byte offsets of the row being consumed, the next one (normalised meanwhile) and the one the DMAs of this stage fill
   unsigned so_cur = 0, so_nxt = SLOT, so_iss = (R - 1) * SLOT;
@@ -322,8 +337,10 @@ __device__ __forceinline__ void conv_band32_body(const BandK& q) {
     }
     cur = nxt;
     nxt = phase(ph + 2);
+    RUA_BTS(3 + ph);
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");       // the over-issued DMAs of the last stages
+  RUA_BTS(16);
 
   // ---- epilogue: bias sum + residual, one write of the band ------------------------------------------------------------------
   // acc[r][k]: channel (k & 3) + 8 * (k >> 2) + 4 * kh of pixel pl; one half-wave exchange per register pair -> this lane holds
@@ -361,12 +378,363 @@ __device__ __forceinline__ void conv_band32_body(const BandK& q) {
       stg16(yrow + co * 2, ET<T>::pack(v[g]));
     }
   }
+  RUA_BTS(17);
+#ifdef RUA_BAND_TS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RUA_BTS(18);
+#endif
 }
 
 // (the body is a __device__ template behind __global__ wrappers, like conv_strip's: the host pass then never has to instantiate it -
 // with the body itself as a __global__ template the host-side stubs silently went missing whenever the body used a device-only
 // construct the host pass rejects)
 template <int NW, int BR, int R, bool FULLW> __global__ __launch_bounds__(NW * 64) void conv_band32(const BandK q) { conv_band32_body<NW, BR, R, FULLW>(q); }
+
+// ---- conv_band32s<NW, R>: the same launch in the staggered form of conv_strip32s (round 4) ------------------------------------------
+// In-kernel stamps of conv_band32 (tools/band_phases.py, 8 x 256 x 256 x 32 x 4 branches, 83 us): 7.7 us tables + BatchNorm fold (the four
+// branches one after the other, two block barriers each), 1.4 - 2.2 us ring fill, 12 phases x 5.44 us = 0.68 us per stage of 6 MFMAs per wave
+// (0.43 where the rows lie outside the image and nothing is normalised), 4.2 - 5.3 us epilogue, ~5 us launch ramp + drain.  A stage's MFMA time is
+// 0.16 us (two waves per SIMD): both waves of a SIMD leave the barrier together, issue their six dependent MFMAs together - in-order issue: neither
+// gets to its vector work while the pipe is busy - and then normalise row s + 1 together with the pipe idle.  Here the halves of the block run the two
+// independent parts of a stage in OPPOSITE order (waves 0 .. NW/2-1: fragments, MFMAs, then the in-place pass of row s + 1; the others: in-place
+// pass, then fragments and MFMAs; a workgroup's waves i and i + 4 share a SIMD), every LDS access is raw asm with counted waits, the zero rows
+// above / below the image pass through the arithmetic with zero coefficients instead of a branch, and the fold of all branches runs at once.
+// Full-width strips with BatchNorm + ReLU on load only (the form the engine records); everything else stays on conv_band32.
+template <int NW, int R>
+__device__ __forceinline__ void conv_band32s_body(const BandK& q) {
+  typedef bf16_t T;
+  constexpr int C = 32, NT = NW * 64, SW = NW * 32, HALO = 32, BR = 8;
+  constexpr int SPX = SW + 2 * HALO, SLOT = SPX * 64;
+  constexpr int NPX = 2;                                // SW * 64 / 1024 = 2 NW row DMA instructions: two per wave
+  constexpr int NWAIT = (R - 3) * NPX;                  // operations behind the DMAs of row s + 3 when stage s waits for them (rows s + 4 .. s + R)
+  constexpr int WPIECES = 18, WST = (WPIECES + NW - 1) / NW;
+  // the weights of branch b + 1 are issued in stages 0 .. WST-1 of the last phase of branch b and read after the barrier that ends it: at the wait of
+  // that phase's last stage at least NWAIT younger operations must lie behind them
+  static_assert(WST <= BR && BR - WST >= R - 3 && R >= 5 && R <= BR, "pipeline depths");
+  constexpr unsigned ROW_OOB = 0x80000000u;
+  constexpr int TAB_BIAS = 4 * 64, TAB_ZERO = 4 * 64 + 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sW = smem + R * SLOT;
+  float* tab = reinterpret_cast<float*>(sW + WPIECES * 1024);          // [nb][2][32] scale, shift ; [32] bias sum ; [64] zeros
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pl = lane & 31, kh = lane >> 5;
+  const int H = q.H, W = q.W, nb = q.nb;
+  const int nwg = q.njobs, bid = blockIdx.x;
+  if (bid >= nwg) return;
+  RUA_BTS(0);
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int job = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int band = job % q.bands, n_ = job / q.bands;
+  const int h0 = band * BR;
+
+  // ---- tables; the BatchNorm fold of ALL branches at once (conv_strip32s: the thread groups are dealt to the branches) --------------
+  if (tid < 32) {
+    const float b = ((ld_f32_or_zero(q.bias[0], tid, 32) + ld_f32_or_zero(nb > 1 ? q.bias[1] : nullptr, tid, 32)) + ld_f32_or_zero(nb > 2 ? q.bias[2] : nullptr, tid, 32)) +
+                    ld_f32_or_zero(nb > 3 ? q.bias[3] : nullptr, tid, 32);
+    tab[TAB_BIAS + tid] = b;
+    tab[TAB_ZERO + tid] = 0.f; tab[TAB_ZERO + 32 + tid] = 0.f;
+  }
+  if (q.has_fold) {
+    rua_fold_members<NT, 32>([&](int m) -> const rua_bn_fold& { return q.f[m]; }, [](int) { return true; }, nb, job == 0, reinterpret_cast<double*>(smem), tid,
+                             [&](int m, int c, float scf, float shf) { tab[m * 64 + c] = scf; tab[m * 64 + 32 + c] = shf; });
+  } else if (tid < 32) {
+    for (int i = 0; i < nb; ++i) { tab[i * 64 + tid] = q.in_scale[i][tid]; tab[i * 64 + 32 + tid] = q.in_shift[i] ? q.in_shift[i][tid] : 0.f; }
+  }
+  __syncthreads();                                      // tables; the fold's scratch (the ring) is dead
+  for (int i = tid; i < R * 2 * (HALO * 64 / 16); i += NT) {            // the halo pixels of every slot: zero once, never written again
+    const int sl = i / (2 * HALO * 4), k = i - sl * (2 * HALO * 4);
+    unsigned char* z = smem + sl * SLOT + (k < HALO * 4 ? k * 16 : (HALO + SW) * 64 + (k - HALO * 4) * 16);
+    *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  RUA_BTS(1);
+
+  // ---- per-lane constants (conv_strip32s) ----------------------------------------------------------------------------------------
+  const int psrc = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned smem_a = (unsigned)(size_t)(lds_void_p)smem;
+  const unsigned tab_a = (unsigned)(size_t)(lds_void_p)tab + (unsigned)(psrc * 32);
+  const unsigned sw_a = (unsigned)(size_t)(lds_void_p)sW + (unsigned)(lane * 16);
+  const unsigned rowbytes = (unsigned)(W * C * 2), imgbase = (unsigned)(n_ * H) * rowbytes;
+  const unsigned xrel = (unsigned)(((wv * 16 + (lane >> 2)) * C + psrc * 8) * 2);
+  const unsigned pdst = (unsigned)(HALO * 64 + wv * 1024 + lane * 16);
+  const int o = wv * 32 + pl;
+  const int d0 = q.d[0], d1 = q.d[1], d2 = q.d[2], d3 = q.d[3];
+  auto dil_of = [&](int b) { return b == 0 ? d0 : (b == 1 ? d1 : (b == 2 ? d2 : d3)); };
+#ifdef RUA_BAND_ABLATE
+  const bool dbg_nox = (q.dbg & 4) != 0, dbg_notr = (q.dbg & 2) != 0, dbg_nomfma = (q.dbg & 16) != 0;
+#else
+  constexpr bool dbg_nox = false, dbg_notr = false, dbg_nomfma = false;
+#endif
+
+  // everything from here on exists once per half of the block
+  auto run = [&](auto GBc) {
+    constexpr bool GB = decltype(GBc)::value;
+    struct Phase { int hb; bool valid; __amdgpu_buffer_rsrc_t rx; unsigned ca; };
+    auto phase = [&](int ph) {
+      Phase p;
+      const int b = ph / 3, ty = ph - 3 * b;
+      p.valid = ph < 3 * nb;
+      p.hb = h0 + (ty - 1) * dil_of(b);
+      p.rx = make_rsrc(q.x[p.valid ? b : 0], q.xbytes);
+      p.ca = tab_a + (unsigned)((p.valid ? b : 0) * 64 * 4);
+      return p;
+    };
+    auto row_valid = [&](const Phase& p, int r) { return p.valid && (unsigned)(p.hb + r) < (unsigned)H; };         // block-uniform
+    auto issue_x = [&](const Phase& p, int r, unsigned so) {
+      const unsigned base = row_valid(p, r) ? imgbase + (unsigned)(p.hb + r) * rowbytes : ROW_OOB;
+#pragma unroll
+      for (int k = 0; k < NPX; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(p.rx, (lds_void_p)(smem + so + HALO * 64 + (k * NW + wv) * 1024), 16, (base + (unsigned)(k * NW * 1024)) + xrel, 0, 0, 0);
+    };
+    auto issue_w = [&](int b, int idx) {
+      if (idx < WPIECES && b < nb) {
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(q.w[b], (unsigned)(9 * C * C * 2));
+        const unsigned off = (unsigned)((((idx >> 1) * C * C) + pl * C + (idx & 1) * 16 + kh * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_p)(sW + idx * 1024), 16, off, 0, 0, 0);
+      }
+    };
+    // the in-place pass of a landed row on this thread's own two DMA pieces; the coefficients of the lane's eight channels come with the pieces
+    // (broadcast reads); a row outside the image reads zeros for them: relu(0 * 0 + 0) leaves the zero padding zero
+    struct TrRegs { u32x4_t r0, r1; f32x4 sa, sb, ha, hb; };
+    auto tr_read = [&](unsigned so, unsigned ca, TrRegs& t) {
+      const unsigned a = smem_a + so + pdst;
+      asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:%c8\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\t"
+                   "ds_read_b128 %4, %7 offset:128\n\tds_read_b128 %5, %7 offset:144"
+                   : "=&v"(t.r0), "=&v"(t.r1), "=&v"(t.sa), "=&v"(t.sb), "=&v"(t.ha), "=&v"(t.hb) : "v"(a), "v"(ca), "n"(NW * 1024) : "memory");
+    };
+    auto tr_wait0 = [&](TrRegs& t) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t.r0), "+v"(t.r1), "+v"(t.sa), "+v"(t.sb), "+v"(t.ha), "+v"(t.hb) :: "memory"); };
+    auto tr_wait6 = [&](TrRegs& t) { asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(t.r0), "+v"(t.r1), "+v"(t.sa), "+v"(t.sb), "+v"(t.ha), "+v"(t.hb) :: "memory"); };
+    auto tr_math1 = [&](u32x4_t& rw, const TrRegs& t) {
+      float f[8];
+      ET<T>::unpack(make_uint4(rw[0], rw[1], rw[2], rw[3]), f);
+      f[0] = fmaf(t.sa[0], f[0], t.ha[0]); f[1] = fmaf(t.sa[1], f[1], t.ha[1]); f[2] = fmaf(t.sa[2], f[2], t.ha[2]); f[3] = fmaf(t.sa[3], f[3], t.ha[3]);
+      f[4] = fmaf(t.sb[0], f[4], t.hb[0]); f[5] = fmaf(t.sb[1], f[5], t.hb[1]); f[6] = fmaf(t.sb[2], f[6], t.hb[2]); f[7] = fmaf(t.sb[3], f[7], t.hb[3]);
+      typedef __attribute__((ext_vector_type(2))) short s16x2;
+      typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+      const s16x2 z = {0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x2_t p2 = {f[2 * k], f[2 * k + 1]};
+        const bf16x2_t b2 = __builtin_convertvector(p2, bf16x2_t);
+        rw[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, b2), z));
+      }
+    };
+    auto tr_write = [&](unsigned so, TrRegs& t) {
+      const unsigned a = smem_a + so + pdst;
+      asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:%c3" :: "v"(a), "v"(t.r0), "v"(t.r1), "n"(NW * 1024) : "memory");
+    };
+    auto frag_read = [&](unsigned so, const unsigned* boff, bf16x8* f) {
+      unsigned a[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a[k] = (boff[k >> 1] + so) ^ ((k & 1) ? 32u : 0u);
+      asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\tds_read_b128 %4, %10\n\tds_read_b128 %5, %11"
+                   : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5])
+                   : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]) : "memory");
+    };
+    auto f_wait0 = [&](bf16x8* f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) :: "memory"); };
+    auto f_wait6 = [&](bf16x8* f) { asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) :: "memory"); };
+
+    f32x16 acc[BR];
+#pragma unroll
+    for (int r = 0; r < BR; ++r)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[r][k] = 0.f;
+
+    // The pipeline of stage s (row r of phase ph), between barrier s and barrier s + 1 - nothing in it waits for an LDS read it has just issued:
+    //   MFMAs of row s           fragments in registers since stage s - 1
+    //   fragment reads, row s+1  its in-place pass was published by barrier s
+    //   in-place pass, row s+2   arithmetic on the pieces read at the end of stage s - 1, written back (published by barrier s + 1)
+    //   reads for the pass, s+3  own DMA pieces: behind the wave's own counted wait, no barrier needed
+    //   DMA issue, row s+R       into the slot of row s (its fragments were read by everyone before barrier s)
+    // first half: MFMAs, fragment reads, then the pass; second half: the pass first.
+    struct Coef { f32x4 sa, sb, ha, hb; };
+    auto coef_read = [&](unsigned ca, Coef& c) {
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:144\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(c.sa), "=&v"(c.sb), "=&v"(c.ha), "=&v"(c.hb) : "v"(ca) : "memory");
+    };
+    auto row_read = [&](unsigned so, u32x4_t& r0, u32x4_t& r1) {
+      const unsigned a = smem_a + so + pdst;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%c3" : "=&v"(r0), "=&v"(r1) : "v"(a), "n"(NW * 1024) : "memory");
+    };
+    auto row_math1 = [&](u32x4_t& rw, const Coef& c) {
+      float f[8];
+      ET<T>::unpack(make_uint4(rw[0], rw[1], rw[2], rw[3]), f);
+      f[0] = fmaf(c.sa[0], f[0], c.ha[0]); f[1] = fmaf(c.sa[1], f[1], c.ha[1]); f[2] = fmaf(c.sa[2], f[2], c.ha[2]); f[3] = fmaf(c.sa[3], f[3], c.ha[3]);
+      f[4] = fmaf(c.sb[0], f[4], c.hb[0]); f[5] = fmaf(c.sb[1], f[5], c.hb[1]); f[6] = fmaf(c.sb[2], f[6], c.hb[2]); f[7] = fmaf(c.sb[3], f[7], c.hb[3]);
+      typedef __attribute__((ext_vector_type(2))) short s16x2;
+      typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+      const s16x2 z = {0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x2_t p2 = {f[2 * k], f[2 * k + 1]};
+        const bf16x2_t b2 = __builtin_convertvector(p2, bf16x2_t);
+        rw[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, b2), z));
+      }
+    };
+    auto row_write = [&](unsigned so, u32x4_t& r0, u32x4_t& r1) {
+      const unsigned a = smem_a + so + pdst;
+      asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:%c3" :: "v"(a), "v"(r0), "v"(r1), "n"(NW * 1024) : "memory");
+    };
+    auto lds_wait_rows = [&](u32x4_t& r0, u32x4_t& r1) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1) :: "memory"); };
+    auto boff_of = [&](int d, unsigned* boff) {          // b-operand fragments: tap column tx reads slot pixel 32 + o + (tx - 1) d (k-step 1: address ^ 32)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int j = HALO + o + (tx - 1) * d;
+        boff[tx] = smem_a + (unsigned)(j * 64 + ((kh ^ ((j >> 2) & 3)) * 16));
+      }
+    };
+    auto slot_next = [&](unsigned so) { return so + SLOT == (unsigned)(R * SLOT) ? 0u : so + SLOT; };
+
+    // ---- prologue: weights of branch 0 and rows 0 .. R-1 in flight, everything landed; rows 0 and 1 normalised, row 2 read -----------
+    Phase cur = phase(0), nxt = phase(1);
+#pragma unroll
+    for (int i = 0; i < WST; ++i) issue_w(0, i * NW + wv);
+#pragma unroll
+    for (int s = 0; s < R; ++s) issue_x(cur, s, (unsigned)(s * SLOT));            // R <= BR: all in phase 0
+    Coef cf;
+    coef_read(cur.ca, cf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    u32x4_t ta0, ta1, tb0, tb1;                          // the pieces of the row being normalised / of the row after it
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (row_valid(cur, s) && !dbg_notr) {
+        row_read((unsigned)(s * SLOT), ta0, ta1); lds_wait_rows(ta0, ta1);
+        row_math1(ta0, cf); row_math1(ta1, cf); row_write((unsigned)(s * SLOT), ta0, ta1);
+      }
+    row_read(2u * SLOT, ta0, ta1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fx[6];
+    {
+      unsigned boff[3];
+      boff_of(d0, boff);
+      frag_read(0u, boff, fx);
+      f_wait0(fx);
+    }
+    RUA_BTS(2);
+
+    // slot byte offsets: so1 = row s + 1 (fragments), so2 = row s + 2 (written), so3 = row s + 3 (read), so_iss = row s (refilled with row s + R)
+    unsigned so_iss = 0, so1 = SLOT, so2 = 2 * SLOT, so3 = 3 * SLOT;
+    for (int ph = 0; ph < 3 * nb; ++ph) {
+      const int b = ph / 3, ty = ph - 3 * b;
+      unsigned boff[3], boffn[3];                        // ... of this phase and of the next one (row s + 1 of the last stage belongs to it)
+      boff_of(dil_of(b), boff);
+      boff_of(dil_of(ty == 2 ? b + 1 : b), boffn);
+      bf16x8 wf[6];
+#ifdef RUA_BAND_TS
+      unsigned long long st_[7], st4_ = 0;
+#endif
+#pragma unroll
+      for (int r = 0; r < BR; ++r) {
+        __builtin_amdgcn_s_barrier();
+#ifdef RUA_BAND_TS
+        if (r == 3) st_[0] = clock64();
+        if (r == 4) st4_ = clock64();
+#endif
+        if (r == 0) {
+          // kernel row ty of this branch's weights (issued during the last phase of the branch before, waited out by every wave, published by the barrier)
+          const unsigned wa = sw_a + (unsigned)(ty * 6 * 1024);
+          asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\tds_read_b128 %3, %6 offset:3072\n\t"
+                       "ds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(wf[0]), "=&v"(wf[1]), "=&v"(wf[2]), "=&v"(wf[3]), "=&v"(wf[4]), "=&v"(wf[5]) : "v"(wa) : "memory");
+        }
+        if (r == 6 && ty == 2 && b + 1 < nb) coef_read(nxt.ca, cf);     // rows s + 2 of the stages r >= 6 belong to the next phase: a new branch
+        if (r < WST && ty == 2) issue_w(b + 1, r * NW + wv);            // (the pieces overwritten are not read any more)
+        if (!dbg_nox) {
+          if (r + R < BR) issue_x(cur, r + R, so_iss);
+          else issue_x(nxt, r + R - BR, so_iss);
+        }
+        const bool tvm = (r + 2 < BR ? row_valid(cur, r + 2) : row_valid(nxt, r + 2 - BR)) && !dbg_notr;     // block-uniform
+        const bool tvr = (r + 3 < BR ? row_valid(cur, r + 3) : row_valid(nxt, r + 3 - BR)) && !dbg_notr;
+        u32x4_t& m0 = (r & 1) ? tb0 : ta0; u32x4_t& m1 = (r & 1) ? tb1 : ta1;       // read at the end of the stage before
+        u32x4_t& n0 = (r & 1) ? ta0 : tb0; u32x4_t& n1 = (r & 1) ? ta1 : tb1;
+        auto mfmas = [&]() {
+          if (dbg_nomfma) return;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k], fx[k], acc[r], 0, 0, 0);
+        };
+        auto pass = [&]() {
+          asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");              // row s + 3 has landed (this wave's pieces)
+          RUA_BST(GB ? 2 : 4);
+          if (tvr) row_read(so3, n0, n1);
+          if (tvm) { row_math1(m0, cf); row_math1(m1, cf); row_write(so2, m0, m1); }
+          RUA_BST(GB ? 3 : 5);
+        };
+        RUA_BST(1);
+        if constexpr (!GB) {
+          mfmas();
+          __builtin_amdgcn_sched_barrier(0);
+          RUA_BST(2);
+          frag_read(so1, r + 1 < BR ? boff : boffn, fx);
+          RUA_BST(3);
+          pass();
+        } else {
+          pass();
+          __builtin_amdgcn_sched_barrier(0);
+          mfmas();
+          __builtin_amdgcn_sched_barrier(0);
+          RUA_BST(4);
+          frag_read(so1, r + 1 < BR ? boff : boffn, fx);
+          RUA_BST(5);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]), "+v"(fx[3]), "+v"(fx[4]), "+v"(fx[5]), "+v"(n0), "+v"(n1) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef RUA_BAND_TS
+        if (r == 3) { st_[6] = clock64(); if (ph == 4 && lane == 0 && bid == 100 && (wv == 0 || wv == NW / 2)) for (int i = 0; i < 7; ++i) g_band_ts[96 + (GB ? 8 : 0) + i] = st_[i]; }
+        if (r == 4 && ph == 4 && lane == 0 && bid == 100 && (wv == 0 || wv == NW / 2)) g_band_ts[96 + (GB ? 8 : 0) + 7] = st4_;
+#endif
+        so_iss = so1; so1 = so2; so2 = so3; so3 = slot_next(so3);
+      }
+      cur = nxt;
+      nxt = phase(ph + 2);
+      RUA_BTS(3 + ph);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");     // the over-issued DMAs of the last stages
+    RUA_BTS(16);
+
+    // ---- epilogue: bias sum + residual, one write of the band (conv_band32) ---------------------------------------------------------
+    const size_t pix0 = (size_t)((n_ * H + h0) * W + o);
+    uint4 rv[BR][2];
+#pragma unroll
+    for (int r = 0; r < BR; ++r)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        rv[r][g] = q.res ? ldg16(q.res + ((pix0 + (size_t)r * W) * C + 16 * g + 8 * kh) * 2) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < BR; ++r) {
+      float v[2][8];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = acc[r][(2 * g) * 4 + j], b2 = acc[r][(2 * g + 1) * 4 + j];
+          if (g == 0 && j == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+          else asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+          v[g][j] = a;
+          v[g][4 + j] = b2;
+        }
+      unsigned char* yrow = q.y + ((pix0 + (size_t)r * W) * C) * 2;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int co = 16 * g + 8 * kh;
+        float a8[8];
+        ET<T>::unpack(rv[r][g], a8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[g][j] += tab[TAB_BIAS + co + j] + a8[j];
+        stg16(yrow + co * 2, ET<T>::pack(v[g]));
+      }
+    }
+    RUA_BTS(17);
+  };
+  if (wv < NW / 2 || (q.dbg & 32)) run(std::false_type{});
+  else run(std::true_type{});
+}
+
+template <int NW, int R> __global__ __launch_bounds__(NW * 64) void conv_band32s(const BandK q) { conv_band32s_body<NW, R>(q); }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 static thread_local int g_sum_last_kernel = 0;
@@ -452,7 +820,19 @@ extern "C" int rua_conv_fwd_sum(const rua_conv_desc* d, int n, void* stream) {
 #define RUA_BAND_GO(NW_, FW_, SLOT_) do { \
     if (!attr[SLOT_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band32<NW_, 8, 4, FW_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[SLOT_] = true; } \
     hipLaunchKernelGGL((conv_band32<NW_, 8, 4, FW_>), dim3(q.njobs), dim3(NW_ * 64), smem, st, q); } while (0)
-  if (nw == 8 && fullw && (q.dbg & 8)) {                 // experiment: the 6-slot ring (4 rows in flight instead of 2)
+  if (g_tune.band_stag && fullw && q.has_bn && q.in_relu) {
+    // conv_band32s: R slots by tuning key (band_stag = number of ring slots; 1 = the default of the shape)
+    const int want = g_tune.band_stag >= 4 ? g_tune.band_stag : (nw == 8 ? 7 : 6);
+    static RuaPerDevFlag sattr[4];
+#define RUA_BANDS_GO(NW_, R_, SLOT_) do { \
+      const int smem_s = R_ * (sw + 64) * 64 + 18 * 1024 + (4 * 64 + 32 + 64) * 4; \
+      bool& a_ = sattr[SLOT_].get(); \
+      if (!a_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band32s<NW_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a_ = true; } \
+      hipLaunchKernelGGL((conv_band32s<NW_, R_>), dim3(q.njobs), dim3(NW_ * 64), smem_s, st, q); } while (0)
+    if (nw == 8) { if (want >= 7) RUA_BANDS_GO(8, 7, 0); else RUA_BANDS_GO(8, 6, 1); }
+    else { if (want >= 6) RUA_BANDS_GO(4, 6, 2); else RUA_BANDS_GO(4, 5, 3); }
+#undef RUA_BANDS_GO
+  } else if (nw == 8 && fullw && (q.dbg & 8)) {                 // experiment: the 6-slot ring (4 rows in flight instead of 2)
     static thread_local bool a6 = false;
     const int smem6 = 6 * (sw + 64) * 64 + 18 * 1024 + nw * 1024 + (4 * 64 + 32) * 4;
     if (!a6) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band32<8, 8, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a6 = true; }

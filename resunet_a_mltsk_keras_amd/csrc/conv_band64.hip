@@ -81,38 +81,8 @@ __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
     tab[4 * 128 + tid] = b;
   }
   if (q.has_fold) {
-    constexpr int NG = NT / 64;
-    double* red = reinterpret_cast<double*>(smem);                    // [NG][2][64]: the ring is still empty
-    const int c = tid & 63, grp = tid >> 6;
-    for (int i = 0; i < nb; ++i) {
-      const rua_bn_fold& f = q.f[i];
-      double a1 = 0, a2 = 0;
-      for (int r = grp; r < f.replicas; r += NG) { a1 += f.stats[(size_t)r * 128 + c]; a2 += f.stats[(size_t)r * 128 + 64 + c]; }
-      red[(grp * 2) * 64 + c] = a1; red[(grp * 2 + 1) * 64 + c] = a2;
-      __syncthreads();
-      if (tid < 64) {
-        double s1 = 0, s2 = 0;
-        for (int g = 0; g < NG; ++g) { s1 += red[(g * 2) * 64 + tid]; s2 += red[(g * 2 + 1) * 64 + tid]; }
-        const double m = s1 / f.count;
-        double v = s2 / f.count - m * m;
-        if (v < 0) v = 0;
-        const double rs = 1.0 / sqrt(v + (double)f.eps);
-        const double sc = (double)f.gamma[tid] * rs;
-        const float scf = (float)sc, shf = (float)((double)f.beta[tid] - m * sc);
-        tab[i * 128 + tid] = scf; tab[i * 128 + 64 + tid] = shf;
-        if (job == 0) {
-          f.scale[tid] = scf; f.shift[tid] = shf;
-          if (f.mean) f.mean[tid] = (float)m;
-          if (f.rstd) f.rstd[tid] = (float)rs;
-          if (f.moving_mean) {
-            const double unb = f.bessel_n > 1 ? v * (f.bessel_n / (f.bessel_n - 1)) : v;
-            f.moving_mean[tid] = (float)((double)f.moving_mean[tid] * f.momentum + m * (1.0 - f.momentum));
-            f.moving_var[tid] = (float)((double)f.moving_var[tid] * f.momentum + unb * (1.0 - f.momentum));
-          }
-        }
-      }
-      __syncthreads();
-    }
+    rua_fold_members<NT, 64>([&](int m) -> const rua_bn_fold& { return q.f[m]; }, [](int) { return true; }, nb, job == 0, reinterpret_cast<double*>(smem), tid,
+                             [&](int m, int c, float scf, float shf) { tab[m * 128 + c] = scf; tab[m * 128 + 64 + c] = shf; });
   } else if (tid < 64) {
     for (int i = 0; i < nb; ++i) {
       tab[i * 128 + tid] = q.in_scale[i] ? q.in_scale[i][tid] : 1.f;

@@ -14,15 +14,24 @@ template <typename T> __device__ __forceinline__ void ld8(const unsigned char* b
 }
 
 // ---- stem ------------------------------------------------------------------------------
-template <typename T>
+template <typename T> __device__ __forceinline__ float stored_value(float v);          // v as the storage type holds it
+template <> __device__ __forceinline__ float stored_value<float>(float v) { return v; }
+template <> __device__ __forceinline__ float stored_value<bf16_t>(float v) { return (float)(__bf16)v; }
+template <typename T, bool STATS>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                        unsigned char* y, long long M, int Cin, int Cout) {
-  extern __shared__ float sw[];                       // [Cout][Cin] then [Cout]
+                                                        unsigned char* y, long long M, int Cin, int Cout, double* stats, int replicas) {
+  extern __shared__ float sw[];                       // [Cout][Cin] then [Cout]; STATS: then [4 waves][2][Cout] partial sums
   for (int i = threadIdx.x; i < Cout * Cin; i += 256) sw[i] = w[i];
   for (int i = threadIdx.x; i < Cout; i += 256) sw[Cout * Cin + i] = b ? b[i] : 0.f;
   __syncthreads();
   const int CG8 = Cout / 8;
   const long long total = M * CG8;
+  // STATS (rua_stem_fwd_stats): per-channel sum / sum of squares of the output AS STORED (rounded to the storage type), the statistics the
+  // first BatchNorm of the encoder wants - the rua_col_stats pass over the tensor just written disappears.  CG8 divides 256 and the grid
+  // stride, so a thread keeps its channel group for the whole sweep and carries the 16 partial sums in registers
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long m = i / CG8; const int cg = (int)(i - m * CG8);
     float o[8];
@@ -34,6 +43,29 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
       for (int j = 0; j < 8; ++j) o[j] = fmaf(xv, sw[(cg * 8 + j) * Cin + c], o[j]);
     }
     st8<T>(y, (size_t)m * Cout + cg * 8, o);
+    if constexpr (STATS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float v = stored_value<T>(o[j]); s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+    }
+  }
+  if constexpr (STATS) {
+    // lanes l and l ^ o (o = CG8 .. 32) hold the same channel group: fold with shuffles, then over the four waves through LDS, one fp64 atomic per
+    // channel, sum and block into the block's replica
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, cg = threadIdx.x % CG8;
+    for (int o = CG8; o < 64; o <<= 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
+    }
+    float* red = sw + Cout * Cin + Cout;
+    if (lane < CG8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { red[(wid * 2) * Cout + cg * 8 + j] = s1[j]; red[(wid * 2 + 1) * Cout + cg * 8 + j] = s2[j]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * Cout; i += 256) {
+      const float t = (red[i] + red[2 * Cout + i]) + (red[4 * Cout + i] + red[6 * Cout + i]);
+      unsafeAtomicAdd(&stats[(size_t)(blockIdx.x % replicas) * 2 * Cout + i], (double)t);
+    }
   }
 }
 
@@ -103,17 +135,36 @@ __global__ __launch_bounds__(STEM_NT) void stem_bwd_kernel(const float* __restri
   }
 }
 
-extern "C" int rua_stem_fwd(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, void* stream) {
-  RUA_CHECK_ARG(x && w && y && M > 0, "rua_stem_fwd: bad arguments");
-  RUA_CHECK_ARG(Cin >= 1 && Cin <= 16, "rua_stem_fwd: Cin=%d must be in 1..16", Cin);
-  RUA_CHECK_ARG(Cout % 8 == 0 && Cout <= 256, "rua_stem_fwd: Cout=%d must be a multiple of 8 (<=256)", Cout);
-  const size_t smem = (size_t)(Cout * Cin + Cout) * 4;
-  int64_t g = (M * (Cout / 8) + 255) / 256; if (g > 4096) g = 4096;
+static int stem_fwd_launch(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, double* stats, int replicas, void* stream,
+                           const char* who) {
+  RUA_CHECK_ARG(x && w && y && M > 0, "%s: bad arguments", who);
+  RUA_CHECK_ARG(Cin >= 1 && Cin <= 16, "%s: Cin=%d must be in 1..16", who, Cin);
+  RUA_CHECK_ARG(Cout % 8 == 0 && Cout <= 256, "%s: Cout=%d must be a multiple of 8 (<=256)", who, Cout);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout);
-  else hipLaunchKernelGGL((stem_fwd_kernel<float>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout);
-  RUA_LAUNCH_CHECK("rua_stem_fwd");
+  int64_t g = (M * (Cout / 8) + 255) / 256;
+  if (stats) {
+    // (every block ends with 2 Cout fp64 atomics into its replica: few, long blocks - two per CU)
+    RUA_CHECK_ARG(replicas >= 1 && 256 % (Cout / 8) == 0, "%s: replicas=%d, Cout=%d", who, replicas, Cout);
+    const int64_t cap = 2 * (int64_t)rua_cu_count();
+    if (g > cap) g = cap;
+    const size_t smem = (size_t)(Cout * Cin + Cout + 8 * Cout) * 4;
+    if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, true>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, stats, replicas);
+    else hipLaunchKernelGGL((stem_fwd_kernel<float, true>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, stats, replicas);
+  } else {
+    if (g > 4096) g = 4096;
+    const size_t smem = (size_t)(Cout * Cin + Cout) * 4;
+    if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, false>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, nullptr, 1);
+    else hipLaunchKernelGGL((stem_fwd_kernel<float, false>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, nullptr, 1);
+  }
+  RUA_LAUNCH_CHECK(who);
   return RUA_OK;
+}
+extern "C" int rua_stem_fwd(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, void* stream) {
+  return stem_fwd_launch(x, w, b, y, M, Cin, Cout, dtype, nullptr, 1, stream, "rua_stem_fwd");
+}
+extern "C" int rua_stem_fwd_stats(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, double* stats, int replicas, void* stream) {
+  RUA_CHECK_ARG(stats != nullptr, "rua_stem_fwd_stats: stats is NULL");
+  return stem_fwd_launch(x, w, b, y, M, Cin, Cout, dtype, stats, replicas, stream, "rua_stem_fwd_stats");
 }
 
 extern "C" int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db, int64_t M, int Cin, int Cout, int dtype, void* stream) {

@@ -1427,7 +1427,12 @@ class Graph:
         stem = self.Lconv([Cin], w0, 1, mfma=False)
         c1 = self.new(self.B, H, W, w0)
         self.cur_tag, F.scope = "stem", "stem"
-        F.add("rua_stem_fwd", self.x_in.ptr, self.P(stem["segs"][0]["off"]), self.P(stem["bias"]), c1.ptr, c1.M, Cin, w0, self.dt)
+        if tr and getattr(self.e, "stem_stats", True):
+            # the statistics the first BatchNorm of the encoder needs, from the kernel that writes the tensor (no rua_col_stats pass over it)
+            c1.stats = self.stat(w0, 2 * 256, burst=True)
+            F.add("rua_stem_fwd_stats", self.x_in.ptr, self.P(stem["segs"][0]["off"]), self.P(stem["bias"]), c1.ptr, c1.M, Cin, w0, self.dt, c1.stats.ptr, c1.stats.R)
+        else:
+            F.add("rua_stem_fwd", self.x_in.ptr, self.P(stem["segs"][0]["off"]), self.P(stem["bias"]), c1.ptr, c1.M, Cin, w0, self.dt)
         if tr:
             def stem_back():
                 self.bwd.add("rua_stem_bwd", self.x_in.ptr, c1.grad.ptr, self.G(stem["segs"][0]["off"]), self.G(stem["bias"]),
@@ -1558,6 +1563,7 @@ class Engine:
         self._t_dev, self._lr_base_dev = -1, None                                         # what lr_state holds (host shadow)
         self._dp_fence = torch.zeros(16, dtype=torch.float32, device=self.dev)            # see _graph_step_dp
         self.use_graph = True
+        self.stem_stats = os.environ.get("RUA_STEM_STATS", "1") != "0"     # rua_stem_fwd_stats instead of a rua_col_stats pass over the stem's output
         self._captured: Dict[int, object] = {}
         self._captured_eval: Dict[int, object] = {}        # batch -> graph of the inference forward (False: capture failed)
         self._eval_seen = set()

@@ -595,6 +595,20 @@ def test_stem_and_head_kernels():
         lib.call("rua_stem_fwd", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, Cin, Cout, dt, stream())
         torch.cuda.synchronize()
         assert rel_err(y.float().cpu().numpy(), x @ w.T + b) < tol(dt)
+        # rua_stem_fwd_stats: the same output bit for bit + the statistics rua_col_stats takes from it (of the values as stored), at a size with
+        # several blocks, a ragged tail and more blocks than replicas
+        for Ms, R in ((M, 4), (70001, 8)):
+            xs = f(rng.standard_normal((Ms, Cin)))
+            y0 = torch.empty((Ms, Cout), dtype=tdt(dt), device=dev()); y1 = torch.empty_like(y0)
+            st = torch.zeros(R * 2 * Cout, dtype=torch.float64, device=dev()); ref = torch.zeros_like(st)
+            lib.call("rua_stem_fwd", xs.data_ptr(), wd.data_ptr(), bd.data_ptr(), y0.data_ptr(), Ms, Cin, Cout, dt, stream())
+            lib.call("rua_stem_fwd_stats", xs.data_ptr(), wd.data_ptr(), bd.data_ptr(), y1.data_ptr(), Ms, Cin, Cout, dt, st.data_ptr(), R, stream())
+            lib.call("rua_col_stats", y0.data_ptr(), Ms, Cout, ref.data_ptr(), R, dt, stream())
+            torch.cuda.synchronize()
+            assert torch.equal(y0, y1)
+            got, want = st.view(R, 2 * Cout).sum(0).cpu().numpy(), ref.view(R, 2 * Cout).sum(0).cpu().numpy()
+            exact = np.concatenate([y0.double().sum(0).cpu().numpy(), (y0.double() ** 2).sum(0).cpu().numpy()])
+            assert np.abs(got - exact).max() <= 2e-6 * Ms + np.abs(want - exact).max(), (np.abs(got - exact).max(), np.abs(want - exact).max())
         dy = rng.standard_normal((M, Cout)).astype(np.float32)
         dyd = to_dev(dy, dt)
         dw = torch.zeros((Cout, Cin), device=dev()); db = torch.zeros(Cout, device=dev())

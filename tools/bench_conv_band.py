@@ -91,7 +91,7 @@ def main():
             timed(f"first convs, grouped (conv_strip32s_g) dbg={dbg}", lambda: lib.call("rua_conv_fwd_group", first, nb, s), 2 * nb)
         lib.set_tuning(band_dbg=0)
     if only in (None, "sum"):
-        lib.set_tuning(conv_band=1)
+        lib.set_tuning(conv_band=1, band_stag=int(os.environ.get("BB_STAG", "1")))      # 0: conv_band32, 4 / 6: conv_band32s with that many ring slots
         for dbg in [int(v) for v in os.environ.get("BB_DBG", "0").split(",")]:
             lib.set_tuning(band_dbg=dbg)
             timed(f"second convs, rua_conv_fwd_sum (conv_band32) dbg={dbg}", lambda: lib.call("rua_conv_fwd_sum", second, nb, s), nb + 2)
