@@ -406,11 +406,10 @@ __device__ __forceinline__ void conv_band32s_body(const BandK& q) {
   constexpr int C = 32, NT = NW * 64, SW = NW * 32, HALO = 32, BR = 8;
   constexpr int SPX = SW + 2 * HALO, SLOT = SPX * 64;
   constexpr int NPX = 2;                                // SW * 64 / 1024 = 2 NW row DMA instructions: two per wave
-  constexpr int NWAIT = (R - 3) * NPX;                  // operations behind the DMAs of row s + 3 when stage s waits for them (rows s + 4 .. s + R)
   constexpr int WPIECES = 18, WST = (WPIECES + NW - 1) / NW;
-  // the weights of branch b + 1 are issued in stages 0 .. WST-1 of the last phase of branch b and read after the barrier that ends it: at the wait of
-  // that phase's last stage at least NWAIT younger operations must lie behind them
-  static_assert(WST <= BR && BR - WST >= R - 3 && R >= 5 && R <= BR, "pipeline depths");
+  // the weights of branch b + 1 are issued in stages 2 .. WST+1 of the last phase of branch b and read after the barrier that ends it: at the wait of
+  // that phase's last stage (2 NPX operations may remain) the row DMAs of stage 6 - 2 NPX of them, issued after the weights - lie behind them
+  static_assert(WST + 2 <= BR - 1 && R == 7 && R <= BR, "pipeline depths");
   constexpr unsigned ROW_OOB = 0x80000000u;
   constexpr int TAB_BIAS = 4 * 64, TAB_ZERO = 4 * 64 + 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -589,23 +588,23 @@ __device__ __forceinline__ void conv_band32s_body(const BandK& q) {
     };
     auto slot_next = [&](unsigned so) { return so + SLOT == (unsigned)(R * SLOT) ? 0u : so + SLOT; };
 
-    // ---- prologue: weights of branch 0 and rows 0 .. R-1 in flight, everything landed; rows 0 and 1 normalised, row 2 read -----------
+    // ---- prologue: weights of branch 0 and rows 0 .. R-2 in flight, everything landed; rows 0 .. 2 normalised, row 3 read --------------
     Phase cur = phase(0), nxt = phase(1);
 #pragma unroll
     for (int i = 0; i < WST; ++i) issue_w(0, i * NW + wv);
 #pragma unroll
-    for (int s = 0; s < R; ++s) issue_x(cur, s, (unsigned)(s * SLOT));            // R <= BR: all in phase 0
+    for (int s = 0; s < R - 1; ++s) issue_x(cur, s, (unsigned)(s * SLOT));        // R - 1 <= BR: all in phase 0
     Coef cf;
     coef_read(cur.ca, cf);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     u32x4_t ta0, ta1, tb0, tb1;                          // the pieces of the row being normalised / of the row after it
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 3; ++s)
       if (row_valid(cur, s) && !dbg_notr) {
         row_read((unsigned)(s * SLOT), ta0, ta1); lds_wait_rows(ta0, ta1);
         row_math1(ta0, cf); row_math1(ta1, cf); row_write((unsigned)(s * SLOT), ta0, ta1);
       }
-    row_read(2u * SLOT, ta0, ta1);
+    row_read(3u * SLOT, ta0, ta1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     bf16x8 fx[6];
@@ -617,24 +616,22 @@ __device__ __forceinline__ void conv_band32s_body(const BandK& q) {
     }
     RUA_BTS(2);
 
-    // slot byte offsets: so1 = row s + 1 (fragments), so2 = row s + 2 (written), so3 = row s + 3 (read), so_iss = row s (refilled with row s + R)
-    unsigned so_iss = 0, so1 = SLOT, so2 = 2 * SLOT, so3 = 3 * SLOT;
+    // slot byte offsets of the rows s - 1 and s (refilled with the rows s + R - 1 and s + R at the even stages), s + 1 (fragments), s + 3 (written),
+    // s + 4 (read)
+    unsigned so_m1 = (R - 1) * SLOT, so_0 = 0, so1 = SLOT, so2 = 2 * SLOT, so3 = 3 * SLOT, so4 = 4 * SLOT;
     for (int ph = 0; ph < 3 * nb; ++ph) {
       const int b = ph / 3, ty = ph - 3 * b;
       unsigned boff[3], boffn[3];                        // ... of this phase and of the next one (row s + 1 of the last stage belongs to it)
       boff_of(dil_of(b), boff);
       boff_of(dil_of(ty == 2 ? b + 1 : b), boffn);
       bf16x8 wf[6];
-#ifdef RUA_BAND_TS
-      unsigned long long st_[7], st4_ = 0;
-#endif
+      auto valid_at = [&](int k) { return (k < BR ? row_valid(cur, k) : row_valid(nxt, k - BR)) && !dbg_notr; };       // row k of this phase, k < 2 BR; block-uniform
 #pragma unroll
       for (int r = 0; r < BR; ++r) {
-        __builtin_amdgcn_s_barrier();
-#ifdef RUA_BAND_TS
-        if (r == 3) st_[0] = clock64();
-        if (r == 4) st4_ = clock64();
-#endif
+        // ONE barrier per two stages: what stage s reads of other waves' work - the in-place pass of row s + 1 - was written two stages
+        // earlier, i.e. before the last barrier whichever parity s has; the slots of the rows s - 1 and s are refilled behind the barrier of
+        // an even stage s (their fragments were read in the stages s - 2 and s - 1)
+        if ((r & 1) == 0) __builtin_amdgcn_s_barrier();
         if (r == 0) {
           // kernel row ty of this branch's weights (issued during the last phase of the branch before, waited out by every wave, published by the barrier)
           const unsigned wa = sw_a + (unsigned)(ty * 6 * 1024);
@@ -642,14 +639,15 @@ __device__ __forceinline__ void conv_band32s_body(const BandK& q) {
                        "ds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(wf[0]), "=&v"(wf[1]), "=&v"(wf[2]), "=&v"(wf[3]), "=&v"(wf[4]), "=&v"(wf[5]) : "v"(wa) : "memory");
         }
-        if (r == 6 && ty == 2 && b + 1 < nb) coef_read(nxt.ca, cf);     // rows s + 2 of the stages r >= 6 belong to the next phase: a new branch
-        if (r < WST && ty == 2) issue_w(b + 1, r * NW + wv);            // (the pieces overwritten are not read any more)
-        if (!dbg_nox) {
-          if (r + R < BR) issue_x(cur, r + R, so_iss);
-          else issue_x(nxt, r + R - BR, so_iss);
+        if (r == 5 && ty == 2 && b + 1 < nb) coef_read(nxt.ca, cf);     // rows s + 3 of the stages r >= 5 belong to the next phase: a new branch
+        // the next branch's weights from stage 2 on: the pieces of kernel row 2 are overwritten by the second round of instructions, and another
+        // wave may still be reading them at stage 0 until the barrier of stage 2
+        if (r >= 2 && r < 2 + WST && ty == 2) issue_w(b + 1, (r - 2) * NW + wv);
+        if ((r & 1) == 0 && !dbg_nox) {
+          if (r + R - 1 < BR) issue_x(cur, r + R - 1, so_m1); else issue_x(nxt, r + R - 1 - BR, so_m1);
+          if (r + R < BR) issue_x(cur, r + R, so_0); else issue_x(nxt, r + R - BR, so_0);
         }
-        const bool tvm = (r + 2 < BR ? row_valid(cur, r + 2) : row_valid(nxt, r + 2 - BR)) && !dbg_notr;     // block-uniform
-        const bool tvr = (r + 3 < BR ? row_valid(cur, r + 3) : row_valid(nxt, r + 3 - BR)) && !dbg_notr;
+        const bool tvm = valid_at(r + 3), tvr = valid_at(r + 4);
         u32x4_t& m0 = (r & 1) ? tb0 : ta0; u32x4_t& m1 = (r & 1) ? tb1 : ta1;       // read at the end of the stage before
         u32x4_t& n0 = (r & 1) ? ta0 : tb0; u32x4_t& n1 = (r & 1) ? ta1 : tb1;
         auto mfmas = [&]() {
@@ -658,36 +656,27 @@ __device__ __forceinline__ void conv_band32s_body(const BandK& q) {
           for (int k = 0; k < 6; ++k) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k], fx[k], acc[r], 0, 0, 0);
         };
         auto pass = [&]() {
-          asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");              // row s + 3 has landed (this wave's pieces)
-          RUA_BST(GB ? 2 : 4);
-          if (tvr) row_read(so3, n0, n1);
-          if (tvm) { row_math1(m0, cf); row_math1(m1, cf); row_write(so2, m0, m1); }
-          RUA_BST(GB ? 3 : 5);
+          // row s + 4 has landed (this wave's pieces): behind it lie the rows s + 5 .. s + 7 at an even stage, s + 5 and s + 6 at an odd one
+          if ((r & 1) == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * NPX) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPX) : "memory");
+          if (tvr) row_read(so4, n0, n1);
+          if (tvm) { row_math1(m0, cf); row_math1(m1, cf); row_write(so3, m0, m1); }
         };
-        RUA_BST(1);
         if constexpr (!GB) {
           mfmas();
           __builtin_amdgcn_sched_barrier(0);
-          RUA_BST(2);
           frag_read(so1, r + 1 < BR ? boff : boffn, fx);
-          RUA_BST(3);
           pass();
         } else {
           pass();
           __builtin_amdgcn_sched_barrier(0);
           mfmas();
           __builtin_amdgcn_sched_barrier(0);
-          RUA_BST(4);
           frag_read(so1, r + 1 < BR ? boff : boffn, fx);
-          RUA_BST(5);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]), "+v"(fx[3]), "+v"(fx[4]), "+v"(fx[5]), "+v"(n0), "+v"(n1) :: "memory");
         __builtin_amdgcn_sched_barrier(0);
-#ifdef RUA_BAND_TS
-        if (r == 3) { st_[6] = clock64(); if (ph == 4 && lane == 0 && bid == 100 && (wv == 0 || wv == NW / 2)) for (int i = 0; i < 7; ++i) g_band_ts[96 + (GB ? 8 : 0) + i] = st_[i]; }
-        if (r == 4 && ph == 4 && lane == 0 && bid == 100 && (wv == 0 || wv == NW / 2)) g_band_ts[96 + (GB ? 8 : 0) + 7] = st4_;
-#endif
-        so_iss = so1; so1 = so2; so2 = so3; so3 = slot_next(so3);
+        so_m1 = so_0; so_0 = so1; so1 = so2; so2 = so3; so3 = so4; so4 = slot_next(so4);
       }
       cur = nxt;
       nxt = phase(ph + 2);
@@ -829,8 +818,9 @@ extern "C" int rua_conv_fwd_sum(const rua_conv_desc* d, int n, void* stream) {
       bool& a_ = sattr[SLOT_].get(); \
       if (!a_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band32s<NW_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a_ = true; } \
       hipLaunchKernelGGL((conv_band32s<NW_, R_>), dim3(q.njobs), dim3(NW_ * 64), smem_s, st, q); } while (0)
-    if (nw == 8) { if (want >= 7) RUA_BANDS_GO(8, 7, 0); else RUA_BANDS_GO(8, 6, 1); }
-    else { if (want >= 6) RUA_BANDS_GO(4, 6, 2); else RUA_BANDS_GO(4, 5, 3); }
+    (void)want;
+    if (nw == 8) RUA_BANDS_GO(8, 7, 0);
+    else RUA_BANDS_GO(4, 7, 2);
 #undef RUA_BANDS_GO
   } else if (nw == 8 && fullw && (q.dbg & 8)) {                 // experiment: the 6-slot ring (4 rows in flight instead of 2)
     static thread_local bool a6 = false;
