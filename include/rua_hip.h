@@ -218,6 +218,10 @@ int rua_head_fwd(const void* x, const float* w, const float* b, float* z, float*
  * rua_seg_metrics (NULL: not); both zeroed by the caller.  Replaces those passes over p (train_ISPRS.py:456-461). */
 int rua_head_fwd_loss(const void* x, const float* w, const float* b, float* z, float* p, const float* y, double* tanimoto_sums,
                       double* metrics, int B, int64_t HW, int Cin, int Cout, int act, int dtype, void* stream);
+/* the same with tanimoto_sums kept in sums_replicas (1..64) copies, [sums_replicas][B][Cout][6]: a block adds into ONE of them, so ~64 blocks of a sample
+ * do not queue up on the same 36 addresses at the end of the launch; rua_tanimoto_finalize_rep adds the copies. */
+int rua_head_fwd_loss_rep(const void* x, const float* w, const float* b, float* z, float* p, const float* y, double* tanimoto_sums,
+                          int sums_replicas, double* metrics, int B, int64_t HW, int Cin, int Cout, int act, int dtype, void* stream);
 /* scratch (optional, >= 1024*(Cout*Cin+Cout)*4 bytes): per-block partials + fixed-order reduce instead of fp32 atomics.
  * mask_dx: x is the output of a fused ReLU (the heads' 3x3 conv + relu, model2.py:153-158): dx *= (x > 0), i.e. the ReLU's
  * backward is applied here instead of in a pass of its own */
@@ -342,6 +346,10 @@ int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t HW, int C, 
  * per_sample[B] (optional): the (B,) vector the reference's loss function returns (multitasking_utils.py:84) */
 int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,
                           float* per_sample, void* stream);
+/* sums [replicas + 1][B][C][6]: `replicas` copies filled by rua_head_fwd_loss_rep; their sum is stored into the extra slot behind them (plain stores:
+ * idempotent) and finalised as above. */
+int rua_tanimoto_finalize_rep(double* sums, int replicas, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,
+                              float* per_sample, void* stream);
 /* Tanimoto_loss(label, pred) itself (multitasking_utils.py:38-68), shape (B,): take the sums with p := label, y := pred
  * (rua_tanimoto_sums(label, pred, ...)), then per_sample[n] = (sum_c w_c*Spl + 1e-5) / (sum_c w_c*(Ssq - Spl) + 1e-5) with
  * w_c = 1 / (mean_n volume of the FIRST argument)^2, inf -> largest finite weight (:46-53); mean_out[0] = mean_n. */

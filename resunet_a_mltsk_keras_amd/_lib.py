@@ -109,6 +109,7 @@ _SIGS = {
     "rua_stem_bwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "rua_head_fwd": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp], i32),
     "rua_head_fwd_loss": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp], i32),
+    "rua_head_fwd_loss_rep": ([vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i32, i32, i32, vp], i32),
     "rua_head_bwd": ([vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp], i32),
     "rua_head_bwd_sums": ([vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp], i32),
     "rua_col_stats": ([vp, i64, i32, vp, i32, i32, vp], i32),
@@ -140,6 +141,7 @@ _SIGS = {
     "rua_fill_zero": ([vp, i64, vp], i32),
     "rua_tanimoto_sums": ([vp, vp, i32, i64, i32, vp, vp], i32),
     "rua_tanimoto_finalize": ([vp, i32, i64, i32, f32, vp, vp, vp, vp], i32),
+    "rua_tanimoto_finalize_rep": ([vp, i32, i32, i64, i32, f32, vp, vp, vp, vp], i32),
     "rua_tanimoto_ratio": ([vp, i32, i32, vp, vp, vp], i32),
     "rua_pixel_loss": ([i32, vp, vp, vp, vp, i64, i32, vp, vp, vp], i32),
     "rua_head_dz": ([i32, i32, vp, vp, vp, vp, f32, i32, i64, i32, vp, vp], i32),

@@ -548,32 +548,38 @@ extern "C" int rua_bn_fwd(const rua_bn_fwd_desc* d, void* stream) {
 template <typename T, int NB, bool MASKED, bool DXS = false>
 __device__ __forceinline__ void bn_bwd_body(const rua_bn_bwd_desc& p, long long pieces, int CG) {
   constexpr int VEC = ET<T>::VEC;
-  extern __shared__ float tab[];                       // [nb][3][C] : A, ms, mt ; then [2][C] : sumB, sumC
+  extern __shared__ float tab[];                       // [nb][3][C] : A, ms, mt ; then [2][C] : sumB, sumC ; then [nb][2][C] : the branches' terms of sumB, sumC
   const int C = p.C;
   float* tB = tab + p.nb * 3 * C;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float sb = 0.f, sc_ = 0.f;
-    for (int b = 0; b < p.nb; ++b) {
-      const rua_bn_bwd_branch& br = p.br[b];
-      double sg, sgx;
-      replica_sum(br.stats2, br.replicas, C, c, sg, sgx);
-      const double mu = br.mean[c], r = br.rstd[c], gm = br.gamma[c];
-      if (br.stats2_out) {                             // slot 1 holds sum g * (scale x + shift): back to sum g * x
-        const double sc = br.scale[c], sh = br.shift[c];
-        sgx = sc != 0.0 ? (sgx - sh * sg) / sc : mu * sg;
-      }
-      const double dga = r * (sgx - mu * sg);
-      const double s = gm * r;
-      tab[(b * 3) * C + c] = (float)s;
-      tab[(b * 3 + 1) * C + c] = (p.masked && br.scale) ? br.scale[c] : 1.f;
-      tab[(b * 3 + 2) * C + c] = (p.masked && br.shift) ? br.shift[c] : 0.f;
-      sb += (float)(-s * r * dga / p.count);
-      sc_ += (float)(-s * sg / p.count + s * r * mu * dga / p.count);
-      if (blockIdx.x == 0) {
-        if (br.dgamma) br.dgamma[c] += (float)dga;
-        if (br.dbeta) br.dbeta[c] += (float)sg;
-      }
+  float* tT = tB + 2 * C;
+  // one thread per (branch, channel): the branches' statistics are fetched side by side - one chain of dependent round trips for
+  // the block instead of one per branch (a four-branch launch began with ~8 of them before its first tensor load)
+  for (int it = threadIdx.x; it < p.nb * C; it += 256) {
+    const int b = it / C, c = it - b * C;
+    const rua_bn_bwd_branch& br = p.br[b];
+    double sg, sgx;
+    replica_sum(br.stats2, br.replicas, C, c, sg, sgx);
+    const double mu = br.mean[c], r = br.rstd[c], gm = br.gamma[c];
+    if (br.stats2_out) {                               // slot 1 holds sum g * (scale x + shift): back to sum g * x
+      const double sc = br.scale[c], sh = br.shift[c];
+      sgx = sc != 0.0 ? (sgx - sh * sg) / sc : mu * sg;
     }
+    const double dga = r * (sgx - mu * sg);
+    const double s = gm * r;
+    tab[(b * 3) * C + c] = (float)s;
+    tab[(b * 3 + 1) * C + c] = (p.masked && br.scale) ? br.scale[c] : 1.f;
+    tab[(b * 3 + 2) * C + c] = (p.masked && br.shift) ? br.shift[c] : 0.f;
+    tT[(b * 2) * C + c] = (float)(-s * r * dga / p.count);
+    tT[(b * 2 + 1) * C + c] = (float)(-s * sg / p.count + s * r * mu * dga / p.count);
+    if (blockIdx.x == 0) {
+      if (br.dgamma) br.dgamma[c] += (float)dga;
+      if (br.dbeta) br.dbeta[c] += (float)sg;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {         // the branches' terms in branch order (the sums of the sequential form, bit for bit)
+    float sb = 0.f, sc_ = 0.f;
+    for (int b = 0; b < p.nb; ++b) { sb += tT[(b * 2) * C + c]; sc_ += tT[(b * 2 + 1) * C + c]; }
     tB[c] = sb; tB[C + c] = sc_;
   }
   __syncthreads();
@@ -740,7 +746,7 @@ extern "C" int rua_bn_bwd_group(const rua_bn_bwd_desc* d, int n, void* stream) {
     return RUA_OK;
   }
   const int CG = d[0].C / vec;
-  const size_t smem = (size_t)(1 * 3 + 2) * d[0].C * 4;
+  const size_t smem = (size_t)(1 * 5 + 2) * d[0].C * 4;
   BnBwdG a;
   long long pieces = 0;                                   // the grid is sized for the largest member (the sweep is grid-stride)
   for (int i = 0; i < n; ++i) { a.k[i] = d[i]; a.pieces[i] = d[i].M * CG; if (a.pieces[i] > pieces) pieces = a.pieces[i]; }
@@ -772,7 +778,7 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
     RUA_CHECK_ARG(br.g && br.stats2 && br.replicas >= 1 && br.gamma && br.mean && br.rstd, "rua_bn_bwd: null branch pointer");
     if (br.replicas > rmax) rmax = br.replicas;
   }
-  size_t smem = (size_t)(d->nb * 3 + 2) * d->C * 4;
+  size_t smem = (size_t)(d->nb * 5 + 2) * d->C * 4;
   RUA_CHECK_ARG(smem <= 64 * 1024, "rua_bn_bwd: coefficient table too large");
   const int CG = d->C / vec;
   if (d->skip_stats) {

@@ -139,13 +139,28 @@ extern "C" int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t 
 // the first term come from the PREDICTION volumes (and carry gradient); loss2 = T(1-label, 1-pred).
 // single != 0: Tanimoto_loss(label, pred) itself (multitasking_utils.py:38-68) for sums taken with p := label, y := pred -
 // the first term's ratio (N1 + 1e-5) / (D1 + 1e-5) with the class weights from the volumes of the FIRST argument.
-__global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B, int C, float grad_scale, double* loss_out, float* coef, float* per_sample,
-                                         int single) {
+__global__ void tanimoto_finalize_kernel(const double* sums, int B, int C, float grad_scale, double* loss_out, float* coef, float* per_sample,
+                                         int single, int replicas) {
   __shared__ double w1[8], w2[8], v1[8], kap[8];
   __shared__ double E1[256], F1[256], E2[256], F2[256];
   __shared__ int inf1[8];
   const int t = threadIdx.x;
   const double smooth = 1e-5;
+  if (replicas > 1) {
+    // sums[replicas + 1][B][C][6]: the producers added into `replicas` copies (rua_head_fwd_loss_rep: fewer same-address atomics in a row); their sum,
+    // in replica order, goes into the extra slot behind them by plain stores (idempotent: calling this twice gives the same result) and is what the
+    // rest of the kernel reads
+    const int ne = B * C * 6;
+    double* folded = const_cast<double*>(sums) + (size_t)replicas * ne;
+    for (int i = t; i < ne; i += blockDim.x) {
+      double a = 0;
+      for (int r = 0; r < replicas; ++r) a += sums[(size_t)r * ne + i];
+      folded[i] = a;
+    }
+    __threadfence_block();
+    __syncthreads();
+    sums = folded;
+  }
   if (t < C) {
     double a = 0, b = 0;
     for (int n = 0; n < B; ++n) { a += sums[((size_t)n * C + t) * 6 + 0]; b += sums[((size_t)n * C + t) * 6 + 1]; }
@@ -206,20 +221,25 @@ __global__ void tanimoto_finalize_kernel(const double* __restrict__ sums, int B,
   }
 }
 
-extern "C" int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,
-                                     float* per_sample, void* stream) {
+extern "C" int rua_tanimoto_finalize_rep(double* sums, int replicas, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,
+                                         float* per_sample, void* stream) {
   RUA_CHECK_ARG(sums && loss_out && B > 0 && B <= 256, "rua_tanimoto_finalize: B must be in 1..256");
   RUA_CHECK_ARG(C >= 1 && C <= 8, "rua_tanimoto_finalize: C=%d must be in 1..8", C);
+  RUA_CHECK_ARG(replicas >= 1 && replicas <= 64, "rua_tanimoto_finalize_rep: replicas=%d must be in 1..64", replicas);
   (void)HW;
-  hipLaunchKernelGGL(tanimoto_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, B, C, grad_scale, loss_out, coef, per_sample, 0);
+  hipLaunchKernelGGL(tanimoto_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)sums, B, C, grad_scale, loss_out, coef, per_sample, 0, replicas);
   RUA_LAUNCH_CHECK("rua_tanimoto_finalize");
   return RUA_OK;
+}
+extern "C" int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,
+                                     float* per_sample, void* stream) {
+  return rua_tanimoto_finalize_rep(const_cast<double*>(sums), 1, B, HW, C, grad_scale, loss_out, coef, per_sample, stream);      // one replica: sums is only read
 }
 
 extern "C" int rua_tanimoto_ratio(const double* sums, int B, int C, double* mean_out, float* per_sample, void* stream) {
   RUA_CHECK_ARG(sums && mean_out && per_sample && B > 0 && B <= 256, "rua_tanimoto_ratio: B must be in 1..256");
   RUA_CHECK_ARG(C >= 1 && C <= 8, "rua_tanimoto_ratio: C=%d must be in 1..8", C);
-  hipLaunchKernelGGL(tanimoto_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, B, C, 0.f, mean_out, (float*)nullptr, per_sample, 1);
+  hipLaunchKernelGGL(tanimoto_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, B, C, 0.f, mean_out, (float*)nullptr, per_sample, 1, 1);
   RUA_LAUNCH_CHECK("rua_tanimoto_ratio");
   return RUA_OK;
 }
@@ -280,7 +300,12 @@ extern "C" int rua_pixel_loss(int kind, const float* p, const float* z, const fl
 __global__ __launch_bounds__(256) void head_dz_kernel(int kind, int act, const float* __restrict__ p, const float* __restrict__ y,
                                                       const float* __restrict__ coef, const float* __restrict__ cw, float gs,
                                                       long long HW, long long M, int C, float* dz) {
-  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+  // blockIdx.y = sample (the Tanimoto coefficients are per sample and class: m / HW per pixel was a 64-bit division - ~100 vector instructions
+  // in a pass that moves 72 bytes per pixel)
+  const int n = blockIdx.y;
+  (void)M;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
+    const long long m = (long long)n * HW + i;
     float pv[8], yv[8], g[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { pv[c] = c < C ? p[m * C + c] : 0.f; yv[c] = c < C ? y[m * C + c] : 0.f; g[c] = 0.f; }
@@ -298,7 +323,6 @@ __global__ __launch_bounds__(256) void head_dz_kernel(int kind, int act, const f
       continue;
     }
     if (kind == RUA_LOSS_TANIMOTO) {
-      const int n = (int)(m / HW);
 #pragma unroll
       for (int c = 0; c < 8; ++c) if (c < C) { const float* k = coef + ((size_t)n * C + c) * 3; g[c] = fmaf(k[1], pv[c], fmaf(k[2], yv[c], k[0])); }
     } else if (kind == RUA_LOSS_WCE) {
@@ -346,8 +370,11 @@ extern "C" int rua_head_dz(int kind, int act, const float* p, const float* y, co
   RUA_CHECK_ARG(kind != RUA_LOSS_TANIMOTO || coef, "rua_head_dz: Tanimoto needs coefficients");
   RUA_CHECK_ARG(kind != RUA_LOSS_WCE || class_w, "rua_head_dz: weighted CE needs class weights");
   const int64_t M = (int64_t)B * HW;
-  int64_t g = (M + 255) / 256; if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(head_dz_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, kind, act, p, y, coef, class_w, grad_scale,
+  int64_t g = (HW + 255) / 256;
+  const int64_t cap = 4096 / B > 0 ? 4096 / B : 1;       // ~4096 blocks over the batch; blockIdx.y = sample
+  if (g > cap) g = cap;
+  RUA_CHECK_ARG(B <= 65535, "rua_head_dz: B=%d too large", B);
+  hipLaunchKernelGGL(head_dz_kernel, dim3((int)g, B), dim3(256), 0, (hipStream_t)stream, kind, act, p, y, coef, class_w, grad_scale,
                      (long long)HW, (long long)M, C, dz);
   RUA_LAUNCH_CHECK("rua_head_dz");
   return RUA_OK;

@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   __syncthreads();
   const int CG8 = Cout / 8;
   const long long total = M * CG8;
+  const bool pow2 = (CG8 & (CG8 - 1)) == 0;
+  const int cgsh = __builtin_ctz((unsigned)CG8);
   // STATS (rua_stem_fwd_stats): per-channel sum / sum of squares of the output AS STORED (rounded to the storage type), the statistics the
   // first BatchNorm of the encoder wants - the rua_col_stats pass over the tensor just written disappears.  CG8 divides 256 and the grid
   // stride, so a thread keeps its channel group for the whole sweep and carries the 16 partial sums in registers
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long m = i / CG8; const int cg = (int)(i - m * CG8);
+    const long long m = pow2 ? (i >> cgsh) : i / CG8; const int cg = (int)(i - m * CG8);
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = sw[Cout * Cin + cg * 8 + j];
@@ -65,6 +67,80 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < 2 * Cout; i += 256) {
       const float t = (red[i] + red[2 * Cout + i]) + (red[4 * Cout + i] + red[6 * Cout + i]);
       unsafeAtomicAdd(&stats[(size_t)(blockIdx.x % replicas) * 2 * Cout + i], (double)t);
+    }
+  }
+}
+
+// Register form of the stem (Cin <= 8, Cout / 8 dividing 256: the reference's 3 / 6 / 7 bands -> 32): a thread keeps its channel group for the whole
+// sweep, so its 8 x Cin weights live in registers (the LDS form above issues 8 x Cin broadcast reads per pixel piece: the launch was bound by
+// LDS instructions, 18 us for a 46 MB pass, 31 us with the statistics) and the input values of the NEXT pixel are loaded before the arithmetic of
+// this one.  Same order of operations per output value: bit-identical to the LDS form.
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256) void stem_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                            unsigned char* y, long long M, int Cin, int Cout, double* stats, int replicas) {
+  constexpr int CINP = 8;
+  extern __shared__ float sw[];                       // STATS: [4 waves][2][Cout] partial sums
+  const int CG8 = Cout / 8;
+  const int cg = threadIdx.x % CG8;
+  float wr[8][CINP], bias[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bias[j] = b ? b[cg * 8 + j] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CINP; ++c) wr[j][c] = c < Cin ? w[(cg * 8 + j) * Cin + c] : 0.f;
+  }
+  const long long total = M * CG8;
+  const long long stride = (long long)gridDim.x * 256;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  float xv[CINP], xn[CINP];
+  const int cgsh = __builtin_ctz((unsigned)CG8);      // CG8 divides 256: a power of two (m = i / CG8 as a 64-bit division was ~100 vector instructions per piece)
+  auto fetch = [&](long long ii, float* v) {
+    const long long m = ii >> cgsh;
+#pragma unroll
+    for (int c = 0; c < CINP; ++c) v[c] = c < Cin ? x[m * Cin + c] : 0.f;
+  };
+#pragma unroll
+  for (int c = 0; c < CINP; ++c) { xv[c] = 0.f; xn[c] = 0.f; }
+  if (i < total) fetch(i, xv);
+  for (; i < total; i += stride) {
+    if (i + stride < total) fetch(i + stride, xn);
+    const long long m = i >> cgsh;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bias[j];
+#pragma unroll
+    for (int c = 0; c < CINP; ++c) {
+      if (c < Cin) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(xv[c], wr[j][c], o[j]);
+      }
+    }
+    st8<T>(y, (size_t)m * Cout + cg * 8, o);
+    if constexpr (STATS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float v = stored_value<T>(o[j]); s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+    }
+#pragma unroll
+    for (int c = 0; c < CINP; ++c) xv[c] = xn[c];
+  }
+  if constexpr (STATS) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int o = CG8; o < 64; o <<= 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
+    }
+    float* red = sw;
+    if (lane < CG8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { red[(wid * 2) * Cout + cg * 8 + j] = s1[j]; red[(wid * 2 + 1) * Cout + cg * 8 + j] = s2[j]; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * Cout; k += 256) {
+      const float t = (red[k] + red[2 * Cout + k]) + (red[4 * Cout + k] + red[6 * Cout + k]);
+      unsafeAtomicAdd(&stats[(size_t)(blockIdx.x % replicas) * 2 * Cout + k], (double)t);
     }
   }
 }
@@ -142,6 +218,21 @@ static int stem_fwd_launch(const float* x, const float* w, const float* b, void*
   RUA_CHECK_ARG(Cout % 8 == 0 && Cout <= 256, "%s: Cout=%d must be a multiple of 8 (<=256)", who, Cout);
   hipStream_t st = (hipStream_t)stream;
   int64_t g = (M * (Cout / 8) + 255) / 256;
+  if (Cin <= 8 && 256 % (Cout / 8) == 0 && g_tune.stem_reg) {
+    RUA_CHECK_ARG(!stats || replicas >= 1, "%s: replicas=%d", who, replicas);
+    const int64_t cap = (stats ? 4 : 8) * (int64_t)rua_cu_count();      // STATS: every block ends with 2 Cout fp64 atomics into its replica
+    if (g > cap) g = cap;
+    const size_t smem = (size_t)(8 * Cout) * 4;
+    if (stats) {
+      if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_fwd_reg_kernel<bf16_t, true>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, stats, replicas);
+      else hipLaunchKernelGGL((stem_fwd_reg_kernel<float, true>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, stats, replicas);
+    } else {
+      if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_fwd_reg_kernel<bf16_t, false>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, nullptr, 1);
+      else hipLaunchKernelGGL((stem_fwd_reg_kernel<float, false>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, nullptr, 1);
+    }
+    RUA_LAUNCH_CHECK(who);
+    return RUA_OK;
+  }
   if (stats) {
     // (every block ends with 2 Cout fp64 atomics into its replica: few, long blocks - two per CU)
     RUA_CHECK_ARG(replicas >= 1 && 256 % (Cout / 8) == 0, "%s: replicas=%d, Cout=%d", who, replicas, Cout);
@@ -274,14 +365,28 @@ __global__ __launch_bounds__(256) void head_fwd2_kernel(const unsigned char* x, 
     for (int k = 0; k < 6; ++k) ts[o][k] = 0.f;
   long long i = (long long)blockIdx.x * pix_per_block + pl;
   long long iend = (long long)(blockIdx.x + 1) * pix_per_block; if (iend > HW) iend = HW;
-  for (; i < iend; i += PL) {
-    const long long m = (long long)n * HW + i;
-    const uint4 xq = ldg16(x + ((size_t)m * CGI + cp) * 16);
-    float yv[NOWN];
+  // the loads of pass k + 1 are issued before the arithmetic of pass k (a block makes ~8 passes, each a chain load -> dot products ->
+  // shuffles -> exp -> stores: with one pass in flight per wave the launch ran at 2 TB/s)
+  uint4 xq = make_uint4(0, 0, 0, 0);
+  float yv[NOWN];
+#pragma unroll
+  for (int o = 0; o < NOWN; ++o) yv[o] = 0.f;
+  auto fetch = [&](long long ii, uint4& q, float* yy) {
+    const long long mm_ = (long long)n * HW + ii;
+    q = ldg16(x + ((size_t)mm_ * CGI + cp) * 16);
     if constexpr (LOSS) {
 #pragma unroll
-      for (int o = 0; o < NOWN; ++o) yv[o] = (cp + o * CGI) < Cout ? y[m * Cout + cp + o * CGI] : 0.f;
+      for (int o = 0; o < NOWN; ++o) yy[o] = (cp + o * CGI) < Cout ? y[mm_ * Cout + cp + o * CGI] : 0.f;
     }
+  };
+  if (i < iend) fetch(i, xq, yv);
+  for (; i < iend; i += PL) {
+    const long long m = (long long)n * HW + i;
+    uint4 xq_n = make_uint4(0, 0, 0, 0);
+    float yv_n[NOWN];
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) yv_n[o] = 0.f;
+    if (i + PL < iend) fetch(i + PL, xq_n, yv_n);
     float xv[VEC], acc[CO];
     ET<T>::unpack(xq, xv);
 #pragma unroll
@@ -346,6 +451,9 @@ __global__ __launch_bounds__(256) void head_fwd2_kernel(const unsigned char* x, 
         if (cp == 0) mt[0] += (ip == iy);
       }
     }
+    xq = xq_n;
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) yv[o] = yv_n[o];
   }
   if constexpr (LOSS) {
     // lanes with the same cp (stride CGI in the wave) hold partial sums of the same classes
@@ -380,6 +488,208 @@ __global__ __launch_bounds__(256) void head_fwd2_kernel(const unsigned char* x, 
       else if (metrics) unsafeAtomicAdd(&metrics[e - 48], t);
     }
   }
+}
+
+// ---- head forward, third form (bf16 storage, Cin = 32): the 32 -> Cout product on the matrix pipe ---------------------------------
+// head_fwd2 is bound by vector-instruction issue (ISA census: ~430 vector instructions per 16 pixels and wave - four lanes share a pixel and each
+// of them redoes the softmax; PMC: 4 waves per SIMD, each 28 % active): a wave takes 64 pixels per pass instead,
+//   D^T[co][px] = W[co][ci] . X^T[ci][px]  as  mfma_f32_32x32x16_bf16  (A = the weights, rows >= Cout zero; B = 16-byte pieces of the pixels' rows:
+//   lane = (pixel & 31, ci half) - two k-steps per 32 pixels),
+// with the fp32 weights split into bf16 hi + lo parts (two products: the weights enter with ~16 mantissa bits, the inputs are bf16 anyway, so
+// the logits agree with the vector form's to ~1e-5 relative - nothing like a bf16 rounding of the weights).  Pixels 0 - 31 of a pass go
+// through one accumulator, pixels 32 - 63 through a second one; class rows 0 - 3 sit in lanes 0 - 31 and rows 4 - 7 in lanes 32 - 63, so four
+// v_permlane32_swap leave EVERY lane with all classes of ITS pixel (lane l: pixel l of the pass): bias, softmax / sigmoid, stores,
+// Tanimoto moments and confusion counts run once per pixel, one lane each.  The loads of pass k + 1 are issued before the arithmetic of pass k.
+template <int CO, bool LOSS>
+__global__ __launch_bounds__(256) void head_fwd3_kernel(const unsigned char* x, const float* __restrict__ w, const float* __restrict__ b,
+                                                         float* z, float* p, const float* __restrict__ y, double* sums, double* metrics,
+                                                         long long HW, int pix_per_block, int Cout, int act, int replicas) {
+  __shared__ float sh[4 * 56];
+  constexpr bool EXACT = CO != 8;                     // CO = 6 / 3 are launched for Cout == CO only: no runtime per-class tests
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int half = lane >> 5, pl = lane & 31;
+  if (LOSS && sums) sums += (size_t)(blockIdx.x % replicas) * gridDim.y * Cout * 6;      // this block's copy of sums[B][Cout][6]
+  const int n = blockIdx.y;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  bf16x8 whi[2], wlo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = pl < Cout ? w[pl * 32 + ks * 16 + half * 8 + j] : 0.f;
+      const __bf16 h = (__bf16)v;
+      whi[ks][j] = h;
+      wlo[ks][j] = (__bf16)(v - (float)h);
+    }
+  float bias[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) bias[c] = ((EXACT || c < Cout) && b) ? b[c] : 0.f;
+  float ts[CO][6], mt[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ts[c][k] = 0.f;
+  const long long blk0 = (long long)blockIdx.x * pix_per_block;
+  long long blk_end = blk0 + pix_per_block; if (blk_end > HW) blk_end = HW;
+  const unsigned char* xn = x + (size_t)n * HW * 64;
+  const size_t row0 = (size_t)n * HW;
+  // B fragments of a pass: [pixel group][k-step]; labels of this lane's pixel
+  auto fetch = [&](long long g0, uint4 (&q)[2][2], float (&yy)[CO]) {
+#pragma unroll
+    for (int pg = 0; pg < 2; ++pg) {
+      const long long pb = g0 + 32 * pg + pl;
+      const bool ok = pb < blk_end;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) q[pg][ks] = ok ? ldg16(xn + (size_t)pb * 64 + ks * 32 + half * 16) : make_uint4(0, 0, 0, 0);
+    }
+    if constexpr (LOSS) {
+      const long long pm = g0 + lane;
+      const bool ok = pm < blk_end;
+      const float* yr = y + (row0 + (size_t)pm) * Cout;
+      if (CO == 6) {                        // 24-byte rows: three 8-byte loads
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) { const float2 t = ok ? *reinterpret_cast<const float2*>(yr + c) : make_float2(0.f, 0.f); yy[c] = t.x; yy[c + 1] = t.y; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) yy[c] = (ok && (EXACT || c < Cout)) ? yr[c] : 0.f;
+      }
+    }
+  };
+  uint4 xq[2][2], xq_n[2][2];
+  float yv[CO], yv_n[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) { yv[c] = 0.f; yv_n[c] = 0.f; }
+  long long g0 = blk0 + (long long)wid * 64;
+  if (g0 < blk_end) fetch(g0, xq, yv);
+  for (; g0 < blk_end; g0 += 256) {
+    if (g0 + 256 < blk_end) fetch(g0 + 256, xq_n, yv_n);
+    f32x16 d1, d2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { d1[i] = 0.f; d2[i] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 f1 = __builtin_bit_cast(bf16x8, xq[0][ks]), f2 = __builtin_bit_cast(bf16x8, xq[1][ks]);
+      d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], f1, d1, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], f2, d2, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[ks], f1, d1, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[ks], f2, d2, 0, 0, 0);
+    }
+    // d1[r] / d2[r], r < 4: class r + 4 * half of pixel pl (first / second group).  v_permlane32_swap(A, B) exchanges the upper half of A with the
+    // lower half of B: afterwards lo[r] = class r and hi[r] = class 4 + r of pixel `lane` of the pass, in every lane.  (Inline asm as in conv_pw: the
+    // builtin form was miscompiled; the s_nops cover the wait states between an MFMA - or the VALU copy out of an accumulator register - and the
+    // exchange that reads its destination, which hipcc does not track for inline asm: without them one class of one pixel came out stale.)
+    float lo[4], hi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = d1[r], bb = d2[r];
+      if (r == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(bb));
+      else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(bb));     // (s_nop: hipcc put the v_accvgpr_read of the operands right in front of the exchange)
+      lo[r] = a; hi[r] = bb;
+    }
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = (c < 4 ? lo[c & 3] : hi[c & 3]) + bias[c];
+    float pr[CO];
+    if (act == RUA_ACT_SOFTMAX) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) if (EXACT || c < Cout) mx = fmaxf(mx, acc[c]);
+      float s_ = 0.f;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) { pr[c] = (EXACT || c < Cout) ? expf(acc[c] - mx) : 0.f; s_ += pr[c]; }
+      const float inv = 1.f / s_;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) pr[c] *= inv;
+    } else if (act == RUA_ACT_SIGMOID) {
+#pragma unroll
+      for (int c = 0; c < CO; ++c) pr[c] = 1.f / (1.f + expf(-acc[c]));
+    } else {
+#pragma unroll
+      for (int c = 0; c < CO; ++c) pr[c] = acc[c];
+    }
+    const long long pm = g0 + lane;
+    if (pm < blk_end) {
+      const size_t m = row0 + (size_t)pm;
+      if (CO == 6) {
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {
+          if (z) *reinterpret_cast<float2*>(z + m * 6 + c) = make_float2(acc[c], acc[c + 1]);
+          *reinterpret_cast<float2*>(p + m * 6 + c) = make_float2(pr[c], pr[c + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) if (EXACT || c < Cout) { if (z) z[m * Cout + c] = acc[c]; p[m * Cout + c] = pr[c]; }
+      }
+      if constexpr (LOSS) {
+        int ip = 0, iy = 0; float bp = pr[0], by = yv[0];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+          if (EXACT || c < Cout) {
+            const float a = pr[c], l = yv[c], q = 1.f - a, mm = 1.f - l;
+            ts[c][0] += a; ts[c][1] += mm; ts[c][2] = fmaf(a, l, ts[c][2]);
+            ts[c][3] += a * a + l * l; ts[c][4] = fmaf(q, mm, ts[c][4]); ts[c][5] += q * q + mm * mm;
+            if (metrics) {
+              if (a > bp) { bp = a; ip = c; }
+              if (l > by) { by = l; iy = c; }
+              const bool t = l > 0.5f, qq = a > 0.5f;
+              mt[1] += (t && qq); mt[2] += (!t && qq); mt[3] += (!t && !qq); mt[4] += (t && !qq);
+            }
+          }
+        }
+        if (metrics) mt[0] += (ip == iy);
+      }
+    }
+#pragma unroll
+    for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) xq[pg][ks] = xq_n[pg][ks];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) yv[c] = yv_n[c];
+  }
+  if constexpr (LOSS) {
+    // the wave's CO * 6 + 5 per-lane partial sums: through an LDS tile [lane][column] (odd row stride: the row writes and the column reads are
+    // conflict-free), column j summed by lane j - 41 writes + 64 reads per wave.  (41 butterfly sums, 6 ds_bpermute each, were what a block cost at
+    // its end: ~3.7 us of the CU's LDS pipe per block, the launch got SLOWER with more blocks per CU.)
+    constexpr int NCOL = CO * 6 + 5, RS = NCOL | 1;
+    __shared__ float red[4][64 * RS];
+    float* rw = red[wid];
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rw[lane * RS + c * 6 + k] = ts[c][k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) rw[lane * RS + CO * 6 + k] = mt[k];
+    __syncthreads();
+    if (lane < NCOL) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 64; r += 4) { t0 += rw[r * RS + lane]; t1 += rw[(r + 1) * RS + lane]; t2 += rw[(r + 2) * RS + lane]; t3 += rw[(r + 3) * RS + lane]; }
+      sh[wid * 56 + (lane < CO * 6 ? lane : 48 + lane - CO * 6)] = (t0 + t1) + (t2 + t3);
+    }
+    __syncthreads();
+    if (threadIdx.x < 53) {
+      const int e = threadIdx.x;
+      if (e >= 48 || e < CO * 6) {
+        const double t = (double)sh[e] + (double)sh[56 + e] + (double)sh[112 + e] + (double)sh[168 + e];
+        if (e < 48) { const int c = e / 6, k = e % 6; if (c < Cout && sums) unsafeAtomicAdd(&sums[((size_t)n * Cout + c) * 6 + k], t); }
+        else if (metrics) unsafeAtomicAdd(&metrics[e - 48], t);
+      }
+    }
+  }
+}
+
+template <bool LOSS>
+static void launch_head_fwd3(const void* x, const float* w, const float* b, float* z, float* p, const float* y, double* sums, double* metrics,
+                             int B, int64_t HW, int Cout, int act, int replicas, hipStream_t st) {
+  const int bpc = g_tune.head_fwd3_bpc > 0 ? g_tune.head_fwd3_bpc : (LOSS ? 3 : 4);       // blocks per CU over the batch (LOSS: a block holds a 42 KB reduction tile and ends in <= 53 fp64 atomics)
+  int64_t per_sample = ((int64_t)bpc * rua_cu_count() + B - 1) / B; if (per_sample < 1) per_sample = 1;
+  int64_t ppb = (HW + per_sample - 1) / per_sample; if (ppb < 256) ppb = 256;
+  ppb = (ppb + 255) / 256 * 256;
+  const int gx = (int)((HW + ppb - 1) / ppb);
+#define RUA_HEAD3(CO_) hipLaunchKernelGGL((head_fwd3_kernel<CO_, LOSS>), dim3(gx, B), dim3(256), 0, st, (const unsigned char*)x, w, b, z, p, y, sums, metrics, (long long)HW, (int)ppb, Cout, act, replicas)
+  if (Cout == 6) RUA_HEAD3(6); else if (Cout == 3) RUA_HEAD3(3); else RUA_HEAD3(8);
+#undef RUA_HEAD3
 }
 
 template <typename T, bool LOSS>
@@ -499,6 +809,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
                                                         unsigned char* dx, int accumulate_dx, float* dw, float* db, float* partial,
                                                         long long M, int Cin, int Cout, int rows_per_block, int mask_dx, float* dxsum) {
   constexpr int VEC = ET<T>::VEC;
+  constexpr bool EXACT = CO != 8;                     // the launcher picks CO = 6 / 3 only for Cout == CO: no per-channel `co < Cout` tests (runtime tests became a branch around
+                                                      // every one of the six dz loads of a row)
   extern __shared__ float red[];                      // [4 waves][Cout*Cin + Cout (+ Cin: per-channel sums of dx)]
   const int NE = Cout * Cin + Cout + (dxsum ? Cin : 0);
   const int CGI = Cin / VEC;
@@ -510,7 +822,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
 #pragma unroll
   for (int co = 0; co < CO; ++co) { bs[co] = 0.f;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { wr[co][j] = co < Cout ? w[co * Cin + cp * VEC + j] : 0.f; acc[co][j] = 0.f; } }
+    for (int j = 0; j < VEC; ++j) { wr[co][j] = (EXACT || co < Cout) ? w[co * Cin + cp * VEC + j] : 0.f; acc[co][j] = 0.f; } }
   long long r = (long long)blockIdx.x * rows_per_block + pl;
   long long rend = (long long)(blockIdx.x + 1) * rows_per_block; if (rend > M) rend = M;
   auto row = [&](const uint4& xq, const float* g, const uint4& oq, long long rr) {
@@ -533,23 +845,49 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
     for (int j = 0; j < VEC; ++j) so[j] += o[j];
     if (dx) stg16(dx + ((size_t)rr * CGI + cp) * 16, ET<T>::pack(o));
   };
-  // two rows per iteration, every load of both issued before the first use
-  for (; r + PL < rend; r += 2 * PL) {
-    const long long r1 = r + PL;
-    const uint4 x0 = ldg16(x + ((size_t)r * CGI + cp) * 16), x1 = ldg16(x + ((size_t)r1 * CGI + cp) * 16);
-    float g0[CO], g1[CO];
+  // the Cout gradients of row rr (CO = 6: a 24-byte row as three 8-byte loads)
+  auto load_g = [&](long long rr, float* g) {
+    if constexpr (CO == 6) {
+      const float2* q = reinterpret_cast<const float2*>(dz + rr * 6);
+      const float2 a = q[0], b2 = q[1], c2 = q[2];
+      g[0] = a.x; g[1] = a.y; g[2] = b2.x; g[3] = b2.y; g[4] = c2.x; g[5] = c2.y;
+    } else {
 #pragma unroll
-    for (int co = 0; co < CO; ++co) { g0[co] = co < Cout ? dz[r * Cout + co] : 0.f; g1[co] = co < Cout ? dz[r1 * Cout + co] : 0.f; }
-    uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
-    if (dx && accumulate_dx) { o0 = ldg16(dx + ((size_t)r * CGI + cp) * 16); o1 = ldg16(dx + ((size_t)r1 * CGI + cp) * 16); }
-    row(x0, g0, o0, r);
-    row(x1, g1, o1, r1);
+      for (int co = 0; co < CO; ++co) g[co] = (EXACT || co < Cout) ? dz[rr * Cout + co] : 0.f;
+    }
+  };
+  // two rows per iteration, software-pipelined: the loads of the NEXT pair are issued before the arithmetic of this one (two blocks per
+  // CU are resident: with one pair in flight a CU had 16 KB of x outstanding, a third of what the HBM latency asks for; four rows
+  // loaded at once cost the second block its registers).  A thread still meets its rows in the same order (same sums, bit for bit).
+  if (r + PL < rend) {
+    uint4 xa = ldg16(x + ((size_t)r * CGI + cp) * 16), xb = ldg16(x + ((size_t)(r + PL) * CGI + cp) * 16);
+    float ga[CO], gb[CO];
+    load_g(r, ga); load_g(r + PL, gb);
+    uint4 oa = make_uint4(0, 0, 0, 0), ob = oa;
+    if (dx && accumulate_dx) { oa = ldg16(dx + ((size_t)r * CGI + cp) * 16); ob = ldg16(dx + ((size_t)(r + PL) * CGI + cp) * 16); }
+    for (; r + PL < rend; r += 2 * PL) {
+      const long long n0 = r + 2 * PL, n1 = r + 3 * PL;
+      const bool more = n1 < rend;
+      uint4 xc = make_uint4(0, 0, 0, 0), xd = xc, oc = xc, od = xc;
+      float gc[CO], gd[CO];
+#pragma unroll
+      for (int co = 0; co < CO; ++co) { gc[co] = 0.f; gd[co] = 0.f; }
+      if (more) {
+        xc = ldg16(x + ((size_t)n0 * CGI + cp) * 16); xd = ldg16(x + ((size_t)n1 * CGI + cp) * 16);
+        load_g(n0, gc); load_g(n1, gd);
+        if (dx && accumulate_dx) { oc = ldg16(dx + ((size_t)n0 * CGI + cp) * 16); od = ldg16(dx + ((size_t)n1 * CGI + cp) * 16); }
+      }
+      row(xa, ga, oa, r);
+      row(xb, gb, ob, r + PL);
+      xa = xc; xb = xd; oa = oc; ob = od;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) { ga[co] = gc[co]; gb[co] = gd[co]; }
+    }
   }
   for (; r < rend; r += PL) {
     const uint4 x0 = ldg16(x + ((size_t)r * CGI + cp) * 16);
     float g0[CO];
-#pragma unroll
-    for (int co = 0; co < CO; ++co) g0[co] = co < Cout ? dz[r * Cout + co] : 0.f;
+    load_g(r, g0);
     uint4 o0 = make_uint4(0, 0, 0, 0);
     if (dx && accumulate_dx) o0 = ldg16(dx + ((size_t)r * CGI + cp) * 16);
     row(x0, g0, o0, r);
@@ -570,7 +908,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
   if (lane < CGI) {
 #pragma unroll
     for (int co = 0; co < CO; ++co) {
-      if (co < Cout) {
+      if (EXACT || co < Cout) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) red[wid * NE + co * Cin + lane * VEC + j] = acc[co][j];
         if (lane == 0) red[wid * NE + Cout * Cin + co] = bs[co];
@@ -630,6 +968,11 @@ extern "C" int rua_head_fwd(const void* x, const float* w, const float* b, float
   const size_t smem = (size_t)(Cout * Cin + Cout) * 4;
   int64_t g = (M + 255) / 256; if (g > 4096) g = 4096;
   hipStream_t st = (hipStream_t)stream;
+  if (Cin == 32 && dtype == RUA_BF16 && g_tune.head_fwd3 && (M * 64) < (1ll << 40)) {     // bf16 storage: the product on the matrix pipe, a lane per pixel
+    launch_head_fwd3<false>(x, w, b, z, p, nullptr, nullptr, nullptr, 1, M, Cout, act, 1, st);
+    RUA_LAUNCH_CHECK("rua_head_fwd");
+    return RUA_OK;
+  }
   if (Cin == 32 && g_tune.head_fwd2) {                  // the reference's heads: weights in registers, a pixel shared by Cin / VEC lanes
     if (dtype == RUA_BF16) launch_head_fwd2<bf16_t, false>(x, w, b, z, p, nullptr, nullptr, nullptr, 1, M, Cin, Cout, act, st);
     else launch_head_fwd2<float, false>(x, w, b, z, p, nullptr, nullptr, nullptr, 1, M, Cin, Cout, act, st);
@@ -642,8 +985,17 @@ extern "C" int rua_head_fwd(const void* x, const float* w, const float* b, float
   return RUA_OK;
 }
 
+extern "C" int rua_head_fwd_loss_rep(const void* x, const float* w, const float* b, float* z, float* p, const float* y, double* tanimoto_sums,
+                                     int sums_replicas, double* metrics, int B, int64_t HW, int Cin, int Cout, int act, int dtype, void* stream);
 extern "C" int rua_head_fwd_loss(const void* x, const float* w, const float* b, float* z, float* p, const float* y, double* tanimoto_sums,
                                  double* metrics, int B, int64_t HW, int Cin, int Cout, int act, int dtype, void* stream) {
+  return rua_head_fwd_loss_rep(x, w, b, z, p, y, tanimoto_sums, 1, metrics, B, HW, Cin, Cout, act, dtype, stream);
+}
+// tanimoto_sums [sums_replicas][B][Cout][6]: a block adds into copy blockIdx.x % sums_replicas (every block ends in <= 48 fp64 atomics on its sample's
+// sums: with one copy the ~64 blocks of a sample queue up on each of them - 11 us of a 24 us launch); rua_tanimoto_finalize_rep adds the copies
+extern "C" int rua_head_fwd_loss_rep(const void* x, const float* w, const float* b, float* z, float* p, const float* y, double* tanimoto_sums,
+                                     int sums_replicas, double* metrics, int B, int64_t HW, int Cin, int Cout, int act, int dtype, void* stream) {
+  RUA_CHECK_ARG(sums_replicas >= 1 && sums_replicas <= 64, "rua_head_fwd_loss_rep: sums_replicas=%d must be in 1..64", sums_replicas);
   RUA_CHECK_ARG(x && w && p && y && B > 0 && HW > 0, "rua_head_fwd_loss: bad arguments");
   RUA_CHECK_ARG(tanimoto_sums || metrics, "rua_head_fwd_loss: nothing to accumulate (use rua_head_fwd)");
   const int vec = dtype == RUA_BF16 ? 8 : 4;
@@ -656,6 +1008,11 @@ extern "C" int rua_head_fwd_loss(const void* x, const float* w, const float* b, 
   ppb = (ppb + 255) / 256 * 256;
   const int gx = (int)((HW + ppb - 1) / ppb);
   hipStream_t st = (hipStream_t)stream;
+  if (Cin == 32 && dtype == RUA_BF16 && g_tune.head_fwd3) {
+    launch_head_fwd3<true>(x, w, b, z, p, y, tanimoto_sums, metrics, B, HW, Cout, act, sums_replicas, st);
+    RUA_LAUNCH_CHECK("rua_head_fwd_loss");
+    return RUA_OK;
+  }
   if (Cin == 32 && g_tune.head_fwd2) {
     if (dtype == RUA_BF16) launch_head_fwd2<bf16_t, true>(x, w, b, z, p, y, tanimoto_sums, metrics, B, HW, Cin, Cout, act, st);
     else launch_head_fwd2<float, true>(x, w, b, z, p, y, tanimoto_sums, metrics, B, HW, Cin, Cout, act, st);

@@ -22,6 +22,7 @@ from . import _lib as L
 
 BN_EPS, BN_MOMENTUM, KERAS_EPS = 1e-3, 0.99, 1e-7
 HEADS = ["seg", "bound", "dist", "color"]
+SUMS_REPLICAS = 8          # copies of a head's Tanimoto moments the blocks of rua_head_fwd_loss_rep spread their atomics over
 
 
 @dataclass
@@ -1353,11 +1354,14 @@ class Graph:
         if sp is not None and not self.dry and self.e.fuse_head_loss and (tani or hname == "seg"):
             # the Tanimoto moments (and the 'seg' head's accuracy / confusion counts) in the head's own epilogue: p is not read again
             if tani:
-                h["sums"] = self.salloc(x.N * cout * 6)
+                # SUMS_REPLICAS copies of sums[B][C][6] (+ the slot rua_tanimoto_finalize_rep folds them into): a block of the head's forward adds
+                # into one copy, so the ~64 blocks of a sample do not queue up on the same 36 fp64 addresses at the end of the launch
+                h["sums_rep"] = SUMS_REPLICAS
+                h["sums"] = self.salloc((SUMS_REPLICAS + 1) * x.N * cout * 6)
             if hname == "seg":
                 h["metrics_done"] = True
-            F.add("rua_head_fwd_loss", x.ptr, self.P(lay["segs"][0]["off"]), self.P(lay["bias"]), z.ptr, p.ptr, y.ptr, h.get("sums"),
-                  self.e.scalars_ptr + 8 * 8 if hname == "seg" else None, x.N, x.H * x.W, x.C, cout, act, self.dt)
+            F.add("rua_head_fwd_loss_rep", x.ptr, self.P(lay["segs"][0]["off"]), self.P(lay["bias"]), z.ptr, p.ptr, y.ptr, h.get("sums"),
+                  h.get("sums_rep", 1), self.e.scalars_ptr + 8 * 8 if hname == "seg" else None, x.N, x.H * x.W, x.C, cout, act, self.dt)
         else:
             F.add("rua_head_fwd", x.ptr, self.P(lay["segs"][0]["off"]), self.P(lay["bias"]), z.ptr, p.ptr, x.M, x.C, cout, act, self.dt)
         self.heads.append(h)
@@ -1378,7 +1382,7 @@ class Graph:
             if sums is None:                                # (the head's forward did not take the moments itself)
                 sums = self.salloc(B * Cc * 6)
                 LP.add("rua_tanimoto_sums", h["p"].ptr, h["y"].ptr, B, HW, Cc, sums)
-            LP.add("rua_tanimoto_finalize", sums, B, HW, Cc, wgt / B, slot, coef.data_ptr(), None)
+            LP.add("rua_tanimoto_finalize_rep", sums, h.get("sums_rep", 1), B, HW, Cc, wgt / B, slot, coef.data_ptr(), None)
             h["norm"] = 1.0
         else:
             LP.add("rua_pixel_loss", kind, h["p"].ptr, h["z"].ptr, h["y"].ptr, self.e.class_w_ptr, M, Cc, slot, None)

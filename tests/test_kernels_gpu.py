@@ -1312,6 +1312,23 @@ def test_head_forward_with_loss_moments_equals_the_separate_passes(dt, act, Cout
     torch.cuda.synchronize()
     assert torch.equal(s2, s1) or np.allclose(s2.cpu().numpy(), s1.cpu().numpy(), rtol=1e-6, atol=1e-4)
     assert lib.raw("rua_head_fwd_loss")(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, p1.data_ptr(), y.data_ptr(), None, None, B, HW, Cin, Cout, act, dt, None) != 0
+    # the moments spread over R copies (rua_head_fwd_loss_rep) + the fold in rua_tanimoto_finalize_rep: same loss, coefficients and per-sample values
+    R = 8
+    sr = torch.zeros((R + 1) * B * Cout * 6, dtype=torch.float64, device=dev())
+    lib.call("rua_head_fwd_loss_rep", x.data_ptr(), w.data_ptr(), b.data_ptr(), None, p1.data_ptr(), y.data_ptr(), sr.data_ptr(), R, None, B, HW, Cin, Cout, act, dt, stream())
+    outs = []
+    for sums, rep in ((s1, 1), (sr, R), (sr, R)):                             # twice: the fold is idempotent
+        lo = torch.zeros(1, dtype=torch.float64, device=dev()); co = torch.zeros(B * Cout * 3, device=dev()); pe = torch.zeros(B, device=dev())
+        lib.call("rua_tanimoto_finalize_rep", sums.data_ptr(), rep, B, HW, Cout, 0.25, lo.data_ptr(), co.data_ptr(), pe.data_ptr(), stream())
+        torch.cuda.synchronize()
+        outs.append((lo.item(), co.cpu().numpy(), pe.cpu().numpy()))
+    folded = sr.view(R + 1, -1)
+    assert np.allclose(folded[:R].sum(0).cpu().numpy(), s1.cpu().numpy(), rtol=1e-5, atol=1e-3)
+    if dt == L.RUA_BF16:
+        assert (folded[1:R].abs().sum(1) > 0).all()                           # every copy was used
+    for o in outs[1:]:
+        assert abs(o[0] - outs[0][0]) < 1e-6 and np.allclose(o[1], outs[0][1], rtol=1e-4, atol=1e-7) and np.allclose(o[2], outs[0][2], rtol=1e-5)
+    assert outs[1][0] == outs[2][0] and np.array_equal(outs[1][1], outs[2][1])
 
 
 BAND_CASES = [

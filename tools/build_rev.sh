@@ -9,7 +9,8 @@ for f in $(git ls-tree --name-only $rev resunet_a_mltsk_keras_amd/csrc/); do git
 git show $rev:include/rua_hip.h > $tmp/include/rua_hip.h
 objs=""
 for s in $tmp/resunet_a_mltsk_keras_amd/csrc/*.hip $tmp/resunet_a_mltsk_keras_amd/csrc/*.cpp; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -x hip -c $s -o $s.o &
+  ff=""; case $s in *conv_strip.hip) ff="-fno-slp-vectorize";; esac      # build.py::FILE_FLAGS
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $ff -x hip -c $s -o $s.o &
   objs="$objs $s.o"
 done
 wait
