@@ -210,6 +210,13 @@ int rua_stem_fwd(const float* x, const float* w, const float* b, void* y, int64_
  * zeroed by the caller) - what rua_col_stats would compute from y in a pass of its own (the first BatchNorm of the encoder, model2.py:102-103). */
 int rua_stem_fwd_stats(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, double* stats, int replicas, void* stream);
 int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db, int64_t M, int Cin, int Cout, int dtype, void* stream);
+/* rua_stem_fwd(_stats) that also writes the input once more as bf16 xpack [M][16] = { hi(x_0..x_7) | lo(x_0..x_6), 1 } (hi = bf16(x), lo = bf16(x - hi); Cin <= 7;
+ * stats may be NULL): with it the stem's weight gradient is a 1x1 weight gradient on the matrix pipe - rua_conv_wgrad(a = xpack, C = 16, dy, dw = tmp [Cout][16],
+ * tmp zero) - followed by rua_stem_bwd_fold: dW[co][c] += tmp[co][c] + tmp[co][8 + c], db[co] += tmp[co][15] (NULL: not), tmp := 0.  The vector form
+ * (rua_stem_bwd) keeps 72 partial sums per thread and ended every block in their butterflies and 288 same-address atomics: 38 us for a 46 MB pass. */
+int rua_stem_fwd_pack(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, double* stats, int replicas,
+                      void* xpack, void* stream);
+int rua_stem_bwd_fold(float* tmp, float* dw, float* db, int Cin, int Cout, void* stream);
 /* heads: Conv2D(num_classes,(1,1)) + softmax / sigmoid (model2.py:145-146,160-162,169-171,181-183,186-188).
  * act: 0 none, 1 softmax over channels, 2 sigmoid.  z (logits) and p are fp32 [M][Cout<=8]. */
 int rua_head_fwd(const void* x, const float* w, const float* b, float* z, float* p, int64_t M, int Cin, int Cout, int act, int dtype, void* stream);
@@ -346,6 +353,17 @@ int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t HW, int C, 
  * per_sample[B] (optional): the (B,) vector the reference's loss function returns (multitasking_utils.py:84) */
 int rua_tanimoto_finalize(const double* sums, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,
                           float* per_sample, void* stream);
+#define RUA_MAX_HEADS 8
+typedef struct rua_tani_head {
+  double* sums; int32_t replicas, B, C; float grad_scale; double* loss_out; float* coef; float* per_sample;   /* as rua_tanimoto_finalize_rep */
+} rua_tani_head;
+/* rua_tanimoto_finalize_rep for n (<= RUA_MAX_HEADS) heads in ONE launch (the seg / bound / dist / color heads of the multitask model, train_ISPRS.py:417-421) */
+int rua_tanimoto_finalize_multi(const rua_tani_head* heads, int n, void* stream);
+typedef struct rua_dz_head {
+  int32_t kind, act; const float* p; const float* y; const float* coef; const float* class_w; float grad_scale; int32_t B; int64_t HW; int32_t C, pad; float* dz;
+} rua_dz_head;
+/* rua_head_dz for n (<= RUA_MAX_HEADS) heads in ONE launch */
+int rua_head_dz_multi(const rua_dz_head* heads, int n, void* stream);
 /* sums [replicas + 1][B][C][6]: `replicas` copies filled by rua_head_fwd_loss_rep; their sum is stored into the extra slot behind them (plain stores:
  * idempotent) and finalised as above. */
 int rua_tanimoto_finalize_rep(double* sums, int replicas, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,

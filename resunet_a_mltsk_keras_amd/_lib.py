@@ -44,6 +44,15 @@ class WgradPending(C.Structure):
                 ("block_begin", i32), ("pad", i32)]
 
 
+class TaniHead(C.Structure):
+    _fields_ = [("sums", vp), ("replicas", i32), ("B", i32), ("C", i32), ("grad_scale", f32), ("loss_out", vp), ("coef", vp), ("per_sample", vp)]
+
+
+class DzHead(C.Structure):
+    _fields_ = [("kind", i32), ("act", i32), ("p", vp), ("y", vp), ("coef", vp), ("class_w", vp), ("grad_scale", f32), ("B", i32), ("HW", i64),
+                ("C", i32), ("pad", i32), ("dz", vp)]
+
+
 class BnBranch(C.Structure):
     _fields_ = [("gamma", vp), ("beta", vp), ("moving_mean", vp), ("moving_var", vp), ("scale", vp), ("shift", vp),
                 ("mean", vp), ("rstd", vp), ("out", vp), ("stats", vp), ("replicas", i32), ("pad", i32), ("out_stats", vp)]
@@ -107,6 +116,8 @@ _SIGS = {
     "rua_stem_fwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "rua_stem_fwd_stats": ([vp, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp], i32),
     "rua_stem_bwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
+    "rua_stem_fwd_pack": ([vp, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp, vp], i32),
+    "rua_stem_bwd_fold": ([vp, vp, vp, i32, i32, vp], i32),
     "rua_head_fwd": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp], i32),
     "rua_head_fwd_loss": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp], i32),
     "rua_head_fwd_loss_rep": ([vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i32, i32, i32, vp], i32),
@@ -142,6 +153,8 @@ _SIGS = {
     "rua_tanimoto_sums": ([vp, vp, i32, i64, i32, vp, vp], i32),
     "rua_tanimoto_finalize": ([vp, i32, i64, i32, f32, vp, vp, vp, vp], i32),
     "rua_tanimoto_finalize_rep": ([vp, i32, i32, i64, i32, f32, vp, vp, vp, vp], i32),
+    "rua_tanimoto_finalize_multi": ([vp, i32, vp], i32),
+    "rua_head_dz_multi": ([vp, i32, vp], i32),
     "rua_tanimoto_ratio": ([vp, i32, i32, vp, vp, vp], i32),
     "rua_pixel_loss": ([i32, vp, vp, vp, vp, i64, i32, vp, vp, vp], i32),
     "rua_head_dz": ([i32, i32, vp, vp, vp, vp, f32, i32, i64, i32, vp, vp], i32),

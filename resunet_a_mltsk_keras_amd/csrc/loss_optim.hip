@@ -139,8 +139,8 @@ extern "C" int rua_tanimoto_sums(const float* p, const float* y, int B, int64_t 
 // the first term come from the PREDICTION volumes (and carry gradient); loss2 = T(1-label, 1-pred).
 // single != 0: Tanimoto_loss(label, pred) itself (multitasking_utils.py:38-68) for sums taken with p := label, y := pred -
 // the first term's ratio (N1 + 1e-5) / (D1 + 1e-5) with the class weights from the volumes of the FIRST argument.
-__global__ void tanimoto_finalize_kernel(const double* sums, int B, int C, float grad_scale, double* loss_out, float* coef, float* per_sample,
-                                         int single, int replicas) {
+__device__ __forceinline__ void tanimoto_finalize_body(const double* sums, int B, int C, float grad_scale, double* loss_out, float* coef, float* per_sample,
+                                                       int single, int replicas) {
   __shared__ double w1[8], w2[8], v1[8], kap[8];
   __shared__ double E1[256], F1[256], E2[256], F2[256];
   __shared__ int inf1[8];
@@ -220,6 +220,29 @@ __global__ void tanimoto_finalize_kernel(const double* sums, int B, int C, float
     coef[i * 3 + 0] = (float)(sc * c0); coef[i * 3 + 1] = (float)(sc * c1); coef[i * 3 + 2] = (float)(sc * c2);
   }
 }
+__global__ void tanimoto_finalize_kernel(const double* sums, int B, int C, float grad_scale, double* loss_out, float* coef, float* per_sample,
+                                         int single, int replicas) {
+  tanimoto_finalize_body(sums, B, C, grad_scale, loss_out, coef, per_sample, single, replicas);
+}
+// the heads of a multitask model in ONE launch (a block per head): four one-block launches of ~5 us each were ~20 us of a 7 ms step
+struct TaniMulti { rua_tani_head h[RUA_MAX_HEADS]; };
+__global__ void tanimoto_finalize_multi_kernel(const TaniMulti a) {
+  const rua_tani_head& h = a.h[blockIdx.x];
+  tanimoto_finalize_body(h.sums, h.B, h.C, h.grad_scale, h.loss_out, h.coef, h.per_sample, 0, h.replicas);
+}
+extern "C" int rua_tanimoto_finalize_multi(const rua_tani_head* heads, int n, void* stream) {
+  RUA_CHECK_ARG(heads && n >= 1 && n <= RUA_MAX_HEADS, "rua_tanimoto_finalize_multi: 1..%d heads", RUA_MAX_HEADS);
+  TaniMulti a;
+  for (int i = 0; i < n; ++i) {
+    const rua_tani_head& h = heads[i];
+    RUA_CHECK_ARG(h.sums && h.loss_out && h.B > 0 && h.B <= 256 && h.C >= 1 && h.C <= 8 && h.replicas >= 1 && h.replicas <= 64,
+                  "rua_tanimoto_finalize_multi: head %d: B must be in 1..256, C in 1..8, replicas in 1..64", i);
+    a.h[i] = h;
+  }
+  hipLaunchKernelGGL(tanimoto_finalize_multi_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, a);
+  RUA_LAUNCH_CHECK("rua_tanimoto_finalize_multi");
+  return RUA_OK;
+}
 
 extern "C" int rua_tanimoto_finalize_rep(double* sums, int replicas, int B, int64_t HW, int C, float grad_scale, double* loss_out, float* coef,
                                          float* per_sample, void* stream) {
@@ -297,29 +320,53 @@ extern "C" int rua_pixel_loss(int kind, const float* p, const float* z, const fl
 }
 
 // d(total loss)/d(logits), one thread per pixel
-__global__ __launch_bounds__(256) void head_dz_kernel(int kind, int act, const float* __restrict__ p, const float* __restrict__ y,
-                                                      const float* __restrict__ coef, const float* __restrict__ cw, float gs,
-                                                      long long HW, long long M, int C, float* dz) {
+// CT: the class count as a template constant (6, 3; 0: runtime, <= 8) - with a runtime C every `c < C` became a branch around one scalar access
+template <int CT>
+__device__ __forceinline__ void head_dz_body(int kind, int act, const float* __restrict__ p, const float* __restrict__ y,
+                                             const float* __restrict__ coef, const float* __restrict__ cw, float gs,
+                                             long long HW, int C_rt, float* dz) {
+  const int C = CT > 0 ? CT : C_rt;
+  auto load_row = [&](const float* src, long long m, float* v) {
+    if constexpr (CT == 6) {                              // 24-byte rows: three 8-byte accesses
+      const float2* q = reinterpret_cast<const float2*>(src + m * 6);
+      const float2 a = q[0], b = q[1], c = q[2];
+      v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = 0.f; v[7] = 0.f;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = c < C ? src[m * C + c] : 0.f;
+    }
+  };
+  auto store_row = [&](long long m, const float* v) {
+    if constexpr (CT == 6) {
+      float2* q = reinterpret_cast<float2*>(dz + m * 6);
+      q[0] = make_float2(v[0], v[1]); q[1] = make_float2(v[2], v[3]); q[2] = make_float2(v[4], v[5]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = v[c];
+    }
+  };
   // blockIdx.y = sample (the Tanimoto coefficients are per sample and class: m / HW per pixel was a 64-bit division - ~100 vector instructions
   // in a pass that moves 72 bytes per pixel)
   const int n = blockIdx.y;
-  (void)M;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
     const long long m = (long long)n * HW + i;
-    float pv[8], yv[8], g[8];
+    float pv[8], yv[8], g[8], o[8];
+    load_row(p, m, pv); load_row(y, m, yv);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { pv[c] = c < C ? p[m * C + c] : 0.f; yv[c] = c < C ? y[m * C + c] : 0.f; g[c] = 0.f; }
+    for (int c = 0; c < 8; ++c) { g[c] = 0.f; o[c] = 0.f; }
     if (kind == RUA_LOSS_CE_LOGITS) {
       float sy = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) sy += yv[c];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = (pv[c] * sy - yv[c]) * gs;
+      for (int c = 0; c < 8; ++c) o[c] = (pv[c] * sy - yv[c]) * gs;
+      store_row(m, o);
       continue;
     }
     if (kind == RUA_LOSS_BCE_LOGITS) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = (pv[c] - yv[c]) * gs / C;
+      for (int c = 0; c < 8; ++c) o[c] = (pv[c] - yv[c]) * gs / C;
+      store_row(m, o);
       continue;
     }
     if (kind == RUA_LOSS_TANIMOTO) {
@@ -351,15 +398,56 @@ __global__ __launch_bounds__(256) void head_dz_kernel(int kind, int act, const f
 #pragma unroll
       for (int c = 0; c < 8; ++c) dot = fmaf(g[c], pv[c], dot);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = pv[c] * (g[c] - dot);
+      for (int c = 0; c < 8; ++c) o[c] = pv[c] * (g[c] - dot);
+      store_row(m, o);
     } else if (act == RUA_ACT_SIGMOID) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = g[c] * pv[c] * (1.f - pv[c]);
+      for (int c = 0; c < 8; ++c) o[c] = g[c] * pv[c] * (1.f - pv[c]);
+      store_row(m, o);
     } else {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) if (c < C) dz[m * C + c] = g[c];
+      for (int c = 0; c < 8; ++c) o[c] = g[c];
+      store_row(m, o);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void head_dz_kernel(int kind, int act, const float* __restrict__ p, const float* __restrict__ y,
+                                                      const float* __restrict__ coef, const float* __restrict__ cw, float gs,
+                                                      long long HW, long long M, int C, float* dz) {
+  (void)M;
+  if (C == 6) head_dz_body<6>(kind, act, p, y, coef, cw, gs, HW, C, dz);
+  else if (C == 3) head_dz_body<3>(kind, act, p, y, coef, cw, gs, HW, C, dz);
+  else head_dz_body<0>(kind, act, p, y, coef, cw, gs, HW, C, dz);
+}
+// d(loss)/d(logits) of several heads in ONE launch: blockIdx.z = head (the four heads of the multitask model: four launches of 4 - 12 us)
+struct DzMulti { rua_dz_head h[RUA_MAX_HEADS]; };
+__global__ __launch_bounds__(256) void head_dz_multi_kernel(const DzMulti a) {
+  const rua_dz_head& h = a.h[blockIdx.z];
+  if ((int)blockIdx.y >= h.B) return;
+  if (h.C == 6) head_dz_body<6>(h.kind, h.act, h.p, h.y, h.coef, h.class_w, h.grad_scale, (long long)h.HW, h.C, h.dz);
+  else if (h.C == 3) head_dz_body<3>(h.kind, h.act, h.p, h.y, h.coef, h.class_w, h.grad_scale, (long long)h.HW, h.C, h.dz);
+  else head_dz_body<0>(h.kind, h.act, h.p, h.y, h.coef, h.class_w, h.grad_scale, (long long)h.HW, h.C, h.dz);
+}
+extern "C" int rua_head_dz_multi(const rua_dz_head* heads, int n, void* stream) {
+  RUA_CHECK_ARG(heads && n >= 1 && n <= RUA_MAX_HEADS, "rua_head_dz_multi: 1..%d heads", RUA_MAX_HEADS);
+  DzMulti a;
+  int64_t g = 1; int Bm = 1;
+  for (int i = 0; i < n; ++i) {
+    const rua_dz_head& h = heads[i];
+    RUA_CHECK_ARG(h.p && h.y && h.dz && h.B > 0 && h.B <= 65535 && h.HW > 0 && h.C >= 1 && h.C <= 8 && h.kind >= 0 && h.kind <= 4 && h.act >= 0 && h.act <= 2,
+                  "rua_head_dz_multi: head %d: bad arguments", i);
+    RUA_CHECK_ARG(h.kind != RUA_LOSS_TANIMOTO || h.coef, "rua_head_dz_multi: Tanimoto needs coefficients");
+    RUA_CHECK_ARG(h.kind != RUA_LOSS_WCE || h.class_w, "rua_head_dz_multi: weighted CE needs class weights");
+    a.h[i] = h;
+    const int64_t gi = (h.HW + 255) / 256; if (gi > g) g = gi;
+    if (h.B > Bm) Bm = h.B;
+  }
+  const int64_t cap = 4096 / ((int64_t)Bm * n) > 0 ? 4096 / ((int64_t)Bm * n) : 1;
+  if (g > cap) g = cap;
+  hipLaunchKernelGGL(head_dz_multi_kernel, dim3((int)g, Bm, n), dim3(256), 0, (hipStream_t)stream, a);
+  RUA_LAUNCH_CHECK("rua_head_dz_multi");
+  return RUA_OK;
 }
 
 extern "C" int rua_head_dz(int kind, int act, const float* p, const float* y, const float* coef, const float* class_w,

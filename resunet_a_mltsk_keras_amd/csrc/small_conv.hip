@@ -72,13 +72,17 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 }
 
 // Register form of the stem (Cin <= 8, Cout / 8 dividing 256: the reference's 3 / 6 / 7 bands -> 32): a thread keeps its channel group for the whole
-// sweep, so its 8 x Cin weights live in registers (the LDS form above issues 8 x Cin broadcast reads per pixel piece: the launch was bound by
-// LDS instructions, 18 us for a 46 MB pass, 31 us with the statistics) and the input values of the NEXT pixel are loaded before the arithmetic of
-// this one.  Same order of operations per output value: bit-identical to the LDS form.
-template <typename T, bool STATS>
+// sweep, so its 8 x Cin weights live in registers (the LDS form above issues 8 x Cin broadcast reads per pixel piece) and the input values of the NEXT
+// pixel are loaded before the arithmetic of this one.  CINT: Cin as a template constant (3, 6, 7; 0: runtime - every `c < Cin` test of a runtime Cin
+// became a branch around one scalar load).  Same order of operations per output value: bit-identical to the LDS form.
+// xpack (optional, Cin <= 7): the input once more as bf16 [M][16] = { hi(x_0..x_7) | lo(x_0..x_6), 1 } with hi = bf16(x), lo = bf16(x - hi) - the operand
+// the weight gradient of the stem takes on the matrix pipe (rua_stem_bwd_fold): dW = dy^T . (hi + lo) to ~16 mantissa bits, the column of ones gives db.
+template <typename T, bool STATS, int CINT>
 __global__ __launch_bounds__(256) void stem_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                            unsigned char* y, long long M, int Cin, int Cout, double* stats, int replicas) {
+                                                            unsigned char* y, long long M, int Cin_rt, int Cout, double* stats, int replicas,
+                                                            unsigned char* xpack) {
   constexpr int CINP = 8;
+  const int Cin = CINT > 0 ? CINT : Cin_rt;
   extern __shared__ float sw[];                       // STATS: [4 waves][2][Cout] partial sums
   const int CG8 = Cout / 8;
   const int cg = threadIdx.x % CG8;
@@ -99,8 +103,14 @@ __global__ __launch_bounds__(256) void stem_fwd_reg_kernel(const float* __restri
   const int cgsh = __builtin_ctz((unsigned)CG8);      // CG8 divides 256: a power of two (m = i / CG8 as a 64-bit division was ~100 vector instructions per piece)
   auto fetch = [&](long long ii, float* v) {
     const long long m = ii >> cgsh;
+    if constexpr (CINT == 6) {                          // 24-byte rows: three 8-byte loads
+      const float2* q = reinterpret_cast<const float2*>(x + m * 6);
+      const float2 a = q[0], b2 = q[1], c2 = q[2];
+      v[0] = a.x; v[1] = a.y; v[2] = b2.x; v[3] = b2.y; v[4] = c2.x; v[5] = c2.y; v[6] = 0.f; v[7] = 0.f;
+    } else {
 #pragma unroll
-    for (int c = 0; c < CINP; ++c) v[c] = c < Cin ? x[m * Cin + c] : 0.f;
+      for (int c = 0; c < CINP; ++c) v[c] = c < Cin ? x[m * Cin + c] : 0.f;
+    }
   };
 #pragma unroll
   for (int c = 0; c < CINP; ++c) { xv[c] = 0.f; xn[c] = 0.f; }
@@ -119,6 +129,13 @@ __global__ __launch_bounds__(256) void stem_fwd_reg_kernel(const float* __restri
       }
     }
     st8<T>(y, (size_t)m * Cout + cg * 8, o);
+    if (xpack && cg < 2) {                              // threads cg = 0 / 1 of the pixel write the two 16-byte halves of its packed row
+      float hf[8], lf[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { hf[c] = stored_value<bf16_t>(xv[c]); lf[c] = xv[c] - hf[c]; }
+      lf[7] = 1.f;
+      st8<bf16_t>(xpack, (size_t)m * 16 + cg * 8, cg == 0 ? hf : lf);
+    }
     if constexpr (STATS) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float v = stored_value<T>(o[j]); s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
@@ -143,6 +160,25 @@ __global__ __launch_bounds__(256) void stem_fwd_reg_kernel(const float* __restri
       unsafeAtomicAdd(&stats[(size_t)(blockIdx.x % replicas) * 2 * Cout + k], (double)t);
     }
   }
+}
+
+// dW[co][c] += tmp[co][c] + tmp[co][8 + c], db[co] += tmp[co][15], tmp := 0 (tmp [Cout][16]: what the 1x1 weight gradient of dy against the packed
+// input of stem_fwd_reg_kernel leaves: hi and lo halves of x, the column of ones)
+__global__ void stem_bwd_fold_kernel(float* tmp, float* dw, float* db, int Cin, int Cout) {
+  for (int i = threadIdx.x; i < Cout * 16; i += blockDim.x) {
+    const int co = i >> 4, c = i & 15;
+    const float v = tmp[i];
+    if (c < Cin) dw[co * Cin + c] += v + tmp[co * 16 + 8 + c];
+    else if (c == 15 && db) db[co] += v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cout * 16; i += blockDim.x) tmp[i] = 0.f;
+}
+extern "C" int rua_stem_bwd_fold(float* tmp, float* dw, float* db, int Cin, int Cout, void* stream) {
+  RUA_CHECK_ARG(tmp && dw && Cin >= 1 && Cin <= 7 && Cout >= 1, "rua_stem_bwd_fold: bad arguments (Cin=%d must be in 1..7)", Cin);
+  hipLaunchKernelGGL(stem_bwd_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tmp, dw, db, Cin, Cout);
+  RUA_LAUNCH_CHECK("rua_stem_bwd_fold");
+  return RUA_OK;
 }
 
 // STEM_NT threads per block: one block per CU (every block ends with one float atomic per weight, and same-address atomics
@@ -212,24 +248,26 @@ __global__ __launch_bounds__(STEM_NT) void stem_bwd_kernel(const float* __restri
 }
 
 static int stem_fwd_launch(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, double* stats, int replicas, void* stream,
-                           const char* who) {
+                           const char* who, void* xpack = nullptr) {
   RUA_CHECK_ARG(x && w && y && M > 0, "%s: bad arguments", who);
   RUA_CHECK_ARG(Cin >= 1 && Cin <= 16, "%s: Cin=%d must be in 1..16", who, Cin);
   RUA_CHECK_ARG(Cout % 8 == 0 && Cout <= 256, "%s: Cout=%d must be a multiple of 8 (<=256)", who, Cout);
   hipStream_t st = (hipStream_t)stream;
   int64_t g = (M * (Cout / 8) + 255) / 256;
-  if (Cin <= 8 && 256 % (Cout / 8) == 0 && g_tune.stem_reg) {
+  const bool reg_ok = Cin <= 8 && 256 % (Cout / 8) == 0;
+  RUA_CHECK_ARG(!xpack || (reg_ok && Cin <= 7 && Cout >= 16), "%s: the packed input needs Cin <= 7 and Cout / 8 a power of two >= 2", who);
+  if (reg_ok && (g_tune.stem_reg || xpack)) {
     RUA_CHECK_ARG(!stats || replicas >= 1, "%s: replicas=%d", who, replicas);
     const int64_t cap = (stats ? 4 : 8) * (int64_t)rua_cu_count();      // STATS: every block ends with 2 Cout fp64 atomics into its replica
     if (g > cap) g = cap;
     const size_t smem = (size_t)(8 * Cout) * 4;
-    if (stats) {
-      if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_fwd_reg_kernel<bf16_t, true>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, stats, replicas);
-      else hipLaunchKernelGGL((stem_fwd_reg_kernel<float, true>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, stats, replicas);
-    } else {
-      if (dtype == RUA_BF16) hipLaunchKernelGGL((stem_fwd_reg_kernel<bf16_t, false>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, nullptr, 1);
-      else hipLaunchKernelGGL((stem_fwd_reg_kernel<float, false>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, nullptr, 1);
-    }
+#define RUA_STEM_GO(T_, ST_, CI_) hipLaunchKernelGGL((stem_fwd_reg_kernel<T_, ST_, CI_>), dim3((int)g), dim3(256), smem, st, x, w, b, (unsigned char*)y, (long long)M, Cin, Cout, \
+                                                     stats, stats ? replicas : 1, (unsigned char*)xpack)
+#define RUA_STEM_CI(T_, ST_) do { if (Cin == 6) RUA_STEM_GO(T_, ST_, 6); else if (Cin == 3) RUA_STEM_GO(T_, ST_, 3); else if (Cin == 7) RUA_STEM_GO(T_, ST_, 7); else RUA_STEM_GO(T_, ST_, 0); } while (0)
+    if (stats) { if (dtype == RUA_BF16) RUA_STEM_CI(bf16_t, true); else RUA_STEM_CI(float, true); }
+    else { if (dtype == RUA_BF16) RUA_STEM_CI(bf16_t, false); else RUA_STEM_CI(float, false); }
+#undef RUA_STEM_CI
+#undef RUA_STEM_GO
     RUA_LAUNCH_CHECK(who);
     return RUA_OK;
   }
@@ -256,6 +294,11 @@ extern "C" int rua_stem_fwd(const float* x, const float* w, const float* b, void
 extern "C" int rua_stem_fwd_stats(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, double* stats, int replicas, void* stream) {
   RUA_CHECK_ARG(stats != nullptr, "rua_stem_fwd_stats: stats is NULL");
   return stem_fwd_launch(x, w, b, y, M, Cin, Cout, dtype, stats, replicas, stream, "rua_stem_fwd_stats");
+}
+extern "C" int rua_stem_fwd_pack(const float* x, const float* w, const float* b, void* y, int64_t M, int Cin, int Cout, int dtype, double* stats, int replicas,
+                                 void* xpack, void* stream) {
+  RUA_CHECK_ARG(xpack != nullptr, "rua_stem_fwd_pack: xpack is NULL");
+  return stem_fwd_launch(x, w, b, y, M, Cin, Cout, dtype, stats, replicas, stream, "rua_stem_fwd_pack", xpack);
 }
 
 extern "C" int rua_stem_bwd(const float* x, const void* dy, float* dw, float* db, int64_t M, int Cin, int Cout, int dtype, void* stream) {
@@ -892,36 +935,34 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned char* x, c
     if (dx && accumulate_dx) o0 = ldg16(dx + ((size_t)r * CGI + cp) * 16);
     row(x0, g0, o0, r);
   }
-  // lanes that share a channel piece (same lane % CGI) are folded with shuffles, then one LDS slot per wave
+  // The block's sums: every thread's CO * VEC + CO + VEC partial sums go into an LDS tile [thread][value] (odd row stride: conflict-free row
+  // writes and column reads), output element e is the sum of one column over the PL threads that share its channel piece - all reads
+  // independent.  (Before: 62 butterflies of 4 dependent ds_bpermute each per wave - latency-bound, ~8 us of the CU's time per block: the
+  // launch took 33 us with 512 blocks and 50 us with 1024.)
+  constexpr int NV = CO * VEC + CO + VEC, RS = NV | 1;
+  (void)lane; (void)wid;
+  float* row_ = red + (size_t)threadIdx.x * RS;
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j)
-      for (int o = CGI; o < 64; o <<= 1) acc[co][j] += __shfl_xor(acc[co][j], o, 64);
-    for (int o = CGI; o < 64; o <<= 1) bs[co] += __shfl_xor(bs[co], o, 64);
+    for (int j = 0; j < VEC; ++j) row_[co * VEC + j] = acc[co][j];
+    row_[CO * VEC + co] = bs[co];
   }
-  if (dxsum) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j)
-      for (int o = CGI; o < 64; o <<= 1) so[j] += __shfl_xor(so[j], o, 64);
-  }
-  if (lane < CGI) {
-#pragma unroll
-    for (int co = 0; co < CO; ++co) {
-      if (EXACT || co < Cout) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) red[wid * NE + co * Cin + lane * VEC + j] = acc[co][j];
-        if (lane == 0) red[wid * NE + Cout * Cin + co] = bs[co];
-      }
-    }
-    if (dxsum) {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) red[wid * NE + Cout * Cin + Cout + lane * VEC + j] = so[j];
-    }
-  }
+  for (int j = 0; j < VEC; ++j) row_[CO * VEC + CO + j] = so[j];
   __syncthreads();
   for (int i = threadIdx.x; i < NE; i += 256) {
-    const float v = red[i] + red[NE + i] + red[2 * NE + i] + red[3 * NE + i];
+    int col, cpi;                                       // column of the tile, channel piece (the threads t = pl * CGI + cpi hold it)
+    if (i < Cout * Cin) { const int co = i / Cin, ci = i - co * Cin; cpi = ci / VEC; col = co * VEC + (ci - cpi * VEC); }
+    else if (i < Cout * Cin + Cout) { cpi = 0; col = CO * VEC + (i - Cout * Cin); }
+    else { const int ci = i - Cout * Cin - Cout; cpi = ci / VEC; col = CO * VEC + CO + (ci - cpi * VEC); }
+    const float* cp_ = red + (size_t)cpi * RS + col;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int q = 0; q < PL; q += 4) {
+      t0 += cp_[(size_t)(q + 0) * CGI * RS]; t1 += cp_[(size_t)(q + 1) * CGI * RS];
+      t2 += cp_[(size_t)(q + 2) * CGI * RS]; t3 += cp_[(size_t)(q + 3) * CGI * RS];
+    }
+    const float v = (t0 + t1) + (t2 + t3);
     if (partial) partial[(size_t)blockIdx.x * NE + i] = v;                       // deterministic two-stage path
     else if (i < Cout * Cin) unsafeAtomicAdd(&dw[i], v);
     else if (i < Cout * Cin + Cout) { if (db) unsafeAtomicAdd(&db[i - Cout * Cin], v); }
@@ -1038,11 +1079,14 @@ extern "C" int rua_head_bwd_sums(const void* x, const float* dz, const float* w,
   const int g = (int)((M + rpb - 1) / rpb);
   RUA_CHECK_ARG(!dxsum || dx, "rua_head_bwd_sums: the sums are those of dx");
   const int ne = Cout * Cin + Cout + (dxsum ? Cin : 0);
-  const size_t smem = (size_t)4 * ne * 4;
+  const int co_t = Cout == 6 ? 6 : (Cout == 3 ? 3 : 8);
+  const size_t smem = (size_t)256 * ((co_t * vec + co_t + vec) | 1) * 4;      // the block's [thread][value] reduction tile
   float* partial = (scratch && scratch_bytes >= (int64_t)g * ne * 4) ? scratch : nullptr;   // else: fp32 atomics
   hipStream_t st = (hipStream_t)stream;
-#define RUA_HEAD_BWD(TT, CO_) hipLaunchKernelGGL((head_bwd_kernel<TT, CO_>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, \
-    (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb, mask_dx, dxsum)
+#define RUA_HEAD_BWD(TT, CO_) do { static RuaPerDevFlag af; bool& a_ = af.get(); \
+    if (!a_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<TT, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); a_ = true; } \
+    hipLaunchKernelGGL((head_bwd_kernel<TT, CO_>), dim3(g), dim3(256), smem, st, (const unsigned char*)x, dz, w, \
+    (unsigned char*)dx, accumulate_dx, dw, db, partial, (long long)M, Cin, Cout, (int)rpb, mask_dx, dxsum); } while (0)
   if (dtype == RUA_BF16) { if (Cout == 6) RUA_HEAD_BWD(bf16_t, 6); else if (Cout == 3) RUA_HEAD_BWD(bf16_t, 3); else RUA_HEAD_BWD(bf16_t, 8); }
   else { if (Cout == 6) RUA_HEAD_BWD(float, 6); else if (Cout == 3) RUA_HEAD_BWD(float, 3); else RUA_HEAD_BWD(float, 8); }
 #undef RUA_HEAD_BWD

@@ -22,7 +22,8 @@ from . import _lib as L
 
 BN_EPS, BN_MOMENTUM, KERAS_EPS = 1e-3, 0.99, 1e-7
 HEADS = ["seg", "bound", "dist", "color"]
-SUMS_REPLICAS = 8          # copies of a head's Tanimoto moments the blocks of rua_head_fwd_loss_rep spread their atomics over
+SUMS_REPLICAS = 1          # copies of a head's Tanimoto moments the blocks of rua_head_fwd_loss_rep spread their atomics over (measured: 8 copies take ~1 us off
+                           # a head's forward and put ~8 us on the one-block finalisation that folds them - one copy it is)
 
 
 @dataclass
@@ -370,6 +371,7 @@ class Graph:
         self.cur_lane = 0
         self.block_tag = ""
         self.pending: List[tuple] = []          # deferred weight-gradient reductions (record, dW offset)
+        self.pending_bytes = 0                  # ... and the bytes of partials they will read (Engine.flush_bytes)
         self.pending_bucket = 0
         self.allocs: List[torch.Tensor] = []
         self.stats_used = 16                 # the first 16 doubles of the arena are the loss / metric scalars
@@ -735,7 +737,7 @@ class Graph:
         defer = (not self.dry) and self.e.defer_reduce and plan is self.bwd
         if defer and may_flush:                             # before G(): a flush is a launch of its own and must not count as this one
             bucket = self.e.dist.bucket_of(dw_off) if self.e.dist is not None else 0
-            if self.pending and bucket != self.pending_bucket:
+            if self.pending and (bucket != self.pending_bucket or self.pending_bytes > self.e.flush_bytes):
                 self.flush_wgrad(plan)
             self.pending_bucket = bucket
         d.dw = self.G(dw_off)
@@ -785,8 +787,10 @@ class Graph:
         lib.call("rua_wgrad_plan", C.byref(d), C.byref(rec))           # the record for the private workspace
         assert rec.kind != 0
         self.pending.append((rec, dw_off))
+        self.pending_bytes += nbytes
 
     def flush_wgrad(self, plan: Plan):
+        self.pending_bytes = 0
         if not self.pending:
             return
         recs = (L.WgradPending * len(self.pending))()
@@ -1382,7 +1386,12 @@ class Graph:
             if sums is None:                                # (the head's forward did not take the moments itself)
                 sums = self.salloc(B * Cc * 6)
                 LP.add("rua_tanimoto_sums", h["p"].ptr, h["y"].ptr, B, HW, Cc, sums)
-            LP.add("rua_tanimoto_finalize_rep", sums, h.get("sums_rep", 1), B, HW, Cc, wgt / B, slot, coef.data_ptr(), None)
+            if self.multi_head:                             # one launch for all heads (_record_losses)
+                th = L.TaniHead()
+                th.sums, th.replicas, th.B, th.C, th.grad_scale, th.loss_out, th.coef, th.per_sample = sums, h.get("sums_rep", 1), B, Cc, wgt / B, slot, coef.data_ptr(), None
+                self._tani_multi.append(th)
+            else:
+                LP.add("rua_tanimoto_finalize_rep", sums, h.get("sums_rep", 1), B, HW, Cc, wgt / B, slot, coef.data_ptr(), None)
             h["norm"] = 1.0
         else:
             LP.add("rua_pixel_loss", kind, h["p"].ptr, h["z"].ptr, h["y"].ptr, self.e.class_w_ptr, M, Cc, slot, None)
@@ -1390,12 +1399,25 @@ class Graph:
         if not self.training:
             return
 
+        dz = self.new(B, h["x"].H, h["x"].W, Cc, f32=True)
+        gs = wgt / B if kind == L.LOSS_TANIMOTO else wgt / M
+        if self.multi_head:
+            dh = L.DzHead()
+            dh.kind, dh.act, dh.p, dh.y, dh.coef, dh.class_w = kind, h["act"], h["p"].ptr, h["y"].ptr, coef.data_ptr() if coef is not None else None, self.e.class_w_ptr
+            dh.grad_scale, dh.B, dh.HW, dh.C, dh.dz = gs, B, HW, Cc, dz.ptr
+            self._dz_multi.append(dh)
+
         def back():
             Bp = self.bwd
-            dz = self.new(B, h["x"].H, h["x"].W, Cc, f32=True)
-            gs = wgt / B if kind == L.LOSS_TANIMOTO else wgt / M
-            Bp.add("rua_head_dz", kind, h["act"], h["p"].ptr, h["y"].ptr, coef.data_ptr() if coef is not None else None,
-                   self.e.class_w_ptr, gs, B, HW, Cc, dz.ptr)
+            if self.multi_head:
+                if not self._dz_emitted:                    # the first backward step of the loss section: d(loss)/d(logits) of ALL heads in one launch
+                    arr = (L.DzHead * len(self._dz_multi))(*self._dz_multi)
+                    Bp.keep.append(arr)
+                    Bp.add("rua_head_dz_multi", arr, len(self._dz_multi))
+                    self._dz_emitted = True
+            else:
+                Bp.add("rua_head_dz", kind, h["act"], h["p"].ptr, h["y"].ptr, coef.data_ptr() if coef is not None else None,
+                       self.e.class_w_ptr, gs, B, HW, Cc, dz.ptr)
             hx = h["x"]
             gx, acc = self.gacc(hx, masked=hx.relu_out)
             lay = h["lay"]
@@ -1431,16 +1453,35 @@ class Graph:
         stem = self.Lconv([Cin], w0, 1, mfma=False)
         c1 = self.new(self.B, H, W, w0)
         self.cur_tag, F.scope = "stem", "stem"
+        # bf16 storage, <= 7 bands: the stem's weight gradient on the matrix pipe - the forward also writes the input as bf16 hi | lo | 1 (xpack), the backward is
+        # the 1x1 weight gradient of dy against it + rua_stem_bwd_fold (include/rua_hip.h)
+        pack = tr and not self.dry and self.e.stem_mfma and self.e.dtype == "bf16" and Cin <= 7 and w0 % 16 == 0 and c1.M >= 2048
+        xpack = self.new(self.B, H, W, 16) if pack else None
         if tr and getattr(self.e, "stem_stats", True):
             # the statistics the first BatchNorm of the encoder needs, from the kernel that writes the tensor (no rua_col_stats pass over it)
             c1.stats = self.stat(w0, 2 * 256, burst=True)
+        if pack:
+            st = getattr(c1, "stats", None)
+            F.add("rua_stem_fwd_pack", self.x_in.ptr, self.P(stem["segs"][0]["off"]), self.P(stem["bias"]), c1.ptr, c1.M, Cin, w0, self.dt,
+                  st.ptr if st is not None else None, st.R if st is not None else 1, xpack.ptr)
+        elif tr and getattr(self.e, "stem_stats", True):
             F.add("rua_stem_fwd_stats", self.x_in.ptr, self.P(stem["segs"][0]["off"]), self.P(stem["bias"]), c1.ptr, c1.M, Cin, w0, self.dt, c1.stats.ptr, c1.stats.R)
         else:
             F.add("rua_stem_fwd", self.x_in.ptr, self.P(stem["segs"][0]["off"]), self.P(stem["bias"]), c1.ptr, c1.M, Cin, w0, self.dt)
         if tr:
             def stem_back():
-                self.bwd.add("rua_stem_bwd", self.x_in.ptr, c1.grad.ptr, self.G(stem["segs"][0]["off"]), self.G(stem["bias"]),
-                             c1.M, Cin, w0, self.dt)
+                Bp = self.bwd
+                if pack:
+                    tmp = self.alloc((w0 * 16,), torch.float32, zero=True)          # [Cout][16]: zero before every launch (the fold leaves it so)
+                    d = self.wgrad_desc(Bp, xpack, c1.grad, stem["segs"][0]["off"], 1, 1, 1)
+                    assert d.defer == 0, "the packed stem weight gradient must reduce inside its own launch (wgrad_pw)"
+                    d.dw = tmp.data_ptr()
+                    Bp.keep.append(d)
+                    Bp.add("rua_conv_wgrad", C.byref(d))
+                    Bp.add("rua_stem_bwd_fold", tmp.data_ptr(), self.G(stem["segs"][0]["off"]), self.G(stem["bias"]), Cin, w0)
+                else:
+                    Bp.add("rua_stem_bwd", self.x_in.ptr, c1.grad.ptr, self.G(stem["segs"][0]["off"]), self.G(stem["bias"]),
+                           c1.M, Cin, w0, self.dt)
             self.back_steps.append(stem_back)
         self.cur_tag, F.scope = None, None
         x = c1
@@ -1482,9 +1523,17 @@ class Graph:
 
     def _record_losses(self):
         """Loss / metric launches and (training) the whole backward plan, in reverse creation order."""
+        # multitask: the heads' Tanimoto finalisations and their d(loss)/d(logits) as one launch each (rua_tanimoto_finalize_multi, rua_head_dz_multi)
+        self.multi_head = len(self.heads) > 1 and self.e.multi_head
+        self._tani_multi, self._dz_multi, self._dz_emitted = [], [], False
         for h in self.heads:
             self.cur_tag = self.loss_plan.scope = "loss_" + h["name"]
             self.head_loss(h)
+        if self._tani_multi:
+            self.loss_plan.scope = "loss_finalize"
+            arr = (L.TaniHead * len(self._tani_multi))(*self._tani_multi)
+            self.loss_plan.keep.append(arr)
+            self.loss_plan.add("rua_tanimoto_finalize_multi", arr, len(self._tani_multi))
         self.cur_tag = self.loss_plan.scope = None
         seg = self.outputs["seg"]
         if not seg.get("metrics_done"):
@@ -1518,6 +1567,9 @@ class Engine:
         self.pool_pyramid = os.environ.get("RUA_POOL_PYRAMID", "1") != "0"   # PSPPooling: the 2 / 4 / 8 poolings (and their adjoints) in single passes
         self.fold_bn = os.environ.get("RUA_FOLD_BN", "1") != "0"     # ... and their coefficient launches folded into the convs' prologues
         self.defer_reduce = os.environ.get("RUA_DEFER_REDUCE", "1") != "0"     # weight-gradient partials summed by batched launches
+        # ... flushed whenever more than this many bytes of partials are pending: the K-slice slabs of levels 3 - 5 are then still in the 256 MB
+        # Infinity Cache when the reduction reads them (one reduction at the end of the backward read all 0.6 GB from HBM)
+        self.flush_bytes = int(float(os.environ.get("RUA_FLUSH_MB", "1e9")) * (1 << 20))
         self.cu_count = 256
         self.split_k = split_k       # False: bit-reproducible convolutions (no fp32-atomic K slices); parity tests on tiny
                                      # inputs use it because a BatchNorm over 2 samples amplifies atomic-order noise ~1e4x
@@ -1567,6 +1619,8 @@ class Engine:
         self._t_dev, self._lr_base_dev = -1, None                                         # what lr_state holds (host shadow)
         self._dp_fence = torch.zeros(16, dtype=torch.float32, device=self.dev)            # see _graph_step_dp
         self.use_graph = True
+        self.multi_head = os.environ.get("RUA_MULTI_HEAD", "1") != "0"     # the heads' loss finalisation / d(loss)/d(logits) as one launch each
+        self.stem_mfma = os.environ.get("RUA_STEM_MFMA", "1") != "0"       # bf16: the stem's weight gradient through rua_stem_fwd_pack / rua_conv_wgrad / rua_stem_bwd_fold
         self.stem_stats = os.environ.get("RUA_STEM_STATS", "1") != "0"     # rua_stem_fwd_stats instead of a rua_col_stats pass over the stem's output
         self._captured: Dict[int, object] = {}
         self._captured_eval: Dict[int, object] = {}        # batch -> graph of the inference forward (False: capture failed)

@@ -617,6 +617,42 @@ def test_stem_and_head_kernels():
         dyr = rnd(dt, dy).numpy()
         assert rel_err(dw.cpu().numpy(), dyr.T @ x) < 1e-4
         assert rel_err(db.cpu().numpy(), dyr.sum(0)) < 1e-4
+        if dt == L.RUA_BF16:
+            # the stem's weight gradient on the matrix pipe: rua_stem_fwd_pack (same y and statistics as rua_stem_fwd_stats + the input as bf16 hi | lo | 1),
+            # the 1x1 weight gradient of dy against it, rua_stem_bwd_fold - against the exact sums (the hi + lo split carries ~16 mantissa bits of x)
+            for Ms, Ci3 in ((4096, 6), (70016, 3), (8192, 7)):
+                xs_h = rng.standard_normal((Ms, Ci3)).astype(np.float32)
+                w3 = f(rng.standard_normal((Cout, Ci3)))
+                xs = f(xs_h)
+                y0 = torch.empty((Ms, Cout), dtype=tdt(dt), device=dev()); y1 = torch.empty_like(y0)
+                R = 8
+                st0 = torch.zeros(R * 2 * Cout, dtype=torch.float64, device=dev()); st1 = torch.zeros_like(st0)
+                xp = torch.zeros((Ms, 16), dtype=torch.bfloat16, device=dev())
+                lib.call("rua_stem_fwd_stats", xs.data_ptr(), w3.data_ptr(), bd.data_ptr(), y0.data_ptr(), Ms, Ci3, Cout, dt, st0.data_ptr(), R, stream())
+                lib.call("rua_stem_fwd_pack", xs.data_ptr(), w3.data_ptr(), bd.data_ptr(), y1.data_ptr(), Ms, Ci3, Cout, dt, st1.data_ptr(), R, xp.data_ptr(), stream())
+                torch.cuda.synchronize()
+                assert torch.equal(y0, y1) and torch.equal(st0, st1)
+                xpf = xp.float().cpu().numpy()
+                assert np.abs(xpf[:, :Ci3] + xpf[:, 8:8 + Ci3] - xs_h).max() < 1e-4 and (xpf[:, 15] == 1).all() and (xpf[:, Ci3:8] == 0).all()
+                dys = rng.standard_normal((Ms, Cout)).astype(np.float32)
+                dysd = to_dev(dys, dt)
+                tmp = torch.zeros((Cout, 16), device=dev())
+                ws = torch.zeros(16 << 20, device=dev())
+                d = L.WgradDesc()
+                d.a, d.C, d.Hs, d.Ws = xp.data_ptr(), 16, 1, Ms
+                d.dy, d.Cout, d.H, d.W = dysd.data_ptr(), Cout, 1, Ms
+                d.N, d.stride, d.dil, d.taps, d.dtype = 1, 1, 1, 1, dt
+                d.dw, d.workspace, d.workspace_bytes = tmp.data_ptr(), ws.data_ptr(), ws.numel() * 4
+                assert lib.raw("rua_wgrad_kind")(C.byref(d)) == 3                  # wgrad_pw
+                dw3 = torch.zeros((Cout, Ci3), device=dev()); db3 = torch.zeros(Cout, device=dev())
+                for _ in range(2):                                                # twice: the fold leaves tmp zero, the gradients accumulate
+                    lib.call("rua_conv_wgrad", C.byref(d), stream())
+                    lib.call("rua_stem_bwd_fold", tmp.data_ptr(), dw3.data_ptr(), db3.data_ptr(), Ci3, Cout, stream())
+                torch.cuda.synchronize()
+                dyr3 = rnd(dt, dys).double().numpy()
+                assert rel_err(dw3.cpu().numpy(), 2 * dyr3.T @ xs_h.astype(np.float64)) < 1e-4
+                assert rel_err(db3.cpu().numpy(), 2 * dyr3.sum(0)) < 1e-4
+                assert (tmp == 0).all()
         # head
         Ci, Co = 32, 6
         hx = rng.standard_normal((M, Ci)).astype(np.float32)
@@ -1329,6 +1365,38 @@ def test_head_forward_with_loss_moments_equals_the_separate_passes(dt, act, Cout
     for o in outs[1:]:
         assert abs(o[0] - outs[0][0]) < 1e-6 and np.allclose(o[1], outs[0][1], rtol=1e-4, atol=1e-7) and np.allclose(o[2], outs[0][2], rtol=1e-5)
     assert outs[1][0] == outs[2][0] and np.array_equal(outs[1][1], outs[2][1])
+
+
+def test_multi_head_loss_launches_equal_the_per_head_ones():
+    """rua_tanimoto_finalize_multi / rua_head_dz_multi (the four heads of the multitask model in one launch each, train_ISPRS.py:417-421) against
+    rua_tanimoto_finalize / rua_head_dz head by head: bit for bit."""
+    rng = np.random.default_rng(77)
+    lib = L.lib()
+    B, HW = 3, 40 * 52
+    M = B * HW
+    heads = [(6, L.ACT_SOFTMAX, 1.0), (6, L.ACT_SIGMOID, 0.5), (6, L.ACT_SOFTMAX, 2.0), (3, L.ACT_SIGMOID, 1.0)]
+    keep, th, dh, ref = [], [], [], []
+    for Cc, act, wgt in heads:
+        p = torch.from_numpy(rng.random((M, Cc)).astype(np.float32)).to(dev())
+        if act == L.ACT_SOFTMAX:
+            p = p / p.sum(1, keepdim=True)
+        y = torch.from_numpy((rng.random((M, Cc)) > 0.6).astype(np.float32)).to(dev())
+        sums = torch.zeros(B * Cc * 6, dtype=torch.float64, device=dev())
+        lib.call("rua_tanimoto_sums", p.data_ptr(), y.data_ptr(), B, HW, Cc, sums.data_ptr(), stream())
+        lo0, co0, dz0 = torch.zeros(1, dtype=torch.float64, device=dev()), torch.zeros(B * Cc * 3, device=dev()), torch.zeros((M, Cc), device=dev())
+        lo1, co1, dz1 = torch.zeros_like(lo0), torch.zeros_like(co0), torch.zeros_like(dz0)
+        lib.call("rua_tanimoto_finalize", sums.data_ptr(), B, HW, Cc, wgt / B, lo0.data_ptr(), co0.data_ptr(), None, stream())
+        lib.call("rua_head_dz", L.LOSS_TANIMOTO, act, p.data_ptr(), y.data_ptr(), co0.data_ptr(), None, wgt / B, B, HW, Cc, dz0.data_ptr(), stream())
+        t = L.TaniHead(); t.sums, t.replicas, t.B, t.C, t.grad_scale, t.loss_out, t.coef, t.per_sample = sums.data_ptr(), 1, B, Cc, wgt / B, lo1.data_ptr(), co1.data_ptr(), None
+        d = L.DzHead(); d.kind, d.act, d.p, d.y, d.coef, d.class_w, d.grad_scale, d.B, d.HW, d.C, d.dz = L.LOSS_TANIMOTO, act, p.data_ptr(), y.data_ptr(), co1.data_ptr(), None, wgt / B, B, HW, Cc, dz1.data_ptr()
+        th.append(t); dh.append(d); keep += [p, y, sums]; ref.append((lo0, co0, dz0, lo1, co1, dz1))
+    ta = (L.TaniHead * len(th))(*th); da = (L.DzHead * len(dh))(*dh)
+    lib.call("rua_tanimoto_finalize_multi", ta, len(th), stream())
+    lib.call("rua_head_dz_multi", da, len(dh), stream())
+    torch.cuda.synchronize()
+    for lo0, co0, dz0, lo1, co1, dz1 in ref:
+        assert torch.equal(lo0, lo1) and torch.equal(co0, co1) and torch.equal(dz0, dz1) and dz0.abs().sum().item() > 0
+    assert lib.raw("rua_tanimoto_finalize_multi")(ta, 0, None) != 0 and lib.raw("rua_head_dz_multi")(da, 9, None) != 0
 
 
 BAND_CASES = [

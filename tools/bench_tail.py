@@ -61,6 +61,11 @@ def main():
         bb = M * (64 * 2 + 4 * Cout)
         for mask in (0, 1):
             timed(f"rua_head_bwd_sums partials mask={mask} 32->{Cout}", bb, lambda: lib.call("rua_head_bwd_sums", x32.data_ptr(), dz.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), db.data_ptr(), ds.data_ptr(), scratch.data_ptr(), scratch.numel() * 4, M, 32, Cout, dt, mask, s))
+        timed(f"rua_head_bwd_sums partials no dx 32->{Cout}", M * (64 + 4 * Cout), lambda: lib.call("rua_head_bwd_sums", x32.data_ptr(), dz.data_ptr(), w.data_ptr(), None, 0, dw.data_ptr(), db.data_ptr(), None, scratch.data_ptr(), scratch.numel() * 4, M, 32, Cout, dt, 0, s))
+        for hb in (256, 1024):
+            lib.set_tuning(head_blocks=hb)
+            timed(f"rua_head_bwd_sums partials mask=1 32->{Cout} ({hb} blocks)", bb, lambda: lib.call("rua_head_bwd_sums", x32.data_ptr(), dz.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), db.data_ptr(), ds.data_ptr(), scratch.data_ptr(), scratch.numel() * 4, M, 32, Cout, dt, 1, s))
+        lib.set_tuning(head_blocks=0)
         timed(f"rua_head_bwd_sums atomics  mask=1 32->{Cout}", bb, lambda: lib.call("rua_head_bwd_sums", x32.data_ptr(), dz.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), db.data_ptr(), ds.data_ptr(), None, 0, M, 32, Cout, dt, 1, s))
     # stem
     Cin = 6
