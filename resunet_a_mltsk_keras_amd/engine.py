@@ -1345,10 +1345,10 @@ class Graph:
             self.back_steps.append(back)
         return y
 
-    def head(self, x: Ten, cout: int, act: int, hname: str, name=None):
+    def head(self, x: Ten, cout: int, act: int, hname: str, name=None, lay=None):
         """Conv2D(C,(1,1)) + softmax/sigmoid, its loss and the gradient w.r.t. the logits."""
         F, tr = self.fwd, self.training
-        lay = self.Lconv([x.C], cout, 1, name=name, mfma=False)
+        lay = lay if lay is not None else self.Lconv([x.C], cout, 1, name=name, mfma=False)
         z = self.new(x.N, x.H, x.W, cout, f32=True)
         p = self.new(x.N, x.H, x.W, cout, f32=True)
         y = self.new(x.N, x.H, x.W, cout, f32=True)           # label buffer (host uploads into it)
@@ -1370,6 +1370,70 @@ class Graph:
             F.add("rua_head_fwd", x.ptr, self.P(lay["segs"][0]["off"]), self.P(lay["bias"]), z.ptr, p.ptr, x.M, x.C, cout, act, self.dt)
         self.heads.append(h)
         return h
+
+    def heads_grouped(self, x_psp: Ten, x_comb: Ten, w0: int, Cc: int):
+        """The multitask heads (model2.py:148-191) with their five 3x3 + ReLU convolutions issued as GROUPS across the heads - forward {seg1, bound1,
+        dist1} and {seg2, dist2}, backward the weight gradients and the data gradients of {seg2, bound1, dist2}, then of {seg1, dist1} - instead of
+        one launch per convolution: members on the same kernel form share one grid of persistent blocks (conv_strip32s_g / wgrad_rows32_g), which
+        runs a 9.66 GFLOP member in ~14 us where a launch of its own takes 17 - 22.  Layers are created in the order of the head-by-head path
+        (parameter layout and Keras names unchanged); same kernels, same arithmetic per convolution."""
+        F, tr = self.fwd, self.training
+        lay = {}
+        lay["seg1"] = self.Lconv([x_psp.C], w0, 9, name="seg1"); lay["seg2"] = self.Lconv([w0], w0, 9, name="seg2")
+        lay["seg3"] = self.Lconv([w0], Cc, 1, name="seg3", mfma=False)
+        lay["bound1"] = self.Lconv([x_psp.C], w0, 9); lay["bound3"] = self.Lconv([w0], Cc, 1, mfma=False)
+        lay["dist1"] = self.Lconv([x_comb.C], w0, 9); lay["dist2"] = self.Lconv([w0], w0, 9); lay["dist3"] = self.Lconv([w0], Cc, 1, mfma=False)
+        lay["color"] = self.Lconv([x_comb.C], 3, 1, name="color", mfma=False)
+
+        def out_of(x: Ten, ly) -> Ten:
+            y = self.new(x.N, x.H, x.W, w0)
+            y.relu_out = True
+            y.bias_offs = [ly["bias"]]
+            return y
+
+        def fdesc(x: Ten, ly, y: Ten):
+            return self.conv_desc([(x, 0, 1, 9)], ly["segs"], w0, self.P(ly["bias"]), y, out_relu=True)
+        s1, b1, d1 = out_of(x_psp, lay["seg1"]), out_of(x_psp, lay["bound1"]), out_of(x_comb, lay["dist1"])
+        self.cur_tag = F.scope = "heads_conv"
+        self.conv_group(F, [fdesc(x_psp, lay["seg1"], s1), fdesc(x_psp, lay["bound1"], b1), fdesc(x_comb, lay["dist1"], d1)])
+        s2, d2 = out_of(s1, lay["seg2"]), out_of(d1, lay["dist2"])
+        self.conv_group(F, [fdesc(s1, lay["seg2"], s2), fdesc(d1, lay["dist2"], d2)])
+        self.cur_tag = F.scope = None
+        if tr:
+            def phase(convs):                              # [(x, y, layer)]: weight gradients, then data gradients, of independent convolutions
+                Bp = self.bwd
+                for x, y, ly in convs:
+                    assert not (y.masked_w and y.plain_w), "mixed masked / unmasked writers of a ReLU output's gradient"
+                    if y.plain_w:
+                        assert not y.bias_done
+                        Bp.add("rua_relu_mask", y.grad.ptr, y.ptr, y.t.numel(), self.dt)
+                    if not y.bias_done:
+                        self.bias_grad(Bp, y.grad, [ly["bias"]])
+                self.wgrad_group(Bp, [(x, y.grad, ly["segs"][0]["off"], 1, 1, 9, None) for x, y, ly in convs])
+                descs, sums = [], []
+                for x, y, ly in convs:
+                    gx, acc = self.gacc(x, masked=x.relu_out)
+                    sx = None
+                    if x.bias_offs and x.relu_out and not acc and not self.dry and self.e.bn_dx_bias:
+                        sx = self.stat(x.C, (x.M + 127) // 128)     # the epilogue's sums of the masked gradient = the bias gradient of the conv behind x
+                        sums.append((sx, x))
+                    descs.append(self.dgrad_desc(y.grad, self.Wd(ly["segs"][0]["dst"]), x.C, 1, 9, gx, acc, mask=(x, None, None) if x.relu_out else None, stats2=sx))
+                self.conv_group(Bp, descs)
+                for sx, x in sums:
+                    self.stats_to_grads(Bp, sx, x.C, x.bias_offs)
+                    x.bias_done = True
+
+            def back():
+                Bp = self.bwd
+                Bp.scope = "heads_conv"
+                phase([(s1, s2, lay["seg2"]), (x_psp, b1, lay["bound1"]), (d1, d2, lay["dist2"])])
+                phase([(x_psp, s1, lay["seg1"]), (x_comb, d1, lay["dist1"])])
+                Bp.scope = None
+            self.back_steps.append(back)
+        self.tagged("head_seg", self.head, s2, Cc, L.ACT_SOFTMAX, "seg", "seg3", lay["seg3"])
+        self.tagged("head_bound", self.head, b1, Cc, L.ACT_SIGMOID, "bound", None, lay["bound3"])
+        self.tagged("head_dist", self.head, d2, Cc, L.ACT_SOFTMAX, "dist", None, lay["dist3"])
+        self.tagged("head_color", self.head, x_comb, 3, L.ACT_SIGMOID, "color", "color", lay["color"])
 
     def head_loss(self, h):
         """Loss value (fp64 scalar slot) and, in training, d(total)/d(logits) -> head weights and x.grad."""
@@ -1503,6 +1567,8 @@ class Graph:
         Cc = cfg.num_classes
         if not cfg.multitasking:
             self.tagged("head_seg", self.head, x_psp, Cc, L.ACT_SOFTMAX, "seg")
+        elif not self.dry and self.e.group_heads and self.e.dtype == "bf16":
+            self.heads_grouped(x_psp, x_comb, w0, Cc)
         else:
             def seg_head():
                 s = self.conv3x3_relu(x_psp, w0, "seg1")
@@ -1619,6 +1685,7 @@ class Engine:
         self._t_dev, self._lr_base_dev = -1, None                                         # what lr_state holds (host shadow)
         self._dp_fence = torch.zeros(16, dtype=torch.float32, device=self.dev)            # see _graph_step_dp
         self.use_graph = True
+        self.group_heads = os.environ.get("RUA_GROUP_HEADS", "1") != "0"   # the heads' 3x3 convolutions (and their gradients) grouped across the heads
         self.multi_head = os.environ.get("RUA_MULTI_HEAD", "1") != "0"     # the heads' loss finalisation / d(loss)/d(logits) as one launch each
         self.stem_mfma = os.environ.get("RUA_STEM_MFMA", "1") != "0"       # bf16: the stem's weight gradient through rua_stem_fwd_pack / rua_conv_wgrad / rua_stem_bwd_fold
         self.stem_stats = os.environ.get("RUA_STEM_STATS", "1") != "0"     # rua_stem_fwd_stats instead of a rua_col_stats pass over the stem's output
