@@ -435,6 +435,39 @@ __device__ __forceinline__ void conv_band32s_body(const BandK& q) {
     tab[TAB_BIAS + tid] = b;
     tab[TAB_ZERO + tid] = 0.f; tab[TAB_ZERO + 32 + tid] = 0.f;
   }
+  // ---- per-lane constants (conv_strip32s) ----------------------------------------------------------------------------------------
+  const int psrc = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned smem_a = (unsigned)(size_t)(lds_void_p)smem;
+  const unsigned tab_a = (unsigned)(size_t)(lds_void_p)tab + (unsigned)(psrc * 32);
+  const unsigned sw_a = (unsigned)(size_t)(lds_void_p)sW + (unsigned)(lane * 16);
+  const unsigned rowbytes = (unsigned)(W * C * 2), imgbase = (unsigned)(n_ * H) * rowbytes;
+  const unsigned xrel = (unsigned)(((wv * 16 + (lane >> 2)) * C + psrc * 8) * 2);
+  const unsigned pdst = (unsigned)(HALO * 64 + wv * 1024 + lane * 16);
+  const int o = wv * 32 + pl;
+  const int d0 = q.d[0], d1 = q.d[1], d2 = q.d[2], d3 = q.d[3];
+  // ---- the weights of branch 0 and the rows 1 .. R-2 of phase 0 go out BEFORE the fold (its scratch, 8 KB, lies in slot 0; the row DMAs write the
+  //      interior pixels of their slots only, the halo zeroing below the others): the ring fill and the fold's dependent loads share one memory round
+  //      trip instead of following one another; row 0 is issued in the prologue of run()
+  {
+    const __amdgpu_buffer_rsrc_t rw0 = make_rsrc(q.w[0], (unsigned)(9 * C * C * 2));
+#pragma unroll
+    for (int i = 0; i < WST; ++i) {
+      const int idx = i * NW + wv;
+      if (idx < WPIECES) {
+        const unsigned off = (unsigned)((((idx >> 1) * C * C) + pl * C + (idx & 1) * 16 + kh * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw0, (lds_void_p)(sW + idx * 1024), 16, off, 0, 0, 0);
+      }
+    }
+    const __amdgpu_buffer_rsrc_t rx0 = make_rsrc(q.x[0], q.xbytes);
+    const int hb0 = h0 - d0;                            // phase 0: kernel row 0 of branch 0
+#pragma unroll
+    for (int s_ = 1; s_ < R - 1; ++s_) {
+      const unsigned base = ((unsigned)(hb0 + s_) < (unsigned)H) ? imgbase + (unsigned)(hb0 + s_) * rowbytes : ROW_OOB;
+#pragma unroll
+      for (int k_ = 0; k_ < NPX; ++k_)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_void_p)(smem + s_ * SLOT + HALO * 64 + (k_ * NW + wv) * 1024), 16, (base + (unsigned)(k_ * NW * 1024)) + xrel, 0, 0, 0);
+    }
+  }
   if (q.has_fold) {
     rua_fold_members<NT, 32>([&](int m) -> const rua_bn_fold& { return q.f[m]; }, [](int) { return true; }, nb, job == 0, reinterpret_cast<double*>(smem), tid,
                              [&](int m, int c, float scf, float shf) { tab[m * 64 + c] = scf; tab[m * 64 + 32 + c] = shf; });
@@ -450,16 +483,6 @@ __device__ __forceinline__ void conv_band32s_body(const BandK& q) {
   __syncthreads();
   RUA_BTS(1);
 
-  // ---- per-lane constants (conv_strip32s) ----------------------------------------------------------------------------------------
-  const int psrc = (lane & 3) ^ ((lane >> 4) & 3);
-  const unsigned smem_a = (unsigned)(size_t)(lds_void_p)smem;
-  const unsigned tab_a = (unsigned)(size_t)(lds_void_p)tab + (unsigned)(psrc * 32);
-  const unsigned sw_a = (unsigned)(size_t)(lds_void_p)sW + (unsigned)(lane * 16);
-  const unsigned rowbytes = (unsigned)(W * C * 2), imgbase = (unsigned)(n_ * H) * rowbytes;
-  const unsigned xrel = (unsigned)(((wv * 16 + (lane >> 2)) * C + psrc * 8) * 2);
-  const unsigned pdst = (unsigned)(HALO * 64 + wv * 1024 + lane * 16);
-  const int o = wv * 32 + pl;
-  const int d0 = q.d[0], d1 = q.d[1], d2 = q.d[2], d3 = q.d[3];
   auto dil_of = [&](int b) { return b == 0 ? d0 : (b == 1 ? d1 : (b == 2 ? d2 : d3)); };
 #ifdef RUA_BAND_ABLATE
   const bool dbg_nox = (q.dbg & 4) != 0, dbg_notr = (q.dbg & 2) != 0, dbg_nomfma = (q.dbg & 16) != 0;
@@ -590,10 +613,7 @@ __device__ __forceinline__ void conv_band32s_body(const BandK& q) {
 
     // ---- prologue: weights of branch 0 and rows 0 .. R-2 in flight, everything landed; rows 0 .. 2 normalised, row 3 read --------------
     Phase cur = phase(0), nxt = phase(1);
-#pragma unroll
-    for (int i = 0; i < WST; ++i) issue_w(0, i * NW + wv);
-#pragma unroll
-    for (int s = 0; s < R - 1; ++s) issue_x(cur, s, (unsigned)(s * SLOT));        // R - 1 <= BR: all in phase 0
+    issue_x(cur, 0, 0u);                                // (the weights of branch 0 and the rows 1 .. R-2 went out in front of the fold)
     Coef cf;
     coef_read(cur.ca, cf);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -127,7 +127,8 @@ static int launch_stats(const void* g, const void* x, const float* ms, const flo
   k.stats = stats; k.R = replicas;
   const int64_t pieces = M * k.CG;
   int64_t gx = pieces / (256 * 8) / gy;                  // >= 8 pieces per thread
-  if (gx > 512 / gy) gx = 512 / gy;
+  const int64_t scap = g_tune.stats_blocks > 0 ? g_tune.stats_blocks : 512;
+  if (gx > scap / gy) gx = scap / gy;
   if (gx < 1) gx = 1;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RUA_BF16) hipLaunchKernelGGL((col_stats_kernel<bf16_t, MODE>), dim3((unsigned)gx, gy), dim3(256), 0, st, k);

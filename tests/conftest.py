@@ -8,8 +8,31 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _cpu_share():
+    """CPUs this process may really use: the affinity mask capped by the cgroup quota (os.cpu_count() reports the HOST's cores; the CPU oracle's
+    intra-op pool sized to that oversubscribes a 16-CPU share of a GPU box many times over)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        import torch
+        torch.set_num_threads(_cpu_share())
+    except Exception:
+        pass
 
 
 def has_gpu():
