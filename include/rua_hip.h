@@ -202,6 +202,10 @@ int rua_wgrad_kind(const rua_wgrad_desc* d);   /* 0: generic tiled kernel, 1: al
 typedef struct rua_wprep_item { int64_t src_off, dst_off; int32_t taps, Cout, C, pad; } rua_wprep_item;
 int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev,
                     int n_items, int max_elems, int dtype, void* stream);
+/* The data-gradient layout alone from the forward-layout bf16 copy (dtype must be RUA_BF16; items as for rua_weight_prep, dst_off = the offset in both copies):
+ * used when the optimizer has just written that copy itself (rua_adam_step_w / rua_sgd_step_w with wcopy_bf16 = the forward copy, whose index space
+ * must then be the master's: dst_off == src_off). */
+int rua_weight_prep_dgrad(const void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev, int n_items, int max_elems, int dtype, void* stream);
 
 /* ---- few-channel 1x1 convolutions (VALU; the stem and the heads) -------------------------
  * stem: KL.Conv2D(32,(1,1)) on the 3/6/7-band input (model2.py:101).  x fp32 [M][Cin<=16]. */
@@ -392,6 +396,11 @@ int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float l
                   float eps, float grad_scale, int zero_grad, void* stream);
 int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, const float* lr_dev, float momentum, float grad_scale,
                  int zero_grad, void* stream);
+/* rua_adam_step / rua_sgd_step that also store the updated parameters as bf16 into wcopy_bf16[i] (NULL: not) - the convolutions' forward-layout weight copy */
+int rua_adam_step_w(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1, float beta2,
+                    float eps, float grad_scale, int zero_grad, void* wcopy_bf16, void* stream);
+int rua_sgd_step_w(float* theta, float* g, float* vel, int64_t n, float lr, const float* lr_dev, float momentum, float grad_scale,
+                   int zero_grad, void* wcopy_bf16, void* stream);
 
 /* ---- data parallel (train_ISPRS.py:347,432: the implicit NCCL all-reduce of tf.distribute.MirroredStrategy).  The library exports
  * no collective: gradients live in ONE flat fp32 buffer in parameter order, so the all-reduce is ncclAllReduce (RCCL) on contiguous

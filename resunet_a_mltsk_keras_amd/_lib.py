@@ -113,6 +113,7 @@ _SIGS = {
     "rua_wgrad_plan": ([C.POINTER(WgradDesc), C.POINTER(WgradPending)], i32),
     "rua_wgrad_reduce_batch": ([vp, i32, i32, vp], i32),
     "rua_weight_prep": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    "rua_weight_prep_dgrad": ([vp, vp, vp, i32, i32, i32, vp], i32),
     "rua_stem_fwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "rua_stem_fwd_stats": ([vp, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp], i32),
     "rua_stem_bwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
@@ -162,6 +163,8 @@ _SIGS = {
     "rua_lr_step": ([vp, vp, i32, f64, f64, vp], i32),
     "rua_adam_step": ([vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, i32, vp], i32),
     "rua_sgd_step": ([vp, vp, vp, i64, f32, vp, f32, f32, i32, vp], i32),
+    "rua_adam_step_w": ([vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, i32, vp, vp], i32),
+    "rua_sgd_step_w": ([vp, vp, vp, i64, f32, vp, f32, f32, i32, vp, vp], i32),
     "rua_set_tuning": ([C.c_char_p, i64], i32),
     "rua_get_tuning": ([C.c_char_p, C.POINTER(i64)], i32),
     "rua_tuning_key": ([i32], C.c_char_p),

@@ -3731,6 +3731,66 @@ extern "C" int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, 
   return RUA_OK;
 }
 
+// The data-gradient layout alone, from the forward-layout bf16 copy the optimizer already wrote (rua_adam_step_w / rua_sgd_step_w): wd[taps reversed][ci][co]
+// = wf[tap][co][ci].  A block moves 64 (co) x 64 (ci) tiles of one tap through a 2-byte LDS tile: 8-byte reads along ci, 8-byte writes along co - half the
+// bytes of rua_weight_prep (no fp32 master read, no forward copy written).
+__global__ __launch_bounds__(256) void wprep_dgrad_kernel(const bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, const rua_wprep_item* __restrict__ items) {
+  __shared__ unsigned short tile[64][66];
+  const rua_wprep_item it = items[blockIdx.y];
+  const int tco = (it.Cout + 63) / 64, tci = (it.C + 63) / 64;
+  const int ntiles = it.taps * tco * tci;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const bool vec = (it.C % 4 == 0) && (it.Cout % 4 == 0);
+  const unsigned short* src = reinterpret_cast<const unsigned short*>(wf) + it.dst_off;
+  unsigned short* dst = reinterpret_cast<unsigned short*>(wd) + it.dst_off;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tap = t / (tco * tci), r = t - tap * tco * tci;
+    const int co0 = (r / tci) * 64, ci0 = (r % tci) * 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int co = co0 + ty + k * 16, ci = ci0 + tx * 4;
+      unsigned short v[4] = {0, 0, 0, 0};
+      if (co < it.Cout) {
+        const size_t o = (size_t)tap * it.Cout * it.C + (size_t)co * it.C + ci;
+        if (vec && ci + 3 < it.C) {
+          const uint2 q = *reinterpret_cast<const uint2*>(src + o);
+          v[0] = (unsigned short)(q.x & 0xffffu); v[1] = (unsigned short)(q.x >> 16); v[2] = (unsigned short)(q.y & 0xffffu); v[3] = (unsigned short)(q.y >> 16);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (ci + j < it.C) v[j] = src[o + j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[ty + k * 16][tx * 4 + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ci = ci0 + ty + k * 16, co = co0 + tx * 4;
+      if (ci < it.C) {
+        unsigned short v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = tile[tx * 4 + j][ty + k * 16];
+        unsigned short* d = dst + (size_t)(it.taps - 1 - tap) * it.Cout * it.C + (size_t)ci * it.Cout + co;
+        if (vec && co + 3 < it.Cout) *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (co + j < it.Cout) d[j] = v[j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+extern "C" int rua_weight_prep_dgrad(const void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev, int n_items, int max_elems, int dtype, void* stream) {
+  RUA_CHECK_ARG(w_fwd && w_dgrad && items_dev && n_items > 0, "rua_weight_prep_dgrad: bad arguments");
+  RUA_CHECK_ARG(dtype == RUA_BF16, "rua_weight_prep_dgrad: bf16 copies only (the fp32 path keeps rua_weight_prep)");
+  int gx = rua_div_up(max_elems, 4096 * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(wprep_dgrad_kernel, dim3(gx, n_items), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_fwd, (bf16_t*)w_dgrad, items_dev);
+  RUA_LAUNCH_CHECK("wprep_dgrad_kernel");
+  return RUA_OK;
+}
+
 // tile width (output channels per block) the launcher picks for a descriptor: identifies the kernel instantiation
 extern "C" int64_t rua_conv_workspace_bytes(const rua_conv_desc* d) {
   if (!d) return 0;

@@ -539,25 +539,48 @@ extern "C" int rua_seg_metrics(const float* p, const float* y, int64_t M, int C,
 }
 
 // ---- optimizers on the flat parameter buffer ---------------------------------------------------
+// Four parameters per thread (16-byte accesses; every slice of the flat buffers is 64-byte aligned and n a multiple of 4 - the tail, if any, element
+// by element); WC: the updated weights also leave as bf16 (wcopy: the forward-layout copy the convolutions read - its index space is the master's -, so
+// rua_weight_prep has only the data-gradient layout left to build, from this copy: rua_weight_prep_dgrad).  Same arithmetic per element as before.
+template <bool WC>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ th, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                   long long n, float lr_t, const float* __restrict__ lr_dev, float b1, float b2, float eps, float gs, int zero) {
+                                                   long long n, float lr_t, const float* __restrict__ lr_dev, float b1, float b2, float eps, float gs, int zero,
+                                                   bf16_t* __restrict__ wcopy) {
   if (lr_dev) lr_t = lr_dev[0];
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float gg = g[i] * gs;
-    const float mm = b1 * m[i] + (1.f - b1) * gg;
-    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
-    m[i] = mm; v[i] = vv;
-    th[i] -= lr_t * mm / (sqrtf(vv) + eps);
+  const long long n4 = n >> 2;
+  auto upd = [&](float gg_, float& mm, float& vv, float& tt) {
+    const float gg = gg_ * gs;
+    mm = b1 * mm + (1.f - b1) * gg;
+    vv = b2 * vv + (1.f - b2) * gg * gg;
+    tt -= lr_t * mm / (sqrtf(vv) + eps);
+  };
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i], t4 = reinterpret_cast<float4*>(th)[i];
+    upd(g4.x, m4.x, v4.x, t4.x); upd(g4.y, m4.y, v4.y, t4.y); upd(g4.z, m4.z, v4.z, t4.z); upd(g4.w, m4.w, v4.w, t4.w);
+    reinterpret_cast<float4*>(m)[i] = m4; reinterpret_cast<float4*>(v)[i] = v4; reinterpret_cast<float4*>(th)[i] = t4;
+    if (zero) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (WC) reinterpret_cast<uint2*>(wcopy)[i] = make_uint2(ET<bf16_t>::pk(t4.x, t4.y), ET<bf16_t>::pk(t4.z, t4.w));
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float mm = m[i], vv = v[i], tt = th[i];
+    upd(g[i], mm, vv, tt);
+    m[i] = mm; v[i] = vv; th[i] = tt;
     if (zero) g[i] = 0.f;
+    if constexpr (WC) wcopy[i] = (bf16_t)tt;
   }
 }
+template <bool WC>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ th, float* __restrict__ g, float* __restrict__ vel,
-                                                  long long n, float lr, const float* __restrict__ lr_dev, float mu, float gs, int zero) {
+                                                  long long n, float lr, const float* __restrict__ lr_dev, float mu, float gs, int zero, bf16_t* __restrict__ wcopy) {
   if (lr_dev) lr = lr_dev[0];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float vv = mu * vel[i] - lr * g[i] * gs;
-    vel[i] = vv; th[i] += vv;
+    vel[i] = vv;
+    const float tt = th[i] + vv;
+    th[i] = tt;
     if (zero) g[i] = 0.f;
+    if constexpr (WC) wcopy[i] = (bf16_t)tt;
   }
 }
 // Step-dependent learning rate on the device, so that a captured training step needs no host-side scalar update between
@@ -578,19 +601,30 @@ extern "C" int rua_lr_step(double* state, float* lr_out, int adam, double beta1,
   RUA_LAUNCH_CHECK("rua_lr_step");
   return RUA_OK;
 }
+extern "C" int rua_adam_step_w(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1, float beta2,
+                               float eps, float grad_scale, int zero_grad, void* wcopy_bf16, void* stream) {
+  RUA_CHECK_ARG(theta && g && m && v && n > 0, "rua_adam_step: bad arguments");
+  RUA_CHECK_ARG((((size_t)theta | (size_t)g | (size_t)m | (size_t)v) & 15) == 0 && ((size_t)wcopy_bf16 & 7) == 0, "rua_adam_step: buffers must be 16-byte aligned");
+  int64_t gr = (n / 4 + 255) / 256; if (gr > 4096) gr = 4096; if (gr < 1) gr = 1;
+  if (wcopy_bf16) hipLaunchKernelGGL((adam_kernel<true>), dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, (long long)n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, zero_grad, (bf16_t*)wcopy_bf16);
+  else hipLaunchKernelGGL((adam_kernel<false>), dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, (long long)n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, zero_grad, (bf16_t*)nullptr);
+  RUA_LAUNCH_CHECK("rua_adam_step");
+  return RUA_OK;
+}
 extern "C" int rua_adam_step(float* theta, float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1, float beta2,
                              float eps, float grad_scale, int zero_grad, void* stream) {
-  RUA_CHECK_ARG(theta && g && m && v && n > 0, "rua_adam_step: bad arguments");
+  return rua_adam_step_w(theta, g, m, v, n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, zero_grad, nullptr, stream);
+}
+extern "C" int rua_sgd_step_w(float* theta, float* g, float* vel, int64_t n, float lr, const float* lr_dev, float momentum, float grad_scale,
+                              int zero_grad, void* wcopy_bf16, void* stream) {
+  RUA_CHECK_ARG(theta && g && vel && n > 0, "rua_sgd_step: bad arguments");
   int64_t gr = (n + 255) / 256; if (gr > 4096) gr = 4096;
-  hipLaunchKernelGGL(adam_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, (long long)n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, zero_grad);
-  RUA_LAUNCH_CHECK("rua_adam_step");
+  if (wcopy_bf16) hipLaunchKernelGGL((sgd_kernel<true>), dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, vel, (long long)n, lr, lr_dev, momentum, grad_scale, zero_grad, (bf16_t*)wcopy_bf16);
+  else hipLaunchKernelGGL((sgd_kernel<false>), dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, vel, (long long)n, lr, lr_dev, momentum, grad_scale, zero_grad, (bf16_t*)nullptr);
+  RUA_LAUNCH_CHECK("rua_sgd_step");
   return RUA_OK;
 }
 extern "C" int rua_sgd_step(float* theta, float* g, float* vel, int64_t n, float lr, const float* lr_dev, float momentum, float grad_scale,
                             int zero_grad, void* stream) {
-  RUA_CHECK_ARG(theta && g && vel && n > 0, "rua_sgd_step: bad arguments");
-  int64_t gr = (n + 255) / 256; if (gr > 4096) gr = 4096;
-  hipLaunchKernelGGL(sgd_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, theta, g, vel, (long long)n, lr, lr_dev, momentum, grad_scale, zero_grad);
-  RUA_LAUNCH_CHECK("rua_sgd_step");
-  return RUA_OK;
+  return rua_sgd_step_w(theta, g, vel, n, lr, lr_dev, momentum, grad_scale, zero_grad, nullptr, stream);
 }

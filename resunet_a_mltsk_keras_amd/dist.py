@@ -127,7 +127,7 @@ class DataParallel:
         side = os.environ.get("RUA_DP_SIDE_STREAM", "0") == "1"
         self.reducer = GradReducer(eng.G[:eng.params.n], self.buckets, group, use_side_stream=overlap and side, host_staged=self.host_staged)
         self._bcast(eng.P); self._bcast(eng.S)
-        eng.weights_dirty = True
+        eng.params_changed()
         # Room for RCCL's kernels: several launchers size their grid at exactly one block per CU; with a bucket's all-reduce in flight
         # its workgroups hold some CUs and the last blocks of such a grid would wait for a second round.  Measured COST on one GPU
         # (nothing to make room for there): 8 CUs +0.3 %, 16 +1.2 %, 32 +2.0 % of the step; the benefit needs N > 1 to show.

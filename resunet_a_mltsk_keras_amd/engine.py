@@ -87,8 +87,8 @@ class ParamStore:
                             cin_total=sum(cins))
             dst = -1
             if mfma:
-                dst = self.nw
-                self.nw += (taps * cout * ci + 15) // 16 * 16
+                dst = off                                  # the activation-dtype copies share the master's index space: the optimizer writes the forward
+                self.nw = self.n                           # copy element for element (rua_adam_step_w), rua_weight_prep_dgrad builds the other from it
             segs.append(dict(off=off, dst=dst, C=ci))
             c0 += ci
         boff = self._add(name + "/bias", cout, kind="bias", layer=name)
@@ -1662,7 +1662,9 @@ class Engine:
         z = lambda n, dt=torch.float32: torch.zeros(max(n, 16), dtype=dt, device=self.dev)
         self.P, self.G, self.M1, self.V1, self.S = z(ps.n), z(ps.n), z(ps.n), z(ps.n), z(ps.ns)
         tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
-        self.Wf, self.Wd = z(ps.nw, tdt), z(ps.nw, tdt)
+        self.Wf, self.Wd = z(ps.n, tdt), z(ps.n, tdt)
+        self.opt_wcopy = dtype == "bf16" and os.environ.get("RUA_OPT_WCOPY", "1") != "0"   # the optimizer writes the forward-layout bf16 copy itself
+        self.wf_fresh = False                               # the forward copy holds bf16(P): written by the optimizer (or a full rua_weight_prep) since P last changed
         items = np.zeros(0, dtype=[("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("cout", "<i4"), ("c", "<i4"), ("pad", "<i4")])
         rows, mx = [], 1
         for lay in self.layers:
@@ -1752,7 +1754,12 @@ class Engine:
     def set_weights(self, keras_dict: Dict[str, np.ndarray]):
         P, S = self.params.from_keras(keras_dict)
         self.P.copy_(torch.from_numpy(P)); self.S.copy_(torch.from_numpy(S))
+        self.params_changed()
+
+    def params_changed(self):
+        """P was written from outside the optimizer (set_weights, a checkpoint, a broadcast): both weight copies are rebuilt from it."""
         self.weights_dirty = True
+        self.wf_fresh = False
 
     def get_weights(self) -> Dict[str, np.ndarray]:
         return self.params.to_keras(self.P.cpu().numpy(), self.S.cpu().numpy())
@@ -1769,9 +1776,20 @@ class Engine:
 
     def _prep_weights(self, s):
         if self.weights_dirty:
-            L.lib().call("rua_weight_prep", self.P.data_ptr(), self.Wf.data_ptr(), self.Wd.data_ptr(), self.wprep_items.data_ptr(),
-                         self.wprep_n, self.wprep_max, self.dt, C.c_void_p(s))
+            if self.opt_wcopy and self.wf_fresh:            # the optimizer left the forward copy: only the data-gradient layout is built, from it
+                L.lib().call("rua_weight_prep_dgrad", self.Wf.data_ptr(), self.Wd.data_ptr(), self.wprep_items.data_ptr(), self.wprep_n, self.wprep_max,
+                             self.dt, C.c_void_p(s))
+            else:
+                L.lib().call("rua_weight_prep", self.P.data_ptr(), self.Wf.data_ptr(), self.Wd.data_ptr(), self.wprep_items.data_ptr(),
+                             self.wprep_n, self.wprep_max, self.dt, C.c_void_p(s))
+                self.wf_fresh = True
             self.weights_dirty = False
+
+    def _ensure_forward_copy(self):
+        """Before a captured step is replayed (its weight refresh is the data-gradient-only one): if P changed from outside, rebuild both copies now."""
+        if self.opt_wcopy and not self.wf_fresh:
+            self.weights_dirty = True
+            self._prep_weights(self._stream())
 
     def _upload(self, g: Graph, x, y):
         def put(dst: torch.Tensor, src):
@@ -1869,12 +1887,13 @@ class Engine:
         sp = self.loss
         L.lib().call("rua_lr_step", self.lr_state.data_ptr(), self.lr_dev.data_ptr(), 1 if sp.optimizer == "adam" else 0,
                      float(sp.beta_1), float(sp.beta_2), C.c_void_p(s))
+        wc = self.Wf.data_ptr() if self.opt_wcopy else None    # bf16 storage: the updated weights leave as the forward-layout copy in the same pass
         if sp.optimizer == "adam":
-            L.lib().call("rua_adam_step", self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.V1.data_ptr(), self.params.n,
-                         0.0, self.lr_dev.data_ptr(), sp.beta_1, sp.beta_2, KERAS_EPS, grad_scale, 1, C.c_void_p(s))
+            L.lib().call("rua_adam_step_w", self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.V1.data_ptr(), self.params.n,
+                         0.0, self.lr_dev.data_ptr(), sp.beta_1, sp.beta_2, KERAS_EPS, grad_scale, 1, wc, C.c_void_p(s))
         else:
-            L.lib().call("rua_sgd_step", self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.params.n, 0.0,
-                         self.lr_dev.data_ptr(), sp.momentum, grad_scale, 1, C.c_void_p(s))
+            L.lib().call("rua_sgd_step_w", self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.params.n, 0.0,
+                         self.lr_dev.data_ptr(), sp.momentum, grad_scale, 1, wc, C.c_void_p(s))
 
     def optimizer_step(self, grad_scale: float = 1.0):
         self._set_lr()
@@ -1908,6 +1927,7 @@ class Engine:
             self.weights_dirty = True
             # the warm-up consumed this step's update; the capture itself launched nothing
             return g
+        self._ensure_forward_copy()
         cap.replay()
         self.weights_dirty = True
         return g
@@ -1967,6 +1987,7 @@ class Engine:
             self.weights_dirty = True
             return g
         self._set_lr()
+        self._ensure_forward_copy()
         red.begin()
         for pi, (cap, buckets) in enumerate(pieces):
             cap.replay()
