@@ -205,7 +205,11 @@ int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, const rua_w
 /* The data-gradient layout alone from the forward-layout bf16 copy (dtype must be RUA_BF16; items as for rua_weight_prep, dst_off = the offset in both copies):
  * used when the optimizer has just written that copy itself (rua_adam_step_w / rua_sgd_step_w with wcopy_bf16 = the forward copy, whose index space
  * must then be the master's: dst_off == src_off). */
-int rua_weight_prep_dgrad(const void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev, int n_items, int max_elems, int dtype, void* stream);
+int rua_weight_prep_dgrad(const void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev, int n_items, int max_elems, const int32_t* blockmap_dev,
+                          int n_blocks, int dtype, void* stream);
+/* blockmap_dev (optional, NULL: a (<= 256, n_items) grid like rua_weight_prep's): int32 [n_blocks][2] = (item, first tile) - item i contributes
+ * rua_wprep_blocks(taps, Cout, C) consecutive entries whose first tiles are 0, 8, 16, ...: the grid is as long as the tensors are large. */
+int rua_wprep_blocks(int taps, int Cout, int C);
 
 /* ---- few-channel 1x1 convolutions (VALU; the stem and the heads) -------------------------
  * stem: KL.Conv2D(32,(1,1)) on the 3/6/7-band input (model2.py:101).  x fp32 [M][Cin<=16]. */

@@ -113,7 +113,8 @@ _SIGS = {
     "rua_wgrad_plan": ([C.POINTER(WgradDesc), C.POINTER(WgradPending)], i32),
     "rua_wgrad_reduce_batch": ([vp, i32, i32, vp], i32),
     "rua_weight_prep": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
-    "rua_weight_prep_dgrad": ([vp, vp, vp, i32, i32, i32, vp], i32),
+    "rua_weight_prep_dgrad": ([vp, vp, vp, i32, i32, vp, i32, i32, vp], i32),
+    "rua_wprep_blocks": ([i32, i32, i32], i32),
     "rua_stem_fwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "rua_stem_fwd_stats": ([vp, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp], i32),
     "rua_stem_bwd": ([vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),

@@ -3731,19 +3731,58 @@ extern "C" int rua_weight_prep(const float* master, void* w_fwd, void* w_dgrad, 
   return RUA_OK;
 }
 
+constexpr int RUA_WPREP_TPB = 8;                      // 64 x 64 tiles a block of the block map takes (two per wave)
 // The data-gradient layout alone, from the forward-layout bf16 copy the optimizer already wrote (rua_adam_step_w / rua_sgd_step_w): wd[taps reversed][ci][co]
 // = wf[tap][co][ci].  A block moves 64 (co) x 64 (ci) tiles of one tap through a 2-byte LDS tile: 8-byte reads along ci, 8-byte writes along co - half the
 // bytes of rua_weight_prep (no fp32 master read, no forward copy written).
-__global__ __launch_bounds__(256) void wprep_dgrad_kernel(const bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, const rua_wprep_item* __restrict__ items) {
+// blockmap (optional): [blocks][2] = (item, first tile) - a block takes RUA_WPREP_TPB tiles of ONE item, the grid is as long as the tensors ask (a (256, items)
+// grid launched 26 000 blocks for ~100 convolutions of which a dozen hold 90 % of the bytes: most blocks fetched their item and left - 60 us for 170 MB)
+__global__ __launch_bounds__(256) void wprep_dgrad_kernel(const bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, const rua_wprep_item* __restrict__ items,
+                                                          const int* __restrict__ blockmap) {
   __shared__ unsigned short tile[64][66];
-  const rua_wprep_item it = items[blockIdx.y];
+  const int item = blockmap ? blockmap[2 * blockIdx.x] : (int)blockIdx.y;
+  const rua_wprep_item it = items[item];
   const int tco = (it.Cout + 63) / 64, tci = (it.C + 63) / 64;
   const int ntiles = it.taps * tco * tci;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const bool vec = (it.C % 4 == 0) && (it.Cout % 4 == 0);
   const unsigned short* src = reinterpret_cast<const unsigned short*>(wf) + it.dst_off;
   unsigned short* dst = reinterpret_cast<unsigned short*>(wd) + it.dst_off;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  if ((it.C & 7) == 0 && (it.Cout & 7) == 0) {
+    // Fast path, no LDS: a wave owns a 64 x 64 tile, lane (cg, pg) its 8 (co) x 8 (ci) block - eight 16-byte loads (lanes pg = 0 .. 7 read 128 contiguous
+    // bytes of a row), the block transposed in registers, eight 16-byte stores (lanes cg = 0 .. 7 write 128 contiguous bytes of a [ci] row).  (The LDS
+    // tile below moved 4 elements per access through 2-byte cells with a 0.40 bank-conflict share: 2.9 TB/s.)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cg = lane >> 3, pg = lane & 7;
+    const int t0 = blockmap ? blockmap[2 * blockIdx.x + 1] : (int)blockIdx.x * 4;
+    const int tend = blockmap ? (t0 + RUA_WPREP_TPB < ntiles ? t0 + RUA_WPREP_TPB : ntiles) : ntiles;
+    const int tstep = blockmap ? 4 : (int)gridDim.x * 4;
+    for (int t = t0 + wv; t < tend; t += tstep) {
+      const int tap = t / (tco * tci), r = t - tap * tco * tci;
+      const int co = (r / tci) * 64 + cg * 8, ci = (r % tci) * 64 + pg * 8;
+      if (co < it.Cout && ci < it.C) {
+        const unsigned short* sp = src + (size_t)tap * it.Cout * it.C + (size_t)co * it.C + ci;
+        uint4 in[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) in[j] = *reinterpret_cast<const uint4*>(sp + (size_t)j * it.C);
+        unsigned short* dp = dst + (size_t)(it.taps - 1 - tap) * it.Cout * it.C + (size_t)ci * it.Cout + co;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                     // output row ci + i: element i of the eight input rows
+          unsigned e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned w = (i >> 1) == 0 ? in[j].x : (i >> 1) == 1 ? in[j].y : (i >> 1) == 2 ? in[j].z : in[j].w;
+            e[j] = (i & 1) ? (w >> 16) : (w & 0xffffu);
+          }
+          *reinterpret_cast<uint4*>(dp + (size_t)i * it.Cout) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        }
+      }
+    }
+    return;
+  }
+  const int s0 = blockmap ? blockmap[2 * blockIdx.x + 1] : (int)blockIdx.x;
+  const int send = blockmap ? (s0 + RUA_WPREP_TPB < ntiles ? s0 + RUA_WPREP_TPB : ntiles) : ntiles;
+  for (int t = s0; t < send; t += blockmap ? 1 : (int)gridDim.x) {
     const int tap = t / (tco * tci), r = t - tap * tco * tci;
     const int co0 = (r / tci) * 64, ci0 = (r % tci) * 64;
 #pragma unroll
@@ -3782,11 +3821,21 @@ __global__ __launch_bounds__(256) void wprep_dgrad_kernel(const bf16_t* __restri
     __syncthreads();
   }
 }
-extern "C" int rua_weight_prep_dgrad(const void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev, int n_items, int max_elems, int dtype, void* stream) {
+extern "C" int rua_wprep_blocks(int taps, int Cout, int C) {           // blocks of the block map a [taps][Cout][C] item takes
+  const int ntiles = taps * ((Cout + 63) / 64) * ((C + 63) / 64);
+  return (ntiles + RUA_WPREP_TPB - 1) / RUA_WPREP_TPB;
+}
+extern "C" int rua_weight_prep_dgrad(const void* w_fwd, void* w_dgrad, const rua_wprep_item* items_dev, int n_items, int max_elems, const int32_t* blockmap_dev,
+                                     int n_blocks, int dtype, void* stream) {
   RUA_CHECK_ARG(w_fwd && w_dgrad && items_dev && n_items > 0, "rua_weight_prep_dgrad: bad arguments");
   RUA_CHECK_ARG(dtype == RUA_BF16, "rua_weight_prep_dgrad: bf16 copies only (the fp32 path keeps rua_weight_prep)");
-  int gx = rua_div_up(max_elems, 4096 * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
-  hipLaunchKernelGGL(wprep_dgrad_kernel, dim3(gx, n_items), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_fwd, (bf16_t*)w_dgrad, items_dev);
+  RUA_CHECK_ARG(!blockmap_dev || n_blocks >= 1, "rua_weight_prep_dgrad: a block map needs its length");
+  if (blockmap_dev) {
+    hipLaunchKernelGGL(wprep_dgrad_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_fwd, (bf16_t*)w_dgrad, items_dev, (const int*)blockmap_dev);
+  } else {
+    int gx = rua_div_up(max_elems, 4096 * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(wprep_dgrad_kernel, dim3(gx, n_items), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_fwd, (bf16_t*)w_dgrad, items_dev, (const int*)nullptr);
+  }
   RUA_LAUNCH_CHECK("wprep_dgrad_kernel");
   return RUA_OK;
 }

@@ -1675,6 +1675,12 @@ class Engine:
         items = np.array(rows, dtype=items.dtype)
         self.wprep_items = torch.from_numpy(np.frombuffer(items.tobytes(), dtype=np.uint8).copy()).to(self.dev)
         self.wprep_n, self.wprep_max = len(rows), mx
+        bm = []                                              # block map of rua_weight_prep_dgrad: (item, first tile) per block
+        for i, (_, _, taps, cout, ci, _) in enumerate(rows):
+            for b in range(L.lib().raw("rua_wprep_blocks")(taps, cout, ci)):
+                bm += [i, 8 * b]
+        self.wprep_map = torch.tensor(bm if bm else [0, 0], dtype=torch.int32, device=self.dev)
+        self.wprep_map_n = len(bm) // 2
         self.stats_arena = torch.zeros(1 << 22, dtype=torch.float64, device=self.dev)
         # one split-K slab workspace and one weight-gradient partial scratch per lane: branches run concurrently
         self.workspaces = [torch.zeros(8 << 20, dtype=torch.float32, device=self.dev) for _ in range(4)]
@@ -1778,7 +1784,7 @@ class Engine:
         if self.weights_dirty:
             if self.opt_wcopy and self.wf_fresh:            # the optimizer left the forward copy: only the data-gradient layout is built, from it
                 L.lib().call("rua_weight_prep_dgrad", self.Wf.data_ptr(), self.Wd.data_ptr(), self.wprep_items.data_ptr(), self.wprep_n, self.wprep_max,
-                             self.dt, C.c_void_p(s))
+                             self.wprep_map.data_ptr() if self.wprep_map_n else None, self.wprep_map_n, self.dt, C.c_void_p(s))
             else:
                 L.lib().call("rua_weight_prep", self.P.data_ptr(), self.Wf.data_ptr(), self.Wd.data_ptr(), self.wprep_items.data_ptr(),
                              self.wprep_n, self.wprep_max, self.dt, C.c_void_p(s))

@@ -392,6 +392,34 @@ def test_weight_prep_layouts(dt):
         assert np.array_equal(wf[o:o + t * co * ci].float().cpu().numpy().reshape(t, co, ci), src)
         exp = src[::-1].transpose(0, 2, 1)
         assert np.array_equal(wd[o:o + t * co * ci].float().cpu().numpy().reshape(t, ci, co), exp)
+    if dt == L.RUA_BF16:
+        # rua_weight_prep_dgrad: the data-gradient layout alone, from the forward copy (the optimizer writes that one itself): same bytes, on the
+        # register-transpose path (C, Cout multiples of 8; tiles that end inside a 64 x 64 block) and on the LDS path (C = 12)
+        specs2 = [(9, 32, 16), (1, 8, 64), (9, 8, 8), (9, 128, 256), (1, 72, 200), (9, 16, 12), (1, 24, 4)]
+        offs2, total2 = [], 0
+        for t, co, ci in specs2:
+            offs2.append(total2); total2 += (t * co * ci + 15) // 16 * 16
+        master2 = rng.standard_normal(total2).astype(np.float32)
+        items2 = np.array([(o, o, t, co, ci, 0) for o, (t, co, ci) in zip(offs2, specs2)], dtype=items.dtype)
+        it2 = torch.from_numpy(np.frombuffer(items2.tobytes(), dtype=np.uint8).copy()).to(dev())
+        m2 = torch.from_numpy(master2).to(dev())
+        wf2 = torch.zeros(total2, dtype=tdt(dt), device=dev()); wd2 = torch.zeros_like(wf2); wd3 = torch.zeros_like(wf2)
+        mx = max(t * co * ci for t, co, ci in specs2)
+        L.lib().call("rua_weight_prep", m2.data_ptr(), wf2.data_ptr(), wd2.data_ptr(), it2.data_ptr(), len(specs2), mx, dt, stream())
+        L.lib().call("rua_weight_prep_dgrad", wf2.data_ptr(), wd3.data_ptr(), it2.data_ptr(), len(specs2), mx, None, 0, dt, stream())
+        bmap = []                                                             # ... and with a block map: the grid follows the tensors' sizes
+        for i, (t, co, ci) in enumerate(specs2):
+            nbk = L.lib().raw("rua_wprep_blocks")(t, co, ci)
+            assert nbk == -(-(t * -(-co // 64) * -(-ci // 64)) // 8)
+            for b in range(nbk):
+                bmap += [i, 8 * b]
+        bm = torch.tensor(bmap, dtype=torch.int32, device=dev())
+        wd4 = torch.zeros_like(wf2)
+        L.lib().call("rua_weight_prep_dgrad", wf2.data_ptr(), wd4.data_ptr(), it2.data_ptr(), len(specs2), mx, bm.data_ptr(), len(bmap) // 2, dt, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(wd2.view(torch.int16), wd3.view(torch.int16)) and wd3.float().abs().sum().item() > 0
+        assert torch.equal(wd2.view(torch.int16), wd4.view(torch.int16))
+        assert L.lib().raw("rua_weight_prep_dgrad")(wf2.data_ptr(), wd3.data_ptr(), it2.data_ptr(), len(specs2), mx, None, 0, L.RUA_F32, None) != 0
 
 
 @pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
