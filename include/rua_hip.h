@@ -169,6 +169,12 @@ typedef struct rua_wgrad_desc {
    * block partials to write and to reduce.  Set it on every member (rua_wgrad_plan must see the same value as the launch). */
   int32_t group_members;
   int32_t pad_group;
+  /* overwrite_dev (optional): a DEVICE int32 read when the kernel runs.  Non-zero: the caller guarantees that dw holds zeros and that this call is its only
+   * writer before it is read (the step's gradient arena: zeroed by the optimizer, every weight has one producer) - kernels that end in a read-modify-write of dw
+   * (one K slice per element, the slab / block-partial reductions) then STORE instead: dw = sum, one pass over dw spared.  Zero / NULL: dw += sum (gradient
+   * accumulation over several backward passes).  A device flag, so that a captured step and an eager accumulating pass can share one recorded plan.  Kernels that
+   * add with atomics or replicas ignore it; the result is the same either way. */
+  const int32_t* overwrite_dev;
 } rua_wgrad_desc;
 typedef struct rua_wgrad_pending {
   int32_t kind;                /* 0: nothing to reduce (single writer / wgrad_pw), 1: all-taps partials, 2: K-slice slabs,
@@ -181,6 +187,7 @@ typedef struct rua_wgrad_pending {
   int32_t CC;                  /* kind 1: channels */
   int32_t blocks;              /* 256-thread blocks the reduction of this record takes */
   int32_t block_begin, pad;    /* filled by the caller: first block of this record in the batched launch (prefix sum of `blocks`) */
+  const int32_t* overwrite_dev; /* as rua_wgrad_desc.overwrite_dev (copied from the descriptor by rua_wgrad_plan) */
 } rua_wgrad_pending;
 /* the record a deferred rua_conv_wgrad(d) leaves behind - computed without launching anything */
 int rua_wgrad_plan(const rua_wgrad_desc* d, rua_wgrad_pending* out);

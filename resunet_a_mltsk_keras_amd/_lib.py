@@ -36,12 +36,12 @@ class BnFold(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [("a", vp), ("C", i32), ("Hs", i32), ("Ws", i32), ("dy", vp), ("Cout", i32), ("H", i32), ("W", i32),
                 ("N", i32), ("stride", i32), ("dil", i32), ("taps", i32), ("dtype", i32), ("dw", vp), ("workspace", vp), ("workspace_bytes", i64),
-                ("in_scale", vp), ("in_shift", vp), ("in_relu", i32), ("defer", i32), ("group_members", i32), ("pad_group", i32)]
+                ("in_scale", vp), ("in_shift", vp), ("in_relu", i32), ("defer", i32), ("group_members", i32), ("pad_group", i32), ("overwrite_dev", vp)]
 
 
 class WgradPending(C.Structure):
     _fields_ = [("kind", i32), ("parts", i32), ("n", i64), ("partials", vp), ("dw", vp), ("CC", i32), ("blocks", i32),
-                ("block_begin", i32), ("pad", i32)]
+                ("block_begin", i32), ("pad", i32), ("overwrite_dev", vp)]
 
 
 class TaniHead(C.Structure):

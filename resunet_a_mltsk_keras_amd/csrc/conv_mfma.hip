@@ -2160,6 +2160,7 @@ struct WgK {
   int wshift, hshift;      // log2(W), log2(H) when both are powers of two, else -1 (generic division path)
   float* slabs;            // K split: slice ks stores its partial dW into slabs[ks * taps * Cout * C ..] (plain stores; summed in a
                            // fixed order by wgrad_slab_reduce: bit-reproducible); null: fp32 atomics into dw
+  const int* overwrite;    // ksplit == 1: a device flag - non-zero: dw = acc instead of dw += acc (rua_wgrad_desc.overwrite_dev: dw is zero and has no other writer)
 };
 
 template <typename T>
@@ -2273,6 +2274,7 @@ __device__ __forceinline__ void wgrad_kernel_body(const WgK& p) {
   }
   if (active) {
     const int ci = ci0 + wc * 32 + lr;
+    const bool ow = p.ksplit == 1 && p.overwrite && *p.overwrite != 0;
     if (ci < p.C) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -2281,7 +2283,7 @@ __device__ __forceinline__ void wgrad_kernel_body(const WgK& p) {
           float* dst = &p.dw[((size_t)tap * p.Cout + co) * p.C + ci];
           // one K slice = one writer per element: a plain read-modify-write (float atomics run at ~1.3 TB/s chip-wide,
           // plain traffic at ~6; the 8x8 level writes its whole 37.7 MB gradient this way)
-          if (p.ksplit == 1) *dst += acc[i];
+          if (p.ksplit == 1) { if (ow) *dst = acc[i]; else *dst += acc[i]; }
           else if (p.slabs) p.slabs[(size_t)ks * p.taps * p.Cout * p.C + ((size_t)tap * p.Cout + co) * p.C + ci] = acc[i];
           else unsafeAtomicAdd(dst, acc[i]);
         }
@@ -2304,7 +2306,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel_g(const WgKG g) {
 // eight loads at a time: a wave reads 1 KiB runs of every slab, nothing is exchanged.  (Before: 16 columns x 16 slice lanes per
 // block folded through LDS - 256-byte runs and 40x the blocks; the batched reduction of a step took 287 us for 1.04 GB.)
 constexpr int SLAB_RED_COLS = 256;                      // float4 columns per block
-__device__ __forceinline__ void wgrad_slab_reduce_body(const float* __restrict__ slabs, float* __restrict__ dw, long long n4, int ksplit, int vblock) {
+__device__ __forceinline__ void wgrad_slab_reduce_body(const float* __restrict__ slabs, float* __restrict__ dw, long long n4, int ksplit, int vblock, int overwrite = 0) {
   const long long i = (long long)vblock * SLAB_RED_COLS + threadIdx.x;
   if (i >= n4) return;
   const float4* s = reinterpret_cast<const float4*>(slabs) + i;
@@ -2321,7 +2323,8 @@ __device__ __forceinline__ void wgrad_slab_reduce_body(const float* __restrict__
   }
   for (; k < ksplit; ++k) add4(t, s[(size_t)k * n4]);
   float4* d = reinterpret_cast<float4*>(dw) + i;
-  float4 o = *d;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!overwrite) o = *d;                               // (overwrite: dw holds zeros and has no other writer - the read is spared, the sum the same)
   add4(o, t);
   *d = o;
 }
@@ -2970,7 +2973,7 @@ template <int NPG, bool BN> __global__ __launch_bounds__(NPG * 192) void wgrad_r
 // reads 1 KiB runs of a partial, eight loads in flight per thread, the four lanes are folded through LDS in a fixed order
 // (deterministic).  (Before: 16 columns x 16 lanes - 256-byte runs, four loads in flight, 4x the blocks.)
 constexpr int TAPS_RED_COLS = 64;
-__device__ __forceinline__ void wgrad_taps_reduce_body(const float* __restrict__ scratch, float* __restrict__ dw, int CC, int gx, int vblock) {
+__device__ __forceinline__ void wgrad_taps_reduce_body(const float* __restrict__ scratch, float* __restrict__ dw, int CC, int gx, int vblock, int overwrite = 0) {
   __shared__ float4 sh[256];
   const int total4 = 9 * CC * CC / 4;
   const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -2999,7 +3002,8 @@ __device__ __forceinline__ void wgrad_taps_reduce_body(const float* __restrict__
     float4 t = sh[el];
     add4(t, sh[64 + el]); add4(t, sh[128 + el]); add4(t, sh[192 + el]);
     float4* d = reinterpret_cast<float4*>(dw + (size_t)e4 * 4);
-    float4 o = *d;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!overwrite) o = *d;
     add4(o, t);
     *d = o;
   }
@@ -3500,7 +3504,7 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   RUA_CHECK_ARG((long long)(d->H - 1) * d->stride < d->Hs && (long long)(d->W - 1) * d->stride < d->Ws,
                 "rua_conv_wgrad: input %dx%d too small for gradient %dx%d stride %d", d->Hs, d->Ws, d->H, d->W, d->stride);
   WgK k;
-  k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.dw = d->dw;
+  k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.dw = d->dw; k.overwrite = d->overwrite_dev;
   k.C = d->C; k.Hs = d->Hs; k.Ws = d->Ws; k.Cout = d->Cout; k.H = d->H; k.W = d->W; k.N = d->N;
   k.stride = d->stride; k.dil = d->dil; k.taps = d->taps;
   k.M = (long long)d->N * d->H * d->W;
@@ -3627,6 +3631,7 @@ extern "C" int rua_wgrad_plan(const rua_wgrad_desc* d, rua_wgrad_pending* out) {
   g_wgrad_pending = out; g_wgrad_dry = true;
   const int rc = rua_conv_wgrad(d, nullptr);
   g_wgrad_pending = nullptr; g_wgrad_dry = false;
+  out->overwrite_dev = d->overwrite_dev;
   return rc;
 }
 
@@ -3638,8 +3643,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const rua_wgrad
   const rua_wgrad_pending it = items[lo];
   const int vb = (int)blockIdx.x - it.block_begin;
   if (vb >= it.blocks) return;
-  if (it.kind == 1) wgrad_taps_reduce_body(it.partials, it.dw, it.CC, it.parts, vb);
-  else if (it.kind == 2) wgrad_slab_reduce_body(it.partials, it.dw, it.n / 4, it.parts, vb);
+  const int ow = (it.overwrite_dev && *it.overwrite_dev != 0) ? 1 : 0;
+  if (it.kind == 1) wgrad_taps_reduce_body(it.partials, it.dw, it.CC, it.parts, vb, ow);
+  else if (it.kind == 2) wgrad_slab_reduce_body(it.partials, it.dw, it.n / 4, it.parts, vb, ow);
   else if (it.kind == 3) {                             // per-channel fp64 sums (replicated statistics) -> += an fp32 vector (bias gradients)
     const int c = vb * 256 + (int)threadIdx.x;
     if (c < (int)it.n) {

@@ -734,6 +734,8 @@ class Graph:
             d.in_scale, d.in_shift, d.in_relu = in_bn.scale, in_bn.shift, 1
         d.dy, d.Cout, d.H, d.W = dy.ptr, dy.C, dy.H, dy.W
         d.N, d.stride, d.dil, d.taps, d.dtype = dy.N, stride, dil, taps, self.dt
+        if not self.dry and self.e.wgrad_overwrite:
+            d.overwrite_dev = self.e.ow_flag.data_ptr()    # whole steps store dW instead of adding to the zeroed arena (Engine._set_overwrite)
         defer = (not self.dry) and self.e.defer_reduce and plan is self.bwd
         if defer and may_flush:                             # before G(): a flush is a launch of its own and must not count as this one
             bucket = self.e.dist.bucket_of(dw_off) if self.e.dist is not None else 0
@@ -1663,6 +1665,11 @@ class Engine:
         self.P, self.G, self.M1, self.V1, self.S = z(ps.n), z(ps.n), z(ps.n), z(ps.n), z(ps.ns)
         tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
         self.Wf, self.Wd = z(ps.n, tdt), z(ps.n, tdt)
+        # first-writer overwrite of the gradient arena: in a whole step every weight gradient has ONE producer and the optimizer left the arena zero, so the kernels
+        # that end in a read-modify-write of dW store instead (a device flag, include/rua_hip.h: forward_backward() called on its own still ACCUMULATES)
+        self.wgrad_overwrite = os.environ.get("RUA_WGRAD_OVERWRITE", "1") != "0"
+        self.ow_flag = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self._ow = 0
         self.opt_wcopy = dtype == "bf16" and os.environ.get("RUA_OPT_WCOPY", "1") != "0"   # the optimizer writes the forward-layout bf16 copy itself
         self.wf_fresh = False                               # the forward copy holds bf16(P): written by the optimizer (or a full rua_weight_prep) since P last changed
         items = np.zeros(0, dtype=[("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("cout", "<i4"), ("c", "<i4"), ("pad", "<i4")])
@@ -1836,8 +1843,15 @@ class Engine:
             return [total] + per + mets
         return [total] + mets
 
-    def forward_backward(self, x=None, y=None):
-        """forward + losses + backward on the current stream; gradients are left in self.G."""
+    def _set_overwrite(self, v: int):
+        if self._ow != v:
+            self.ow_flag.fill_(v)
+            self._ow = v
+
+    def forward_backward(self, x=None, y=None, _whole_step: bool = False):
+        """forward + losses + backward on the current stream; gradients are ADDED to self.G (several calls before one optimizer_step accumulate, e.g. the
+        replicas of a data-parallel step played one after the other); _whole_step (train_step): the arena is zero and this is the step's only backward."""
+        self._set_overwrite(1 if (_whole_step and self.wgrad_overwrite) else 0)
         B = x.shape[0] if x is not None else self._last_B
         self._last_B = B
         g = self.graph(B, True)
@@ -1914,6 +1928,7 @@ class Engine:
         g = self.graph(B, True)
         self._upload(g, x, y)
         self._set_lr()
+        self._set_overwrite(1 if self.wgrad_overwrite else 0)
         cap = self._captured.get(B)
         if cap is None:
             # warm-up run outside capture (sets kernel attributes, pays first-launch costs), then capture
@@ -1950,7 +1965,7 @@ class Engine:
         pieces = self._captured_dp.get(B)
         if pieces is None:
             # one eager step (first-launch costs, kernel attributes, RCCL channel set-up), then capture the pieces
-            self.forward_backward(None, None)
+            self.forward_backward(None, None, _whole_step=True)
             self.dist.reduce_gradients(self)
             self.optimizer_step(1.0 / self.world)
             torch.cuda.synchronize()
@@ -1993,6 +2008,7 @@ class Engine:
             self.weights_dirty = True
             return g
         self._set_lr()
+        self._set_overwrite(1 if self.wgrad_overwrite else 0)
         self._ensure_forward_copy()
         red.begin()
         for pi, (cap, buckets) in enumerate(pieces):
@@ -2026,7 +2042,7 @@ class Engine:
         if self.use_graph and self.dp_graph and not self.dist.host_staged and not self.use_lanes:
             g = self._graph_step_dp(x, y)
             return self._results(g) if fetch else None
-        g = self.forward_backward(x, y)
+        g = self.forward_backward(x, y, _whole_step=True)
         if self.dist is not None:
             self.dist.reduce_gradients(self)
         self.optimizer_step(1.0 / self.world)
