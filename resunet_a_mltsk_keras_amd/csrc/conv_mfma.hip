@@ -2969,6 +2969,219 @@ template <int NPG, bool BN> __global__ __launch_bounds__(NPG * 192) void wgrad_r
   wgrad_rows32_body<NPG, BN>(p);
 }
 
+// wgrad_rows64<BN> (round 4): wgrad_rows32's scheme at C = Cout = 64 for rows of exactly 128 pixels (the level-2 ResBlock at 128 x 128, model2.py:15-34,104).
+// wgrad_taps_kernel<64> runs one block per output-channel HALF (both halves load, stage through registers and normalise the same input rows), two barriers and
+// 12 MFMAs per wave and 64-pixel stage.  Here a block owns WHOLE rows and all 64 output channels: 12 waves = 2 pixel groups x 3 kernel rows x 2 input-channel
+// halves, six accumulators (2 output-channel halves x 3 tap columns) and 24 MFMAs per wave and stage; rows by LDS-DMA into one shared ring (five input slots of
+// [128 pixels | 32 zero pixels] x 128 B + three dy slots: 153 KB), BatchNorm + ReLU in place one row ahead, ONE barrier per stage.  128-byte pixel rows would put
+// the four pixel rows of a transposing read on two banks: the 16-byte chunks of a pixel are XOR-swizzled with bit 1 of the pixel index (chunk ^ 4), applied on
+// the DMA's SOURCE side (the LDS destination of a DMA is lane-linear) and in the fragment / coefficient addresses.
+// Same jobs, same block partials (one per output-channel half) and deterministic reduction as wgrad_taps_kernel<64>.
+template <bool BN>
+__device__ __forceinline__ void wgrad_rows64_body(const WgtK& p) {
+  constexpr int C = 64, NPG = 2, NW = 6 * NPG, NT = NW * 64, SW = 64 * NPG, PADPX = 32, PXB = C * 2;
+  constexpr int SLOT = (SW + PADPX) * PXB, DSLOT = SW * PXB, R = 5, RD = 3;
+  constexpr int NPS = SW * PXB / 1024;                  // 1-KiB DMA pieces per row (8 pixels each)
+  constexpr int KDMA = (2 * NPS + NW - 1) / NW;         // operations per wave and stage
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sX = smem + PADPX * PXB;               // slot 0 (the 4 KiB in front of it: the zero pad of row pixels < 0)
+  unsigned char* sDy = sX + R * SLOT;
+  float* tab = reinterpret_cast<float*>(sDy + RD * DSLOT);            // [64] scale, [64] shift, [128] zeros
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pgx = wv / 6, rem = wv - 6 * pgx, ty = rem >> 1, cih = rem & 1;
+  const int H = p.H, d = p.dil;
+  const unsigned rowbytes = (unsigned)(SW * PXB);
+
+  if (tid < 64) {
+    tab[tid] = BN ? p.in_scale[tid] : 1.f; tab[64 + tid] = (BN && p.in_shift) ? p.in_shift[tid] : 0.f;
+    tab[128 + tid] = 0.f; tab[192 + tid] = 0.f;
+  }
+  for (int i = tid; i < (R + 1) * (PADPX * PXB / 16); i += NT) {       // zero pads: the front pad and the 32 pixels behind every row slot
+    const int sl = i / (PADPX * PXB / 16), k = i - sl * (PADPX * PXB / 16);
+    unsigned char* z = (sl == 0 ? smem : sX + (sl - 1) * SLOT + SW * PXB) + k * 16;
+    *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.a, p.abytes), rd = make_rsrc(p.dy, p.dybytes);
+  const unsigned sx_a = (unsigned)(size_t)(lds_void_p)sX, sd_a = (unsigned)(size_t)(lds_void_p)sDy;
+  const unsigned tab_a = (unsigned)(size_t)(lds_void_p)tab;
+  // lane l of a DMA piece: LDS position = pixel (l >> 3), chunk (l & 7); it fetches the chunk (l & 7) ^ (bit 1 of the pixel << 2) of that pixel
+  const int gchunk = (lane & 7) ^ (((lane >> 4) & 1) << 2);
+  const unsigned srel = (unsigned)((lane >> 3) * PXB + gchunk * 16);
+  const unsigned lrel = (unsigned)(lane * 16);
+  // transposing-read lane geometry (wgrad_kernel): a 32-channel x 16-pixel fragment = two ds_read_b64_tr_b16, 4 pixel rows apart
+  const int li = lane & 15, g = lane >> 4;
+  const int q4 = li >> 2, pp = li & 3;
+  const int chan = 16 * (g & 1) + 4 * pp;
+  const int hrow = 8 * (g >> 1) + q4;
+  auto frag_off = [&](int pix_rel, int ch) {             // byte offset of channel ch of slot pixel 64 pgx + hrow + pix_rel (its swizzle bit: bit 1 of hrow + pix_rel)
+    const int v = hrow + pix_rel;
+    const int sb = (v >> 1) & 1;
+    return (64 * pgx + v) * PXB + (((ch >> 3) ^ (sb << 2)) * 16) + (ch & 7) * 2;
+  };
+  const int dyo0 = frag_off(0, chan);                    // dy: output-channel half 0; half 1 is 32 channels = 4 chunks further: the chunk index ^ 4, i.e. the address ^ 64
+  const int xo0 = frag_off(-d, cih * 32 + chan), xo1 = frag_off(0, cih * 32 + chan), xo2 = frag_off(d, cih * 32 + chan);   // x: tap columns, this wave's ci half
+
+  int n_ = 0, r_ = 0, i0 = 0, nit = 0;
+  auto enter_job = [&](int job) {
+    n_ = 0; r_ = 0; i0 = 0; nit = 0;
+    if (job < p.njobs) {
+      const int chain = job / p.spc, seg = job - chain * p.spc;
+      r_ = chain % d; n_ = chain / d;
+      const int ny = (H - r_ + d - 1) / d;
+      i0 = seg * p.seglen;
+      int i1 = i0 + p.seglen; if (i1 > ny) i1 = ny;
+      nit = i1 > i0 ? i1 - i0 : 0;
+    }
+  };
+  auto xrow_ok = [&](int rho) { const int h = r_ + (i0 + rho) * d; return nit > 0 && rho <= nit && h >= 0 && h < H; };
+  auto xslot = [&](int rho) { return (unsigned)(((rho + 1 + R) % R) * SLOT); };
+  auto dslot = [&](int j) { return (unsigned)(((j + RD) % RD) * DSLOT); };
+  auto issue = [&](int xr, int dr) {
+    const unsigned xbase = xrow_ok(xr) ? (unsigned)(n_ * H + r_ + (i0 + xr) * d) * rowbytes : OOB;
+    const unsigned dbase = (dr >= 0 && dr < nit) ? (unsigned)(n_ * H + r_ + (i0 + dr) * d) * rowbytes : OOB;
+    const unsigned xs = xslot(xr), ds = dslot(dr);
+#pragma unroll
+    for (int k = 0; k < KDMA; ++k) {
+      const int pi = k * NW + wv;
+      if (pi < NPS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sX + xs + pi * 1024), 16, (xbase + (unsigned)(pi * 1024)) + srel, 0, 0, 0);
+      else if (pi < 2 * NPS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_p)(sDy + ds + (pi - NPS) * 1024), 16, (dbase + (unsigned)((pi - NPS) * 1024)) + srel, 0, 0, 0);
+      else { const unsigned z = 0u, off = OOB; asm volatile("buffer_store_dword %0, %1, %2, 0 offen" :: "v"(z), "v"(off), "s"(rd) : "memory"); }
+    }
+  };
+  // BatchNorm + ReLU of input row rho in place, on this wave's own pieces of it (piece pi = k NW + wv < NPS); the piece of lane l holds the channels of chunk gchunk
+  auto transform = [&](int rho) {
+    if constexpr (BN) {
+      const unsigned ca = (tab_a + (xrow_ok(rho) ? 0u : 128u * 4u)) + (unsigned)(gchunk * 32);
+      const unsigned xs = sx_a + xslot(rho) + lrel;
+#pragma unroll
+      for (int k = 0; k < KDMA; ++k) {
+        const int pi = k * NW + wv;
+        if (pi < NPS) {                                 // wave-uniform
+          u32x4_t rw; f32x4 sa, sb, ha, hb;
+          const unsigned a = xs + (unsigned)(pi * 1024);
+          asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\tds_read_b128 %3, %6 offset:256\n\tds_read_b128 %4, %6 offset:272\n\t"
+                       "s_waitcnt lgkmcnt(0)" : "=&v"(rw), "=&v"(sa), "=&v"(sb), "=&v"(ha), "=&v"(hb) : "v"(a), "v"(ca) : "memory");
+          float f[8];
+          ET<bf16_t>::unpack(make_uint4(rw[0], rw[1], rw[2], rw[3]), f);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { f[j] = fmaf(sa[j], f[j], ha[j]); f[4 + j] = fmaf(sb[j], f[4 + j], hb[j]); }
+          typedef __attribute__((ext_vector_type(2))) short s16x2;
+          typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+          const s16x2 z = {0, 0};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x2_t p2 = {f[2 * j], f[2 * j + 1]};
+            const bf16x2_t b2 = __builtin_convertvector(p2, bf16x2_t);
+            rw[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, b2), z));
+          }
+          asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(rw) : "memory");
+        }
+      }
+    }
+  };
+
+  f32x16 acc[6];                                         // [output-channel half][tap column]
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  // fragments of k-step ks of the stage (16 pixels): dy (the a-operand) of both output-channel halves and the three tap columns of input row `it + ty - 1`
+  struct Frags { s16x4 d0[2], d1[2], x0[3], x1[3]; };
+  auto read_frags = [&](unsigned da, unsigned xa, int ks, Frags& f) {
+    const unsigned dk0 = da + (unsigned)(dyo0 + ks * 16 * PXB), dk1 = dk0 ^ 64u;
+    const unsigned xk0 = (unsigned)((int)xa + xo0 + ks * 16 * PXB), xk1 = (unsigned)((int)xa + xo1 + ks * 16 * PXB), xk2 = (unsigned)((int)xa + xo2 + ks * 16 * PXB);
+    asm volatile("ds_read_b64_tr_b16 %0, %10\n\tds_read_b64_tr_b16 %1, %10 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %2, %11\n\tds_read_b64_tr_b16 %3, %11 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %12 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %6, %13\n\tds_read_b64_tr_b16 %7, %13 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %8, %14\n\tds_read_b64_tr_b16 %9, %14 offset:512"
+                 : "=&v"(f.d0[0]), "=&v"(f.d1[0]), "=&v"(f.d0[1]), "=&v"(f.d1[1]), "=&v"(f.x0[0]), "=&v"(f.x1[0]), "=&v"(f.x0[1]), "=&v"(f.x1[1]), "=&v"(f.x0[2]), "=&v"(f.x1[2])
+                 : "v"(dk0), "v"(dk1), "v"(xk0), "v"(xk1), "v"(xk2) : "memory");
+  };
+  auto wait_frags = [&](Frags& f, int pending) {
+    if (pending) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(f.d0[0]), "+v"(f.d1[0]), "+v"(f.d0[1]), "+v"(f.d1[1]), "+v"(f.x0[0]), "+v"(f.x1[0]), "+v"(f.x0[1]), "+v"(f.x1[1]), "+v"(f.x0[2]), "+v"(f.x1[2]) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.d0[0]), "+v"(f.d1[0]), "+v"(f.d0[1]), "+v"(f.d1[1]), "+v"(f.x0[0]), "+v"(f.x1[0]), "+v"(f.x0[1]), "+v"(f.x1[1]), "+v"(f.x0[2]), "+v"(f.x1[2]) :: "memory");
+  };
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto mfma6 = [&](const Frags& f) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const s16x8 fd = {f.d0[h][0], f.d0[h][1], f.d0[h][2], f.d0[h][3], f.d1[h][0], f.d1[h][1], f.d1[h][2], f.d1[h][3]};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const s16x8 fx = {f.x0[j][0], f.x0[j][1], f.x0[j][2], f.x0[j][3], f.x1[j][0], f.x1[j][1], f.x1[j][2], f.x1[j][3]};
+        acc[h * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc[h * 3 + j], 0, 0, 0);
+      }
+    }
+  };
+
+  for (int jb = 0; jb < p.jpw; ++jb) {
+    enter_job((int)blockIdx.x + jb * p.gx);
+    // ---- window fill: input rows -1 .. 2 and dy rows 0, 1 in flight, all landed; rows -1, 0, 1 normalised ---------------------------
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // the previous job's last stage is done with the rings
+    issue(-1, -1); issue(0, 0); issue(1, 1); issue(2, -1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    transform(-1); transform(0); transform(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = 0; it < nit; ++it) {
+      __builtin_amdgcn_s_barrier();                     // input row it + 1 is normalised and dy row it has landed, for everyone
+      issue(it + 3, it + 2);                            // input row it + 3 into the slot of row it - 2, dy row it + 2 into the slot of dy row it - 1
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KDMA) : "memory");          // the operations of stage it - 1 (input row it + 2, dy row it + 1) are done
+      const unsigned da = sd_a + dslot(it);
+      const unsigned xa = sx_a + xslot(it + ty - 1);
+      Frags fa, fb;
+      read_frags(da, xa, 0, fa);
+      read_frags(da, xa, 1, fb);
+      wait_frags(fa, 1); mfma6(fa);
+      read_frags(da, xa, 2, fa);
+      wait_frags(fb, 1); mfma6(fb);
+      read_frags(da, xa, 3, fb);
+      wait_frags(fa, 1); mfma6(fa);
+      wait_frags(fb, 0); mfma6(fb);
+      transform(it + 2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // this wave's LDS writes are done before the barrier publishes them
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  // ---- reduce the pixel groups through LDS, then one partial per block and output-channel half (wgrad_taps_kernel<64>'s layout) -------
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+  if (pgx > 0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[((rem * 6 + j) * 16 + i) * 64 + lane] = acc[j][i];
+  }
+  __syncthreads();
+  if (pgx == 0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float* part = p.scratch + (size_t)(h * p.gx + (int)blockIdx.x) * 9 * 32 * C;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[h * 3 + j][i] + red[((rem * 6 + h * 3 + j) * 16 + i) * 64 + lane];
+          const int co = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+          part[((ty * 3 + j) * 32 + co) * C + cih * 32 + (lane & 31)] = v;
+        }
+    }
+  }
+}
+template <bool BN> __global__ __launch_bounds__(768) void wgrad_rows64(const WgtK p) { wgrad_rows64_body<BN>(p); }
+template <bool BN> __global__ __launch_bounds__(768) void wgrad_rows64_g(const WgtKG g) {       // blockIdx.z = member
+  const WgtK& p = g.k[blockIdx.z];
+  if ((int)blockIdx.x >= p.gx) return;
+  wgrad_rows64_body<BN>(p);
+}
+
 // dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 64 float4 columns x 4 slice lanes: a wave
 // reads 1 KiB runs of a partial, eight loads in flight per thread, the four lanes are folded through LDS in a fixed order
 // (deterministic).  (Before: 16 columns x 16 lanes - 256-byte runs, four loads in flight, 4x the blocks.)
@@ -3026,19 +3239,27 @@ static thread_local WgGroupCapture* g_wg_group = nullptr;
 
 // wgrad_rows32 variants: kind 4 + 2 * (NPG == 2) + (no BatchNorm on load)
 static void launch_rows32(int kind, bool grouped, dim3 grid, int smem, hipStream_t st, const WgtK* one, const WgtKG* many) {
-  static RuaPerDevFlag attr_[8];
+  static RuaPerDevFlag attr_[12];
   bool& attr = attr_[(kind - 4) * 2 + (grouped ? 1 : 0)].get();
 #define RUA_ROWS_GO(NPG_, BN_) do { \
     if (grouped) { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows32_g<NPG_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
                    hipLaunchKernelGGL((wgrad_rows32_g<NPG_, BN_>), grid, dim3(NPG_ * 192), smem, st, *many); } \
     else { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows32<NPG_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
            hipLaunchKernelGGL((wgrad_rows32<NPG_, BN_>), grid, dim3(NPG_ * 192), smem, st, *one); } } while (0)
+#define RUA_ROWS64_GO(BN_) do { \
+    if (grouped) { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows64_g<BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+                   hipLaunchKernelGGL((wgrad_rows64_g<BN_>), grid, dim3(768), smem, st, *many); } \
+    else { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows64<BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+           hipLaunchKernelGGL((wgrad_rows64<BN_>), grid, dim3(768), smem, st, *one); } } while (0)
   switch (kind) {
     case 4: RUA_ROWS_GO(4, true); break;
     case 5: RUA_ROWS_GO(4, false); break;
     case 6: RUA_ROWS_GO(2, true); break;
-    default: RUA_ROWS_GO(2, false); break;
+    case 7: RUA_ROWS_GO(2, false); break;
+    case 8: RUA_ROWS64_GO(true); break;                  // C = 64, 128-pixel rows
+    default: RUA_ROWS64_GO(false); break;
   }
+#undef RUA_ROWS64_GO
 #undef RUA_ROWS_GO
 }
 
@@ -3099,6 +3320,25 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
     smem = (size_t)32 * 64 + 6 * (size_t)(d->W + 32) * 64 + 3 * (size_t)d->W * 64 + 128 * 4;
     const size_t red2 = (size_t)(npg - 1) * 3 * 3 * 16 * 64 * 4;
     if (red2 > smem) smem = red2;
+  }
+  // C = 64 on 128-pixel rows (the level-2 ResBlock): wgrad_rows64 - a block owns whole rows and BOTH output-channel halves (tuning key wgrad_rows & 2)
+  if ((g_tune.wgrad_rows & 2) && CC == 64 && d->W == 128 && d->dil <= 31 && (!d->in_scale || d->in_relu) && (size_t)M * CC * 2 < 0x80000000ull) {
+    rows_kind = 8 + (d->in_scale ? 0 : 1);
+    k.NPG = 2; k.strips = 1;
+    k.nchains = d->N * d->dil;
+    int blocks = ncu / share > 0 ? ncu / share : 1;     // one round of blocks for the group; a block leaves TWO partials (one per output-channel half) and the
+    if (blocks > ncu / 2) blocks = ncu / 2;             // scratch of wgrad_taps_kernel<64> holds ncu of them per weight gradient
+    int spc2 = blocks / k.nchains;
+    if (spc2 < 1) spc2 = 1;
+    if (spc2 > (ny + 3) / 4) spc2 = (ny + 3) / 4;       // >= 4 rows per segment (a segment re-reads two window rows)
+    if (spc2 < 1) spc2 = 1;
+    k.seglen = (ny + spc2 - 1) / spc2;
+    k.spc = (ny + k.seglen - 1) / k.seglen;
+    k.njobs = k.nchains * k.spc;
+    gx = k.njobs < blocks ? k.njobs : blocks;
+    k.gx = gx; k.nworkers = gx;
+    k.jpw = (k.njobs + gx - 1) / gx;
+    smem = (size_t)32 * 128 + 5 * (size_t)(128 + 32) * 128 + 3 * (size_t)128 * 128 + 256 * 4;
   }
   const int rblocks = rua_div_up(9 * CC * CC / 4, TAPS_RED_COLS);
   note_pending(1, gx, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks);

@@ -298,7 +298,8 @@ def test_conv_wgrad(case, dt):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 32, 1), (1, 128, 64, 32, 3), (2, 64, 128, 32, 15), (1, 64, 64, 32, 31),
-                                  (2, 64, 64, 64, 1), (1, 64, 128, 64, 15), (1, 128, 64, 64, 31), (3, 64, 64, 64, 3)])
+                                  (2, 64, 64, 64, 1), (1, 64, 128, 64, 15), (1, 128, 64, 64, 31), (3, 64, 64, 64, 3),
+                                  (2, 128, 128, 64, 31), (1, 128, 128, 64, 1), (3, 40, 128, 64, 3)])     # C = 64 on 128-pixel rows: wgrad_rows64
 def test_wgrad_all_taps_kernel(case):
     """Top-level weight gradient (C = Cout in {32, 64}, W % 64 == 0, bf16): all nine taps from one LDS halo,
     deterministic partial reduction; must add into dW and match autograd."""
@@ -940,7 +941,7 @@ def test_conv_strip_streaming_kernel(N, H, W, dil, mode):
     assert lib.raw("rua_conv_fused_input_ok")(C.byref(d)) == 0
 
 
-@pytest.mark.parametrize("Cs,H,W,dil", [(32, 256, 256, 1), (32, 256, 256, 31), (64, 128, 128, 3), (32, 136, 192, 15)])
+@pytest.mark.parametrize("Cs,H,W,dil", [(32, 256, 256, 1), (32, 256, 256, 31), (64, 128, 128, 3), (32, 136, 192, 15), (64, 128, 128, 31), (64, 72, 128, 1)])
 def test_wgrad_all_taps_normalise_on_load(Cs, H, W, dil):
     """rua_conv_wgrad with in_scale / in_shift / in_relu (all-taps kernel of the two top levels): the conv input is
     BatchNorm'ed + ReLU'ed as it enters LDS, so the weight gradient equals the one taken against the materialised
