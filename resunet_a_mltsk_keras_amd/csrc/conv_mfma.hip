@@ -3182,6 +3182,158 @@ template <bool BN> __global__ __launch_bounds__(768) void wgrad_rows64_g(const W
   wgrad_rows64_body<BN>(p);
 }
 
+// wgrad_rows128 (round 4): the same scheme one level down - C = Cout = 128 on 64-pixel rows (the level-3 ResBlock at 64 x 64, model2.py:105-106; its input is a
+// materialised BatchNorm output: no normalise-on-load).  The generic wgrad_kernel runs this level on 64 x 64 tiles with two barriers per 64-pixel stage and 4 MFMAs per
+// wave (PMC: matrix pipe 5 % busy).  Here a block owns whole rows, ALL 128 input channels and a SLICE of 64 output channels (blockIdx.y): 12 waves = 3 kernel rows x 4
+// input-channel quarters, six accumulators (2 output-channel halves x 3 tap columns), 24 MFMAs per wave and stage; the input rows (64 pixels x 256 B) and the slice of
+// the dy rows (64 x 128 B, gathered from 256-byte pixels by the DMA's per-lane source address) stream through one shared ring, one barrier per stage.  256-byte pixels
+// put all four pixel rows of a transposing read on ONE bank group: the 16-byte chunks are XOR-swizzled with bits 0 - 1 of the pixel index (chunk ^ (p & 3) << 2), the
+// 128-byte dy pixels with bit 1 (as wgrad_rows64).  Block partials [output-channel quarter][block][9][32][128] and the deterministic reduction of wgrad_taps_kernel.
+__device__ __forceinline__ void wgrad_rows128_body(const WgtK& p, int slice) {
+  constexpr int C = 128, NW = 12, SW = 64, PADPX = 32, PXB = C * 2, DPB = 128;
+  constexpr int SLOT = (SW + PADPX) * PXB, DSLOT = SW * DPB, R = 5, RD = 3;
+  constexpr int NPX = SW * PXB / 1024, NPD = DSLOT / 1024;             // 1-KiB DMA pieces per input row (4 pixels each) / per dy slice row (8 pixels each)
+  constexpr int KDMA = (NPX + NPD) / NW;                // operations per wave and stage: exactly 2
+  static_assert((NPX + NPD) % NW == 0, "every wave issues the same number of DMA operations per stage");
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sX = smem + PADPX * PXB;               // slot 0 (the 8 KiB in front of it: the zero pad of row pixels < 0)
+  unsigned char* sDy = sX + R * SLOT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ty = wv >> 2, ciq = wv & 3;
+  const int H = p.H, d = p.dil;
+  const unsigned rowbytes = (unsigned)(SW * PXB);
+
+  for (int i = tid; i < (R + 1) * (PADPX * PXB / 16); i += NW * 64) {  // zero pads: the front pad and the 32 pixels behind every row slot
+    const int sl = i / (PADPX * PXB / 16), k = i - sl * (PADPX * PXB / 16);
+    unsigned char* z = (sl == 0 ? smem : sX + (sl - 1) * SLOT + SW * PXB) + k * 16;
+    *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.a, p.abytes), rd = make_rsrc(p.dy, p.dybytes);
+  const unsigned sx_a = (unsigned)(size_t)(lds_void_p)sX, sd_a = (unsigned)(size_t)(lds_void_p)sDy;
+  // x piece: lane l sits at pixel (l >> 4), chunk (l & 15) of the piece's four pixels and fetches chunk (l & 15) ^ ((pixel & 3) << 2) of that pixel
+  const unsigned srel_x = (unsigned)((lane >> 4) * PXB + (((lane & 15) ^ ((lane >> 4) << 2)) * 16));
+  // dy piece: lane l sits at pixel (l >> 3), chunk (l & 7) of the piece's eight 128-byte slice pixels; the source pixels are 256 bytes apart
+  const unsigned srel_d = (unsigned)((lane >> 3) * PXB + slice * DPB + (((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 16));
+  const int li = lane & 15, g = lane >> 4;
+  const int q4 = li >> 2, pp = li & 3;
+  const int chan = 16 * (g & 1) + 4 * pp;
+  const int hrow = 8 * (g >> 1) + q4;
+  auto x_off = [&](int pix_rel) {                        // channel ciq * 32 + chan of slot pixel hrow + pix_rel
+    const int v = hrow + pix_rel, ch = ciq * 32 + chan;
+    return v * PXB + (((ch >> 3) ^ ((v & 3) << 2)) * 16) + (ch & 7) * 2;
+  };
+  const int dyo0 = hrow * DPB + (((chan >> 3) ^ (((hrow >> 1) & 1) << 2)) * 16) + (chan & 7) * 2;      // output-channel half 0 of the slice; half 1: ^ 64
+  const int xo0 = x_off(-d), xo1 = x_off(0), xo2 = x_off(d);
+
+  int n_ = 0, r_ = 0, i0 = 0, nit = 0;
+  auto enter_job = [&](int job) {
+    n_ = 0; r_ = 0; i0 = 0; nit = 0;
+    if (job < p.njobs) {
+      const int chain = job / p.spc, seg = job - chain * p.spc;
+      r_ = chain % d; n_ = chain / d;
+      const int ny = (H - r_ + d - 1) / d;
+      i0 = seg * p.seglen;
+      int i1 = i0 + p.seglen; if (i1 > ny) i1 = ny;
+      nit = i1 > i0 ? i1 - i0 : 0;
+    }
+  };
+  auto xrow_ok = [&](int rho) { const int h = r_ + (i0 + rho) * d; return nit > 0 && rho <= nit && h >= 0 && h < H; };
+  auto xslot = [&](int rho) { return (unsigned)(((rho + 1 + R) % R) * SLOT); };
+  auto dslot = [&](int j) { return (unsigned)(((j + RD) % RD) * DSLOT); };
+  auto issue = [&](int xr, int dr) {
+    const unsigned xbase = xrow_ok(xr) ? (unsigned)(n_ * H + r_ + (i0 + xr) * d) * rowbytes : OOB;
+    const unsigned dbase = (dr >= 0 && dr < nit) ? (unsigned)(n_ * H + r_ + (i0 + dr) * d) * rowbytes : OOB;
+    const unsigned xs = xslot(xr), ds = dslot(dr);
+#pragma unroll
+    for (int k = 0; k < KDMA; ++k) {
+      const int pi = k * NW + wv;
+      if (pi < NPX) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sX + xs + pi * 1024), 16, (xbase + (unsigned)(pi * 1024)) + srel_x, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_p)(sDy + ds + (pi - NPX) * 1024), 16, (dbase + (unsigned)((pi - NPX) * 8 * PXB)) + srel_d, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[6];                                         // [output-channel half of the slice][tap column]
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  struct Frags { s16x4 d0[2], d1[2], x0[3], x1[3]; };
+  auto read_frags = [&](unsigned da, unsigned xa, int ks, Frags& f) {
+    const unsigned dk0 = da + (unsigned)(dyo0 + ks * 16 * DPB), dk1 = dk0 ^ 64u;
+    const unsigned xk0 = (unsigned)((int)xa + xo0 + ks * 16 * PXB), xk1 = (unsigned)((int)xa + xo1 + ks * 16 * PXB), xk2 = (unsigned)((int)xa + xo2 + ks * 16 * PXB);
+    asm volatile("ds_read_b64_tr_b16 %0, %10\n\tds_read_b64_tr_b16 %1, %10 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %2, %11\n\tds_read_b64_tr_b16 %3, %11 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %12 offset:1024\n\t"
+                 "ds_read_b64_tr_b16 %6, %13\n\tds_read_b64_tr_b16 %7, %13 offset:1024\n\t"
+                 "ds_read_b64_tr_b16 %8, %14\n\tds_read_b64_tr_b16 %9, %14 offset:1024"
+                 : "=&v"(f.d0[0]), "=&v"(f.d1[0]), "=&v"(f.d0[1]), "=&v"(f.d1[1]), "=&v"(f.x0[0]), "=&v"(f.x1[0]), "=&v"(f.x0[1]), "=&v"(f.x1[1]), "=&v"(f.x0[2]), "=&v"(f.x1[2])
+                 : "v"(dk0), "v"(dk1), "v"(xk0), "v"(xk1), "v"(xk2) : "memory");
+  };
+  auto wait_frags = [&](Frags& f, int pending) {
+    if (pending) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(f.d0[0]), "+v"(f.d1[0]), "+v"(f.d0[1]), "+v"(f.d1[1]), "+v"(f.x0[0]), "+v"(f.x1[0]), "+v"(f.x0[1]), "+v"(f.x1[1]), "+v"(f.x0[2]), "+v"(f.x1[2]) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.d0[0]), "+v"(f.d1[0]), "+v"(f.d0[1]), "+v"(f.d1[1]), "+v"(f.x0[0]), "+v"(f.x1[0]), "+v"(f.x0[1]), "+v"(f.x1[1]), "+v"(f.x0[2]), "+v"(f.x1[2]) :: "memory");
+  };
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto mfma6 = [&](const Frags& f) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const s16x8 fd = {f.d0[h][0], f.d0[h][1], f.d0[h][2], f.d0[h][3], f.d1[h][0], f.d1[h][1], f.d1[h][2], f.d1[h][3]};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const s16x8 fx = {f.x0[j][0], f.x0[j][1], f.x0[j][2], f.x0[j][3], f.x1[j][0], f.x1[j][1], f.x1[j][2], f.x1[j][3]};
+        acc[h * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc[h * 3 + j], 0, 0, 0);
+      }
+    }
+  };
+
+  for (int jb = 0; jb < p.jpw; ++jb) {
+    enter_job((int)blockIdx.x + jb * p.gx);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // the previous job's last stage is done with the rings
+    issue(-1, -1); issue(0, 0); issue(1, 1); issue(2, -1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int it = 0; it < nit; ++it) {
+      __builtin_amdgcn_s_barrier();                     // input row it + 1 and dy row it have landed, for everyone
+      issue(it + 3, it + 2);                            // input row it + 3 into the slot of row it - 2, dy row it + 2 into the slot of dy row it - 1
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KDMA) : "memory");          // the operations of stage it - 1 (input row it + 2, dy row it + 1) are done
+      const unsigned da = sd_a + dslot(it);
+      const unsigned xa = sx_a + xslot(it + ty - 1);
+      Frags fa, fb;
+      read_frags(da, xa, 0, fa);
+      read_frags(da, xa, 1, fb);
+      wait_frags(fa, 1); mfma6(fa);
+      read_frags(da, xa, 2, fa);
+      wait_frags(fb, 1); mfma6(fb);
+      read_frags(da, xa, 3, fb);
+      wait_frags(fa, 1); mfma6(fa);
+      wait_frags(fb, 0); mfma6(fb);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float* part = p.scratch + (size_t)((2 * slice + h) * p.gx + (int)blockIdx.x) * 9 * 32 * C;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        part[((ty * 3 + j) * 32 + co) * C + ciq * 32 + (lane & 31)] = acc[h * 3 + j][i];
+      }
+  }
+}
+__global__ __launch_bounds__(768) void wgrad_rows128(const WgtK p) { wgrad_rows128_body(p, (int)blockIdx.y); }
+__global__ __launch_bounds__(768) void wgrad_rows128_g(const WgtKG g) {       // blockIdx.z = member, blockIdx.y = output-channel slice
+  const WgtK& p = g.k[blockIdx.z];
+  if ((int)blockIdx.x >= p.gx) return;
+  wgrad_rows128_body(p, (int)blockIdx.y);
+}
+
 // dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 64 float4 columns x 4 slice lanes: a wave
 // reads 1 KiB runs of a partial, eight loads in flight per thread, the four lanes are folded through LDS in a fixed order
 // (deterministic).  (Before: 16 columns x 16 lanes - 256-byte runs, four loads in flight, 4x the blocks.)
@@ -3239,7 +3391,7 @@ static thread_local WgGroupCapture* g_wg_group = nullptr;
 
 // wgrad_rows32 variants: kind 4 + 2 * (NPG == 2) + (no BatchNorm on load)
 static void launch_rows32(int kind, bool grouped, dim3 grid, int smem, hipStream_t st, const WgtK* one, const WgtKG* many) {
-  static RuaPerDevFlag attr_[12];
+  static RuaPerDevFlag attr_[14];
   bool& attr = attr_[(kind - 4) * 2 + (grouped ? 1 : 0)].get();
 #define RUA_ROWS_GO(NPG_, BN_) do { \
     if (grouped) { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows32_g<NPG_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
@@ -3257,7 +3409,13 @@ static void launch_rows32(int kind, bool grouped, dim3 grid, int smem, hipStream
     case 6: RUA_ROWS_GO(2, true); break;
     case 7: RUA_ROWS_GO(2, false); break;
     case 8: RUA_ROWS64_GO(true); break;                  // C = 64, 128-pixel rows
-    default: RUA_ROWS64_GO(false); break;
+    case 9: RUA_ROWS64_GO(false); break;
+    default:                                             // 10: C = 128, 64-pixel rows (grid.y = output-channel slice)
+      if (grouped) { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows128_g), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+                     hipLaunchKernelGGL(wgrad_rows128_g, grid, dim3(768), smem, st, *many); }
+      else { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows128), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+             hipLaunchKernelGGL(wgrad_rows128, grid, dim3(768), smem, st, *one); }
+      break;
   }
 #undef RUA_ROWS64_GO
 #undef RUA_ROWS_GO
@@ -3270,6 +3428,44 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   k.H = d->H; k.W = d->W; k.N = d->N; k.dil = d->dil;
   k.in_scale = d->in_scale; k.in_shift = d->in_shift; k.in_relu = d->in_relu;
   const long long M = (long long)d->N * d->H * d->W;
+  if (CC == 128) {
+    // wgrad_rows128: blocks (x) per output-channel slice (y = 2); a block leaves two partials (the halves of its slice), the scratch holds ncu of them
+    const int ncu_ = rua_cu_count();
+    const int share_ = (g_tune.wgrad_taps_share && d->group_members > 1) ? d->group_members : 1;
+    int blocks = ncu_ / share_ / 2 > 0 ? ncu_ / share_ / 2 : 1;
+    if (blocks > ncu_ / 4) blocks = ncu_ / 4;
+    const int ny_ = (d->H + d->dil - 1) / d->dil;
+    k.NPG = 1; k.strips = 1; k.halo = 0; k.halo4 = 0; k.group_bytes = 0;
+    k.nchains = d->N * d->dil;
+    int spc2 = blocks / k.nchains;
+    if (spc2 < 1) spc2 = 1;
+    if (spc2 > (ny_ + 3) / 4) spc2 = (ny_ + 3) / 4;
+    if (spc2 < 1) spc2 = 1;
+    k.seglen = (ny_ + spc2 - 1) / spc2;
+    k.spc = (ny_ + k.seglen - 1) / k.seglen;
+    k.njobs = k.nchains * k.spc;
+    const int gx_ = k.njobs < blocks ? k.njobs : blocks;
+    k.gx = gx_; k.nworkers = gx_;
+    k.jpw = (k.njobs + gx_ - 1) / gx_;
+    k.abytes = (unsigned)((size_t)M * CC * 2); k.dybytes = k.abytes;
+    const size_t smem_ = (size_t)32 * 256 + 5 * (size_t)(64 + 32) * 256 + 3 * (size_t)64 * 128;
+    const int rblocks_ = rua_div_up(9 * CC * CC / 4, TAPS_RED_COLS);
+    note_pending(1, gx_, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks_);
+    if (g_wgrad_dry) return RUA_OK;
+    if (g_wg_group && (g_tune.wgrad_group & 4) && g_wg_group->n < RUA_MAX_BRANCH) {
+      WgGroupCapture& c = *g_wg_group; const int i = c.n++;
+      c.kind[i] = 10; c.gx[i] = gx_; c.smem[i] = (int)smem_; c.t[i] = k;
+      c.post[i] = d->defer ? 0 : 1; c.part[i] = k.scratch; c.dw[i] = d->dw; c.CC[i] = CC; c.parts[i] = gx_; c.rblocks[i] = rblocks_; c.ndw[i] = 0;
+      return RUA_OK;
+    }
+    launch_rows32(10, false, dim3(gx_, 2), (int)smem_, st, &k, nullptr);
+    RUA_LAUNCH_CHECK("wgrad_rows128");
+    if (d->defer) return RUA_OK;
+    record_mid_event(st);
+    hipLaunchKernelGGL(wgrad_taps_reduce, dim3(rblocks_), dim3(256), 0, st, (const float*)k.scratch, d->dw, CC, gx_);
+    RUA_LAUNCH_CHECK("wgrad_taps_reduce");
+    return RUA_OK;
+  }
   k.halo = 64 + 2 * d->dil;
   k.halo4 = (k.halo + 3) / 4 * 4;
   k.group_bytes = 64 * 64 + 3 * k.halo4 * CC * 2;
@@ -3725,7 +3921,8 @@ extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
       if (on == 2 || (tiles >= mint && tiles <= 64 && stages >= 64)) return 2;
     }
   }
-  const bool ok = d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->C == d->Cout && (d->C == 32 || d->C == 64) &&
+  const bool rows128 = (g_tune.wgrad_rows & 4) && d->C == 128 && d->W == 64 && !d->in_scale;      // wgrad_rows128 (the level-3 ResBlock)
+  const bool ok = d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->C == d->Cout && (d->C == 32 || d->C == 64 || rows128) &&
                   d->W % 64 == 0 && d->Hs == d->H && d->Ws == d->W && d->dil >= 1 && d->dil <= 31 && d->workspace &&
                   d->workspace_bytes >= wg_taps_bytes(d) && (long long)d->N * d->H * d->W * d->C * 2 < (1ll << 31);
   return ok ? 1 : 0;
@@ -3837,8 +4034,9 @@ extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream
       else { WgdKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.d[idx[q]]; hipLaunchKernelGGL(wgrad_dmap_g, dim3((gx + 7) / 8 * 8, m), dim3(256), smem, st, g); }
     } else if (kd >= 4) {
       WgtKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.t[idx[q]];
-      if (m == 1) launch_rows32(kd, false, dim3(gx), smem, st, &g.k[0], nullptr);
-      else launch_rows32(kd, true, dim3(gx, 1, m), smem, st, nullptr, &g);
+      const unsigned gyr = kd == 10 ? 2u : 1u;             // wgrad_rows128: grid.y = output-channel slice
+      if (m == 1) launch_rows32(kd, false, dim3(gx, gyr), smem, st, &g.k[0], nullptr);
+      else launch_rows32(kd, true, dim3(gx, gyr, m), smem, st, nullptr, &g);
     } else {
       const int gy = kd == 1 ? 1 : 2;
       if (!attr[kd]) {

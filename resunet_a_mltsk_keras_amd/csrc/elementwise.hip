@@ -127,7 +127,7 @@ static int launch_stats(const void* g, const void* x, const float* ms, const flo
   k.stats = stats; k.R = replicas;
   const int64_t pieces = M * k.CG;
   int64_t gx = pieces / (256 * 8) / gy;                  // >= 8 pieces per thread
-  const int64_t scap = g_tune.stats_blocks > 0 ? g_tune.stats_blocks : 512;
+  const int64_t scap = g_tune.stats_blocks > 0 ? g_tune.stats_blocks : 1024;     // (512 until round 4: 1024 measured -0.03 ms per step, same-box A/B)
   if (gx > scap / gy) gx = scap / gy;
   if (gx < 1) gx = 1;
   hipStream_t st = (hipStream_t)stream;

@@ -441,8 +441,8 @@ class Graph:
         return 0 if self.dry else self.e.Wd.data_ptr() + dst * self.e.esize
 
     def stat_blocks(self, x: Ten) -> int:
-        """Workgroups rua_col_stats / rua_col_stats2 launch for x (>= 8 pieces per thread, at most 512)."""
-        return max(1, min(512, x.M * (x.C // self.vec) // 2048))
+        """Workgroups rua_col_stats / rua_col_stats2 launch for x (>= 8 pieces per thread, at most 1024)."""
+        return max(1, min(1024, x.M * (x.C // self.vec) // 2048))
 
     def col_stats(self, plan: Plan, x: Ten) -> Stat:
         s = self.stat(x.C, self.stat_blocks(x), burst=True)

@@ -299,7 +299,8 @@ def test_conv_wgrad(case, dt):
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 32, 1), (1, 128, 64, 32, 3), (2, 64, 128, 32, 15), (1, 64, 64, 32, 31),
                                   (2, 64, 64, 64, 1), (1, 64, 128, 64, 15), (1, 128, 64, 64, 31), (3, 64, 64, 64, 3),
-                                  (2, 128, 128, 64, 31), (1, 128, 128, 64, 1), (3, 40, 128, 64, 3)])     # C = 64 on 128-pixel rows: wgrad_rows64
+                                  (2, 128, 128, 64, 31), (1, 128, 128, 64, 1), (3, 40, 128, 64, 3),      # C = 64 on 128-pixel rows: wgrad_rows64
+                                  (2, 64, 64, 128, 1), (1, 64, 64, 128, 15), (3, 40, 64, 128, 3), (8, 64, 64, 128, 31)])  # C = 128 on 64-pixel rows: wgrad_rows128
 def test_wgrad_all_taps_kernel(case):
     """Top-level weight gradient (C = Cout in {32, 64}, W % 64 == 0, bf16): all nine taps from one LDS halo,
     deterministic partial reduction; must add into dW and match autograd."""
