@@ -1885,6 +1885,13 @@ __device__ __forceinline__ void conv_small_body(const ConvK& p) {
   conv_epilogue<T, BM, BN>(p, m0, n0, bm_i, part, CSTR, sred);
 }
 template <int BNT> __global__ __launch_bounds__(256) void conv_small(const ConvK p) { conv_small_body<BNT>(p); }
+// the members of a group (the four branch convolutions of a PSPPooling at the bottleneck - 512 / 128 / 32 / 8 pixels -, the fuse conv's data gradients towards
+// them): blockIdx.y = member, grids of unequal size (a launch of 4 - 64 blocks is all latency: ~10 us each whatever its pixel count - side by side they cost one)
+template <int BNT> __global__ __launch_bounds__(256) void conv_small_g(const ConvKG g) {
+  const ConvK& p = g.k[blockIdx.y];
+  if ((int)blockIdx.x >= p.nbm * p.nbn) return;
+  conv_small_body<BNT>(p);
+}
 
 // conv_small eligibility: bf16, every source 1x1 with a multiple of 16 channels, few pixels (the K-split regime of the tiled kernels)
 static bool pick_small(const rua_conv_desc* d) {
@@ -1899,6 +1906,10 @@ static int launch_conv_small(ConvK& k, hipStream_t st) {
   k.nbm = (int)((k.M + 31) / 32); k.nbn = (k.Cout + 63) / 64;
   k.ksplit = 1; k.stages_per_split = 0; k.ws = nullptr; k.cnt = nullptr;
   constexpr int smem = (4 * 32 * 68 + 4 * 8 * 16) * 4;
+  if (g_conv_group && (g_tune.conv_group & 16)) {       // capture mode: issued by rua_conv_fwd_group, side by side with its siblings
+    if (!g_conv_group->add(7, (unsigned)(k.nbm * k.nbn), smem, k)) { rua_set_error("rua_conv_fwd_group: more than %d captured members", RUA_MAX_BRANCH); return RUA_ERR_ARG; }
+    return RUA_OK;
+  }
   hipLaunchKernelGGL((conv_small<2>), dim3(k.nbm * k.nbn), dim3(256), smem, st, k);
   RUA_LAUNCH_CHECK("conv_small");
   return RUA_OK;
@@ -2129,6 +2140,16 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
   for (int i = 0; i < cap.n; ++i) {
     if (done[i]) continue;
     int idx[RUA_MAX_BRANCH], m = 0;
+    if (cap.kind[i] == 7) {                                 // conv_small: members of unequal grids share one launch (the grid of the largest)
+      unsigned gmax = 0;
+      for (int j = i; j < cap.n; ++j)
+        if (!done[j] && cap.kind[j] == 7) { idx[m++] = j; done[j] = true; if (cap.grid[j] > gmax) gmax = cap.grid[j]; }
+      if (m == 1) hipLaunchKernelGGL((conv_small<2>), dim3(cap.grid[idx[0]]), dim3(256), cap.smem[idx[0]], st, cap.k[idx[0]]);
+      else { ConvKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.k[idx[q]]; hipLaunchKernelGGL((conv_small_g<2>), dim3(gmax, m), dim3(256), cap.smem[idx[0]], st, g); }
+      RUA_LAUNCH_CHECK("conv_small (group)");
+      ++grids;
+      continue;
+    }
     for (int j = i; j < cap.n; ++j)
       if (!done[j] && cap.kind[j] == cap.kind[i] && cap.grid[j] == cap.grid[i] && cap.smem[j] == cap.smem[i]) { idx[m++] = j; done[j] = true; }
     const bool chain = m >= 2 && (cap.kind[i] == 1 || cap.kind[i] == 2) && (g_tune.dmap_chain & cap.kind[i]) && chain_ok(cap, idx, m);

@@ -689,6 +689,10 @@ class Graph:
             plan.keep.append(descs[0])
             plan.add("rua_conv_fwd", C.byref(descs[0]))
             return
+        if len(descs) > L.RUA_MAX_BRANCH:                      # (the five sources of a PSPPooling fuse conv: the library takes RUA_MAX_BRANCH members per call)
+            self.conv_group(plan, descs[:L.RUA_MAX_BRANCH])
+            self.conv_group(plan, descs[L.RUA_MAX_BRANCH:])
+            return
         arr = (L.ConvDesc * len(descs))()
         for i, dsc in enumerate(descs):
             C.memmove(C.byref(arr, i * C.sizeof(L.ConvDesc)), C.byref(dsc), C.sizeof(L.ConvDesc))
@@ -762,6 +766,10 @@ class Graph:
         if len(specs) == 1 or self.dry:
             for sp in specs:
                 self.wgrad(plan, *sp)
+            return
+        if len(specs) > L.RUA_MAX_BRANCH:
+            self.wgrad_group(plan, specs[:L.RUA_MAX_BRANCH])
+            self.wgrad_group(plan, specs[L.RUA_MAX_BRANCH:])
             return
         descs = [self.wgrad_desc(plan, *sp, may_flush=(i == 0), group=len(specs)) for i, sp in enumerate(specs)]
         arr = (L.WgradDesc * len(descs))()
@@ -1104,13 +1112,17 @@ class Graph:
             return dict(out=g, mask=(node["x"], node["coef"].scale, node["coef"].shift), stats2=node["s2"])
         return dict(out=g, stat_aux=node["x"], stats2=node["s2"])
 
-    def conv1x1_multi(self, segs, cout, out_hw, want_stats=True):
-        """1x1 conv over concatenated sources [(Ten, up_shift)] -> raw output (with statistics)."""
+    def conv1x1_multi(self, segs, cout, out_hw, want_stats=True, defer: Optional[List] = None):
+        """1x1 conv over concatenated sources [(Ten, up_shift)] -> raw output (with statistics).  defer: the descriptor is appended to this list
+        instead of being launched (the caller issues independent convolutions as one group: Graph.conv_group)."""
         F, tr = self.fwd, self.training
         lay = self.Lconv([t.C for t, _ in segs], cout, 1)
         y = self.new(self.B, out_hw[0], out_hw[1], cout)
         st = self.stat(cout, (y.M + 127) // 128) if (tr and want_stats) else None
-        self.conv(F, [(t, up, 1, 1) for t, up in segs], lay["segs"], cout, self.P(lay["bias"]), y, stats=st)
+        if defer is not None:
+            defer.append(self.conv_desc([(t, up, 1, 1) for t, up in segs], lay["segs"], cout, self.P(lay["bias"]), y, stats=st))
+        else:
+            self.conv(F, [(t, up, 1, 1) for t, up in segs], lay["segs"], cout, self.P(lay["bias"]), y, stats=st)
         y.stats = st
         return y, lay
 
@@ -1134,14 +1146,25 @@ class Graph:
                 pd = self.new(dy.N, dy.H // k, dy.W // k, dy.C)
                 Bp.add("rua_sumpool", dy.ptr, pd.ptr, dy.N, dy.H, dy.W, dy.C, k, self.dt)
                 pooled[up] = pd
+        grouped = len(segs) > 1 and not self.dry and self.e.group_1x1 and self.dt == L.RUA_BF16
+        ddescs = []
+        for (t, up), seg, tg in zip(segs, lay["segs"], targets):
             d = pooled[up]
-            self.wgrad(Bp, t, d, seg["off"], 1, 1, 1)
+            self.wgrad(Bp, t, d, seg["off"], 1, 1, 1)          # (one launch each: as a group these unequal, tiny weight gradients measured slower - 18 vs 12 us)
             if tg is None:
                 gx, acc = self.gacc(t)
-                self.dgrad(Bp, d, self.Wd(seg["dst"]), t.C, 1, 1, gx, acc)
+                dd = self.dgrad_desc(d, self.Wd(seg["dst"]), t.C, 1, 1, gx, acc)
             else:
-                self.dgrad(Bp, d, self.Wd(seg["dst"]), t.C, 1, 1, tg["out"], 0, mask=tg.get("mask"), stats2=tg.get("stats2"),
-                           stat_aux=tg.get("stat_aux"))
+                dd = self.dgrad_desc(d, self.Wd(seg["dst"]), t.C, 1, 1, tg["out"], 0, tg.get("mask"), tg.get("stats2"), tg.get("stat_aux"))
+            if grouped:
+                ddescs.append(dd)
+            else:
+                Bp.keep.append(dd)
+                Bp.add("rua_conv_fwd", C.byref(dd))
+        if grouped:
+            # the sources of a concatenating 1x1 conv have their own gradients: the data gradients of all sources as one group (members on the same
+            # kernel share a grid: the pooled PSPPooling branches are ~10 us of latency apiece)
+            self.conv_group(Bp, ddescs)
 
     def psp(self, x: Ten, nf: int) -> Ten:
         """PSPPooling + the ReLU the caller applies (model2.py:41-79,116,142): max-pool k -> [nearest up] ->
@@ -1172,13 +1195,16 @@ class Graph:
         br, bds = [], []
         group_bn = not self.dry and self.dt == L.RUA_BF16      # the branches' BatchNorms (equal channels, unequal pixel counts) as ONE launch
         zs = []
+        bdescs = [] if (not self.dry and self.e.group_1x1 and self.dt == L.RUA_BF16) else None       # the branch convolutions as ONE group
         for k, p in zip(ks, pooled):
-            z, lay = self.conv1x1_multi([(p, 0)], nf // 4, (p.H, p.W))
+            z, lay = self.conv1x1_multi([(p, 0)], nf // 4, (p.H, p.W), defer=bdescs)
             bn = self.Lbn(nf // 4)
             zs.append((k, p, z, lay, bn))
             if not group_bn:
                 zb, node = self.bn_node(z, bn, False, count=z.M, bessel=z.M * k * k, stats=z.stats)
                 br.append((k, p, z, lay, zb, node))
+        if bdescs:                                             # (only with group_bn: the BatchNorms follow as one launch)
+            self.conv_group(F, bdescs)
         if group_bn:
             for k, p, z, lay, bn in zs:
                 zb, node = self.bn_node(z, bn, False, count=z.M, bessel=z.M * k * k, stats=z.stats, defer=bds)
@@ -1199,13 +1225,23 @@ class Graph:
                     for b_ in br:
                         b_[5]["back"](defer=bbs)
                     self.issue_bn_bwd(Bp, bbs)
-                for (k, p, z, lay, zb, node), idx in zip(br, idxs):
-                    if bbs is None:
-                        node["back"]()                             # zb.grad -> z.grad
-                    self.conv1x1_multi_back(Bp, [(p, 0)], lay, z, [None])   # -> p.grad (p is x for k == 1)
-                    if k > 1 and not pyramid:
-                        gx, acc = self.gacc(x)
-                        Bp.add("rua_maxpool_bwd", p.grad.ptr, idx.data_ptr(), gx.ptr, acc, x.N, x.H, x.W, x.C, k, self.dt)
+                if bbs is not None and pyramid and bdescs is not None:
+                    # the branch convolutions' data gradients as one group (independent: own source gradients)
+                    for (k, p, z, lay, zb, node) in br:
+                        self.wgrad(Bp, p, z.grad, lay["segs"][0]["off"], 1, 1, 1)
+                    dd = []
+                    for (k, p, z, lay, zb, node) in br:
+                        gx, acc = self.gacc(p)
+                        dd.append(self.dgrad_desc(z.grad, self.Wd(lay["segs"][0]["dst"]), p.C, 1, 1, gx, acc))
+                    self.conv_group(Bp, dd)
+                else:
+                    for (k, p, z, lay, zb, node), idx in zip(br, idxs):
+                        if bbs is None:
+                            node["back"]()                             # zb.grad -> z.grad
+                        self.conv1x1_multi_back(Bp, [(p, 0)], lay, z, [None])   # -> p.grad (p is x for k == 1)
+                        if k > 1 and not pyramid:
+                            gx, acc = self.gacc(x)
+                            Bp.add("rua_maxpool_bwd", p.grad.ptr, idx.data_ptr(), gx.ptr, acc, x.N, x.H, x.W, x.C, k, self.dt)
                 if pyramid:                                        # the three pooled gradients scattered in ONE pass over x.grad
                     gx, acc = self.gacc(x)
                     dys = L.ptr_array([b_[1].grad.ptr for b_ in br[1:]]); ixs = L.ptr_array([i.data_ptr() for i in idxs[1:]])
@@ -1700,6 +1736,7 @@ class Engine:
         self._t_dev, self._lr_base_dev = -1, None                                         # what lr_state holds (host shadow)
         self._dp_fence = torch.zeros(16, dtype=torch.float32, device=self.dev)            # see _graph_step_dp
         self.use_graph = True
+        self.group_1x1 = os.environ.get("RUA_GROUP_1X1", "1") != "0"       # PSPPooling's branch convolutions and the per-source gradients of concatenating 1x1 convolutions as groups
         self.group_heads = os.environ.get("RUA_GROUP_HEADS", "1") != "0"   # the heads' 3x3 convolutions (and their gradients) grouped across the heads
         self.multi_head = os.environ.get("RUA_MULTI_HEAD", "1") != "0"     # the heads' loss finalisation / d(loss)/d(logits) as one launch each
         self.stem_mfma = os.environ.get("RUA_STEM_MFMA", "1") != "0"       # bf16: the stem's weight gradient through rua_stem_fwd_pack / rua_conv_wgrad / rua_stem_bwd_fold
