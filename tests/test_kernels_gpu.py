@@ -1886,6 +1886,60 @@ def test_conv_small_data_gradient_epilogues(aux_mode):
         assert rel_err(st[Cout:], (exp * a).sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
 
 
+def test_conv_small_members_of_unequal_size_share_one_launch():
+    """rua_conv_fwd_group over the four branch convolutions of the bottleneck PSPPooling (model2.py:47-66 at 8 x 8 x 1024: 512 / 128 / 32 / 8 pooled pixels,
+    1024 -> 256, statistics in the epilogue): ONE conv_small_g launch (members with grids of unequal size), outputs and statistics bit-identical to four
+    rua_conv_fwd calls; the five per-source data gradients of the fuse conv go as 4 + 1 members the same way (Graph.conv_group splits at RUA_MAX_BRANCH)."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(123)
+    N, Cin, Cout = 8, 1024, 256
+    keep, descs = [], []
+    for hw in (8, 4, 2, 1):
+        x = to_dev(rng.standard_normal((N, hw, hw, Cin)).astype(np.float32), dt)
+        w = to_dev((rng.standard_normal((1, Cout, Cin)) / 32).astype(np.float32), dt)
+        b = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32)).to(dev())
+        ys = [torch.zeros((N, hw, hw, Cout), dtype=torch.bfloat16, device=dev()) for _ in range(2)]
+        sts = [torch.zeros(2 * 2 * Cout, dtype=torch.float64, device=dev()) for _ in range(2)]
+        keep += [x, w, b, ys, sts]
+        pair = []
+        for y, st in zip(ys, sts):
+            d = L.ConvDesc()
+            d.nseg = 1
+            sg = d.seg[0]
+            sg.x, sg.w, sg.C, sg.Hs, sg.Ws, sg.up_shift, sg.dil, sg.taps = x.data_ptr(), w.data_ptr(), Cin, hw, hw, 0, 1, 1
+            d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, hw, hw, Cout, 1, dt
+            d.bias = b.data_ptr()
+            d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, hw, hw
+            d.stats, d.stats_mode, d.stats_replicas = st.data_ptr(), 1, 2
+            assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 6
+            pair.append(d)
+        descs.append(pair)
+    for pair in descs:
+        lib.call("rua_conv_fwd", C.byref(pair[0]), stream())
+    arr = (L.ConvDesc * 4)()
+    for i, pair in enumerate(descs):
+        C.memmove(C.byref(arr, i * C.sizeof(L.ConvDesc)), C.byref(pair[1]), C.sizeof(L.ConvDesc))
+    lib.call("rua_conv_fwd_group", arr, 4, stream())
+    assert lib.raw("rua_conv_group_last_grids")() == 1
+    torch.cuda.synchronize()
+    for i in range(4):
+        ys, sts = keep[5 * i + 3], keep[5 * i + 4]
+        assert torch.equal(ys[0], ys[1]) and ys[0].float().abs().sum().item() > 0, i
+        assert torch.equal(sts[0], sts[1]), i
+    lib.set_tuning(conv_group=15)                          # without the conv_small bit: four launches, same results
+    try:
+        for i in range(4):
+            keep[5 * i + 3][1].zero_(); keep[5 * i + 4][1].zero_()
+        lib.call("rua_conv_fwd_group", arr, 4, stream())
+        assert lib.raw("rua_conv_group_last_grids")() == 4
+        torch.cuda.synchronize()
+    finally:
+        lib.set_tuning(conv_group=31)
+    for i in range(4):
+        assert torch.equal(keep[5 * i + 3][0], keep[5 * i + 3][1]) and torch.equal(keep[5 * i + 4][0], keep[5 * i + 4][1]), i
+
+
 @pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
 def test_bn_fwd_output_statistics_from_coefficients(dt):
     """rua_bn_branch.out_stats: the per-channel sum / sum of squares of a training-mode BatchNorm's output WITHOUT ReLU, written from the coefficients
