@@ -3355,6 +3355,128 @@ __global__ __launch_bounds__(768) void wgrad_rows128_g(const WgtKG g) {       //
   wgrad_rows128_body(p, (int)blockIdx.y);
 }
 
+// wgrad_img<W> (round 4): the 3x3 weight gradients of the two deepest levels (16 x 16 x 512 and 8 x 8 x 1024, dilation 1: model2.py:109-112 and their decoder mirror).  The generic
+// wgrad_kernel cuts dW into 64 x 64 tiles per TAP - 2 304 blocks at 8 x 8 x 1024, each staging all 512 pixels of its two operand slices through registers and LDS again, 64 pixels
+// and two barriers at a time: ~0.3 GB of L2 -> LDS traffic per launch, 22 - 28 us for 9.66 GFLOP.  Here a block owns a 64 x 64 tile of dW for ALL NINE taps over a chunk of 512
+// pixels (8 images of 8 x 8, or 2 of 16 x 16: whole images): its slices of dy and of the input - 512 pixels x 64 channels each, 64 KB + 64 KB - enter LDS ONCE by LDS-DMA
+// (per-lane source addresses gather the 128-byte slices out of the C-channel pixels, chunks XOR-swizzled with bit 1 of the pixel index as in wgrad_rows64), then 12 waves =
+// 3 kernel rows x 2 output-channel halves x 2 input-channel halves run 32 k-steps of three MFMAs with NO barrier: a tap is a shift of the input pixels by (dh W + dw), read
+// straight from the resident tile; pixels the shift carries across an image border are zeroed in the fragment (their position inside a transposed fragment is fixed per tap column;
+// the rows are a per-k-step predicate) - the tile has a slack of 18 pixels at either end for the shifted addresses.  256 blocks = one per CU at both levels (16 x 16: four
+// pixel chunks, i.e. four K slices through the deterministic slab reduction).
+template <int W>
+__global__ __launch_bounds__(768) void wgrad_img(const WgK p) {
+  constexpr int PC = 512, PXB = 128, SLACK = 18 * PXB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sX = smem + SLACK;                     // [512 pixels][64 ci] + slack either side
+  unsigned char* sD = sX + PC * PXB + SLACK;            // [512 pixels][64 co]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ty = wv >> 2, coh = (wv >> 1) & 1, cih = wv & 1;
+  int b = blockIdx.x;
+  const int ti = b % p.nti; b /= p.nti;
+  const int tc = b % p.ntc; b /= p.ntc;
+  const int chunk = b;                                  // pixel chunk = K slice
+  const int co0 = tc * 64, ci0 = ti * 64;
+  const unsigned cbytes = (unsigned)(p.C * 2), obytes = (unsigned)(p.Cout * 2);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.a, (unsigned)((size_t)p.M * p.C * 2)), rd = make_rsrc(p.dy, (unsigned)((size_t)p.M * p.Cout * 2));
+  {
+    // piece = 8 pixels x 128 bytes; lane l sits at pixel (l >> 3), chunk (l & 7) and fetches chunk (l & 7) ^ (bit 1 of the pixel << 2) of that pixel's slice
+    const unsigned gch = (unsigned)(((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 16);
+    const unsigned pix0 = (unsigned)(chunk * PC + (lane >> 3));
+    for (int pi = wv; pi < 2 * (PC / 8); pi += 12) {
+      if (pi < PC / 8)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sX + pi * 1024), 16, (pix0 + (unsigned)(pi * 8)) * cbytes + (unsigned)(ci0 * 2) + gch, 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_p)(sD + (pi - PC / 8) * 1024), 16, (pix0 + (unsigned)((pi - PC / 8) * 8)) * obytes + (unsigned)(co0 * 2) + gch, 0, 0, 0);
+    }
+  }
+  const unsigned sx_a = (unsigned)(size_t)(lds_void_p)sX, sd_a = (unsigned)(size_t)(lds_void_p)sD;
+  const int li = lane & 15, g = lane >> 4;
+  const int q4 = li >> 2, pp = li & 3;
+  const int chan = 16 * (g & 1) + 4 * pp;
+  const int kh = g >> 1;                                // which 8 pixels of the 16-pixel k-step this lane's fragment elements come from
+  const int hrow = 8 * kh + q4;
+  auto off_of = [&](int pix, int ch) {                   // byte offset of channel ch (of the 64-channel slice) of tile pixel `pix` (may be negative: slack)
+    return pix * PXB + ((((ch >> 3)) ^ (((pix >> 1) & 1) << 2)) * 16) + (ch & 7) * 2;
+  };
+  const unsigned dyo = sd_a + (unsigned)off_of(hrow, coh * 32 + chan);
+  unsigned xo[3];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) xo[tx] = (unsigned)((int)sx_a + off_of(hrow + (ty - 1) * W + (tx - 1), cih * 32 + chan));
+  // fragment element masks: a transposed read returns, per lane, its channel of the four pixels 8 kh + {0..3} (second read: + 4).  Tap column 0 reads pixel w - 1: invalid at
+  // w = 0 (element 0 of the first read where the group starts a row); tap column 2 reads w + 1: invalid at w = W - 1 (element 3 of the second read where the group ends a row)
+  const bool row_start = (W == 8) || kh == 0, row_end = (W == 8) || kh == 1;
+  const unsigned m_l = row_start ? 0xffff0000u : 0xffffffffu;      // first read, low dword (elements 0, 1): element 0 off
+  const unsigned m_r = row_end ? 0x0000ffffu : 0xffffffffu;        // second read, high dword (elements 2, 3): element 3 off
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  struct Frags { s16x4 d0, d1, x0[3], x1[3]; };
+  auto read_frags = [&](int ks, Frags& f) {
+    const unsigned dk = dyo + (unsigned)(ks * 16 * PXB);
+    const unsigned x0a = xo[0] + (unsigned)(ks * 16 * PXB), x1a = xo[1] + (unsigned)(ks * 16 * PXB), x2a = xo[2] + (unsigned)(ks * 16 * PXB);
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:512"
+                 : "=&v"(f.d0), "=&v"(f.d1), "=&v"(f.x0[0]), "=&v"(f.x1[0]), "=&v"(f.x0[1]), "=&v"(f.x1[1]), "=&v"(f.x0[2]), "=&v"(f.x1[2])
+                 : "v"(dk), "v"(x0a), "v"(x1a), "v"(x2a) : "memory");
+  };
+  auto wait_frags = [&](Frags& f, int pending) {
+    if (pending) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f.d0), "+v"(f.d1), "+v"(f.x0[0]), "+v"(f.x1[0]), "+v"(f.x0[1]), "+v"(f.x1[1]), "+v"(f.x0[2]), "+v"(f.x1[2]) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.d0), "+v"(f.d1), "+v"(f.x0[0]), "+v"(f.x1[0]), "+v"(f.x0[1]), "+v"(f.x1[1]), "+v"(f.x0[2]), "+v"(f.x1[2]) :: "memory");
+  };
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  auto mfma3 = [&](const Frags& f, int ks) {
+    // the image row of this lane's pixels: W = 8: row (2 ks + kh) & 7 (a k-step spans two rows); W = 16: row ks & 15 (one row).  Kernel row 0 reads row h - 1, kernel row 2 row h + 1
+    const int h = (W == 8) ? ((2 * ks + kh) & 7) : (ks & 15);
+    const bool rows_ok = !((ty == 0 && h == 0) || (ty == 2 && h == W - 1));
+    const unsigned rm = rows_ok ? 0xffffffffu : 0u;
+    const s16x8 fd = {f.d0[0], f.d0[1], f.d0[2], f.d0[3], f.d1[0], f.d1[1], f.d1[2], f.d1[3]};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      u32x2 a = __builtin_bit_cast(u32x2, f.x0[j]), c = __builtin_bit_cast(u32x2, f.x1[j]);
+      a[0] &= rm & (j == 0 ? m_l : 0xffffffffu); a[1] &= rm;
+      c[0] &= rm; c[1] &= rm & (j == 2 ? m_r : 0xffffffffu);
+      const s16x4 xa = __builtin_bit_cast(s16x4, a), xc = __builtin_bit_cast(s16x4, c);
+      const s16x8 fx = {xa[0], xa[1], xa[2], xa[3], xc[0], xc[1], xc[2], xc[3]};
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc[j], 0, 0, 0);
+    }
+  };
+  {
+    Frags fa, fb;
+    read_frags(0, fa);
+    for (int ks = 0; ks < PC / 16; ks += 2) {
+      read_frags(ks + 1, fb);
+      wait_frags(fa, 1); mfma3(fa, ks);
+      if (ks + 2 < PC / 16) read_frags(ks + 2, fa);
+      if (ks + 2 < PC / 16) wait_frags(fb, 1); else wait_frags(fb, 0);
+      mfma3(fb, ks + 1);
+    }
+  }
+  // ---- the 64 x 64 x 9 tile of dW: one writer per element (K slices: slabs summed in a fixed order) ---------------------------------
+  const bool ow = p.ksplit == 1 && p.overwrite && *p.overwrite != 0;
+  const int ci = ci0 + cih * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co0 + coh * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      const size_t idx = ((size_t)(ty * 3 + j) * p.Cout + co) * p.C + ci;
+      if (p.ksplit > 1) p.slabs[(size_t)chunk * 9 * p.Cout * p.C + idx] = acc[j][i];
+      else if (ow) p.dw[idx] = acc[j][i];
+      else p.dw[idx] += acc[j][i];
+    }
+}
+
 // dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 64 float4 columns x 4 slice lanes: a wave
 // reads 1 KiB runs of a partial, eight loads in flight per thread, the four lanes are folded through LDS in a fixed order
 // (deterministic).  (Before: 16 columns x 16 lanes - 256-byte runs, four loads in flight, 4x the blocks.)
@@ -3972,6 +4094,31 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   k.wshift = lg2(d->W); k.hshift = lg2(d->H);
   if (k.wshift < 0 || k.hshift < 0) k.wshift = k.hshift = -1;
   k.ntc = (d->Cout + 63) / 64; k.nti = (d->C + 63) / 64;
+  if ((g_tune.wgrad_rows & 8) && d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->dil == 1 && d->Hs == d->H && d->Ws == d->W && d->H == d->W &&
+      (d->W == 8 || d->W == 16) && d->C % 64 == 0 && d->Cout % 64 == 0 && k.M % 512 == 0 && (k.M == 512 || (g_tune.wgrad_slabs && slab_capacity(d, (long long)9 * d->Cout * d->C) >= (int)(k.M / 512)))) {
+    // wgrad_img: whole images resident in LDS, a 64 x 64 tile of dW for all nine taps per block, 512-pixel chunks as K slices
+    hipStream_t st_ = (hipStream_t)stream;
+    const long long ndw_ = (long long)9 * d->Cout * d->C;
+    k.ksplit = (int)(k.M / 512);
+    k.pix_per_block = 512;
+    k.slabs = k.ksplit > 1 ? (float*)d->workspace : nullptr;
+    if (k.slabs) note_pending(2, k.ksplit, ndw_, k.slabs, d->dw, 0, (int)((ndw_ / 4 + SLAB_RED_COLS - 1) / SLAB_RED_COLS));
+    if (g_wgrad_dry) return RUA_OK;
+    const unsigned grid_ = (unsigned)(k.ntc * k.nti * k.ksplit);
+    constexpr int smem_ = 2 * 512 * 128 + 2 * 18 * 128;
+    static RuaPerDevFlag attr_;
+    bool& attr = attr_.get();
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_img<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_img<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    if (d->W == 8) hipLaunchKernelGGL(wgrad_img<8>, dim3(grid_), dim3(768), smem_, st_, k);
+    else hipLaunchKernelGGL(wgrad_img<16>, dim3(grid_), dim3(768), smem_, st_, k);
+    RUA_LAUNCH_CHECK("wgrad_img");
+    if (k.slabs && !d->defer) { record_mid_event(st_); return launch_slab_reduce(k.slabs, d->dw, ndw_, k.ksplit, st_); }
+    return RUA_OK;
+  }
   const long long tiles = (long long)k.ntc * k.nti * d->taps;
   // K split: every slice adds the whole dW tile with fp32 atomics (~1.3 TB/s chip-wide), so slices x |dW| must stay
   // small: ~512 blocks fill the chip; 2048 blocks meant 33 MB of atomics (~25 us) per launch.

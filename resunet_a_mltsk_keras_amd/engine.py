@@ -1727,7 +1727,7 @@ class Engine:
         self.stats_arena = torch.zeros(1 << 22, dtype=torch.float64, device=self.dev)
         # one split-K slab workspace and one weight-gradient partial scratch per lane: branches run concurrently
         self.workspaces = [torch.zeros(8 << 20, dtype=torch.float32, device=self.dev) for _ in range(4)]
-        self.scratches = [torch.zeros((32 if i == 0 else 8) << 20, dtype=torch.float32, device=self.dev) for i in range(4)]   # lane 0: room for the fp32 K-slice slabs of the deterministic weight gradients (128 MB)
+        self.scratches = [torch.zeros((32 if i == 0 else 16) << 20, dtype=torch.float32, device=self.dev) for i in range(4)]   # lane 0: room for the fp32 K-slice slabs of the deterministic weight gradients (128 MB)
         self.workspace, self.scratch = self.workspaces[0], self.scratches[0]
         self.side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(3)]
         self.use_lanes = False      # measured: no gain (13.5 vs 14.0 ms/step), the step is bound by shared memory-side resources

@@ -332,6 +332,46 @@ def test_wgrad_all_taps_kernel(case):
     assert rel_err(outs[0] - base, w.grad.numpy()) < 2e-3
 
 
+@pytest.mark.parametrize("case", [(8, 8, 1024, 1024), (8, 16, 512, 512), (2, 16, 128, 64), (16, 8, 64, 128), (8, 8, 64, 64), (24, 8, 128, 128), (4, 16, 64, 192)])
+def test_wgrad_whole_image_kernel(case):
+    """The deepest levels' 3x3 weight gradient (8 x 8 and 16 x 16 maps, dilation 1, bf16: wgrad_img): whole images resident in LDS, all nine taps per block,
+    512-pixel chunks as K slices through slabs; adds into dW (or stores, under the first-writer flag), deterministic, matches autograd."""
+    N, H, Cs, Cout = case
+    dt = L.RUA_BF16
+    rng = np.random.default_rng(17)
+    a = rng.standard_normal((N, H, H, Cs)).astype(np.float32)
+    dy = rng.standard_normal((N, H, H, Cout)).astype(np.float32)
+    ad, dyd = to_dev(a, dt), to_dev(dy, dt)
+    base = rng.standard_normal((9, Cout, Cs)).astype(np.float32)
+    dw = torch.from_numpy(base).to(dev())
+    ws = torch.empty((64 << 20) // 4, dtype=torch.float32, device=dev())
+    flag = torch.zeros(4, dtype=torch.int32, device=dev())
+    d = L.WgradDesc()
+    d.a, d.C, d.Hs, d.Ws = ad.data_ptr(), Cs, H, H
+    d.dy, d.Cout, d.H, d.W = dyd.data_ptr(), Cout, H, H
+    d.N, d.stride, d.dil, d.taps, d.dtype = N, 1, 1, 9, dt
+    d.dw, d.workspace, d.workspace_bytes = dw.data_ptr(), ws.data_ptr(), ws.numel() * 4
+    d.overwrite_dev = flag.data_ptr()
+    assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 0
+    w = torch.zeros((9, Cout, Cs), dtype=torch.float64, requires_grad=True)
+    y = ref_conv_nhwc(rnd(dt, a).double(), w, None, 1, 9, 1)
+    y.backward(rnd(dt, dy).double())
+    outs = []
+    for rep in range(2):
+        dw.copy_(torch.from_numpy(base))
+        ws.uniform_(-1e3, 1e3)
+        L.lib().call("rua_conv_wgrad", C.byref(d), stream())
+        torch.cuda.synchronize()
+        outs.append(dw.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
+    assert rel_err(outs[0] - base, w.grad.numpy()) < 2e-3
+    if N * H * H == 512:                                       # one K slice: the block stores dW itself when the flag is up
+        flag.fill_(1)
+        L.lib().call("rua_conv_wgrad", C.byref(d), stream())
+        torch.cuda.synchronize()
+        assert rel_err(dw.cpu().numpy(), w.grad.numpy()) < 2e-3
+
+
 PW_CASES = [
     # N, Hs, Ws, C, Cout, stride
     (2, 64, 64, 32, 32, 1), (1, 128, 128, 32, 8, 1), (2, 64, 64, 8, 32, 1), (2, 64, 64, 64, 64, 1), (2, 64, 64, 32, 64, 2),
