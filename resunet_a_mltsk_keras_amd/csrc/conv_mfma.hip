@@ -3384,11 +3384,14 @@ __global__ __launch_bounds__(768) void wgrad_img(const WgK p) {
     // piece = 8 pixels x 128 bytes; lane l sits at pixel (l >> 3), chunk (l & 7) and fetches chunk (l & 7) ^ (bit 1 of the pixel << 2) of that pixel's slice
     const unsigned gch = (unsigned)(((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 16);
     const unsigned pix0 = (unsigned)(chunk * PC + (lane >> 3));
-    for (int pi = wv; pi < 2 * (PC / 8); pi += 12) {
-      if (pi < PC / 8)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sX + pi * 1024), 16, (pix0 + (unsigned)(pi * 8)) * cbytes + (unsigned)(ci0 * 2) + gch, 0, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_p)(sD + (pi - PC / 8) * 1024), 16, (pix0 + (unsigned)((pi - PC / 8) * 8)) * obytes + (unsigned)(co0 * 2) + gch, 0, 0, 0);
+    // 128 pieces in pixel order, the two operands alternating; wave wv issues pieces wv, wv + 12, ...: eleven operations each (the last four waves end with a dummy), so that
+    // "operation k of every wave is done" means "the first 48 (k + 1) pixels of both tiles have landed" and the k-steps start while the rest is in flight
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const int q = k * 12 + wv, pb = q >> 1;
+      if (q >= 2 * (PC / 8)) { const unsigned z = 0u, off = 0x80000000u; asm volatile("buffer_store_dword %0, %1, %2, 0 offen" :: "v"(z), "v"(off), "s"(rd) : "memory"); }
+      else if (!(q & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sX + pb * 1024), 16, (pix0 + (unsigned)(pb * 8)) * cbytes + (unsigned)(ci0 * 2) + gch, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_p)(sD + pb * 1024), 16, (pix0 + (unsigned)(pb * 8)) * obytes + (unsigned)(co0 * 2) + gch, 0, 0, 0);
     }
   }
   const unsigned sx_a = (unsigned)(size_t)(lds_void_p)sX, sd_a = (unsigned)(size_t)(lds_void_p)sD;
@@ -3415,9 +3418,6 @@ __global__ __launch_bounds__(768) void wgrad_img(const WgK p) {
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   struct Frags { s16x4 d0, d1, x0[3], x1[3]; };
   auto read_frags = [&](int ks, Frags& f) {
     const unsigned dk = dyo + (unsigned)(ks * 16 * PXB);
@@ -3451,14 +3451,23 @@ __global__ __launch_bounds__(768) void wgrad_img(const WgK p) {
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc[j], 0, 0, 0);
     }
   };
-  {
+  // four stages of eight k-steps (128 pixels); a stage reads input pixels up to 17 beyond its own: it starts once 146 / 274 / 402 / 512 pixels have landed = operation 3 / 5 / 8 / 10 of every wave
+#pragma unroll
+  for (int sg = 0; sg < 4; ++sg) {
+    if (sg == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (sg == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (sg == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     Frags fa, fb;
-    read_frags(0, fa);
-    for (int ks = 0; ks < PC / 16; ks += 2) {
+    read_frags(8 * sg, fa);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2 += 2) {
+      const int ks = 8 * sg + k2;
       read_frags(ks + 1, fb);
       wait_frags(fa, 1); mfma3(fa, ks);
-      if (ks + 2 < PC / 16) read_frags(ks + 2, fa);
-      if (ks + 2 < PC / 16) wait_frags(fb, 1); else wait_frags(fb, 0);
+      if (k2 + 2 < 8) read_frags(ks + 2, fa);
+      if (k2 + 2 < 8) wait_frags(fb, 1); else wait_frags(fb, 0);
       mfma3(fb, ks + 1);
     }
   }
