@@ -3486,6 +3486,140 @@ __global__ __launch_bounds__(768) void wgrad_img(const WgK p) {
     }
 }
 
+// wgrad_imgs (round 4): wgrad_img for maps of 16 x 16 with MORE than 512 pixels (8 x 16 x 16 x 512: four chunks) WITHOUT K slices.  wgrad_img's 64 x 64 tiles need the
+// four chunks as four K slices to fill the chip - 37.7 MB of fp32 slabs written per launch and read again by the batched reduction (151 MB per step at this level).  Here a block
+// owns a 32 x 32 tile of dW for all nine taps (256 blocks at 512 x 512) and STREAMS the chunks through a two-stage LDS ring (512 pixels x 32 channels x 2 operands per stage:
+// 64-byte pixel rows, the four pixel rows of a transposing read are one contiguous 256 bytes - no swizzle): chunk c + 1 lands while chunk c multiplies.  12 waves = 3 kernel
+// rows x 4 k-quarters of a chunk (8 k-steps each, 3 MFMAs per k-step, fragment reads pipelined as in wgrad_img); the quarters meet once, at the end, through LDS; dW is written
+// once (stored under the first-writer flag, added otherwise): no slabs, no reduction.
+__global__ __launch_bounds__(768) void wgrad_imgs(const WgK p) {
+  constexpr int W = 16, PC = 512, PXB = 64, SLACK = 18 * PXB, TILE = PC * PXB, STAGE = 2 * SLACK + 2 * TILE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ty = wv >> 2, kq = wv & 3;
+  const int ti = (int)blockIdx.x % p.nti, tc = (int)blockIdx.x / p.nti;
+  const int co0 = tc * 32, ci0 = ti * 32;
+  const int nch = p.ksplit;                             // chunks of 512 pixels (host: M / 512; NOT K slices here)
+  const unsigned cbytes = (unsigned)(p.C * 2), obytes = (unsigned)(p.Cout * 2);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.a, (unsigned)((size_t)p.M * p.C * 2)), rd = make_rsrc(p.dy, (unsigned)((size_t)p.M * p.Cout * 2));
+  // a DMA piece = 16 pixels x 64 bytes: lane l -> pixel (l >> 2), 16-byte chunk (l & 3)
+  const unsigned srcx = (unsigned)(lane >> 2) * cbytes + (unsigned)(ci0 * 2 + (lane & 3) * 16);
+  const unsigned srcd = (unsigned)(lane >> 2) * obytes + (unsigned)(co0 * 2 + (lane & 3) * 16);
+  auto issue = [&](int c, int st) {                     // chunk c into stage st: 64 pieces, six operations per wave (the last eight slots: dummies)
+    unsigned char* sX = smem + st * STAGE + SLACK;
+    unsigned char* sD = sX + TILE + SLACK;
+    const unsigned pix0 = (unsigned)(c * PC);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int q = k * 12 + wv, pb = q >> 1;
+      if (q >= 2 * (PC / 16)) { const unsigned z = 0u, off = 0x80000000u; asm volatile("buffer_store_dword %0, %1, %2, 0 offen" :: "v"(z), "v"(off), "s"(rd) : "memory"); }
+      else if (!(q & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sX + pb * 1024), 16, (pix0 + (unsigned)(pb * 16)) * cbytes + srcx, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_p)(sD + pb * 1024), 16, (pix0 + (unsigned)(pb * 16)) * obytes + srcd, 0, 0, 0);
+    }
+  };
+  issue(0, 0);
+  if (nch > 1) issue(1, 1);
+
+  const unsigned s_a = (unsigned)(size_t)(lds_void_p)smem;
+  const int li = lane & 15, g = lane >> 4;
+  const int q4 = li >> 2, pp = li & 3;
+  const int kh = g >> 1;
+  const int hrow = 8 * kh + q4;
+  const int chb = 32 * (g & 1) + 8 * pp;                // byte offset of this lane's four channels inside the 64-byte pixel row
+  const unsigned dyo = (unsigned)(2 * SLACK + TILE + (kq * 128 + hrow) * PXB + chb);
+  unsigned xo[3];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) xo[tx] = (unsigned)(SLACK + (kq * 128 + hrow + (ty - 1) * W + (tx - 1)) * PXB + chb);
+  const unsigned m_l = kh == 0 ? 0xffff0000u : 0xffffffffu;        // tap column 0 reads pixel w - 1: off at w = 0 (element 0 of the first read of the row's first half)
+  const unsigned m_r = kh == 1 ? 0x0000ffffu : 0xffffffffu;        // tap column 2 reads pixel w + 1: off at w = 15 (element 3 of the second read of the row's second half)
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  struct Frags { s16x4 d0, d1, x0[3], x1[3]; };
+  auto read_frags = [&](unsigned base, int k, Frags& f) {
+    const unsigned dk = base + dyo + (unsigned)(k * 16 * PXB);
+    const unsigned x0a = base + xo[0] + (unsigned)(k * 16 * PXB), x1a = base + xo[1] + (unsigned)(k * 16 * PXB), x2a = base + xo[2] + (unsigned)(k * 16 * PXB);
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:256\n\t"
+                 "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:256\n\t"
+                 "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:256\n\t"
+                 "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:256"
+                 : "=&v"(f.d0), "=&v"(f.d1), "=&v"(f.x0[0]), "=&v"(f.x1[0]), "=&v"(f.x0[1]), "=&v"(f.x1[1]), "=&v"(f.x0[2]), "=&v"(f.x1[2])
+                 : "v"(dk), "v"(x0a), "v"(x1a), "v"(x2a) : "memory");
+  };
+  auto wait_frags = [&](Frags& f, int pending) {
+    if (pending) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f.d0), "+v"(f.d1), "+v"(f.x0[0]), "+v"(f.x1[0]), "+v"(f.x0[1]), "+v"(f.x1[1]), "+v"(f.x0[2]), "+v"(f.x1[2]) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.d0), "+v"(f.d1), "+v"(f.x0[0]), "+v"(f.x1[0]), "+v"(f.x0[1]), "+v"(f.x1[1]), "+v"(f.x0[2]), "+v"(f.x1[2]) :: "memory");
+  };
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  auto mfma3 = [&](const Frags& f, int k) {             // k-step 8 kq + k of the chunk = image row (8 kq + k) & 15 (two images per chunk)
+    const int h = (8 * kq + k) & 15;
+    const bool rows_ok = !((ty == 0 && h == 0) || (ty == 2 && h == W - 1));
+    const unsigned rm = rows_ok ? 0xffffffffu : 0u;
+    const s16x8 fd = {f.d0[0], f.d0[1], f.d0[2], f.d0[3], f.d1[0], f.d1[1], f.d1[2], f.d1[3]};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      u32x2 a = __builtin_bit_cast(u32x2, f.x0[j]), c = __builtin_bit_cast(u32x2, f.x1[j]);
+      a[0] &= rm & (j == 0 ? m_l : 0xffffffffu); a[1] &= rm;
+      c[0] &= rm; c[1] &= rm & (j == 2 ? m_r : 0xffffffffu);
+      const s16x4 xa = __builtin_bit_cast(s16x4, a), xc = __builtin_bit_cast(s16x4, c);
+      const s16x8 fx = {xa[0], xa[1], xa[2], xa[3], xc[0], xc[1], xc[2], xc[3]};
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd), __builtin_bit_cast(bf16x8, fx), acc[j], 0, 0, 0);
+    }
+  };
+
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // chunk c has landed (chunk c + 1 stays in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned base = s_a + (unsigned)((c & 1) * STAGE);
+    Frags fa, fb;
+    read_frags(base, 0, fa);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2 += 2) {
+      read_frags(base, k2 + 1, fb);
+      wait_frags(fa, 1); mfma3(fa, k2);
+      if (k2 + 2 < 8) read_frags(base, k2 + 2, fa);
+      if (k2 + 2 < 8) wait_frags(fb, 1); else wait_frags(fb, 0);
+      mfma3(fb, k2 + 1);
+    }
+    if (c + 2 < nch) {
+      __builtin_amdgcn_s_barrier();                     // every wave is done with this stage
+      issue(c + 2, c & 1);
+    }
+  }
+  // ---- the k-quarters meet in LDS (the ring is free), quarter 0 writes the 32 x 32 x 9 tile -----------------------------------------
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+  if (kq > 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[((((kq - 1) * 3 + ty) * 3 + j) * 16 + i) * 64 + lane] = acc[j][i];
+  }
+  __syncthreads();
+  if (kq == 0) {
+    const bool ow = p.overwrite && *p.overwrite != 0;
+    const int ci = ci0 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = acc[j][i];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v += red[(((q * 3 + ty) * 3 + j) * 16 + i) * 64 + lane];
+        const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const size_t idx = ((size_t)(ty * 3 + j) * p.Cout + co) * p.C + ci;
+        if (ow) p.dw[idx] = v; else p.dw[idx] += v;
+      }
+  }
+}
+
 // dw[tap][co][ci] += sum over the gx partials of its output-channel half.  256 threads = 64 float4 columns x 4 slice lanes: a wave
 // reads 1 KiB runs of a partial, eight loads in flight per thread, the four lanes are folded through LDS in a fixed order
 // (deterministic).  (Before: 16 columns x 16 lanes - 256-byte runs, four loads in flight, 4x the blocks.)
@@ -4104,10 +4238,24 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   if (k.wshift < 0 || k.hshift < 0) k.wshift = k.hshift = -1;
   k.ntc = (d->Cout + 63) / 64; k.nti = (d->C + 63) / 64;
   if ((g_tune.wgrad_rows & 8) && d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->dil == 1 && d->Hs == d->H && d->Ws == d->W && d->H == d->W &&
-      (d->W == 8 || d->W == 16) && d->C % 64 == 0 && d->Cout % 64 == 0 && k.M % 512 == 0 && (k.M == 512 || (g_tune.wgrad_slabs && slab_capacity(d, (long long)9 * d->Cout * d->C) >= (int)(k.M / 512)))) {
+      (d->W == 8 || d->W == 16) && d->C % 64 == 0 && d->Cout % 64 == 0 && k.M % 512 == 0 && (k.M == 512 || ((g_tune.wgrad_rows & 16) && d->W == 16 && (long long)(d->C / 32) * (d->Cout / 32) >= rua_cu_count() / 2) ||
+       (g_tune.wgrad_slabs && slab_capacity(d, (long long)9 * d->Cout * d->C) >= (int)(k.M / 512)))) {
     // wgrad_img: whole images resident in LDS, a 64 x 64 tile of dW for all nine taps per block, 512-pixel chunks as K slices
     hipStream_t st_ = (hipStream_t)stream;
     const long long ndw_ = (long long)9 * d->Cout * d->C;
+    if ((g_tune.wgrad_rows & 16) && d->W == 16 && k.M >= 1024 && (long long)(d->C / 32) * (d->Cout / 32) >= rua_cu_count() / 2) {
+      // wgrad_imgs: 32 x 32 tiles, the chunks streamed through a two-stage ring - no K slices, no slabs
+      if (g_wgrad_dry) return RUA_OK;
+      k.ksplit = (int)(k.M / 512); k.pix_per_block = 512; k.slabs = nullptr;
+      k.nti = d->C / 32; k.ntc = d->Cout / 32;
+      constexpr int smems_ = 2 * (2 * 18 * 64 + 2 * 512 * 64);
+      static RuaPerDevFlag attrs_;
+      bool& attrs = attrs_.get();
+      if (!attrs) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_imgs), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrs = true; }
+      hipLaunchKernelGGL(wgrad_imgs, dim3((unsigned)(k.nti * k.ntc)), dim3(768), smems_, st_, k);
+      RUA_LAUNCH_CHECK("wgrad_imgs");
+      return RUA_OK;
+    }
     k.ksplit = (int)(k.M / 512);
     k.pix_per_block = 512;
     k.slabs = k.ksplit > 1 ? (float*)d->workspace : nullptr;

@@ -332,10 +332,12 @@ def test_wgrad_all_taps_kernel(case):
     assert rel_err(outs[0] - base, w.grad.numpy()) < 2e-3
 
 
-@pytest.mark.parametrize("case", [(8, 8, 1024, 1024), (8, 16, 512, 512), (2, 16, 128, 64), (16, 8, 64, 128), (8, 8, 64, 64), (24, 8, 128, 128), (4, 16, 64, 192)])
+@pytest.mark.parametrize("case", [(8, 8, 1024, 1024), (8, 16, 512, 512), (2, 16, 128, 64), (16, 8, 64, 128), (8, 8, 64, 64), (24, 8, 128, 128), (4, 16, 64, 192),
+                                  (4, 16, 512, 256), (6, 16, 256, 512), (10, 16, 384, 352)])      # 16 x 16, > 512 pixels, >= 128 tiles of 32 x 32: wgrad_imgs (streamed chunks, no K slices)
 def test_wgrad_whole_image_kernel(case):
     """The deepest levels' 3x3 weight gradient (8 x 8 and 16 x 16 maps, dilation 1, bf16: wgrad_img): whole images resident in LDS, all nine taps per block,
-    512-pixel chunks as K slices through slabs; adds into dW (or stores, under the first-writer flag), deterministic, matches autograd."""
+    512-pixel chunks as K slices through slabs - or, at 16 x 16 with enough 32 x 32 tiles to fill the chip, streamed through an LDS ring by one block (wgrad_imgs);
+    adds into dW (or stores, under the first-writer flag), deterministic, matches autograd."""
     N, H, Cs, Cout = case
     dt = L.RUA_BF16
     rng = np.random.default_rng(17)
@@ -365,7 +367,7 @@ def test_wgrad_whole_image_kernel(case):
         outs.append(dw.cpu().numpy().copy())
     assert np.array_equal(outs[0], outs[1])
     assert rel_err(outs[0] - base, w.grad.numpy()) < 2e-3
-    if N * H * H == 512:                                       # one K slice: the block stores dW itself when the flag is up
+    if N * H * H == 512 or (H == 16 and (Cs // 32) * (Cout // 32) >= 128):      # no K slices: the block stores dW itself when the flag is up
         flag.fill_(1)
         L.lib().call("rua_conv_wgrad", C.byref(d), stream())
         torch.cuda.synchronize()
