@@ -3510,6 +3510,9 @@ __global__ __launch_bounds__(768) void wgrad_imgs(const WgK p) {
     unsigned char* sX = smem + st * STAGE + SLACK;
     unsigned char* sD = sX + TILE + SLACK;
     const unsigned pix0 = (unsigned)(c * PC);
+#ifdef RUA_IMGS_DBG_NODMA                               // (timing experiments only - results are garbage)
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const int q = k * 12 + wv, pb = q >> 1;
@@ -3579,6 +3582,9 @@ __global__ __launch_bounds__(768) void wgrad_imgs(const WgK p) {
     __builtin_amdgcn_s_barrier();
     const unsigned base = s_a + (unsigned)((c & 1) * STAGE);
     Frags fa, fb;
+#ifdef RUA_IMGS_DBG_NOMFMA
+    if (p.M > 0) continue;
+#endif
     read_frags(base, 0, fa);
 #pragma unroll
     for (int k2 = 0; k2 < 8; k2 += 2) {
@@ -3595,28 +3601,30 @@ __global__ __launch_bounds__(768) void wgrad_imgs(const WgK p) {
   }
   // ---- the k-quarters meet in LDS (the ring is free), quarter 0 writes the 32 x 32 x 9 tile -----------------------------------------
   __syncthreads();
+#ifdef RUA_IMGS_DBG_NOEPI
+  if (p.M > 0) { if (acc[0][0] == 123.456f) p.dw[0] = 1; return; }
+#endif
+  // every wave leaves its three accumulators in LDS ([k-quarter][tap][register][lane]: 144 KB, the ring is free); then all 768 threads sum the four quarters of three float4
+  // each - four consecutive input channels of one (tap, output channel) = four consecutive lanes of one register - and write dW in 128-byte row segments
   float* red = reinterpret_cast<float*>(smem);
-  if (kq > 0) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+  for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) red[((((kq - 1) * 3 + ty) * 3 + j) * 16 + i) * 64 + lane] = acc[j][i];
-  }
+    for (int i = 0; i < 16; ++i) red[(((kq * 3 + ty) * 3 + j) * 16 + i) * 64 + lane] = acc[j][i];
   __syncthreads();
-  if (kq == 0) {
-    const bool ow = p.overwrite && *p.overwrite != 0;
-    const int ci = ci0 + (lane & 31);
+  const bool ow = p.overwrite && *p.overwrite != 0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+  for (int r = 0; r < 3; ++r) {
+    const int o4 = tid + 768 * r;                       // float4 index in [tap][32 co][8 x 4 ci]
+    const int tap = o4 >> 8, col = (o4 >> 3) & 31, c4 = (o4 & 7) * 4;
+    const int i = (col & 3) + 4 * (col >> 3), lh = (col >> 2) & 1;
+    const float* src = red + (tap * 16 + i) * 64 + lh * 32 + c4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float v = acc[j][i];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) v += red[(((q * 3 + ty) * 3 + j) * 16 + i) * 64 + lane];
-        const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        const size_t idx = ((size_t)(ty * 3 + j) * p.Cout + co) * p.C + ci;
-        if (ow) p.dw[idx] = v; else p.dw[idx] += v;
-      }
+    for (int q = 1; q < 4; ++q) v += *reinterpret_cast<const f32x4*>(src + q * 9 * 16 * 64);
+    float* dst = p.dw + ((size_t)tap * p.Cout + co0 + col) * p.C + ci0 + c4;
+    if (!ow) v += *reinterpret_cast<const f32x4*>(dst);
+    *reinterpret_cast<f32x4*>(dst) = v;
   }
 }
 
@@ -4248,7 +4256,7 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
       if (g_wgrad_dry) return RUA_OK;
       k.ksplit = (int)(k.M / 512); k.pix_per_block = 512; k.slabs = nullptr;
       k.nti = d->C / 32; k.ntc = d->Cout / 32;
-      constexpr int smems_ = 2 * (2 * 18 * 64 + 2 * 512 * 64);
+      constexpr int smems_ = 4 * 9 * 16 * 64 * 4;             // the ring (2 x 67 840 B) and, after it, the four k-quarters' accumulators (147 456 B)
       static RuaPerDevFlag attrs_;
       bool& attrs = attrs_.get();
       if (!attrs) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_imgs), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrs = true; }
