@@ -272,6 +272,9 @@ def profile_kernels(eng, g, dtype):
                     fl, tag, second = conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags), f"conv_splitk_finish<{tname}>"
                 else:
                     wk = lib.raw("rua_wgrad_kind")(C.byref(d)); kn = (f"wgrad_kernel<{tname}>", f"wgrad_taps_kernel<{d.C}>", "wgrad_dmap", "wgrad_pw")[wk]
+                    ik = lib.raw("rua_wgrad_img_kind")(C.byref(d)) if wk == 0 else 0
+                    if ik:
+                        kn = f"wgrad_img<{d.W}>" if ik == 1 else "wgrad_imgs"
                     two = fired
                     fl, tag, second = wgrad_flops(d), (d.N * d.H * d.W, d.Cout, d.C * d.taps, d.dil, ""), ("wgrad_taps_reduce" if wk == 1 else "wgrad_slab_reduce")
                 if two:                                     # per-kernel rows, as rocprofv3 names them

@@ -110,6 +110,7 @@ _SIGS = {
     "rua_conv_wgrad": ([C.POINTER(WgradDesc), vp], i32),
     "rua_wgrad_workspace_bytes": ([C.POINTER(WgradDesc)], i64),
     "rua_wgrad_kind": ([C.POINTER(WgradDesc)], i32),
+    "rua_wgrad_img_kind": ([C.POINTER(WgradDesc)], i32),
     "rua_wgrad_plan": ([C.POINTER(WgradDesc), C.POINTER(WgradPending)], i32),
     "rua_wgrad_reduce_batch": ([vp, i32, i32, vp], i32),
     "rua_weight_prep": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),

@@ -4222,6 +4222,18 @@ extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
   return ok ? 1 : 0;
 }
 
+// the whole-image kernels of the deepest levels (kind 0 of rua_wgrad_kind): 0 none (generic tiles), 1 wgrad_img (64 x 64 tiles, 512-pixel chunks as K slices through slabs),
+// 2 wgrad_imgs (16 x 16 maps, 32 x 32 tiles, chunks streamed - when those tiles fill at least half the chip)
+static int wgrad_img_pick(const rua_wgrad_desc* d) {
+  const long long M = (long long)d->N * d->H * d->W;
+  if (!((g_tune.wgrad_rows & 8) && d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->dil == 1 && d->Hs == d->H && d->Ws == d->W && d->H == d->W &&
+        (d->W == 8 || d->W == 16) && d->C % 64 == 0 && d->Cout % 64 == 0 && M % 512 == 0 && !d->in_scale)) return 0;
+  if ((g_tune.wgrad_rows & 16) && d->W == 16 && M >= 1024 && (long long)(d->C / 32) * (d->Cout / 32) >= rua_cu_count() / 2) return 2;
+  if (M == 512 || (g_tune.wgrad_slabs && slab_capacity(d, (long long)9 * d->Cout * d->C) >= (int)(M / 512))) return 1;
+  return 0;
+}
+extern "C" int rua_wgrad_img_kind(const rua_wgrad_desc* d) { return (d && rua_wgrad_kind(d) == 0) ? wgrad_img_pick(d) : 0; }
+
 extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   RUA_CHECK_ARG(d && d->a && d->dy && d->dw, "rua_conv_wgrad: null pointer");
   RUA_CHECK_ARG(d->dtype == RUA_F32 || d->dtype == RUA_BF16, "rua_conv_wgrad: bad dtype");
@@ -4245,13 +4257,12 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   k.wshift = lg2(d->W); k.hshift = lg2(d->H);
   if (k.wshift < 0 || k.hshift < 0) k.wshift = k.hshift = -1;
   k.ntc = (d->Cout + 63) / 64; k.nti = (d->C + 63) / 64;
-  if ((g_tune.wgrad_rows & 8) && d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->dil == 1 && d->Hs == d->H && d->Ws == d->W && d->H == d->W &&
-      (d->W == 8 || d->W == 16) && d->C % 64 == 0 && d->Cout % 64 == 0 && k.M % 512 == 0 && (k.M == 512 || ((g_tune.wgrad_rows & 16) && d->W == 16 && (long long)(d->C / 32) * (d->Cout / 32) >= rua_cu_count() / 2) ||
-       (g_tune.wgrad_slabs && slab_capacity(d, (long long)9 * d->Cout * d->C) >= (int)(k.M / 512)))) {
+  const int img_kind = wgrad_img_pick(d);
+  if (img_kind) {
     // wgrad_img: whole images resident in LDS, a 64 x 64 tile of dW for all nine taps per block, 512-pixel chunks as K slices
     hipStream_t st_ = (hipStream_t)stream;
     const long long ndw_ = (long long)9 * d->Cout * d->C;
-    if ((g_tune.wgrad_rows & 16) && d->W == 16 && k.M >= 1024 && (long long)(d->C / 32) * (d->Cout / 32) >= rua_cu_count() / 2) {
+    if (img_kind == 2) {
       // wgrad_imgs: 32 x 32 tiles, the chunks streamed through a two-stage ring - no K slices, no slabs
       if (g_wgrad_dry) return RUA_OK;
       k.ksplit = (int)(k.M / 512); k.pix_per_block = 512; k.slabs = nullptr;

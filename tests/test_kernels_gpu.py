@@ -355,6 +355,8 @@ def test_wgrad_whole_image_kernel(case):
     d.dw, d.workspace, d.workspace_bytes = dw.data_ptr(), ws.data_ptr(), ws.numel() * 4
     d.overwrite_dev = flag.data_ptr()
     assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 0
+    streamed = H == 16 and N * H * H > 512 and (Cs // 32) * (Cout // 32) >= 128
+    assert L.lib().raw("rua_wgrad_img_kind")(C.byref(d)) == (2 if streamed else 1)
     w = torch.zeros((9, Cout, Cs), dtype=torch.float64, requires_grad=True)
     y = ref_conv_nhwc(rnd(dt, a).double(), w, None, 1, 9, 1)
     y.backward(rnd(dt, dy).double())
@@ -367,7 +369,7 @@ def test_wgrad_whole_image_kernel(case):
         outs.append(dw.cpu().numpy().copy())
     assert np.array_equal(outs[0], outs[1])
     assert rel_err(outs[0] - base, w.grad.numpy()) < 2e-3
-    if N * H * H == 512 or (H == 16 and (Cs // 32) * (Cout // 32) >= 128):      # no K slices: the block stores dW itself when the flag is up
+    if N * H * H == 512 or streamed:                           # no K slices: the block stores dW itself when the flag is up
         flag.fill_(1)
         L.lib().call("rua_conv_wgrad", C.byref(d), stream())
         torch.cuda.synchronize()
