@@ -4227,8 +4227,9 @@ extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
 static int wgrad_img_pick(const rua_wgrad_desc* d) {
   const long long M = (long long)d->N * d->H * d->W;
   if (!((g_tune.wgrad_rows & 8) && d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->dil == 1 && d->Hs == d->H && d->Ws == d->W && d->H == d->W &&
-        (d->W == 8 || d->W == 16) && d->C % 64 == 0 && d->Cout % 64 == 0 && M % 512 == 0 && !d->in_scale)) return 0;
+        (d->W == 8 || d->W == 16) && d->C % 32 == 0 && d->Cout % 32 == 0 && M % 512 == 0 && !d->in_scale)) return 0;
   if ((g_tune.wgrad_rows & 16) && d->W == 16 && M >= 1024 && (long long)(d->C / 32) * (d->Cout / 32) >= rua_cu_count() / 2) return 2;
+  if (d->C % 64 || d->Cout % 64) return 0;
   if (M == 512 || (g_tune.wgrad_slabs && slab_capacity(d, (long long)9 * d->Cout * d->C) >= (int)(M / 512))) return 1;
   return 0;
 }
