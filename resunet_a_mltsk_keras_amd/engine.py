@@ -1735,7 +1735,7 @@ class Engine:
         self.lr_state = torch.zeros(2, dtype=torch.float64, device=self.dev)              # [steps taken, base learning rate]
         self._t_dev, self._lr_base_dev = -1, None                                         # what lr_state holds (host shadow)
         self._dp_fence = torch.zeros(16, dtype=torch.float32, device=self.dev)            # see _graph_step_dp
-        self.use_graph = True
+        self.use_graph = os.environ.get("RUA_USE_GRAPH", "1") != "0"                      # 0 (experiments): the single-GPU step as eager launches too
         self.group_1x1 = os.environ.get("RUA_GROUP_1X1", "1") != "0"       # PSPPooling's branch convolutions and the per-source gradients of concatenating 1x1 convolutions as groups
         self.group_heads = os.environ.get("RUA_GROUP_HEADS", "1") != "0"   # the heads' 3x3 convolutions (and their gradients) grouped across the heads
         self.multi_head = os.environ.get("RUA_MULTI_HEAD", "1") != "0"     # the heads' loss finalisation / d(loss)/d(logits) as one launch each
