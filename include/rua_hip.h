@@ -204,8 +204,8 @@ int64_t rua_wgrad_workspace_bytes(const rua_wgrad_desc* d);
 int rua_wgrad_kind(const rua_wgrad_desc* d);   /* 0: generic tiled kernel, 1: all-taps kernel + deterministic partial reduce,
                                                   2: wgrad_dmap (wide levels), 3: wgrad_pw (narrow 1x1) */
 int rua_wgrad_img_kind(const rua_wgrad_desc* d);   /* within kind 0: the whole-image kernels of the 8 x 8 / 16 x 16 levels (3x3, dilation 1, bf16, channels % 64 == 0 - % 32 for wgrad_imgs -,
-                                                      N H W % 512 == 0): 1 wgrad_img (64 x 64 tiles of dW, 512-pixel chunks as K slices), 2 wgrad_imgs (16 x 16 maps with
-                                                      more than 512 pixels: 32 x 32 tiles, the chunks streamed by one block, no K slices), 0 the generic tiles */
+                                                      N H W % 512 == 0): 1 wgrad_img (64 x 64 tiles of dW, 512-pixel chunks as K slices), 2 wgrad_imgs (more than 512 pixels and at
+                                                      least half as many 32 x 32 tiles as CUs: the chunks streamed by one block, no K slices), 0 the generic tiles */
 
 /* Master fp32 weights [taps][Cout][C] -> activation-dtype copies: forward layout (same) and
  * data-gradient layout [taps reversed][C][Cout].  One launch for the whole parameter table. */

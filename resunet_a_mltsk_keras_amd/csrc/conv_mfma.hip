@@ -3486,14 +3486,15 @@ __global__ __launch_bounds__(768) void wgrad_img(const WgK p) {
     }
 }
 
-// wgrad_imgs (round 4): wgrad_img for maps of 16 x 16 with MORE than 512 pixels (8 x 16 x 16 x 512: four chunks) WITHOUT K slices.  wgrad_img's 64 x 64 tiles need the
+// wgrad_imgs<W> (round 4): wgrad_img for MORE than 512 pixels (8 x 16 x 16 x 512: four chunks; the 8 x 8 level at batches above 8) WITHOUT K slices.  wgrad_img's 64 x 64 tiles need the
 // four chunks as four K slices to fill the chip - 37.7 MB of fp32 slabs written per launch and read again by the batched reduction (151 MB per step at this level).  Here a block
 // owns a 32 x 32 tile of dW for all nine taps (256 blocks at 512 x 512) and STREAMS the chunks through a two-stage LDS ring (512 pixels x 32 channels x 2 operands per stage:
 // 64-byte pixel rows, the four pixel rows of a transposing read are one contiguous 256 bytes - no swizzle): chunk c + 1 lands while chunk c multiplies.  12 waves = 3 kernel
 // rows x 4 k-quarters of a chunk (8 k-steps each, 3 MFMAs per k-step, fragment reads pipelined as in wgrad_img); the quarters meet once, at the end, through LDS; dW is written
 // once (stored under the first-writer flag, added otherwise): no slabs, no reduction.
+template <int W>
 __global__ __launch_bounds__(768) void wgrad_imgs(const WgK p) {
-  constexpr int W = 16, PC = 512, PXB = 64, SLACK = 18 * PXB, TILE = PC * PXB, STAGE = 2 * SLACK + 2 * TILE;
+  constexpr int PC = 512, PXB = 64, SLACK = 18 * PXB, TILE = PC * PXB, STAGE = 2 * SLACK + 2 * TILE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3534,8 +3535,10 @@ __global__ __launch_bounds__(768) void wgrad_imgs(const WgK p) {
   unsigned xo[3];
 #pragma unroll
   for (int tx = 0; tx < 3; ++tx) xo[tx] = (unsigned)(SLACK + (kq * 128 + hrow + (ty - 1) * W + (tx - 1)) * PXB + chb);
-  const unsigned m_l = kh == 0 ? 0xffff0000u : 0xffffffffu;        // tap column 0 reads pixel w - 1: off at w = 0 (element 0 of the first read of the row's first half)
-  const unsigned m_r = kh == 1 ? 0x0000ffffu : 0xffffffffu;        // tap column 2 reads pixel w + 1: off at w = 15 (element 3 of the second read of the row's second half)
+  // tap column 0 reads pixel w - 1: off at w = 0 (element 0 of the first read where the lane's eight pixels start a row); tap column 2 reads w + 1: off at w = W - 1 (element 3 of the
+  // second read where they end one) - W = 16: the first / second half of the k-step, W = 8: both (a k-step is two rows)
+  const unsigned m_l = (W == 8 || kh == 0) ? 0xffff0000u : 0xffffffffu;
+  const unsigned m_r = (W == 8 || kh == 1) ? 0x0000ffffu : 0xffffffffu;
 
   f32x16 acc[3];
 #pragma unroll
@@ -3560,8 +3563,8 @@ __global__ __launch_bounds__(768) void wgrad_imgs(const WgK p) {
   };
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-  auto mfma3 = [&](const Frags& f, int k) {             // k-step 8 kq + k of the chunk = image row (8 kq + k) & 15 (two images per chunk)
-    const int h = (8 * kq + k) & 15;
+  auto mfma3 = [&](const Frags& f, int k) {             // k-step 8 kq + k of the chunk = image row (8 kq + k) & 15 (W = 16: two images per chunk), rows 2 (8 kq + k) + {0, 1} (W = 8)
+    const int h = (W == 8) ? ((2 * (8 * kq + k) + kh) & 7) : ((8 * kq + k) & 15);
     const bool rows_ok = !((ty == 0 && h == 0) || (ty == 2 && h == W - 1));
     const unsigned rm = rows_ok ? 0xffffffffu : 0u;
     const s16x8 fd = {f.d0[0], f.d0[1], f.d0[2], f.d0[3], f.d1[0], f.d1[1], f.d1[2], f.d1[3]};
@@ -4223,12 +4226,12 @@ extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
 }
 
 // the whole-image kernels of the deepest levels (kind 0 of rua_wgrad_kind): 0 none (generic tiles), 1 wgrad_img (64 x 64 tiles, 512-pixel chunks as K slices through slabs),
-// 2 wgrad_imgs (16 x 16 maps, 32 x 32 tiles, chunks streamed - when those tiles fill at least half the chip)
+// 2 wgrad_imgs (more than 512 pixels: 32 x 32 tiles, chunks streamed - when those tiles fill at least half the chip)
 static int wgrad_img_pick(const rua_wgrad_desc* d) {
   const long long M = (long long)d->N * d->H * d->W;
   if (!((g_tune.wgrad_rows & 8) && d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->dil == 1 && d->Hs == d->H && d->Ws == d->W && d->H == d->W &&
         (d->W == 8 || d->W == 16) && d->C % 32 == 0 && d->Cout % 32 == 0 && M % 512 == 0 && !d->in_scale)) return 0;
-  if ((g_tune.wgrad_rows & 16) && d->W == 16 && M >= 1024 && (long long)(d->C / 32) * (d->Cout / 32) >= rua_cu_count() / 2) return 2;
+  if ((g_tune.wgrad_rows & 16) && M >= 1024 && (long long)(d->C / 32) * (d->Cout / 32) >= rua_cu_count() / 2) return 2;
   if (d->C % 64 || d->Cout % 64) return 0;
   if (M == 512 || (g_tune.wgrad_slabs && slab_capacity(d, (long long)9 * d->Cout * d->C) >= (int)(M / 512))) return 1;
   return 0;
@@ -4271,8 +4274,13 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
       constexpr int smems_ = 4 * 9 * 16 * 64 * 4;             // the ring (2 x 67 840 B) and, after it, the four k-quarters' accumulators (147 456 B)
       static RuaPerDevFlag attrs_;
       bool& attrs = attrs_.get();
-      if (!attrs) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_imgs), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrs = true; }
-      hipLaunchKernelGGL(wgrad_imgs, dim3((unsigned)(k.nti * k.ntc)), dim3(768), smems_, st_, k);
+      if (!attrs) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_imgs<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_imgs<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attrs = true;
+      }
+      if (d->W == 8) hipLaunchKernelGGL(wgrad_imgs<8>, dim3((unsigned)(k.nti * k.ntc)), dim3(768), smems_, st_, k);
+      else hipLaunchKernelGGL(wgrad_imgs<16>, dim3((unsigned)(k.nti * k.ntc)), dim3(768), smems_, st_, k);
       RUA_LAUNCH_CHECK("wgrad_imgs");
       return RUA_OK;
     }

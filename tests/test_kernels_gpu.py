@@ -333,7 +333,7 @@ def test_wgrad_all_taps_kernel(case):
 
 
 @pytest.mark.parametrize("case", [(8, 8, 1024, 1024), (8, 16, 512, 512), (2, 16, 128, 64), (16, 8, 64, 128), (8, 8, 64, 64), (24, 8, 128, 128), (4, 16, 64, 192),
-                                  (4, 16, 512, 256), (6, 16, 256, 512), (10, 16, 384, 352)])      # 16 x 16, > 512 pixels, >= 128 tiles of 32 x 32: wgrad_imgs (streamed chunks, no K slices)
+                                  (4, 16, 512, 256), (6, 16, 256, 512), (10, 16, 384, 352), (16, 8, 512, 256), (24, 8, 256, 544)])      # 16 x 16, > 512 pixels, >= 128 tiles of 32 x 32: wgrad_imgs (streamed chunks, no K slices)
 def test_wgrad_whole_image_kernel(case):
     """The deepest levels' 3x3 weight gradient (8 x 8 and 16 x 16 maps, dilation 1, bf16: wgrad_img): whole images resident in LDS, all nine taps per block,
     512-pixel chunks as K slices through slabs - or, at 16 x 16 with enough 32 x 32 tiles to fill the chip, streamed through an LDS ring by one block (wgrad_imgs);
@@ -355,7 +355,7 @@ def test_wgrad_whole_image_kernel(case):
     d.dw, d.workspace, d.workspace_bytes = dw.data_ptr(), ws.data_ptr(), ws.numel() * 4
     d.overwrite_dev = flag.data_ptr()
     assert L.lib().raw("rua_wgrad_kind")(C.byref(d)) == 0
-    streamed = H == 16 and N * H * H > 512 and (Cs // 32) * (Cout // 32) >= 128
+    streamed = N * H * H > 512 and (Cs // 32) * (Cout // 32) >= 128
     assert L.lib().raw("rua_wgrad_img_kind")(C.byref(d)) == (2 if streamed else 1)
     w = torch.zeros((9, Cout, Cs), dtype=torch.float64, requires_grad=True)
     y = ref_conv_nhwc(rnd(dt, a).double(), w, None, 1, 9, 1)
