@@ -1339,8 +1339,9 @@ def test_conv_strip_folded_batchnorm_coefficients(N, H, W, dil, R):
     assert lib.raw("rua_conv_fwd")(C.byref(d), None) != 0
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 56, 16), (2, 32, 64, 32)])      # the second: every extent a power of two (rua_maxpool_bwd_multi's shift-and-mask form)
 @pytest.mark.parametrize("dt", [L.RUA_BF16, L.RUA_F32])
-def test_pooling_pyramid_passes_equal_the_separate_launches(dt):
+def test_pooling_pyramid_passes_equal_the_separate_launches(dt, shape):
     """PSPPooling's 2 / 4 / 8 pyramid (model2.py:47-60): rua_maxpool_derive gives the values AND the argmax bytes of a direct
     rua_maxpool_fwd with twice the window from the level below (many ties: the input is quantised, the first maximum in row-major
     order must win),
@@ -1348,7 +1349,7 @@ def test_pooling_pyramid_passes_equal_the_separate_launches(dt):
     window sums."""
     rng = np.random.default_rng(21)
     lib = L.lib()
-    N, H, W, Cc = 2, 40, 56, 16
+    N, H, W, Cc = shape
     x = np.round(rng.standard_normal((N, H, W, Cc)) * 2).astype(np.float32) / 2          # ties
     xd = to_dev(x, dt)
     ys, ids, gs = {}, {}, {}
