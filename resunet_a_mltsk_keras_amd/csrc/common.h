@@ -84,6 +84,7 @@ struct RuaTuning {
   int head_fwd3 = 1;                    // bf16 heads with Cin = 32: the MFMA form, a lane per pixel (0: head_fwd2)
   int head_fwd3_bpc = 0;                // its blocks per CU over the batch (0: 2)
   int head_fwd2 = 1;                    // heads with Cin = 32: the register-weights kernel (0: the LDS-weights one)
+  int conv_img = 0;                     // 1: conv_img - the 3x3 convolutions of the 8 x 8 / 16 x 16 levels with a whole image resident in LDS instead of conv_dmap + split K (measured level: 28 - 29 us either way)
   int conv_small = 4096;                // conv_small serves 1x1 convolutions of at most this many output pixels (0: off)
   int bn_bwd_group = 1;                 // rua_bn_bwd_group: the one-branch BatchNorm backwards of a ResBlock in one grid
   int dmap_spread = 1;                  // conv_dmap: 0 the DMA instructions of a stage in one burst behind its barrier, 1 spread between the MFMAs (conv_dmap_s), 2 issued by waves of their own (conv_dmap_w; | 4: the 64-row tiles too).

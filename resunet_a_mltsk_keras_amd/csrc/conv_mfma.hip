@@ -1776,6 +1776,165 @@ static int launch_conv_halo(const ConvK& k, int dil, hipStream_t st) {
   return RUA_OK;
 }
 
+// =========================================================================================
+// conv_img<W, KS> (round 4): the 3x3 convolutions (and data gradients) of the two deepest levels - 8 x 8 x 1024 and 16 x 16 x 512 maps, dilation 1 (model2.py:109-112
+// and the decoder's mirror).  On conv_dmap they are 128 x 128 tiles with 8 / 4 K slices: every block gathers its input pixels nine times (once per tap) through LDS-DMA,
+// the weights are re-read by every pixel tile, the K slices leave 16.8 MB of fp32 slabs that a finisher launch reads again - 21 + 7 us for 9.66 GFLOP.  Here a block owns ONE
+// WHOLE IMAGE x 32 output channels: the image's input (64 pixels x 1024 channels, or 256 pixels x 256 channels = half the channels: KS = 2) is RESIDENT in LDS (128 KB, once,
+// by LDS-DMA; 16-byte chunks XOR-swizzled with the pixel index for the 2-KiB / 512-B pixel rows), a tap is a shifted read of it (border lanes read a zero slot), and the
+// weights - the only stream - go from L2 straight into registers (a B fragment is 16 bytes per lane of w[tap][co][ci .. ci + 8): no LDS staging, four k-steps prefetched).
+// MEASURED AND NOT THE DEFAULT (tuning key conv_img): 28 - 29 us per convolution at both levels, what conv_dmap_s + its finisher take - 45 us with four fragments in flight per
+// wave, no better with 24 than with 16: only 32 (64) distinct weight streams exist chip-wide (an output-channel tile's eight images read the same bytes in lockstep), so HBM sees
+// a few MB in flight where the K-sliced tiling has every CU stream a slice of its own, and a fragment gathered as 32 x 32-byte row pieces costs the texture path 32 line look-ups.
+// Four waves split the K range (nine taps x the block's channels) in quarters and meet once through LDS.  KS = 1: the tile leaves through the shared epilogue (bias, residual /
+// mask, statistics) - no K slices, no slabs, no finisher; KS = 2: two slabs, the usual finisher.  Blocks that share weights (the eight images of an output-channel tile) sit
+// on one XCD.
+template <int W, int KS, int D>
+__global__ __launch_bounds__(256) void conv_img(const ConvK p) {
+  typedef bf16_t T;
+  constexpr int HW = W * W, NT = HW / 32, CSTR = 36;
+  constexpr int WSH = (W == 8) ? 3 : 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sZ = smem;                             // 1 KiB of zeros (what a tap reads across an image border)
+  unsigned char* sX = smem + 1024;                      // [HW pixels][CS channels] bf16, chunk-swizzled
+  const SegK& sg = p.seg[0];
+  const int C = sg.C, CS = C / KS, CS2 = CS * 2;
+  const int csh = 31 - __builtin_clz((unsigned)CS2);    // CS * 2 is a power of two (host)
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int nimg = (int)(p.M / HW);
+  const int img = vid % nimg, rr = vid / nimg;
+  const int ks_i = rr % KS, ct = rr / KS;
+  const long long m0 = (long long)img * HW;
+  const int n0 = ct * 32, ci0 = ks_i * CS;
+
+  if (tid < 64) reinterpret_cast<uint4*>(sZ)[tid] = make_uint4(0, 0, 0, 0);
+  {
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(sg.x, sg.xbytes);
+    const int npieces = (HW * CS2) >> 10;
+    for (int q = wv; q < npieces; q += 4) {
+      const unsigned o = (unsigned)(q * 1024 + lane * 16);
+      const unsigned P = o >> csh, sl = (o & (unsigned)(CS2 - 1)) >> 4;
+      const unsigned src = ((unsigned)m0 + P) * (unsigned)(C * 2) + (unsigned)(ci0 * 2) + ((sl ^ (P & 7u)) << 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_p)(sX + q * 1024), 16, src, 0, 0, 0);
+    }
+  }
+  // this wave's quarter of the K range: k-step = (tap, 16 channels), taps outermost
+  const int kpt = CS >> 4, kpsh = 31 - __builtin_clz((unsigned)kpt);
+  const int nk = (9 * kpt) >> 2, ks0 = wv * nk;
+  const unsigned char* wb = sg.w + ((size_t)(n0 + lr) * C + ci0 + 8 * lh) * 2;        // + (tap * Cout * C + cik * 16) * 2
+  const size_t wtap = (size_t)p.Cout * C * 2;
+  auto bsrc = [&](int ks) { const int tap = ks >> kpsh, cik = ks & (kpt - 1); return wb + (size_t)tap * wtap + (size_t)cik * 32; };
+  int ph[NT], pw[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { const int px = t * 32 + lr; ph[t] = px >> WSH; pw[t] = px & (W - 1); }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  // D weight fragments in flight per wave (4 D KiB per CU): a block streams 590 KB (8 x 8 x 1024) or 147 KB of weights and nothing else - at 16 KiB in flight the
+  // 8 x 8 level ran 45 us (8 GB/s and CU)
+  uint4 bq[D];
+#pragma unroll
+  for (int u = 0; u < D; ++u) bq[u] = *reinterpret_cast<const uint4*>(bsrc(ks0 + u));
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D) : "memory");                 // the image's DMAs (issued first) have landed; the weight fragments stay in flight
+  __syncthreads();
+  for (int kk = 0; kk < nk; kk += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int ks = ks0 + kk + u;
+      const int tap = ks >> kpsh, cik = ks & (kpt - 1);
+      const int t3 = (tap >= 6) ? 2 : (tap >= 3) ? 1 : 0;
+      const int dh = t3 - 1, dw = tap - 3 * t3 - 1;
+      const uint4 bcur = bq[u];
+      { const int kn = ks + D < ks0 + nk ? ks + D : ks0 + nk - 1; bq[u] = *reinterpret_cast<const uint4*>(bsrc(kn)); }      // unconditional (clamped): the compiler counts the loads in flight exactly, no branch
+      const bf16x8 fb = __builtin_bit_cast(bf16x8, bcur);
+      const int c16 = 2 * cik + lh;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int hh = ph[t] + dh, ww = pw[t] + dw;
+        const bool ok = (unsigned)hh < (unsigned)W && (unsigned)ww < (unsigned)W;
+        const int pp = (hh << WSH) + ww;
+        const unsigned char* a = ok ? sX + (pp << csh) + ((c16 ^ (pp & 7)) << 4) : sZ;
+        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(a);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // ---- the four K quarters meet: [quarter][pixel][32 co] fp32 in LDS (the image is dead), summed in place into quarter 0 ----------------
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[((size_t)wv * HW + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh) * CSTR + lr] = acc[t][i];
+  __syncthreads();
+  for (int e = tid; e < HW * 8; e += 256) {             // float4 columns: 8 per pixel
+    const int px = e >> 3, c4 = (e & 7) * 4;
+    float* d0 = red + (size_t)px * CSTR + c4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(d0);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) v += *reinterpret_cast<const f32x4*>(d0 + (size_t)q * HW * CSTR);
+    if constexpr (KS > 1) *reinterpret_cast<f32x4*>(p.ws + ((size_t)ks_i * p.M + m0 + px) * p.Cout + n0 + c4) = v;      // the slice's slab: conv_splitk_finish sums them
+    else *reinterpret_cast<f32x4*>(d0) = v;
+  }
+  if constexpr (KS == 1) {
+    __syncthreads();
+    conv_epilogue_pick<T, HW, 32>(p, m0, n0, img, red, CSTR, red + 4 * HW * CSTR);
+  }
+}
+template <int W, int KS> static constexpr int conv_img_smem() {
+  constexpr int HW = W * W;
+  constexpr int tile = 1024 + 131072, redb = 4 * HW * 36 * 4;
+  return (tile > redb ? tile : redb) + 4 * 4 * 16 * 4;
+}
+// eligibility + K slices (0: not this kernel)
+static int pick_img(const rua_conv_desc* d) {
+  if (!g_tune.conv_img || g_conv_group || d->dtype != RUA_BF16 || d->nseg != 1 || d->in_scale || d->in_fold) return 0;
+  const rua_conv_seg& g = d->seg[0];
+  if (g.taps != 9 || g.dil != 1 || d->stride != 1 || g.up_shift != 0 || g.Hs != d->H || g.Ws != d->W || d->H != d->W || (d->W != 8 && d->W != 16)) return 0;
+  const int HW = d->H * d->W;
+  if (g.C % 64 || d->Cout % 32) return 0;
+  const int KS = ((long long)HW * g.C * 2 <= 131072) ? 1 : 2;
+  const int CS = g.C / KS;
+  if ((long long)HW * CS * 2 > 131072 || CS % 256 || (CS & (CS - 1))) return 0;      // 9 CS / 16 k-steps in four quarters of whole groups of four
+  const long long M = (long long)d->N * HW;
+  if (M * d->Cout * 4 >= (1ll << 31)) return 0;
+  if ((long long)d->N * (d->Cout / 32) * KS < rua_cu_count() / 2) return 0;
+  if (KS > 1) {
+    const size_t ws_usable = d->workspace_bytes > 4096 ? (size_t)d->workspace_bytes - 4096 : 0;
+    if (!d->workspace || ws_usable / ((size_t)M * d->Cout * sizeof(float)) < (size_t)KS) return 0;
+  }
+  return KS;
+}
+static int launch_conv_img(ConvK& k, const rua_conv_desc* d, int KS, hipStream_t st) {
+  k.nbn = d->Cout / 32; k.nbm = d->N; k.ksplit = KS; k.stages_per_split = 0; k.ws = KS > 1 ? (float*)d->workspace : nullptr; k.cnt = nullptr;
+  const unsigned grid = (unsigned)(d->N * (d->Cout / 32) * KS);
+  static RuaPerDevFlag attr_;
+  bool& attr = attr_.get();
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_img<8, 1, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_img_smem<8, 1>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_img<8, 1, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_img_smem<8, 1>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_img<16, 1, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_img_smem<16, 1>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_img<16, 2, 18>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_img_smem<16, 2>());
+    attr = true;
+  }
+  constexpr int s81 = conv_img_smem<8, 1>(), s161 = conv_img_smem<16, 1>(), s162 = conv_img_smem<16, 2>();
+  const int nk = 9 * (d->seg[0].C / KS / 16) / 4;        // k-steps per wave: 144 (CS = 1024), 72, 36 (CS = 256) - a multiple of the prefetch depth
+  if (d->W == 8 && KS == 1 && nk % 24 == 0) hipLaunchKernelGGL((conv_img<8, 1, 24>), dim3(grid), dim3(256), s81, st, k);
+  else if (d->W == 8 && KS == 1) hipLaunchKernelGGL((conv_img<8, 1, 12>), dim3(grid), dim3(256), s81, st, k);
+  else if (d->W == 16 && KS == 1) hipLaunchKernelGGL((conv_img<16, 1, 12>), dim3(grid), dim3(256), s161, st, k);
+  else if (d->W == 16 && KS == 2) hipLaunchKernelGGL((conv_img<16, 2, 18>), dim3(grid), dim3(256), s162, st, k);
+  else { rua_set_error("conv_img: no instantiation for W=%d KS=%d", d->W, KS); return RUA_ERR_ARG; }
+  RUA_LAUNCH_CHECK("conv_img");
+  if (KS > 1) { launch_splitk_finish<bf16_t>(k, st); RUA_LAUNCH_CHECK("conv_splitk_finish"); }
+  return RUA_OK;
+}
+
 // conv_dmap eligibility: bf16, wide outputs, every segment a whole number of 64-channel stages
 static bool pick_dmap(const rua_conv_desc* d) {
   const int mode = g_tune.conv_dmap;      // 0: off (experiments)
@@ -1990,6 +2149,10 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   if (pick_small(d)) {
     g_last_ksplit = 1;
     return launch_conv_small(k, st);
+  }
+  if (const int img_ks = pick_img(d)) {
+    g_last_ksplit = img_ks;
+    return launch_conv_img(k, d, img_ks, st);
   }
   if (pick_dmap(d)) {
     // 128 x 128 tiles; split K until the grid covers the chip once (every level of the reference network then runs
@@ -4658,6 +4821,7 @@ extern "C" int rua_conv_kernel_id(const rua_conv_desc* d) {
   if (pick_halo(d)) return 3;
   if (pick_pw(d)) return 4;
   if (pick_small(d)) return 6;
+  if (pick_img(d)) return 7;
   if (pick_dmap(d)) return 2;
   return pick_dma(d, pick_bn(d, (long long)d->N * d->H * d->W)) ? 1 : 0;
 }

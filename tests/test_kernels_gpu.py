@@ -910,6 +910,73 @@ def test_conv_halo_lattice_tiles(H, W, dil, Cs, mode):
     assert rel_err(st[Cout:], s2) < 5 * tol(dt) + 1e-4
 
 
+@pytest.mark.parametrize("mode", ["residual_stats", "mask_acc_stats2", "plain"])
+@pytest.mark.parametrize("case", [(8, 8, 1024, 1024), (8, 16, 512, 512), (8, 16, 256, 512), (16, 8, 512, 256), (8, 16, 512, 256)])
+def test_conv_whole_image_kernel(case, mode):
+    """conv_img (opt-in, tuning key conv_img): the 3x3 convolutions of the 8 x 8 / 16 x 16 levels with a whole image resident in LDS (one image x 32 output channels per block, weights streamed from
+    L2 into registers; 16 x 16 x 512 and wider: two channel halves as K slices + the finisher).  Both epilogue families and the plain form, against PyTorch."""
+    N, H, Cs, Cout = case
+    dt = L.RUA_BF16
+    rng = np.random.default_rng(N + Cs)
+    lib = L.lib()
+    x = rng.standard_normal((N, H, H, Cs)).astype(np.float32)
+    w = (rng.standard_normal((9, Cout, Cs)) / np.sqrt(9 * Cs)).astype(np.float32)
+    aux = rng.standard_normal((N, H, H, Cout)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    y0 = rng.standard_normal((N, H, H, Cout)).astype(np.float32)
+    sc = (0.5 + rng.random(Cout)).astype(np.float32); sh = (0.3 * rng.standard_normal(Cout)).astype(np.float32)
+    xd, wd, ad, bd = to_dev(x, dt), to_dev(w, dt), to_dev(aux, dt), torch.from_numpy(bias).to(dev())
+    scd, shd = torch.from_numpy(sc).to(dev()), torch.from_numpy(sh).to(dev())
+    y = to_dev(y0, dt)
+    R = 4
+    stats = torch.zeros(R * 2 * Cout, dtype=torch.float64, device=dev())
+    ws = torch.zeros((2 * N * H * H * Cout * 4 + 8192) // 4, dtype=torch.float32, device=dev())
+    d = L.ConvDesc()
+    d.nseg = 1
+    s = d.seg[0]
+    s.x, s.w, s.C, s.Hs, s.Ws, s.up_shift, s.dil, s.taps = xd.data_ptr(), wd.data_ptr(), Cs, H, H, 0, 1, 9
+    d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, H, Cout, 1, dt
+    d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, H
+    d.stats, d.stats_replicas = stats.data_ptr(), R
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    conv = ref_conv_nhwc(rnd(dt, x), rnd(dt, w), None, 1, 9).numpy()
+    a = rnd(dt, aux).double().numpy()
+    s2 = None
+    if mode == "residual_stats":
+        d.bias, d.aux, d.aux_mode, d.stats_mode = bd.data_ptr(), ad.data_ptr(), 1, 1
+        exp = conv + bias.astype(np.float64) + a
+        s2 = (exp ** 2).sum(axis=(0, 1, 2))
+    elif mode == "mask_acc_stats2":
+        d.aux, d.aux_mode, d.mscale, d.mshift, d.accumulate, d.stats_mode = ad.data_ptr(), 2, scd.data_ptr(), shd.data_ptr(), 1, 2
+        exp = (conv + rnd(dt, y0).double().numpy()) * ((a * sc + sh) > 0)
+        s2 = (exp * a).sum(axis=(0, 1, 2))
+    else:
+        d.stats, d.stats_mode = None, 0
+        exp = conv
+    assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 2     # not the default: level with conv_dmap + split K in the step (tuning key conv_img)
+    lib.set_tuning(conv_img=1)
+    try:
+        assert lib.raw("rua_conv_kernel_id")(C.byref(d)) == 7
+        lib.call("rua_conv_fwd", C.byref(d), stream())
+        torch.cuda.synchronize()
+        assert lib.raw("rua_conv_last_ksplit")() == (1 if H * H * Cs * 2 <= 131072 else 2)
+    finally:
+        lib.set_tuning(conv_img=0)
+    got = y.float().cpu().numpy()
+    assert rel_err(got, exp) < tol(dt)
+    if s2 is not None:
+        st = stats.cpu().numpy().reshape(R, 2 * Cout).sum(0)
+        assert rel_err(st[:Cout], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4
+        assert rel_err(st[Cout:], s2) < 5 * tol(dt) + 1e-4
+    y2 = to_dev(y0, dt)                                          # the same call through conv_dmap + split K: the two paths agree to storage rounding
+    d.y = y2.data_ptr()
+    if d.stats_mode:
+        stats.zero_()
+    lib.call("rua_conv_fwd", C.byref(d), stream())
+    torch.cuda.synchronize()
+    assert rel_err(y2.float().cpu().numpy(), got) < tol(dt)
+
+
 STRIP_CASES = [
     # N, H, W, dil  (C = Cout = 32; W % 256 == 0: 8-wave blocks; W % 128 == 0: 4-wave blocks; ragged H: residue classes of unequal size)
     (1, 256, 256, 1), (1, 256, 256, 3), (1, 256, 256, 15), (1, 256, 256, 31), (4, 128, 128, 3), (4, 128, 128, 31),
