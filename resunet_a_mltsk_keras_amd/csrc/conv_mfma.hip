@@ -1786,6 +1786,9 @@ static int launch_conv_halo(const ConvK& k, int dil, hipStream_t st) {
 // MEASURED AND NOT THE DEFAULT (tuning key conv_img): 28 - 29 us per convolution at both levels, what conv_dmap_s + its finisher take - 45 us with four fragments in flight per
 // wave, no better with 24 than with 16: only 32 (64) distinct weight streams exist chip-wide (an output-channel tile's eight images read the same bytes in lockstep), so HBM sees
 // a few MB in flight where the K-sliced tiling has every CU stream a slice of its own, and a fragment gathered as 32 x 32-byte row pieces costs the texture path 32 line look-ups.
+// Ablations at 8 x 8 x 1024 (tools/bench_conv_levels.py, -DRUA_IMG_DBG_NOB / NOA; event pair included): 32.6 us; without the weight loads 22.6; without the fragment reads of the
+// image no faster - the K loop of ONE wave per SIMD (two dependent accumulators, ~100 cycles per k-step), the cold 128 KB image and the epilogue are ~17 us before any weight
+// arrives, the gathered weight fragments add ~10.  Starting each image's K quarter at another point (rot below) changed nothing: not a matter of distinct HBM streams.
 // Four waves split the K range (nine taps x the block's channels) in quarters and meet once through LDS.  KS = 1: the tile leaves through the shared epilogue (bias, residual /
 // mask, statistics) - no K slices, no slabs, no finisher; KS = 2: two slabs, the usual finisher.  Blocks that share weights (the eight images of an output-channel tile) sit
 // on one XCD.
@@ -1838,20 +1841,30 @@ __global__ __launch_bounds__(256) void conv_img(const ConvK p) {
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   // D weight fragments in flight per wave (4 D KiB per CU): a block streams 590 KB (8 x 8 x 1024) or 147 KB of weights and nothing else - at 16 KiB in flight the
   // 8 x 8 level ran 45 us (8 GB/s and CU)
+  // the images of an output-channel tile read the SAME weights: each starts its K quarter at another point (rot), so that at any moment the eight blocks have different lines
+  // in flight - eight times the distinct HBM requests, and whoever comes second finds the line in L2
+  const int rot = (int)(((long long)(img & 7) * nk) >> 3);
+  auto kmap = [&](int j) { int r = j + rot; if (r >= nk) r -= nk; return ks0 + r; };
   uint4 bq[D];
 #pragma unroll
-  for (int u = 0; u < D; ++u) bq[u] = *reinterpret_cast<const uint4*>(bsrc(ks0 + u));
+  for (int u = 0; u < D; ++u) bq[u] = *reinterpret_cast<const uint4*>(bsrc(kmap(u)));
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D) : "memory");                 // the image's DMAs (issued first) have landed; the weight fragments stay in flight
   __syncthreads();
   for (int kk = 0; kk < nk; kk += D) {
 #pragma unroll
     for (int u = 0; u < D; ++u) {
-      const int ks = ks0 + kk + u;
+      const int ks = kmap(kk + u);
       const int tap = ks >> kpsh, cik = ks & (kpt - 1);
       const int t3 = (tap >= 6) ? 2 : (tap >= 3) ? 1 : 0;
       const int dh = t3 - 1, dw = tap - 3 * t3 - 1;
+#ifdef RUA_IMG_DBG_NOB                                 // (timing experiments - results are garbage: no weight loads in the loop)
+      const uint4 bcur = make_uint4(ks, tap, cik, 1);
+#else
       const uint4 bcur = bq[u];
-      { const int kn = ks + D < ks0 + nk ? ks + D : ks0 + nk - 1; bq[u] = *reinterpret_cast<const uint4*>(bsrc(kn)); }      // unconditional (clamped): the compiler counts the loads in flight exactly, no branch
+#endif
+#ifndef RUA_IMG_DBG_NOB
+      { const int jn = kk + u + D < nk ? kk + u + D : nk - 1; bq[u] = *reinterpret_cast<const uint4*>(bsrc(kmap(jn))); }
+#endif      // unconditional (clamped): the compiler counts the loads in flight exactly, no branch
       const bf16x8 fb = __builtin_bit_cast(bf16x8, bcur);
       const int c16 = 2 * cik + lh;
 #pragma unroll
@@ -1860,7 +1873,11 @@ __global__ __launch_bounds__(256) void conv_img(const ConvK p) {
         const bool ok = (unsigned)hh < (unsigned)W && (unsigned)ww < (unsigned)W;
         const int pp = (hh << WSH) + ww;
         const unsigned char* a = ok ? sX + (pp << csh) + ((c16 ^ (pp & 7)) << 4) : sZ;
+#ifdef RUA_IMG_DBG_NOA                                 // (no fragment reads from the resident image)
+        const bf16x8 fa = __builtin_bit_cast(bf16x8, make_uint4((unsigned)(size_t)a, ok, pp, 3));
+#else
         const bf16x8 fa = *reinterpret_cast<const bf16x8*>(a);
+#endif
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
       }
     }
