@@ -1784,8 +1784,7 @@ static int launch_conv_halo(const ConvK& k, int dil, hipStream_t st) {
 // by LDS-DMA; 16-byte chunks XOR-swizzled with the pixel index for the 2-KiB / 512-B pixel rows), a tap is a shifted read of it (border lanes read a zero slot), and the
 // weights - the only stream - go from L2 straight into registers (a B fragment is 16 bytes per lane of w[tap][co][ci .. ci + 8): no LDS staging, four k-steps prefetched).
 // MEASURED AND NOT THE DEFAULT (tuning key conv_img): 28 - 29 us per convolution at both levels, what conv_dmap_s + its finisher take - 45 us with four fragments in flight per
-// wave, no better with 24 than with 16: only 32 (64) distinct weight streams exist chip-wide (an output-channel tile's eight images read the same bytes in lockstep), so HBM sees
-// a few MB in flight where the K-sliced tiling has every CU stream a slice of its own, and a fragment gathered as 32 x 32-byte row pieces costs the texture path 32 line look-ups.
+// wave, no better with 24 than with 16; a fragment gathered as 32 x 32-byte row pieces costs the texture path 32 line look-ups per KiB (the ablations below).
 // Ablations at 8 x 8 x 1024 (tools/bench_conv_levels.py, -DRUA_IMG_DBG_NOB / NOA; event pair included): 32.6 us; without the weight loads 22.6; without the fragment reads of the
 // image no faster - the K loop of ONE wave per SIMD (two dependent accumulators, ~100 cycles per k-step), the cold 128 KB image and the epilogue are ~17 us before any weight
 // arrives, the gathered weight fragments add ~10.  Starting each image's K quarter at another point (rot below) changed nothing: not a matter of distinct HBM streams.
