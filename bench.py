@@ -201,7 +201,8 @@ def profile_kernels(eng, g, dtype):
         a = mark(); eng._zero_arena(g, s); b = mark(); cal1.append((a, b))
         a = mark(); eng._zero_arena(g, s); eng._zero_arena(g, s); b = mark(); cal2.append((a, b))
     eng._zero_arena(g, s)
-    eng._prep_weights(s)
+    e0 = mark(); eng._prep_weights(s); e1 = mark()            # the per-step weight refresh (data-gradient layout from the optimizer's bf16 copy)
+    other.append(("rua_weight_prep", e0, e1, None))
     empty = []
     for pname, plan in (("fwd", g.fwd), ("loss", g.loss_plan), ("bwd", g.bwd)):
         for ci, (fn, name, args, _lane) in enumerate(plan.calls):
@@ -674,6 +675,22 @@ def main():
                 comp.setdefault(sc, {})[pn + "_us"] = round(1e6 * sec, 1)
         out["roofline"]["other_composites"] = comp
         out["roofline"]["composites_total_us"] = round(1e6 * sum(v[0] for v in blocks.values()), 1)
+        # the same sub-metrics as FLAT scalars (a record that keeps only the scalar keys of `roofline` still carries them)
+        rf = out["roofline"]
+        if top is not None:
+            rf["d6_block_us"], rf["d6_block_frac"] = top["fwd_us"], top["fwd_frac"]
+            rf["d6_block_bwd_us"], rf["d6_block_bwd_frac"] = top.get("bwd_us"), top.get("bwd_frac")
+        fr = [r[k] for r in lv for k in ("fwd_frac", "bwd_frac") if k in r]
+        if fr:
+            rf["worst_resblock_frac"] = min(fr)
+            rf["resblocks_ms"] = round(sum(r.get("fwd_us", 0.0) + r.get("bwd_us", 0.0) for r in lv) / 1e3, 3)
+        for r in lv:                                            # per level: enc3_fwd_us, enc3_bwd_us, ... (levels 3 - 4 are this round's target)
+            tag = r["block"].split(":", 1)[0]
+            rf[tag + "_fwd_us"], rf[tag + "_bwd_us"] = r.get("fwd_us"), r.get("bwd_us")
+        rf["glue_ms"] = round(sum(v for c in comp.values() for v in c.values()) / 1e3, 3)
+        opt_rows = ("rua_adam_step", "rua_sgd_step", "rua_wgrad_reduce_batch", "rua_weight_prep")
+        rf["optimizer_ms"] = round(1e3 * sum(v[1] for k, v in entries.items() if k in opt_rows), 3)
+        rf["dispatches_per_step"] = eng.count_step_dispatches(B)
     if world == 1 and not args.force_dp and rank == 0:
         if not args.no_also and args.workload == "cfg3" and args.dtype == "bf16" and not args.batch:
             # the other BASELINE configurations, short runs on the same GPU right after the headline one

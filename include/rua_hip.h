@@ -421,6 +421,9 @@ int rua_sgd_step_w(float* theta, float* g, float* vel, int64_t n, float lr, cons
  * slices of it, issued by the host as the backward completes them (the Python engine: torch.distributed, dist.py; a C embedder:
  * INTEGRATION.md section 2).  rua_adam_step / rua_sgd_step take grad_scale = 1 / replicas. */
 
+/* kernel nodes / all nodes of a captured hipGraph_t (diagnostics: dispatches per whole-step graph) */
+int rua_graph_kernel_nodes(void* graph, int* kernels, int* total);
+
 /* ---- tuning switches (experiments, A/B runs).  The launchers never read the environment and keep no other global
  * state: a heuristic changes only through this call.  Keys: rua_tuning_key(0..) until NULL.  Grid-size keys
  * ("*_blocks", "*_target", "*_grid") default to 0 = derived from the device's compute-unit count. */

@@ -27,8 +27,8 @@ NSAMPLE = 20000
 # name: (input shape, classes, multitask, loss, batch, data seed, class weights, depth)   - the tests' configurations (tests/test_model_gpu.py)
 CONFIGS = {
     "cfg1": ((256, 256, 3), 6, False, "weighted_cross_entropy", 4, 1234, [1.0] * 6, 6),
-    "cfg2": ((256, 256, 6), 6, False, "tanimoto", 2, 4321, None, 6),
-    "cfg3": ((256, 256, 6), 6, True, "tanimoto", 2, 1234, None, 6),
+    "cfg2": ((256, 256, 6), 6, False, "tanimoto", 8, 4321, None, 6),       # BASELINE's batch 8 (rounds 1 - 4: batch 2)
+    "cfg3": ((256, 256, 6), 6, True, "tanimoto", 8, 1234, None, 6),
     "cfg4": ((512, 512, 6), 6, True, "tanimoto", 4, 777, None, 7),
     "cfg5": ((128, 128, 7), 2, False, "tanimoto", 32, 555, None, 6),
 }

@@ -106,6 +106,7 @@ _SIGS = {
     "rua_prof_event_record": ([vp, vp], i32),
     "rua_prof_event_elapsed_us": ([vp, vp, C.POINTER(f64)], i32),
     "rua_prof_event_destroy": ([vp], None),
+    "rua_graph_kernel_nodes": ([vp, C.POINTER(i32), C.POINTER(i32)], i32),
     "rua_conv_workspace_bytes": ([C.POINTER(ConvDesc)], i64),
     "rua_conv_wgrad": ([C.POINTER(WgradDesc), vp], i32),
     "rua_wgrad_workspace_bytes": ([C.POINTER(WgradDesc)], i64),

@@ -57,6 +57,23 @@ extern "C" int rua_prof_event_elapsed_us(void* start, void* stop, double* us) {
 }
 extern "C" void rua_prof_event_destroy(void* ev) { (void)hipEventDestroy((hipEvent_t)ev); }
 
+// Kernel nodes of a captured HIP graph (bench.py: dispatches per step of the whole-step graph, counted instead of read off a profile).
+extern "C" int rua_graph_kernel_nodes(void* graph, int* kernels, int* total) {
+  size_t n = 0;
+  if (!graph || hipGraphGetNodes((hipGraph_t)graph, nullptr, &n) != hipSuccess) { (void)hipGetLastError(); rua_set_error("rua_graph_kernel_nodes: hipGraphGetNodes failed"); return RUA_ERR_ARG; }
+  hipGraphNode_t* nodes = n ? new hipGraphNode_t[n] : nullptr;
+  int k = 0;
+  if (n && hipGraphGetNodes((hipGraph_t)graph, nodes, &n) == hipSuccess)
+    for (size_t i = 0; i < n; ++i) {
+      hipGraphNodeType t;
+      if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++k;
+    }
+  delete[] nodes;
+  if (kernels) *kernels = k;
+  if (total) *total = (int)n;
+  return RUA_OK;
+}
+
 int rua_device_index() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) { (void)hipGetLastError(); dev = 0; }

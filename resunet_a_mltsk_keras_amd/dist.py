@@ -130,11 +130,16 @@ class DataParallel:
         eng.params_changed()
         # Room for RCCL's kernels: several launchers size their grid at exactly one block per CU; with a bucket's all-reduce in flight
         # its workgroups hold some CUs and the last blocks of such a grid would wait for a second round.  Measured COST on one GPU
-        # (nothing to make room for there): 8 CUs +0.3 %, 16 +1.2 %, 32 +2.0 % of the step; the benefit needs N > 1 to show.
-        self.cu_reserve = int(os.environ.get("RUA_DP_CU_RESERVE", "8")) if (self.world > 1 and eng.P.is_cuda) else 0
+        # (nothing to make room for there): 8 CUs +0.3 %, 16 +1.2 %, 32 +2.0 % of the step; the benefit needs N > 1 to show - so the
+        # default is 0 (the configuration every GPU test runs) until an N > 1 box has measured it; RUA_DP_CU_RESERVE opts in.
+        # The CU count is read at plan time (partial counts recorded in the deferred reductions) AND at launch time: a change drops
+        # every recorded plan and captured graph of the engine, so no plan outlives the count it was recorded with.
+        self.cu_reserve = int(os.environ.get("RUA_DP_CU_RESERVE", "0")) if (self.world > 1 and eng.P.is_cuda) else 0
         if eng.P.is_cuda:
             from . import _lib as L
-            L.lib().set_tuning(cu_reserve=self.cu_reserve)
+            if L.lib().get_tuning("cu_reserve") != self.cu_reserve:
+                L.lib().set_tuning(cu_reserve=self.cu_reserve)
+                eng.drop_plans()
 
     def _bcast(self, t):
         if self.host_staged:

@@ -1706,6 +1706,7 @@ class Engine:
         self.wgrad_overwrite = os.environ.get("RUA_WGRAD_OVERWRITE", "1") != "0"
         self.ow_flag = torch.zeros(4, dtype=torch.int32, device=self.dev)
         self._ow = 0
+        self._g_pending = False                             # G holds gradients no optimizer step has consumed (forward_backward() on its own)
         self.opt_wcopy = dtype == "bf16" and os.environ.get("RUA_OPT_WCOPY", "1") != "0"   # the optimizer writes the forward-layout bf16 copy itself
         self.wf_fresh = False                               # the forward copy holds bf16(P): written by the optimizer (or a full rua_weight_prep) since P last changed
         items = np.zeros(0, dtype=[("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("cout", "<i4"), ("c", "<i4"), ("pad", "<i4")])
@@ -1800,6 +1801,19 @@ class Engine:
         else:
             self.class_w_ptr = None
 
+    def drop_plans(self):
+        """Forget every recorded plan and captured graph (they are rebuilt on the next step): a launch heuristic that is read when a plan
+        is RECORDED - the CU count behind the weight gradients' partial counts - has changed (rua_set_tuning(cu_reserve))."""
+        if self.dev is not None and (self.graphs or self._captured or self._captured_eval or self._captured_dp):
+            torch.cuda.synchronize()
+        self._captured, self._captured_eval, self._captured_dp = {}, {}, {}
+        self._eval_seen = set()
+        self._opt_graph = None
+        self.graphs = {}
+        cu = C.c_int32(0)
+        if self.dev is not None and L.lib().raw("rua_device_info")(C.byref(cu), None, None, 0) == 0 and cu.value > 0:
+            self.cu_count = cu.value
+
     # -- weights ---------------------------------------------------------------------------------------
     def set_weights(self, keras_dict: Dict[str, np.ndarray]):
         P, S = self.params.from_keras(keras_dict)
@@ -1888,7 +1902,11 @@ class Engine:
     def forward_backward(self, x=None, y=None, _whole_step: bool = False):
         """forward + losses + backward on the current stream; gradients are ADDED to self.G (several calls before one optimizer_step accumulate, e.g. the
         replicas of a data-parallel step played one after the other); _whole_step (train_step): the arena is zero and this is the step's only backward."""
-        self._set_overwrite(1 if (_whole_step and self.wgrad_overwrite) else 0)
+        # first-writer overwrite needs a ZERO gradient arena: after a standalone forward_backward() (which accumulates) the arena holds
+        # unapplied gradients, and the next whole step must accumulate on top of them too (mixing the two calls keeps its old meaning)
+        self._set_overwrite(1 if (_whole_step and self.wgrad_overwrite and not self._g_pending) else 0)
+        if not _whole_step:
+            self._g_pending = True
         B = x.shape[0] if x is not None else self._last_B
         self._last_B = B
         g = self.graph(B, True)
@@ -1956,6 +1974,7 @@ class Engine:
         self._set_lr()
         self._launch_optimizer(grad_scale, self._stream())
         self.weights_dirty = True
+        self._g_pending = False                             # the optimizer zeroed the arena as it consumed it
 
     def _graph_step(self, x, y):
         """Single-GPU fast path: the whole step (arena zeroing, weight refresh, forward, losses, backward, optimizer)
@@ -1965,7 +1984,8 @@ class Engine:
         g = self.graph(B, True)
         self._upload(g, x, y)
         self._set_lr()
-        self._set_overwrite(1 if self.wgrad_overwrite else 0)
+        self._set_overwrite(1 if (self.wgrad_overwrite and not self._g_pending) else 0)
+        self._g_pending = False                             # the step's optimizer launch zeroes the arena
         cap = self._captured.get(B)
         if cap is None:
             # warm-up run outside capture (sets kernel attributes, pays first-launch costs), then capture
@@ -1989,6 +2009,29 @@ class Engine:
         cap.replay()
         self.weights_dirty = True
         return g
+
+    def count_step_dispatches(self, batch: int) -> Optional[int]:
+        """Kernel nodes of the whole training step (arena fill, weight refresh, forward, losses, backward, optimizer) captured
+        into a throw-away HIP graph: the number of dispatches a step costs, counted rather than read off a profile.  The step must
+        have run at least once (kernel attributes set); the capture launches nothing."""
+        try:
+            g = self.graph(batch, True)
+            torch.cuda.synchronize()
+            cap = torch.cuda.CUDAGraph(keep_graph=True)
+            dirty, fresh = self.weights_dirty, self.wf_fresh
+            with torch.cuda.graph(cap):
+                s = self._stream()
+                self._zero_arena(g, s); self.weights_dirty = True; self._prep_weights(s)
+                g.fwd.run(s); g.loss_plan.run(s); g.bwd.run(s)
+                self._launch_optimizer(1.0, s)
+            self.weights_dirty, self.wf_fresh = dirty, fresh
+            k = C.c_int32(0)
+            L.lib().call("rua_graph_kernel_nodes", C.c_void_p(cap.raw_cuda_graph()), C.byref(k), None)
+            del cap
+            return int(k.value)
+        except Exception:                                   # diagnostics only
+            torch.cuda.synchronize()
+            return None
 
     def _graph_step_dp(self, x, y):
         """Data-parallel fast path: the step is cut at the launches after which a gradient bucket is complete; every
@@ -2045,7 +2088,8 @@ class Engine:
             self.weights_dirty = True
             return g
         self._set_lr()
-        self._set_overwrite(1 if self.wgrad_overwrite else 0)
+        self._set_overwrite(1 if (self.wgrad_overwrite and not self._g_pending) else 0)
+        self._g_pending = False
         self._ensure_forward_copy()
         red.begin()
         for pi, (cap, buckets) in enumerate(pieces):

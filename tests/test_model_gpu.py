@@ -261,15 +261,21 @@ CFG3 = ("cfg3", (256, 256, 6), 6, True, "tanimoto", 2, 1234)
 def test_cfg3_full_size_fp32_loss_and_logits():
     """BASELINE config 3 at full size (256x256x6, 6 classes, multitask Tanimoto, reference width), batch 2:
     loss and per-head logits within the north-star 1e-3 relative tolerance of the CPU oracle."""
-    o = oracle_step(*CFG3)
+    o = oracle_step(*CFG3)                                   # the one LIVE full-size oracle step of the suite (batch 2, with its backward)
     eng = hip_engine((256, 256, 6), 6, True, "tanimoto", "f32", o["params"])
     compare_full_size(o, eng, True, 1e-3, 1e-3)
     assert eng.count_params() == 42736869
+    del eng
+    torch.cuda.empty_cache()
+    # ... and BASELINE's own batch 8 against the committed fixture (oracle forward at batch 8, re-derived live by the CPU suite)
+    o8 = golden_step("cfg3")
+    assert o8["x"].shape[0] == 8
+    compare_full_size(o8, hip_engine((256, 256, 6), 6, True, "tanimoto", "f32", o8["params"]), True, 1e-3, 1e-3)
 
 
 def test_cfg3_full_size_bf16_bound_and_trajectory():
-    """The BENCHMARKED storage type at the benchmarked size.  (a) bf16 activations / bf16 weight copies
-    (fp32 master weights, statistics, losses) against the oracle on the same batch-2 step as the fp32 test: loss within
+    """The BENCHMARKED storage type at the benchmarked size AND batch.  (a) bf16 activations / bf16 weight copies
+    (fp32 master weights, statistics, losses) against the oracle's batch-8 fixture (tests/golden/fullsize_cfg3.npz): loss within
     2e-3, per-head logits within 5e-2 of their scale (measured: 2.4e-5 and 2.8e-2).  (b) batch 8 (the bench's), ten Adam steps from the same weights,
     bf16 against fp32 storage on the HIP path: the loss trajectories stay within 2e-3 of each other at every step
     (measured: 1.3e-4) and both fall."""
@@ -295,6 +301,7 @@ def test_cfg2_full_size_single_task_fp32_and_bf16():
     logits within 1e-3 of the oracle in fp32 storage, within the bf16 bounds of the cfg3 test in bf16 (the configuration's
     own dtype)."""
     o = golden_step("cfg2")
+    assert o["x"].shape[0] == 8                              # BASELINE's batch
     eng = hip_engine((256, 256, 6), 6, False, "tanimoto", "f32", o["params"])
     compare_full_size(o, eng, False, 1e-3, 1e-3)
     assert eng.count_params() == 42690134
@@ -515,6 +522,39 @@ def test_cfg3_full_size_gradients_fp32_vs_float64_oracle_and_bf16_at_batch8():
         print("   least aligned: %-28s cosine %.4f distance %.3f |g| max %.3g" % (keys[i], cos[i], dist[i], np.abs(gf[keys[i]]).max()))
     assert all(np.isfinite(gb[k]).all() for k in gb)
     assert np.median(dist) < BF16_GRAD_MEDIAN_B8 and dist.max() < BF16_GRAD_MAX_B8 and np.median(cos) > BF16_GRAD_COS_B8 and cos.min() > BF16_GRAD_COSMIN_B8
+
+
+def test_first_writer_overwrite_step_equals_the_accumulating_backward():
+    """The gradient arena's two conventions: forward_backward() on its own ADDS to G; inside a whole step (train_step, the
+    captured graph) the weight-gradient kernels with one producer per tensor STORE over the zeroed arena (rua_wgrad_desc.overwrite_dev: the
+    single-K-slice epilogues, the slab / block-partial reductions, wgrad_img).  Same batch, same weights, both conventions on a zeroed
+    arena: every gradient tensor agrees to fp32 summation noise (the deterministic kernels bit for bit) - at cfg3's full size, where every
+    kernel family takes its full-size dispatch.  And a whole step that FOLLOWS an unapplied forward_backward() accumulates on top of it."""
+    o = golden_step("cfg3")
+    x, y = o["x"][:2], {k: v[:2] for k, v in o["y"].items()}
+    eng = hip_engine((256, 256, 6), 6, True, "tanimoto", "bf16", o["params"])
+    n = eng.params.n
+    eng.forward_backward(x, y)
+    torch.cuda.synchronize()
+    g_acc = eng.G[:n].clone()
+    assert eng._g_pending and eng._ow == 0
+    eng.G.zero_(); eng._g_pending = False
+    eng.forward_backward(x, y, _whole_step=True)
+    torch.cuda.synchronize()
+    assert eng._ow == 1
+    g_ow = eng.G[:n].clone()
+    scale = float(g_acc.abs().max())
+    diff = float((g_ow - g_acc).abs().max())
+    same = float((g_ow == g_acc).float().mean())
+    print("overwrite vs accumulate on a zero arena: max |diff| %.3g of scale %.3g, %.2f %% of the elements bit-identical" % (diff, scale, 100 * same))
+    assert diff <= 1e-5 * scale and same > 0.9
+    # unapplied gradients in the arena: the next whole step must not overwrite them
+    eng._g_pending = True
+    eng.forward_backward(x, y, _whole_step=True)
+    torch.cuda.synchronize()
+    assert eng._ow == 0
+    twice = eng.G[:n]
+    assert float((twice - 2 * g_acc).abs().max()) <= 2e-5 * scale
 
 
 BF16_GRAD_COSMIN_B8 = 0.81                                                      # 1 - cosine within twice the measured 0.094 of the least aligned tensor

@@ -254,11 +254,10 @@ def test_tiny_model_forward_matches_numpy_composition():
     assert np.allclose(nv.softmax(z), out_t, atol=1e-3)
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
 def test_fullsize_goldens_match_the_live_oracle(name):
     """tests/golden/fullsize_<cfg>.npz (what the GPU tests compare the HIP path with at full size) against the oracle run HERE: the same
-    training-mode forward, the same digest.  Two of the five configurations (1 s and 4 s of host time; the others are produced by the
-    same code path, oracle/make_golden_fullsize.py)."""
+    training-mode forward, the same digest - every BASELINE configuration at its own size and batch (cfg2 / cfg3 at batch 8 since round 5)."""
     import os
     from oracle import make_golden_fullsize as mg
     exp, taps = mg.oracle_forward(name)
