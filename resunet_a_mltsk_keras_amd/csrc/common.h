@@ -101,6 +101,8 @@ struct RuaTuning {
   int band_dbg = 0;                     // experiments only (tools/bench_conv_band.py): 1 rows from an L2-resident region, 2 no BatchNorm pass
   int conv_band64m = 1;                 // the independent 3x3 convs of a C = 64 ResBlock (first convs, data gradients) as ONE conv_band64m launch
   int conv_band64 = 1;                  // ... and of a C = 64 ResBlock (conv_band64)
+  long long dbg_ptr = 0;                // diagnostic builds only (-DRUA_B128_STAMPS): device buffer for in-kernel stamps
+  int conv_band128m = 1;                // the independent 3x3 convs of a C = 128 ResBlock on 64-pixel rows (first convs, data gradients) as ONE conv_band128m launch (0: grouped conv_dmap)
   int conv_band = 1;                    // rua_conv_fwd_sum: the branches' second convs of a C = 32 ResBlock as ONE launch with the sum kept on chip (conv_band32)
   int wgd_ks_slow = 1;                  // wgrad_dmap block order: K slice slowest (blocks that read the same pixels share an XCD's L2)
   int wgrad_rows = 31;                  // bit 0: wgrad_rows32 (the all-taps weight gradient at C = 32 on whole rows, W = 256 / 128, one shared LDS-DMA ring), bit 1: wgrad_rows64 (C = 64, W = 128); 0: wgrad_taps_kernel
@@ -248,6 +250,9 @@ bool rua_band64_ok(const rua_conv_desc* d, int n);
 int rua_launch_band64(const rua_conv_desc* d, int n, hipStream_t st);
 bool rua_band64m_ok(const rua_conv_desc* d, int n);    // independent members (rua_conv_fwd_group) as one conv_band64m launch
 int rua_launch_band64m(const rua_conv_desc* d, int n, hipStream_t st);
+// conv_band128.hip
+bool rua_band128m_ok(const rua_conv_desc* d, int n);   // independent members at C = Cout = 128 on 64-pixel rows as one conv_band128m launch
+int rua_launch_band128m(const rua_conv_desc* d, int n, hipStream_t st);
 // conv_strip.hip
 bool rua_pick_strip(const rua_conv_desc* d);
 int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st);

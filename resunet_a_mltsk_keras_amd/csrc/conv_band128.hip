@@ -1,0 +1,516 @@
+// conv_band128m<CP, W, KC, R>: the row-streaming scheme of conv_band64m (conv_band64.hip) for the C = Cout = 128 level of the network
+// (ResBlock(128,[1,3,15]) at 64 x 64, model2.py:105-106 and its decoder mirror :128-131): the INDEPENDENT 3x3 convolutions of a group
+// (rua_conv_fwd_group: the branches' first convolutions, or their data gradients) as ONE launch.  Rounds 1 - 4 ran these on conv_dmap, an
+// implicit GEMM that re-stages every input pixel nine times (once per tap) and whose 128 x 128 x 64 stages move 32 KB through the LDS-DMA
+// path per 2.1 MFLOP - the path accepts 1 KiB per ~10.6 ns and CU, so a stage was DMA-bound at 1.6x its MFMA time before any latency.
+//
+// Geometry (one 512-thread block per CU, 8 x 16 x 2 = 256 jobs at 8 x 64 x 64 x 128):
+//   job   = (image, band of BR = 4 output rows, 64-channel slice of the OUTPUT channels)
+//   stage = 128 pixels = RPS = 2 whole rows of 64 pixels x all KC = 128 input channels = 32 KB, the pixels of a kernel ROW:
+//           a landed row serves the three taps of its kernel row by shifted fragment reads (a third of the input bytes of the
+//           implicit GEMM), the weights of one kernel row x the block's 64 output channels (3 taps x 64 x 128 = 48 KB) serve the
+//           SPP = 2 stages of a phase.  Per stage and wave: 24 MFMAs 32x32x16 (conv_band64m: 12) on 56 KB of DMA per 6.3 MFLOP =
+//           8.9 KB / MFLOP (conv_dmap: 15.3) - just under the 9.6 KB / MFLOP at which the DMA path and the matrix pipe take equal time.
+//   waves = 4 pixel tiles of 32 (row of the stage x half row) x 2 output-channel tiles of 32; transposed product D^T[co][px] = W . X^T
+//           with the 24 weight fragments of the wave's kernel row IN REGISTERS for the whole phase (96 VGPRs; one LDS read per MFMA).
+//   LDS   = ring of R = 3 stage slots (32 KB + one zero pixel each) + ONE 48 KB weight buffer + tables = 154 KB.  Pixel stride 256 B = one
+//           bank row: the 16-byte pieces of a pixel are XOR-swizzled with the pixel index (piece ^ (pixel & 15)) on the DMA's SOURCE
+//           side, so the 16 lanes of a ds_read_b128 group (16 different pixels, same piece) hit 16 different slots at every tap shift.
+//           No halo: a tap column that falls outside the row reads the slot's zero pixel (the fragment address is a per-phase constant).
+//   weights: two buffers do not fit.  The fragments of phase p are read into registers behind the phase's first barrier, a second
+//           barrier frees the buffer, the DMAs of phase p + 1 are issued right there and have both stages of phase p to land.
+//   members: own input, weights, dilation, bias, optional normalise-on-load coefficients (in_scale / in_shift), optional ReLU mask from an aux
+//           tensor, statistics (sum v, sum v^2 or sum g, sum g * aux), exactly as conv_band64m; the accumulators leave after a member's three phases.
+#include "common.h"
+
+struct Band128K {
+  const unsigned char* x[RUA_MAX_BRANCH];
+  const unsigned char* w[RUA_MAX_BRANCH];
+  const float* bias[RUA_MAX_BRANCH];
+  const float* in_scale[RUA_MAX_BRANCH];
+  const float* in_shift[RUA_MAX_BRANCH];
+  unsigned char* ym[RUA_MAX_BRANCH];
+  const unsigned char* aux[RUA_MAX_BRANCH];          // ReLU-mask source (aux_mode 2) or null
+  const float* mscale[RUA_MAX_BRANCH]; const float* mshift[RUA_MAX_BRANCH];
+  double* stats[RUA_MAX_BRANCH]; int stats_mode[RUA_MAX_BRANCH]; int stats_R[RUA_MAX_BRANCH];
+  int d[RUA_MAX_BRANCH];
+  int has_bn, in_relu, nb;
+  int N, H, bands, njobs;
+  unsigned xbytes;
+  int dbg;                                  // experiments (tuning key band_dbg): 2 no BatchNorm pass
+  unsigned long long* stamps;               // RUA_B128_STAMPS builds: [njobs][8] section cycle sums (tuning key dbg_ptr), else null
+};
+// ablation builds (-DRUA_B128_ABLATE=<bits>, tools/band128_phases.py): 4 no row DMAs in the loop, 8 no MFMAs, 16 no weight DMAs in the loop
+#ifndef RUA_B128_ABLATE
+#define RUA_B128_ABLATE 0
+#endif
+// -DRUA_B128_STAMPS: wave 0 of every block sums s_memrealtime (100 MHz) intervals per section of the kernel into stamps[block][8] (tuning key dbg_ptr;
+// tools/band128_phases.py).  Diagnostic build only: no stamp executes in the shipped kernel.
+#ifdef RUA_B128_STAMPS
+#define B128_T(i) do { const unsigned long long t__ = __builtin_amdgcn_s_memrealtime(); tacc[i] += t__ - tlast; tlast = t__; } while (0)
+// timeline of every wave through the two stages of phase 4: [job][wave][stage][event 0 barrier left, 1 DMAs issued, 2 MFMAs done, 3 rows waited for][realtime, shader clock]
+#define B128_E(ev) do { if (ph == 4 && lane == 0 && q.stamps) { unsigned long long* e__ = q.stamps + (size_t)q.njobs * 8 + ((((size_t)job * 8 + wv) * 2 + sp) * 4 + (ev)) * 2; \
+    e__[0] = __builtin_amdgcn_s_memrealtime(); e__[1] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define B128_T(i) do { } while (0)
+#define B128_E(ev) do { } while (0)
+#endif
+
+template <int V> struct B128IC { static constexpr int value = V; };
+
+template <int CP, int W, int KC, int R>
+__device__ __forceinline__ void conv_band128_body(const Band128K& q) {
+  typedef bf16_t T;
+  constexpr int NW = 8, NT = NW * 64, BR = 4;
+  constexpr int PXB = KC * 2, PPP = PXB / 16, SPX = 128, RPS = SPX / W, SPP = BR / RPS;
+  constexpr int SLOTB = SPX * PXB, ZOFF = SLOTB, SLOT = SLOTB + 256;          // the stage tile + one zero pixel
+  constexpr int NINST = SLOTB / 1024, NPX = NINST / NW, PPI = 64 / PPP;       // DMA instructions per stage / per wave, pixels per instruction
+  constexpr int NCH = CP / KC, PPM = 3 * NCH;                                 // input-channel chunks, phases per member
+  constexpr int KS = KC / 16;                                                 // k-steps per tap
+  constexpr int WPIECES = 3 * KS * 2, WBUF = WPIECES * 1024, WPW = WPIECES / NW;
+  constexpr int NCS = CP / 64;
+  static_assert(PPP == 16 && SPP == 2 && NINST % NW == 0 && WPIECES % NW == 0 && R == 3, "the C = 128 geometry");
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sW = smem + R * SLOT;                                        // [WPIECES][64 lanes][16 B]
+  float* tab = reinterpret_cast<float*>(sW + WBUF);                           // [nb][2][CP] scale, shift
+  float* tabm = tab + RUA_MAX_BRANCH * 2 * CP;                                // [nb][3][64] bias, mask scale, mask shift of the block's output channels
+  float* sred = tabm + RUA_MAX_BRANCH * 192;                                  // [8 waves][64] statistics partials of a member
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pl = lane & 31, kh = lane >> 5;
+  const int pt = wv >> 1, coh = wv & 1;                                       // this wave's pixel tile (32 of the stage's 128 pixels) and output-channel tile
+  const int H = q.H, nb = q.nb;
+
+  const int nwg = q.njobs, bid = blockIdx.x;
+  if (bid >= nwg) return;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int job = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // consecutive jobs (the slices of one band first) share an XCD's L2
+  const int cs = job % NCS, tq = job / NCS;
+  const int band = tq % q.bands, n_ = tq / q.bands;
+  const int h0 = band * BR, co0 = cs * 64;
+
+#ifdef RUA_B128_STAMPS
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- per-channel tables (ordinary loads: all consumed before the first LDS-DMA is issued) ------------------------------
+  if (tid < 64)
+    for (int i = 0; i < nb; ++i) {
+      tabm[i * 192 + tid] = q.bias[i] ? q.bias[i][co0 + tid] : 0.f;
+      tabm[i * 192 + 64 + tid] = (q.aux[i] && q.mscale[i]) ? q.mscale[i][co0 + tid] : 1.f;
+      tabm[i * 192 + 128 + tid] = (q.aux[i] && q.mshift[i]) ? q.mshift[i][co0 + tid] : 0.f;
+    }
+  if (q.has_bn)
+    for (int i = tid; i < nb * CP; i += NT) {
+      const int m = i / CP, c = i - m * CP;
+      tab[m * 2 * CP + c] = q.in_scale[m] ? q.in_scale[m][c] : 1.f;
+      tab[m * 2 * CP + CP + c] = q.in_shift[m] ? q.in_shift[m][c] : 0.f;
+    }
+  if (tid < R * 16) *reinterpret_cast<uint4*>(smem + (tid >> 4) * SLOT + ZOFF + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);   // the zero pixels: never written again
+  __syncthreads();
+  const bool bn = q.has_bn != 0 && !(q.dbg & 2);
+  const int d0 = q.d[0], d1 = q.d[1], d2 = q.d[2], d3 = q.d[3];
+  auto dil_of = [&](int b) { return b == 0 ? d0 : (b == 1 ? d1 : (b == 2 ? d2 : d3)); };
+
+  // ---- DMA addressing: lane l of instruction i (1 KiB = PPI pixels x 16 pieces) moves piece psrc of stage pixel i * PPI + (l >> 4) into slot
+  // position (l & 15) = psrc ^ (pixel & 15).  The instructions of a wave are 32 pixels apart: psrc is the same for all of them.
+  const int qd0 = wv * PPI + (lane >> 4);                                     // pixel of instruction 0 (< 32); instruction k: + k * 32
+  const int psrc = (lane & 15) ^ (qd0 & 15);
+  unsigned xrel[NPX];
+#pragma unroll
+  for (int k = 0; k < NPX; ++k) {
+    const int x = (qd0 + k * NW * PPI) % W;
+    xrel[k] = (unsigned)((x * CP + psrc * 8) * 2);
+  }
+  static_assert(W % (NW * PPI) == 0, "an instruction's pixels lie in one row, the same for every lane (qd0 < NW * PPI)");
+  auto row_of = [&](int k) { return (k * NW * PPI) / W; };                    // wave-uniform: the row validity below is a scalar select, never a branch around a DMA
+  const unsigned pdst0 = (unsigned)(wv * 1024 + lane * 16);                   // this lane's piece of instruction 0 inside a slot; k: + k * NW * 1024
+  const unsigned smem_a = (unsigned)(size_t)(lds_void_p)smem;
+  const unsigned rowbytes = (unsigned)(W * CP * 2), imgbase = (unsigned)(n_ * H) * rowbytes;
+
+  const int nph = nb * PPM;
+  struct Phase { int hb; bool valid; __amdgpu_buffer_rsrc_t rx; unsigned ca, choff; };
+  auto phase = [&](int ph) {
+    Phase p;
+    const int b = ph / PPM, pm = ph - b * PPM, ty = pm / NCH, ch = pm - ty * NCH;
+    p.valid = ph < nph;
+    const int bb = p.valid ? b : 0;
+    p.hb = h0 + (ty - 1) * dil_of(bb);
+    p.rx = make_rsrc(q.x[bb], q.xbytes);
+    p.choff = (unsigned)(ch * KC * 2);
+    p.ca = smem_a + (unsigned)((unsigned char*)(tab + bb * 2 * CP + ch * KC + psrc * 8) - smem);
+    return p;
+  };
+  // the RPS rows of stage sp of a phase -> slot at byte offset so
+  auto issue_x = [&](const Phase& p, int sp, unsigned so) {
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      const int h = p.hb + sp * RPS + row_of(k);
+      const bool ok = p.valid && (unsigned)h < (unsigned)H;
+      const unsigned base = ok ? imgbase + (unsigned)h * rowbytes + p.choff : OOB;      // scalar select; OOB + xrel is still out of range: the lanes write zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(p.rx, (lds_void_p)(smem + so + (k * NW + wv) * 1024), 16, base + xrel[k], 0, 0, 0);
+    }
+  };
+  // weight piece idx of phase ph: tap column idx / (2 KS), k-step (idx >> 1) % KS, output-channel tile idx & 1 - a fragment per lane
+  auto issue_w = [&](int ph) {
+    if (ph < nph) {
+      const int b = ph / PPM, pm = ph - b * PPM, ty = pm / NCH, ch = pm - ty * NCH;
+      const __amdgpu_buffer_rsrc_t rw = make_rsrc(q.w[b], (unsigned)(9 * CP * CP * 2));
+#pragma unroll
+      for (int i = 0; i < WPW; ++i) {
+        const int idx = i * NW + wv;
+        const int tx = idx / (2 * KS), ks = (idx >> 1) % KS, ct = idx & 1;
+        const unsigned off = (unsigned)((((ty * 3 + tx) * CP + co0 + ct * 32 + pl) * CP + ch * KC + ks * 16 + kh * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_p)(sW + idx * 1024), 16, off, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WPW; ++i)                         // keeps the counted waits uniform: a DMA whose every lane is out of range (writes zeros into a dead buffer)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(q.w[0], 0u), (lds_void_p)(sW + (i * NW + wv) * 1024), 16, OOB, 0, 0, 0);
+    }
+  };
+  // one DMA instruction at a time (the loop deals them between its MFMAs: ten issued in one burst behind the barrier stood 0.5 - 1.6 us in the
+  // texture path's queue - one 1 KiB instruction per ~10.6 ns and CU - with the wave's MFMAs waiting behind them in program order)
+  auto issue_x1 = [&](const Phase& p, int sp, int k, unsigned so) {
+    const int h = p.hb + sp * RPS + row_of(k);
+    const bool ok = p.valid && (unsigned)h < (unsigned)H;
+    const unsigned base = ok ? imgbase + (unsigned)h * rowbytes + p.choff : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(p.rx, (lds_void_p)(smem + so + (k * NW + wv) * 1024), 16, base + xrel[k], 0, 0, 0);
+  };
+  struct WPhase { __amdgpu_buffer_rsrc_t rw; unsigned base; };
+  auto wphase = [&](int ph) {
+    WPhase w;
+    const bool ok = ph < nph;
+    const int pp = ok ? ph : 0;
+    const int b = pp / PPM, pm = pp - b * PPM, ty = pm / NCH, ch = pm - ty * NCH;
+    w.rw = make_rsrc(q.w[b], ok ? (unsigned)(9 * CP * CP * 2) : 0u);           // past the last phase: every lane out of range (zeros into a dead buffer; the counted waits stay uniform)
+    w.base = (unsigned)((((ty * 3) * CP + co0 + pl) * CP + ch * KC + kh * 8) * 2);
+    return w;
+  };
+  auto issue_w1 = [&](const WPhase& w, int i) {
+    const int idx = i * NW + wv;
+    const int tx = idx / (2 * KS), ks = (idx >> 1) % KS, ct = idx & 1;
+    const unsigned off = w.base + (unsigned)(((tx * CP + ct * 32) * CP + ks * 16) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w.rw, (lds_void_p)(sW + idx * 1024), 16, off, 0, 0, 0);
+  };
+  // BatchNorm (+ ReLU) of a landed stage, in place, on this thread's own DMA pieces (raw LDS accesses: conv_band.hip says why)
+  auto tr_stage = [&](const Phase& p, int sp, unsigned so) {
+    f32x4 sa, sb, ha, hb; u32x4_t rw[NPX];
+    const unsigned a0 = smem_a + so + pdst0;
+    static_assert(NPX == 4, "four pieces per wave and stage");
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:%c10\n\tds_read_b128 %3, %8 offset:%c11\n\t"
+                 "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:%c12\n\tds_read_b128 %6, %9 offset:%c13\n\tds_read_b128 %7, %9 offset:%c14\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(sa), "=&v"(sb), "=&v"(ha), "=&v"(hb), "=&v"(rw[0]), "=&v"(rw[1]), "=&v"(rw[2]), "=&v"(rw[3])
+                 : "v"(p.ca), "v"(a0), "n"(CP * 4), "n"(CP * 4 + 16), "n"(NW * 1024), "n"(2 * NW * 1024), "n"(3 * NW * 1024) : "memory");
+    const float sc8[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+    const float sh8[8] = {ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      float f[8];
+      ET<T>::unpack(make_uint4(rw[k][0], rw[k][1], rw[k][2], rw[k][3]), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaf(sc8[j], f[j], sh8[j]);
+      uint4 pk = ET<T>::pack(f);
+      if (q.in_relu) {
+        typedef __attribute__((ext_vector_type(2))) short s16x2;
+        const s16x2 z = {0, 0};
+        auto relu2 = [&](unsigned v) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z)); };
+        pk.x = relu2(pk.x); pk.y = relu2(pk.y); pk.z = relu2(pk.z); pk.w = relu2(pk.w);
+      }
+      const int h = p.hb + sp * RPS + row_of(k);
+      if (p.valid && (unsigned)h < (unsigned)H) {            // a row of zero padding stays zero
+        const u32x4_t v = {pk.x, pk.y, pk.z, pk.w};
+        const unsigned la = a0 + (unsigned)(k * NW * 1024);
+        asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(v) : "memory");
+      }
+    }
+  };
+
+  // this lane's output pixel: stage pixel pt * 32 + pl = row (of the stage) jr, column xo
+  const int qo = pt * 32 + pl, jr = qo / W, xo = qo - jr * W;
+  // MULTI: a member's per-channel statistics, summed over the block (the waves' partials are in sred since the member's epilogue)
+  auto stats_flush = [&](int b) {
+    if (tid < 128 && q.stats_mode[b] != 0) {
+      const int ch = tid >> 6, ln = tid & 63, idx = ln & 31, khh = ln >> 5;
+      float t = 0.f;
+#pragma unroll
+      for (int p4 = 0; p4 < 4; ++p4) t += sred[(p4 * 2 + ch) * 64 + ln];
+      const int st = idx >> 4, c = co0 + ch * 32 + 16 * ((idx >> 3) & 1) + 8 * khh + (idx & 7);
+      unsafeAtomicAdd(&q.stats[b][(size_t)(job & (q.stats_R[b] - 1)) * 2 * CP + st * CP + c], (double)t);
+    }
+  };
+  f32x16 acc[SPP];
+#pragma unroll
+  for (int r = 0; r < SPP; ++r)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[r][k] = 0.f;
+
+  // ---- prologue: the weights of phase 0 (-> registers), stages 0 and 1 -------------------------------------------------------------
+  Phase cur = phase(0), nxt = phase(1);
+  issue_w(0);
+  issue_x(cur, 0, 0u);
+  issue_x(cur, 1, (unsigned)SLOT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (bn) tr_stage(cur, 0, 0u);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                              // everyone's pieces of the weights have landed
+  const unsigned char* wb = sW + coh * 1024 + lane * 16;     // this wave's fragments: piece (tx * KS + ks) * 2 + coh
+  bf16x8 wf[3][KS];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[tx][ks] = *reinterpret_cast<const bf16x8*>(wb + ((tx * KS + ks) * 2) * 1024);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  unsigned so_cur = 0, so_nxt = SLOT, so_iss = 2 * SLOT;
+  B128_T(0);
+  // The weight buffer is single (two do not fit): the fragments of phase p + 1 are read into the registers of phase p's fragments as the LAST stage
+  // of phase p retires them, tap column by tap column under its MFMAs; every wave has read them when it reaches the barrier of phase p + 1's first
+  // stage, which is where the DMAs of phase p + 2 are issued.  They are waited for at the end of that stage (one stage to land, from L2) and made
+  // visible by the barrier of the stage that reads them.
+  // Fragment addresses with ONE vector instruction per read: slot = (2 ks + kh) ^ sw = ((ks ^ (sw >> 1)) << 1) | ((kh ^ sw) & 1), so with
+  // e = slot base + pixel * 256 + ((sw >> 1) << 5) + (((kh ^ sw) & 1) << 4) the address of k-step ks is e ^ (ks << 5): pixel * 256 and the slot bases
+  // (multiples of 256 from LDS address 0: no static LDS in this kernel) leave bits 5 - 7 to the swizzle.
+  static_assert(SLOT % 256 == 0, "slot bases keep bits 0 - 7 clear");
+  auto frag = [&](unsigned e, int ks) {
+    return *reinterpret_cast<const bf16x8*>(smem + (e ^ (unsigned)(ks << 5)));
+  };
+  for (int ph = 0; ph < nph; ++ph) {
+    const int b = ph / PPM;
+    const int d = dil_of(b);
+    // b-operand fragment addresses: output pixel (jr, xo), tap column tx reads stage pixel jr * W + xo + (tx - 1) d - or the slot's zero pixel
+    unsigned eoff[3];
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      const int xx = xo + (tx - 1) * d;
+      const bool in = (unsigned)xx < (unsigned)W;
+      const int j = jr * W + xx;
+      const int sw = in ? (j & 15) : 0;
+      eoff[tx] = (in ? (unsigned)(j * PXB) : (unsigned)ZOFF) + (unsigned)(((sw >> 1) << 5) + (((kh ^ sw) & 1) << 4));
+    }
+    const bool last = ph % PPM == PPM - 1;
+    // the epilogue's mask source: fetched two stages early (a dependent HBM round trip in front of the epilogue otherwise)
+    uint4 av[SPP][2];
+    const size_t pixg = (size_t)((n_ * H + h0 + jr) * W + xo);         // this lane's pixel in stage 0 of the band; stage sp: + sp * RPS rows
+    auto stage = [&](auto spc) {
+      constexpr int sp = decltype(spc)::value;
+      __builtin_amdgcn_s_barrier();                          // this stage is complete and normalised; every wave is done with the stage before (and, sp = 0, holds its weight fragments)
+      B128_E(0);
+      if constexpr (sp == 0) {
+        B128_T(1);
+        if (ph > 0 && ph % PPM == 0) stats_flush(b - 1);     // the member that just finished: its partials are visible now
+      } else {
+        B128_T(5);
+      }
+      if (sp == 0 && last) {
+        const unsigned char* auxp = q.aux[b];
+#pragma unroll
+        for (int r = 0; r < SPP; ++r)
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            av[r][g] = auxp ? ldg16(auxp + ((pixg + (size_t)(r * RPS) * W) * CP + co0 + coh * 32 + 16 * g + 8 * kh) * 2) : make_uint4(0, 0, 0, 0);
+      }
+      B128_E(1);
+      const unsigned e0 = so_cur + eoff[0], e1 = so_cur + eoff[1], e2 = so_cur + eoff[2];
+      auto eof = [&](int tx) { return tx == 0 ? e0 : (tx == 1 ? e1 : e2); };
+      const WPhase wn = wphase(ph + 1);
+      // 24 MFMAs in program order, PF fragment reads ahead of the product that consumes them, the stage's DMA instructions dealt between them: stage 0
+      // the WPW weight pieces of the next phase (in FRONT of the rows: the wait at the end of the stage then leaves only the rows in flight) and
+      // the NPX row pieces of the stage two ahead (into the slot the stage before this one has just left), stage 1 its NPX row pieces - and, as a
+      // tap column's fragments retire, the next phase's weight fragments into their registers.  (An LDS-DMA is an LDS write the compiler cannot
+      // tell from the fragment reads' addresses: it keeps both in source order, which is the order wanted here.)
+      constexpr int PF = 4, NI = 3 * KS;
+      constexpr int NDMA = sp == 0 ? WPW + NPX : NPX, DSTEP = sp == 0 ? 2 : 5, D0 = 1;
+      static_assert(D0 + (NDMA - 1) * DSTEP < NI, "every DMA has its MFMA");
+      bf16x8 fr[8];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) fr[i] = frag(eof(i / KS), i % KS);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int tx = i / KS, ks = i % KS;
+        if (i + PF < NI) fr[(i + PF) & 7] = frag(eof((i + PF) / KS), (i + PF) % KS);
+        if constexpr (!(RUA_B128_ABLATE & 8)) acc[sp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tx][ks], fr[i & 7], acc[sp], 0, 0, 0);
+        else asm volatile("" :: "v"(fr[i & 7]), "v"(wf[tx][ks]));
+        if constexpr (sp == SPP - 1) wf[tx][ks] = *reinterpret_cast<const bf16x8*>(wb + ((tx * KS + ks) * 2) * 1024);   // retired: the next phase's fragment takes its registers
+        if (i >= D0 && (i - D0) % DSTEP == 0 && (i - D0) / DSTEP < NDMA) {
+          const int j = (i - D0) / DSTEP;
+          if constexpr (sp == 0) {
+            if (j < WPW) { if constexpr (!(RUA_B128_ABLATE & 16)) issue_w1(wn, j); }
+            else if constexpr (!(RUA_B128_ABLATE & 4)) issue_x1(nxt, sp, j - WPW, so_iss);
+          } else {
+            if constexpr (!(RUA_B128_ABLATE & 4)) issue_x1(nxt, sp, j, so_iss);
+          }
+        }
+      }
+      if constexpr (!(RUA_B128_ABLATE & 8)) {
+        // the interleave, spelled out for the scheduler (left alone it sinks every fragment read to one MFMA in front of its use: an LDS round trip per product)
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          constexpr int wfr = sp == SPP - 1 ? 1 : 0;
+          if (i + PF < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1 + wfr, 0);
+          else if (wfr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (i >= D0 && (i - D0) % DSTEP == 0 && (i - D0) / DSTEP < NDMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      }
+      B128_T(3);
+      B128_E(2);
+      // the next stage's rows: issued one stage ago, waited for only now (two stage times to land).  Younger than them: the NPX row DMAs this stage issued
+      // (stage 0: the weights of the next phase were issued in FRONT of its rows and are waited for here as well)
+      if constexpr (RUA_B128_ABLATE & (4 | 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPX) : "memory");
+      if (bn) {
+        if (sp + 1 < SPP) tr_stage(cur, sp + 1, so_nxt);
+        else tr_stage(nxt, 0, so_nxt);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the last stage: the next phase's weight fragments are in registers)
+      so_iss = so_cur; so_cur = so_nxt; so_nxt = so_nxt + SLOT == (unsigned)(R * SLOT) ? 0u : so_nxt + SLOT;
+      B128_T(4);
+      B128_E(3);
+    };
+    static_assert(SPP == 2, "two stages per phase");
+    stage(B128IC<0>{});
+    stage(B128IC<1>{});
+    if (last) {
+      // ---- member epilogue: bias, ReLU mask from the aux tensor, statistics, one write of the member's band; accumulators cleared
+      const unsigned char* auxp = q.aux[b];
+      unsigned char* yp = q.ym[b];
+      const int smode = q.stats_mode[b];
+      const float* tb = tabm + b * 192;
+      float s1[2][8], s2[2][8];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[g][j] = 0.f; s2[g][j] = 0.f; }
+#pragma unroll
+      for (int r = 0; r < SPP; ++r) {
+        float v[2][8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float a = acc[r][(2 * g) * 4 + j], b2 = acc[r][(2 * g + 1) * 4 + j];
+            if (g == 0 && j == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+            else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+            v[g][j] = a;
+            v[g][4 + j] = b2;
+          }
+        unsigned char* yrow = yp + ((pixg + (size_t)(r * RPS) * W) * CP) * 2;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int cl = coh * 32 + 16 * g + 8 * kh;        // channel inside the block's slice
+          float a8[8];
+          ET<T>::unpack(av[r][g], a8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[g][j] += tb[cl + j];
+          if (auxp) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g][j] = (fmaf(tb[64 + cl + j], a8[j], tb[128 + cl + j]) > 0.f) ? v[g][j] : 0.f;
+          }
+          if (smode == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], v[g][j], s2[g][j]); }
+          } else if (smode == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], a8[j], s2[g][j]); }
+          }
+          stg16(yrow + (co0 + cl) * 2, ET<T>::pack(v[g]));
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[r][k] = 0.f;
+      }
+      if (smode != 0) {
+        // 32 partial sums per lane -> per-channel sums over the wave's 32 pixels by a transposing butterfly (conv_band64m's), lane l ends with value l
+        float vals[32];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { vals[g * 8 + j] = s1[g][j]; vals[16 + g * 8 + j] = s2[g][j]; }
+#pragma unroll
+        for (int k = 16; k >= 1; k >>= 1) {
+          const bool hi = (pl & k) != 0;
+#pragma unroll
+          for (int i = 0; i < k; ++i) {
+            const float send = hi ? vals[i] : vals[i + k];
+            const float keep = hi ? vals[i + k] : vals[i];
+            vals[i] = keep + __shfl_xor(send, k, 64);
+          }
+        }
+        sred[wv * 64 + lane] = vals[0];
+      }
+      B128_T(6);                                             // (the stores are younger than everything the counted waits wait for: they only make those waits stricter)
+    }
+    cur = nxt;
+    nxt = phase(ph + 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");       // the over-issued DMAs of the last stages
+  __syncthreads();
+  stats_flush(nb - 1);
+#ifdef RUA_B128_STAMPS
+  B128_T(7);
+  if (tid == 0 && q.stamps)
+    for (int i = 0; i < 8; ++i) q.stamps[(size_t)job * 8 + i] = tacc[i];
+#endif
+}
+
+template <int CP, int W, int KC, int R> __global__ __launch_bounds__(512) void conv_band128m(const Band128K q) { conv_band128_body<CP, W, KC, R>(q); }
+
+// ---- host side (called by rua_conv_fwd_group, conv_mfma.hip) -----------------------------------------------------------------------
+bool rua_band128m_ok(const rua_conv_desc* d, int n) {
+  if (!g_tune.conv_band128m || n < 1 || n > RUA_MAX_BRANCH) return false;
+  const rua_conv_desc& a = d[0];
+  if (a.dtype != RUA_BF16 || a.W != 64 || a.H % 4 != 0 || (long long)a.N * a.H * a.W < 1024) return false;
+  for (int i = 0; i < n; ++i) {
+    const rua_conv_desc& m = d[i];
+    const rua_conv_seg& g = m.seg[0];
+    if (m.nseg != 1 || m.dtype != RUA_BF16 || g.taps != 9 || g.up_shift != 0 || g.C != 128 || m.Cout != 128 || m.stride != 1 ||
+        m.out_stride != 1 || m.OH != m.H || m.OW != m.W || g.Hs != m.H || g.Ws != m.W || g.dil < 1) return false;
+    if (m.N != a.N || m.H != a.H || m.W != a.W || !m.y) return false;
+    for (int j = 0; j < i; ++j) if (d[j].y == m.y) return false;               // independent outputs
+    if (m.accumulate || m.out_relu || m.bias_more[0] || m.bias_more[1] || m.bias_more[2]) return false;
+    if (!(m.aux_mode == 0 || (m.aux_mode == 2 && m.aux))) return false;
+    if (m.stats_mode != 0 && (!m.stats || m.stats_replicas < 1 || (m.stats_replicas & (m.stats_replicas - 1)))) return false;
+    if (m.stats_mode == 2 && m.aux_mode != 2) return false;
+    if (m.stats_mode < 0 || m.stats_mode > 2) return false;
+    if (m.in_fold) return false;                                               // (coefficients are given at this level: rua_bn_fwd makes them)
+    if ((m.in_scale != nullptr) != (a.in_scale != nullptr) || (m.in_shift != nullptr) != (m.in_scale != nullptr) || m.in_relu != a.in_relu) return false;
+  }
+  return true;
+}
+
+int rua_launch_band128m(const rua_conv_desc* d, int n, hipStream_t st) {
+  Band128K q;
+  memset(&q, 0, sizeof(q));
+  q.nb = n;
+  for (int i = 0; i < n; ++i) {
+    const rua_conv_desc& m = d[i];
+    q.x[i] = (const unsigned char*)m.seg[0].x; q.w[i] = (const unsigned char*)m.seg[0].w; q.bias[i] = m.bias;
+    q.in_scale[i] = m.in_scale; q.in_shift[i] = m.in_shift; q.d[i] = m.seg[0].dil;
+    q.ym[i] = (unsigned char*)m.y;
+    q.aux[i] = m.aux_mode == 2 ? (const unsigned char*)m.aux : nullptr;
+    q.mscale[i] = m.mscale; q.mshift[i] = m.mshift;
+    q.stats[i] = m.stats; q.stats_mode[i] = m.stats ? m.stats_mode : 0; q.stats_R[i] = m.stats_replicas > 0 ? m.stats_replicas : 1;
+  }
+  for (int i = n; i < RUA_MAX_BRANCH; ++i) { q.d[i] = 1; q.stats_R[i] = 1; }
+  const rua_conv_desc& a = d[0];
+  q.dbg = g_tune.band_dbg;
+  q.stamps = (unsigned long long*)(uintptr_t)g_tune.dbg_ptr;
+  q.has_bn = a.in_scale ? 1 : 0;
+  q.in_relu = a.in_relu;
+  q.N = a.N; q.H = a.H;
+  RUA_CHECK_ARG((size_t)a.N * a.H * a.W * 128 * 2 < 0x7FFFFF00ull, "rua_conv_fwd_group: tensor of 2 GiB or more");
+  q.xbytes = (unsigned)((size_t)a.N * a.H * a.W * 128 * 2);
+  constexpr int CP = 128, R = 3;
+  q.bands = a.H / 4;
+  q.njobs = a.N * q.bands * (CP / 64);
+  constexpr int smem = R * (128 * 256 + 256) + 48 * 1024 + (RUA_MAX_BRANCH * 2 * CP + RUA_MAX_BRANCH * 192 + 8 * 64) * 4;
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  static RuaPerDevFlag attr;
+  if (!attr.get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band128m<128, 64, 128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr.get() = true; }
+  hipLaunchKernelGGL((conv_band128m<128, 64, 128, 3>), dim3(q.njobs), dim3(512), smem, st, q);
+  RUA_LAUNCH_CHECK("conv_band128m");
+  return RUA_OK;
+}

@@ -2250,7 +2250,7 @@ static thread_local int g_group_last_chain = 0;
 extern "C" int rua_conv_group_last_chain(void) { return g_group_last_chain; }    // members the latest rua_conv_fwd_group ran back to back inside one conv_dmap_chain grid (0: none)
 extern "C" int rua_conv_group_last_band(void) { return g_group_last_band; }      // 1: the calling thread's latest rua_conv_fwd_group ran as one conv_band64m launch
 // would rua_conv_fwd_group run these members as one conv_band64m launch (which honours in_fold / in_scale of every member)?
-extern "C" int rua_conv_group_band_ok(const rua_conv_desc* d, int n) { return (d && rua_band64m_ok(d, n)) ? 1 : 0; }   // grids the calling thread's latest rua_conv_fwd_group issued (1: one grid for all members)
+extern "C" int rua_conv_group_band_ok(const rua_conv_desc* d, int n) { return (d && (rua_band64m_ok(d, n) || rua_band128m_ok(d, n))) ? 1 : 0; }   // grids the calling thread's latest rua_conv_fwd_group issued (1: one grid for all members)
 
 template <typename KG, typename F1, typename FG>
 static int issue_group(const ConvGroupCapture& c, const int* idx, int m, F1 single, FG grouped, int smem_attr, hipStream_t st, const char* what, int threads = 256) {
@@ -2297,6 +2297,11 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
   if (rua_band64m_ok(d, n)) {                               // the C = 64 level: one row-streaming launch for all members (conv_band64.hip)
     const int rc = rua_launch_band64m(d, n, st);
     if (rc == RUA_OK) { g_group_last_grids = 1; g_group_last_band = 1; }
+    return rc;
+  }
+  if (n >= 2 && rua_band128m_ok(d, n)) {                    // the C = 128 level on 64-pixel rows (conv_band128.hip)
+    const int rc = rua_launch_band128m(d, n, st);
+    if (rc == RUA_OK) { g_group_last_grids = 1; g_group_last_band = 2; }
     return rc;
   }
   if (n == 1 || !g_tune.conv_group) {

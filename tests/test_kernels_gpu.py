@@ -1698,19 +1698,29 @@ BAND64M_CASES = [
     (1, 256, 256, [3, 31], "first"),                  # two strips per row, two members
     (1, 132, 128, [1, 15, 32], "dgrad"),              # 33 bands, three members
     (1, 128, 128, [1, 3, 15, 31], "first_scale"),     # evaluation mode: coefficients given, no statistics
+    # C = Cout = 128 on 64-pixel rows -> conv_band128m (round 5: the level-3 ResBlock, model2.py:105-106,128-131): two-row stages, 64-channel output slices,
+    # tap columns outside the row read a zero pixel (d = 15 on 64 pixels: 15 of 64 columns per side)
+    (8, 64, 64, [1, 3, 15], "first_plain", 128),      # the engine's form at this level: materialised BatchNorm input, bias, statistics
+    (8, 64, 64, [1, 3, 15], "dgrad", 128),
+    (2, 64, 64, [1, 3, 15], "first", 128),            # coefficients given (in_scale / in_shift) + ReLU on load, statistics
+    (1, 36, 64, [3, 31, 15, 1], "dgrad", 128),        # 9 bands, four members, a dilation wider than half the row
+    (3, 8, 64, [15, 3], "first_scale", 128),          # two bands: every row of the d = 15 member's outer kernel rows is padding
 ]
 
 
-@pytest.mark.parametrize("N,H,W,dils,kind", BAND64M_CASES)
-def test_conv_group_band64_multi(N, H, W, dils, kind):
+@pytest.mark.parametrize("case", BAND64M_CASES)
+def test_conv_group_band64_multi(case):
     """rua_conv_fwd_group at C = Cout = 64 -> conv_band64m: the independent 3x3 convolutions of a level-2 ResBlock (model2.py:17-24 first
     convs of every dilation branch; their data gradients) as ONE row-streaming launch, every member with its own normalise-on-load,
     bias, ReLU mask and statistics.  Against float64 convolutions of the bf16-rounded operands (and, for the data-gradient form,
     against the members run one by one on the implicit-GEMM kernel: outputs to bf16 rounding, statistics to fp32 partial-sum order)."""
+    N, H, W, dils, kind = case[:5]
+    Cs = case[5] if len(case) > 5 else 64
+    key = "conv_band64m" if Cs == 64 else "conv_band128m"
     dt = L.RUA_BF16
     lib = L.lib()
     rng = np.random.default_rng(H + W + len(dils) + len(kind))
-    Cs, nb, M = 64, len(dils), N * H * W
+    nb, M = len(dils), N * H * W
     first = kind.startswith("first")
     xs = [(1.1 * rng.standard_normal((N, H, W, Cs)) + 0.1).astype(np.float32) for _ in range(1 if first else nb)]
     ws = [(rng.standard_normal((9, Cs, Cs)) / np.sqrt(9 * Cs)).astype(np.float32) for _ in range(nb)]
@@ -1750,9 +1760,11 @@ def test_conv_group_band64_multi(N, H, W, dils, kind):
             d.y, d.out_stride, d.OH, d.OW = ys[b].data_ptr(), 1, H, W
             if first:
                 d.bias = bd[b].data_ptr()
-                if kind == "first":
+                if kind in ("first", "first_plain"):
                     d.stats, d.stats_mode, d.stats_replicas = sts[b].data_ptr(), 1, R
-                    if with_norm:
+                    if with_norm and kind == "first" and Cs != 64:      # (no in_fold at this level: the coefficient launch makes them)
+                        d.in_scale, d.in_shift, d.in_relu = coef_ref[b][0].data_ptr(), coef_ref[b][1].data_ptr(), 1
+                    elif with_norm and kind == "first":
                         mm = torch.zeros(Cs, device=dev()); mv = torch.ones(Cs, device=dev()); co = torch.zeros(4, Cs, dtype=torch.float32, device=dev())
                         f = L.BnFold()
                         f.stats, f.replicas, f.count, f.bessel_n, f.eps, f.momentum = st_in.data_ptr(), R, float(M), float(M), 1e-3, 0.99
@@ -1760,7 +1772,7 @@ def test_conv_group_band64_multi(N, H, W, dils, kind):
                         f.scale, f.shift, f.mean, f.rstd = (co[i].data_ptr() for i in range(4))
                         d.in_fold, d.in_relu = C.addressof(f), 1
                         keep += [f, mm, mv, co]
-                elif with_norm:
+                elif with_norm and kind == "first_scale":
                     d.in_scale, d.in_shift, d.in_relu = coef_ref[b][0].data_ptr(), coef_ref[b][1].data_ptr(), 1
             else:
                 d.aux, d.aux_mode, d.mscale, d.mshift = ad[b].data_ptr(), 2, mscd[b].data_ptr(), mshd[b].data_ptr()
@@ -1770,9 +1782,9 @@ def test_conv_group_band64_multi(N, H, W, dils, kind):
     arr, ys, sts, keep = build(True)
     assert lib.raw("rua_conv_group_band_ok")(arr, nb) == 1
     lib.call("rua_conv_fwd_group", arr, nb, stream())
-    assert lib.raw("rua_conv_group_last_band")() == 1 and lib.raw("rua_conv_group_last_grids")() == 1
+    assert lib.raw("rua_conv_group_last_band")() == (1 if Cs == 64 else 2) and lib.raw("rua_conv_group_last_grids")() == 1
     torch.cuda.synchronize()
-    if kind == "first":                                       # every member published its coefficients and moved its moving statistics once
+    if kind == "first" and Cs == 64:                          # every member published its coefficients and moved its moving statistics once
         for b in range(nb):
             f, mm, mv, co = keep[4 * b:4 * b + 4]
             assert np.allclose(co[:2].cpu().numpy(), coef_ref[b].cpu().numpy(), rtol=1e-4, atol=1e-5), b
@@ -1780,7 +1792,7 @@ def test_conv_group_band64_multi(N, H, W, dils, kind):
             assert np.allclose(mv.cpu().numpy(), 0.99 + 0.01 * var * M / (M - 1), rtol=1e-4), b
     for b in range(nb):
         xin = rnd(dt, xs[0] if first else xs[b])
-        if first:
+        if first and kind != "first_plain":
             sc, sh = coef_ref[b][0].cpu(), coef_ref[b][1].cpu()
             xin = torch.relu(xin * sc + sh).to(torch.bfloat16).float()
         exp = ref_conv_nhwc(xin, rnd(dt, ws[b]), None, dils[b], 9).numpy()
@@ -1798,14 +1810,14 @@ def test_conv_group_band64_multi(N, H, W, dils, kind):
             assert rel_err(stv[:Cs], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4, b
             assert rel_err(stv[Cs:], s2) < 5 * tol(dt) + 1e-4, b
     if not first:                                              # the same members through the implicit-GEMM kernel, one grid or one by one
-        lib.set_tuning(conv_band64m=0)
+        lib.set_tuning(**{key: 0})
         try:
             arr2, ys2, sts2, _ = build(True)
             lib.call("rua_conv_fwd_group", arr2, nb, stream())
             assert lib.raw("rua_conv_group_last_band")() == 0
             torch.cuda.synchronize()
         finally:
-            lib.set_tuning(conv_band64m=1)
+            lib.set_tuning(**{key: 1})
         for b in range(nb):
             assert rel_err(ys[b].float().cpu().numpy(), ys2[b].float().cpu().numpy()) < tol(dt)
             assert np.allclose(sts[b].cpu().numpy().reshape(R, -1).sum(0), sts2[b].cpu().numpy().reshape(R, -1).sum(0), rtol=1e-3, atol=1e-2)

@@ -557,32 +557,39 @@ def test_first_writer_overwrite_step_equals_the_accumulating_backward():
     assert float((twice - 2 * g_acc).abs().max()) <= 2e-5 * scale
 
 
-BF16_GRAD_COSMIN_B8 = 0.81                                                      # 1 - cosine within twice the measured 0.094 of the least aligned tensor
+BF16_GRAD_COSMIN_B8 = 0.85                                                      # 1 - cosine within twice the measured 0.094 of the least aligned tensor
 BF16_GRAD_MEDIAN_B8, BF16_GRAD_MAX_B8, BF16_GRAD_COS_B8 = 0.10, 0.6, 0.95     # measured: median 0.053 / p90 0.198 / max 0.321 of a tensor's scale, cosine median 0.976 / min 0.906 (batch 1: median 0.17)
 
 
 def test_cfg3_bf16_training_tracks_fp32_over_200_steps_on_varying_batches():
-    """Training quality of the BENCHMARKED storage type: 200 Adam steps of cfg3 (256x256x6 multitask, Tanimoto-dual on
-    all heads, batch 8, lr 1e-3) over eight DIFFERENT synthetic batches in rotation, bf16 storage against fp32 storage on the HIP path from
-    the same initial weights.  Both runs must fall, and the bf16 run must end where the fp32 run ends: the mean total loss of the last 20
-    steps within BF16_TRAIN_GAP (relative; twice the measured gap), no step of the bf16 run further than BF16_TRAIN_STEP_GAP from the
-    fp32 run's step (the two runs see the same batches in the same order, so their losses are comparable step by step)."""
+    """Training quality of the BENCHMARKED storage type (VERDICT r3 next#5, r4 next#5c): 200 Adam steps of cfg3 (256x256x6 multitask,
+    Tanimoto-dual on all heads, batch 8, lr 1e-3) over eight DIFFERENT synthetic batches in rotation, bf16 storage against fp32 storage on
+    the HIP path from the same initial weights - and a SECOND fp32 run whose initial weights differ by 1e-6 relative noise.  Round 5's
+    diagnosis (tools/bf16_gap.py): this training problem is chaotic at the percent level - two fp32 runs 1e-6 apart end 1.4 %
+    apart (worst step 4.8 %), fp32 with bf16-rounded weight copies -0.2 %, fp32 from bf16-rounded initial weights -0.7 %, bf16 +0.4 % (round
+    4's run: +4.6 %), bf16 with materialised BatchNorm -3.0 %: the bf16 run lands on either side of the fp32 run, inside the spread fp32
+    shows against itself - trajectory divergence, not a bias of the storage type.  The fp32 pair's own gap is printed beside the bf16
+    run's (a single draw of a quantity that scatters over 0.1 - 5 %, so it is context, not the bound); the bounds are absolute:
+    BF16_TRAIN_GAP at the end, BF16_TRAIN_STEP_GAP at the worst step; all runs fall to about 60 % of the first loss."""
     batches = [make_batch(8, 256, 6, 6, True, seed=9000 + i) for i in range(8)]
     o = golden_step("cfg3")
+    rng = np.random.default_rng(7)
+    w_eps = {k: (v * (1.0 + 1e-6 * rng.standard_normal(v.shape))).astype(np.float32) for k, v in o["params"].items()}
     traj = {}
-    for dtype in ("f32", "bf16"):
-        e = hip_engine((256, 256, 6), 6, True, "tanimoto", dtype, o["params"])
-        traj[dtype] = np.array([e.train_step(*batches[i % len(batches)])[:5] for i in range(200)])
+    for name, dtype, w in (("f32", "f32", o["params"]), ("f32_eps", "f32", w_eps), ("bf16", "bf16", o["params"])):
+        e = hip_engine((256, 256, 6), 6, True, "tanimoto", dtype, w)
+        traj[name] = np.array([e.train_step(*batches[i % len(batches)])[:5] for i in range(200)])
         del e
         torch.cuda.empty_cache()
-    a, b = traj["f32"][:, 0], traj["bf16"][:, 0]
-    gap_end = abs(b[-20:].mean() - a[-20:].mean()) / a[-20:].mean()
-    gap_step = float(np.max(np.abs(b - a) / a))
-    print("cfg3 B=8, 200 steps on 8 rotating batches: total loss f32 %.4f -> %.4f, bf16 %.4f -> %.4f; mean of the last 20 steps: f32 %.4f bf16 %.4f "
-          "(relative gap %.2e); largest per-step gap %.2e" % (a[0], a[-1], b[0], b[-1], a[-20:].mean(), b[-20:].mean(), gap_end, gap_step))
-    assert np.all(np.isfinite(traj["bf16"])) and np.all(np.isfinite(traj["f32"]))
-    assert a[-20:].mean() < 0.8 * a[:8].mean() and b[-20:].mean() < 0.8 * b[:8].mean()       # both fall (measured: to about half)
-    assert gap_end < BF16_TRAIN_GAP and gap_step < BF16_TRAIN_STEP_GAP, (gap_end, gap_step)
+    a, a2, b = traj["f32"][:, 0], traj["f32_eps"][:, 0], traj["bf16"][:, 0]
+    end = lambda v: abs(v[-20:].mean() - a[-20:].mean()) / a[-20:].mean()
+    step = lambda v: float(np.max(np.abs(v - a) / a))
+    print("cfg3 B=8, 200 steps on 8 rotating batches: total loss f32 %.4f -> %.4f, bf16 %.4f -> %.4f; mean of the last 20 steps: f32 %.4f, f32 + 1e-6 %.4f, "
+          "bf16 %.4f; relative gap at the end: fp32 pair %.2e, bf16 %.2e; largest per-step gap: fp32 pair %.2e, bf16 %.2e"
+          % (a[0], a[-1], b[0], b[-1], a[-20:].mean(), a2[-20:].mean(), b[-20:].mean(), end(a2), end(b), step(a2), step(b)))
+    assert all(np.all(np.isfinite(v)) for v in traj.values())
+    assert a[-20:].mean() < 0.8 * a[:8].mean() and b[-20:].mean() < 0.8 * b[:8].mean()       # both fall (measured: to about 60 %)
+    assert end(b) < BF16_TRAIN_GAP and step(b) < BF16_TRAIN_STEP_GAP, (end(b), step(b), end(a2), step(a2))
 
 
-BF16_TRAIN_GAP, BF16_TRAIN_STEP_GAP = 0.10, 0.21     # measured (round 4): 4.6e-2 at the end (f32 1.1505, bf16 1.2035 over the last 20 steps), 1.05e-1 at the worst step; both runs fall 1.903 -> ~1.15
+BF16_TRAIN_GAP, BF16_TRAIN_STEP_GAP = 0.07, 0.16     # absolute caps = 1.5x the largest gaps ever measured (round 4: 4.6e-2 at the end, 1.05e-1 at the worst step; round 5: 3.8e-3 / 4.1e-2)
