@@ -152,23 +152,32 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(p.rx, (lds_void_p)(smem + so + (k * NW + wv) * 1024), 16, base + xrel[k], 0, 0, 0);
     }
   };
-  // weight piece idx of phase ph: tap column idx / (2 KS), k-step (idx >> 1) % KS, output-channel tile idx & 1 - a fragment per lane
+  // The weights of a phase in LDS: [tap column 3][output channel 64][input channel 128] = the image of the pixel tiles (256-byte rows, 16-byte pieces
+  // XOR-swizzled with the row index on the DMA's source side), so a DMA instruction moves four whole 256-byte weight rows (fully coalesced).  The first
+  // build staged them fragment by fragment - a lane per (output channel, 16 bytes of a 32-byte segment): 32 partly used lines per instruction, and the
+  // stamps showed ~30 ns per weight instruction against ~12.5 ns per row instruction in the texture path.
+  static_assert(WPIECES == 3 * 16 && KC * 2 == 256 && NCH == 1, "a tap column = 16 instructions of 4 weight rows");
+  const int wrow0 = 4 * (wv & 3) + (lane >> 4);                               // weight row of instruction idx inside its 16-row group: idx & 3 == wv & 3 for every instruction of the wave
+  const unsigned wsrc = (unsigned)((wrow0 * CP + (((lane & 15) ^ wrow0) * 8)) * 2);
+  struct WPhase { __amdgpu_buffer_rsrc_t rw; unsigned base; };
+  auto wphase = [&](int ph) {
+    WPhase w;
+    const bool ok = ph < nph;
+    const int pp = ok ? ph : 0;
+    const int b = pp / PPM, ty = pp - b * PPM;
+    w.rw = make_rsrc(q.w[b], ok ? (unsigned)(9 * CP * CP * 2) : 0u);           // past the last phase: every lane out of range (zeros into a dead buffer; the counted waits stay uniform)
+    w.base = (unsigned)((((ty * 3) * CP + co0) * CP) * 2) + wsrc;
+    return w;
+  };
+  auto issue_w1 = [&](const WPhase& w, int i) {
+    const int idx = i * NW + wv;                                                // tap column idx >> 4, weight rows 4 (idx & 15) ..
+    const unsigned off = w.base + (unsigned)((((idx >> 4) * CP + 4 * ((idx & 15) & ~3)) * CP) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w.rw, (lds_void_p)(sW + idx * 1024), 16, off, 0, 0, 0);
+  };
   auto issue_w = [&](int ph) {
-    if (ph < nph) {
-      const int b = ph / PPM, pm = ph - b * PPM, ty = pm / NCH, ch = pm - ty * NCH;
-      const __amdgpu_buffer_rsrc_t rw = make_rsrc(q.w[b], (unsigned)(9 * CP * CP * 2));
+    const WPhase w = wphase(ph);
 #pragma unroll
-      for (int i = 0; i < WPW; ++i) {
-        const int idx = i * NW + wv;
-        const int tx = idx / (2 * KS), ks = (idx >> 1) % KS, ct = idx & 1;
-        const unsigned off = (unsigned)((((ty * 3 + tx) * CP + co0 + ct * 32 + pl) * CP + ch * KC + ks * 16 + kh * 8) * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_p)(sW + idx * 1024), 16, off, 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < WPW; ++i)                         // keeps the counted waits uniform: a DMA whose every lane is out of range (writes zeros into a dead buffer)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(q.w[0], 0u), (lds_void_p)(sW + (i * NW + wv) * 1024), 16, OOB, 0, 0, 0);
-    }
+    for (int i = 0; i < WPW; ++i) issue_w1(w, i);
   };
   // one DMA instruction at a time (the loop deals them between its MFMAs: ten issued in one burst behind the barrier stood 0.5 - 1.6 us in the
   // texture path's queue - one 1 KiB instruction per ~10.6 ns and CU - with the wave's MFMAs waiting behind them in program order)
@@ -177,22 +186,6 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
     const bool ok = p.valid && (unsigned)h < (unsigned)H;
     const unsigned base = ok ? imgbase + (unsigned)h * rowbytes + p.choff : OOB;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(p.rx, (lds_void_p)(smem + so + (k * NW + wv) * 1024), 16, base + xrel[k], 0, 0, 0);
-  };
-  struct WPhase { __amdgpu_buffer_rsrc_t rw; unsigned base; };
-  auto wphase = [&](int ph) {
-    WPhase w;
-    const bool ok = ph < nph;
-    const int pp = ok ? ph : 0;
-    const int b = pp / PPM, pm = pp - b * PPM, ty = pm / NCH, ch = pm - ty * NCH;
-    w.rw = make_rsrc(q.w[b], ok ? (unsigned)(9 * CP * CP * 2) : 0u);           // past the last phase: every lane out of range (zeros into a dead buffer; the counted waits stay uniform)
-    w.base = (unsigned)((((ty * 3) * CP + co0 + pl) * CP + ch * KC + kh * 8) * 2);
-    return w;
-  };
-  auto issue_w1 = [&](const WPhase& w, int i) {
-    const int idx = i * NW + wv;
-    const int tx = idx / (2 * KS), ks = (idx >> 1) % KS, ct = idx & 1;
-    const unsigned off = w.base + (unsigned)(((tx * CP + ct * 32) * CP + ks * 16) * 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w.rw, (lds_void_p)(sW + idx * 1024), 16, off, 0, 0, 0);
   };
   // BatchNorm (+ ReLU) of a landed stage, in place, on this thread's own DMA pieces (raw LDS accesses: conv_band.hip says why)
   auto tr_stage = [&](const Phase& p, int sp, unsigned so) {
@@ -256,12 +249,15 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   if (bn) tr_stage(cur, 0, 0u);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                              // everyone's pieces of the weights have landed
-  const unsigned char* wb = sW + coh * 1024 + lane * 16;     // this wave's fragments: piece (tx * KS + ks) * 2 + coh
+  // this wave's weight fragments: row coh * 32 + pl of the tap column's image, k-step ks at e ^ (ks << 5) like the pixel fragments
+  static_assert((R * SLOT) % 256 == 0, "the weight image keeps bits 0 - 7 of its rows clear");
+  const unsigned ew0 = (unsigned)(R * SLOT + (coh * 32 + pl) * 256 + (((pl & 15) >> 1) << 5) + (((kh ^ pl) & 1) << 4));
+  auto wfrag = [&](int tx, int ks) { return *reinterpret_cast<const bf16x8*>(smem + ((ew0 + (unsigned)(tx * 16384)) ^ (unsigned)(ks << 5))); };
   bf16x8 wf[3][KS];
 #pragma unroll
   for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[tx][ks] = *reinterpret_cast<const bf16x8*>(wb + ((tx * KS + ks) * 2) * 1024);
+    for (int ks = 0; ks < KS; ++ks) wf[tx][ks] = wfrag(tx, ks);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   unsigned so_cur = 0, so_nxt = SLOT, so_iss = 2 * SLOT;
@@ -333,7 +329,7 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
         if (i + PF < NI) fr[(i + PF) & 7] = frag(eof((i + PF) / KS), (i + PF) % KS);
         if constexpr (!(RUA_B128_ABLATE & 8)) acc[sp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tx][ks], fr[i & 7], acc[sp], 0, 0, 0);
         else asm volatile("" :: "v"(fr[i & 7]), "v"(wf[tx][ks]));
-        if constexpr (sp == SPP - 1) wf[tx][ks] = *reinterpret_cast<const bf16x8*>(wb + ((tx * KS + ks) * 2) * 1024);   // retired: the next phase's fragment takes its registers
+        if constexpr (sp == SPP - 1) wf[tx][ks] = wfrag(tx, ks);   // retired: the next phase's fragment takes its registers
         if (i >= D0 && (i - D0) % DSTEP == 0 && (i - D0) / DSTEP < NDMA) {
           const int j = (i - D0) / DSTEP;
           if constexpr (sp == 0) {
@@ -455,6 +451,13 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
     for (int i = 0; i < 8; ++i) q.stamps[(size_t)job * 8 + i] = tacc[i];
 #endif
 }
+
+// (Measured and not kept, round 5: the same job with the waves SPECIALISED - waves 4 - 7 issue every DMA of the block, wait for the landings and do the in-place
+// BatchNorm, waves 0 - 3 only read fragments and multiply, a whole row x 32 output channels each (conv_band128w, 250 lines).  Bit-identical; 38 - 40 us against 37 - 39 us
+// for the first-convolution group and 50 against 43 us for the data-gradient group, whose member epilogue - mask, statistics, stores - then runs on four waves
+// instead of eight.  What the stamps had blamed on DMA instructions holding up the MFMAs behind them was mostly the WEIGHT DMAs: staged a fragment per lane they
+// touched 32 partly used lines per instruction and cost ~30 ns each in the texture path against ~12.5 ns for a row instruction; as whole swizzled rows - the
+// form above - the first form went 43 - 46 -> 37 - 39 us and the specialised one lost its reason.)
 
 template <int CP, int W, int KC, int R> __global__ __launch_bounds__(512) void conv_band128m(const Band128K q) { conv_band128_body<CP, W, KC, R>(q); }
 

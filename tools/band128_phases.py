@@ -15,6 +15,7 @@ from resunet_a_mltsk_keras_amd import _lib as L  # noqa: E402
 
 def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "first"
+    form = int(sys.argv[2]) if len(sys.argv) > 2 else 1     # value of the tuning key conv_band128m (experiment builds with more than one form)
     lib = L.lib()
     dev = torch.device("cuda", 0)
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -45,13 +46,13 @@ def main():
             d.aux, d.aux_mode, d.mscale, d.mshift, d.stats_mode = aux[b].data_ptr(), 2, msc[b].data_ptr(), msh[b].data_ptr(), 2
     njobs = N * (HW // 4) * 2
     stamps = torch.zeros(njobs * 8 + njobs * 8 * 2 * 4 * 2, dtype=torch.int64, device=dev)
-    lib.set_tuning(dbg_ptr=stamps.data_ptr())
+    lib.set_tuning(dbg_ptr=stamps.data_ptr(), conv_band128m=form)
     for _ in range(20):
         lib.call("rua_conv_fwd_group", arr, nb, s)
     torch.cuda.synchronize()
     t = stamps[:njobs * 8].view(njobs, 8).double().cpu()
     ev = stamps[njobs * 8:].view(njobs, 8, 2, 4, 2).double().cpu()
-    lib.set_tuning(dbg_ptr=0)
+    lib.set_tuning(dbg_ptr=0, conv_band128m=1)
     names = ["prologue", "phase top wait+barrier", "weights->regs", "stage MFMAs", "wait next rows", "stage-1 barrier", "epilogues", "tail"]
     print(f"{kind}: s_memrealtime ticks (100 MHz): median over {njobs} blocks; us = ticks / 100")
     tot = 0.0

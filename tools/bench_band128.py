@@ -65,22 +65,24 @@ def main():
         t = sorted(e[2 * i].elapsed_time(e[2 * i + 1]) * 1e3 for i in range(reps))
         return t[len(t) // 2], t[0]
 
+    variants = [int(v) for v in os.environ.get("BB_VARIANTS", "1").split(",")]      # conv_band128m forms to time against conv_dmap (1: the kernel; other values: experiment builds)
     for kind in ("first", "dgrad"):
         arr = group(kind)
         outs = {}
-        for v in (1, 0):
+        for v in variants + [0]:
             lib.set_tuning(conv_band128m=v)
             for st in stats:
                 st.zero_()
             lib.call("rua_conv_fwd_group", arr, nb, s)
             torch.cuda.synchronize()
             outs[v] = ([y.float().clone() for y in ys], [st.view(32, -1).sum(0).clone() for st in stats], lib.raw("rua_conv_group_last_band")())
-        for b in range(nb):
-            dy = (outs[1][0][b] - outs[0][0][b]).abs().max().item() / outs[0][0][b].abs().max().item()
-            ds = ((outs[1][1][b] - outs[0][1][b]).abs().max() / outs[0][1][b].abs().max()).item()
-            print(f"{kind} member {b} (d = {dils[b]}): band128m vs conv_dmap: output {dy:.2e} of scale, statistics {ds:.2e}   (band flags {outs[1][2]} / {outs[0][2]})")
+        for v in variants:
+            for b in range(nb):
+                dy = (outs[v][0][b] - outs[0][0][b]).abs().max().item() / outs[0][0][b].abs().max().item()
+                ds = ((outs[v][1][b] - outs[0][1][b]).abs().max() / outs[0][1][b].abs().max()).item()
+                print(f"{kind} member {b} (d = {dils[b]}): band128 form {v} vs conv_dmap: output {dy:.2e} of scale, statistics {ds:.2e}   (band flags {outs[v][2]} / {outs[0][2]})")
         for rnd in range(2):
-            for v, name in ((1, "conv_band128m"), (0, "conv_dmap group")):
+            for v, name in [(v, "conv_band128%s" % ("m" if v == 1 else "w")) for v in variants] + [(0, "conv_dmap group")]:
                 lib.set_tuning(conv_band128m=v)
                 for cold in (False, True):
                     med, best = timed(arr, cold)
