@@ -222,8 +222,9 @@ def profile_kernels(eng, g, dtype):
                 kn = (f"conv_igemm_g<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", dmap_name(bm_, bn_, True), f"conv_halo<{d0.Cout}>", "conv_pw", f"conv_strip_g<{d0.Cout}>", "conv_small<2>")[kid]
                 grids = lib.raw("rua_conv_group_last_grids")()
                 nl = 1
-                if lib.raw("rua_conv_group_last_band")() == 1:   # C = 64: the members as ONE row-streaming launch
-                    kn = "conv_band64m"
+                band = lib.raw("rua_conv_group_last_band")()
+                if band:                                    # the members as ONE row-streaming launch (1: conv_band64m, 2: conv_band128m at C = 64 / 128)
+                    kn = "conv_band64m" if band == 1 else f"conv_band128m<{d0.Cout}>"
                 elif grids == n and all(lib.raw("rua_conv_kernel_id")(C.byref(arr[i])) == kid for i in range(n)):
                     kn, nl = ungrouped(kn), n              # not grouped: n launches of the plain kernel
                 elif grids != 1:                            # members the launchers could not put into one grid

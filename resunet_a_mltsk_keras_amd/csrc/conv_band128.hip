@@ -1,4 +1,4 @@
-// conv_band128m<CP, W, KC, R>: the row-streaming scheme of conv_band64m (conv_band64.hip) for the C = Cout = 128 level of the network
+// conv_band128m<CP, W>: the row-streaming scheme of conv_band64m (conv_band64.hip) for the C = Cout = 128 level of the network
 // (ResBlock(128,[1,3,15]) at 64 x 64, model2.py:105-106 and its decoder mirror :128-131): the INDEPENDENT 3x3 convolutions of a group
 // (rua_conv_fwd_group: the branches' first convolutions, or their data gradients) as ONE launch.  Rounds 1 - 4 ran these on conv_dmap, an
 // implicit GEMM that re-stages every input pixel nine times (once per tap) and whose 128 x 128 x 64 stages move 32 KB through the LDS-DMA
@@ -29,17 +29,19 @@ struct Band128K {
   const float* bias[RUA_MAX_BRANCH];
   const float* in_scale[RUA_MAX_BRANCH];
   const float* in_shift[RUA_MAX_BRANCH];
+  rua_bn_fold f[RUA_MAX_BRANCH];
   unsigned char* ym[RUA_MAX_BRANCH];
   const unsigned char* aux[RUA_MAX_BRANCH];          // ReLU-mask source (aux_mode 2) or null
   const float* mscale[RUA_MAX_BRANCH]; const float* mshift[RUA_MAX_BRANCH];
   double* stats[RUA_MAX_BRANCH]; int stats_mode[RUA_MAX_BRANCH]; int stats_R[RUA_MAX_BRANCH];
   int d[RUA_MAX_BRANCH];
-  int has_bn, in_relu, nb;
+  int has_fold, has_bn, in_relu, nb;
   int N, H, bands, njobs;
   unsigned xbytes;
   int dbg;                                  // experiments (tuning key band_dbg): 2 no BatchNorm pass
   unsigned long long* stamps;               // RUA_B128_STAMPS builds: [njobs][8] section cycle sums (tuning key dbg_ptr), else null
 };
+static_assert(sizeof(Band128K) <= 4096, "kernel arguments are limited to 4 KiB");
 // ablation builds (-DRUA_B128_ABLATE=<bits>, tools/band128_phases.py): 4 no row DMAs in the loop, 8 no MFMAs, 16 no weight DMAs in the loop
 #ifndef RUA_B128_ABLATE
 #define RUA_B128_ABLATE 0
@@ -48,7 +50,7 @@ struct Band128K {
 // tools/band128_phases.py).  Diagnostic build only: no stamp executes in the shipped kernel.
 #ifdef RUA_B128_STAMPS
 #define B128_T(i) do { const unsigned long long t__ = __builtin_amdgcn_s_memrealtime(); tacc[i] += t__ - tlast; tlast = t__; } while (0)
-// timeline of every wave through the two stages of phase 4: [job][wave][stage][event 0 barrier left, 1 DMAs issued, 2 MFMAs done, 3 rows waited for][realtime, shader clock]
+// timeline of every wave through the two stages of phase 4: [job][wave][stage][event 0 barrier left, 1 stage set up, 2 MFMAs done, 3 rows waited for][realtime, shader clock]
 #define B128_E(ev) do { if (ph == 4 && lane == 0 && q.stamps) { unsigned long long* e__ = q.stamps + (size_t)q.njobs * 8 + ((((size_t)job * 8 + wv) * 2 + sp) * 4 + (ev)) * 2; \
     e__[0] = __builtin_amdgcn_s_memrealtime(); e__[1] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
@@ -58,21 +60,25 @@ struct Band128K {
 
 template <int V> struct B128IC { static constexpr int value = V; };
 
-template <int CP, int W, int KC, int R>
+// CP = C = Cout (128: one pixel tile per wave; 64: two), W = row width (a stage is SPX / W whole rows)
+template <int CP, int W>
 __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   typedef bf16_t T;
-  constexpr int NW = 8, NT = NW * 64, BR = 4;
-  constexpr int PXB = KC * 2, PPP = PXB / 16, SPX = 128, RPS = SPX / W, SPP = BR / RPS;
-  constexpr int SLOTB = SPX * PXB, ZOFF = SLOTB, SLOT = SLOTB + 256;          // the stage tile + one zero pixel
+  constexpr int NW = 8, NT = NW * 64, R = 3;
+  constexpr int PXB = CP * 2, PPP = PXB / 16;                                 // bytes / 16-byte pieces per pixel (256 / 16 or 128 / 8)
+  constexpr int SLOTB = 32768, SPX = SLOTB / PXB, RPS = SPX / W, SPP = 2, BR = SPP * RPS;     // a stage = 32 KB = 128 or 256 pixels = RPS rows; a band = two stages
+  constexpr int TPW = SPX / 128;                                              // pixel tiles (of 32) per wave: 4 pixel groups x 2 output-channel tiles = 8 waves
+  constexpr int ZOFF = SLOTB, SLOT = SLOTB + 256;                             // the stage tile + one zero pixel
   constexpr int NINST = SLOTB / 1024, NPX = NINST / NW, PPI = 64 / PPP;       // DMA instructions per stage / per wave, pixels per instruction
-  constexpr int NCH = CP / KC, PPM = 3 * NCH;                                 // input-channel chunks, phases per member
-  constexpr int KS = KC / 16;                                                 // k-steps per tap
-  constexpr int WPIECES = 3 * KS * 2, WBUF = WPIECES * 1024, WPW = WPIECES / NW;
+  constexpr int PPM = 3;                                                      // phases (kernel rows) per member
+  constexpr int KS = CP / 16;                                                 // k-steps per tap
+  constexpr int TAPB = 64 * PXB, WBUF = 3 * TAPB, WPIECES = WBUF / 1024, WPW = WPIECES / NW, RPI = 1024 / PXB;   // weight image [tap column][64 rows][CP]; rows per DMA instruction
   constexpr int NCS = CP / 64;
-  static_assert(PPP == 16 && SPP == 2 && NINST % NW == 0 && WPIECES % NW == 0 && R == 3, "the C = 128 geometry");
+  static_assert((CP == 128 || CP == 64) && SPX % W == 0 && RPS >= 1 && W % (NW * PPI) == 0 && W % 32 == 0, "geometry");
+  static_assert(NINST % NW == 0 && WPIECES % NW == 0 && SLOT % 256 == 0 && (R * SLOT) % 256 == 0, "geometry");
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sW = smem + R * SLOT;                                        // [WPIECES][64 lanes][16 B]
+  unsigned char* sW = smem + R * SLOT;                                        // the weight image of one phase
   float* tab = reinterpret_cast<float*>(sW + WBUF);                           // [nb][2][CP] scale, shift
   float* tabm = tab + RUA_MAX_BRANCH * 2 * CP;                                // [nb][3][64] bias, mask scale, mask shift of the block's output channels
   float* sred = tabm + RUA_MAX_BRANCH * 192;                                  // [8 waves][64] statistics partials of a member
@@ -80,8 +86,9 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pl = lane & 31, kh = lane >> 5;
-  const int pt = wv >> 1, coh = wv & 1;                                       // this wave's pixel tile (32 of the stage's 128 pixels) and output-channel tile
+  const int pg = wv >> 1, coh = wv & 1;                                       // this wave's pixel group (TPW tiles of the stage) and output-channel tile
   const int H = q.H, nb = q.nb;
+  auto swz = [](int i) { return PPP == 16 ? (i & 15) : ((i >> 1) & 7); };     // piece slot = piece ^ swz(row or pixel index): 16 pieces per 256-byte bank row, or 8 per half of it
 
   const int nwg = q.njobs, bid = blockIdx.x;
   if (bid >= nwg) return;
@@ -101,7 +108,13 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
       tabm[i * 192 + 64 + tid] = (q.aux[i] && q.mscale[i]) ? q.mscale[i][co0 + tid] : 1.f;
       tabm[i * 192 + 128 + tid] = (q.aux[i] && q.mshift[i]) ? q.mshift[i][co0 + tid] : 0.f;
     }
-  if (q.has_bn)
+  if constexpr (CP == 64) {
+    if (q.has_fold) {                                                         // every member derives (and job 0 publishes) its BatchNorm coefficients from the replicated statistics
+      rua_fold_members<NT, 64>([&](int m) -> const rua_bn_fold& { return q.f[m]; }, [](int) { return true; }, nb, job == 0, reinterpret_cast<double*>(smem), tid,
+                               [&](int m, int c, float scf, float shf) { tab[m * 2 * CP + c] = scf; tab[m * 2 * CP + CP + c] = shf; });
+    }
+  }
+  if (q.has_bn && !q.has_fold)
     for (int i = tid; i < nb * CP; i += NT) {
       const int m = i / CP, c = i - m * CP;
       tab[m * 2 * CP + c] = q.in_scale[m] ? q.in_scale[m][c] : 1.f;
@@ -113,52 +126,49 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   const int d0 = q.d[0], d1 = q.d[1], d2 = q.d[2], d3 = q.d[3];
   auto dil_of = [&](int b) { return b == 0 ? d0 : (b == 1 ? d1 : (b == 2 ? d2 : d3)); };
 
-  // ---- DMA addressing: lane l of instruction i (1 KiB = PPI pixels x 16 pieces) moves piece psrc of stage pixel i * PPI + (l >> 4) into slot
-  // position (l & 15) = psrc ^ (pixel & 15).  The instructions of a wave are 32 pixels apart: psrc is the same for all of them.
-  const int qd0 = wv * PPI + (lane >> 4);                                     // pixel of instruction 0 (< 32); instruction k: + k * 32
-  const int psrc = (lane & 15) ^ (qd0 & 15);
+  // ---- DMA addressing: lane l of instruction i (1 KiB = PPI pixels x PPP pieces) moves piece psrc of stage pixel i * PPI + l / PPP into slot
+  // position l % PPP = psrc ^ swz(pixel).  The instructions of a wave are NW * PPI pixels apart (a multiple of 16): psrc is the same for all of them.
+  const int qd0 = wv * PPI + lane / PPP;                                      // pixel of instruction 0 (< NW * PPI <= W); instruction k: + k * NW * PPI
+  const int psrc = (lane % PPP) ^ swz(qd0);
   unsigned xrel[NPX];
 #pragma unroll
-  for (int k = 0; k < NPX; ++k) {
-    const int x = (qd0 + k * NW * PPI) % W;
-    xrel[k] = (unsigned)((x * CP + psrc * 8) * 2);
-  }
-  static_assert(W % (NW * PPI) == 0, "an instruction's pixels lie in one row, the same for every lane (qd0 < NW * PPI)");
+  for (int k = 0; k < NPX; ++k) xrel[k] = (unsigned)((((qd0 + k * NW * PPI) % W) * CP + psrc * 8) * 2);
   auto row_of = [&](int k) { return (k * NW * PPI) / W; };                    // wave-uniform: the row validity below is a scalar select, never a branch around a DMA
   const unsigned pdst0 = (unsigned)(wv * 1024 + lane * 16);                   // this lane's piece of instruction 0 inside a slot; k: + k * NW * 1024
   const unsigned smem_a = (unsigned)(size_t)(lds_void_p)smem;
   const unsigned rowbytes = (unsigned)(W * CP * 2), imgbase = (unsigned)(n_ * H) * rowbytes;
 
   const int nph = nb * PPM;
-  struct Phase { int hb; bool valid; __amdgpu_buffer_rsrc_t rx; unsigned ca, choff; };
+  struct Phase { int hb; bool valid; __amdgpu_buffer_rsrc_t rx; unsigned ca; };
   auto phase = [&](int ph) {
     Phase p;
-    const int b = ph / PPM, pm = ph - b * PPM, ty = pm / NCH, ch = pm - ty * NCH;
+    const int b = ph / PPM, ty = ph - b * PPM;
     p.valid = ph < nph;
     const int bb = p.valid ? b : 0;
     p.hb = h0 + (ty - 1) * dil_of(bb);
     p.rx = make_rsrc(q.x[bb], q.xbytes);
-    p.choff = (unsigned)(ch * KC * 2);
-    p.ca = smem_a + (unsigned)((unsigned char*)(tab + bb * 2 * CP + ch * KC + psrc * 8) - smem);
+    p.ca = smem_a + (unsigned)((unsigned char*)(tab + bb * 2 * CP + psrc * 8) - smem);
     return p;
   };
-  // the RPS rows of stage sp of a phase -> slot at byte offset so
+  // one DMA instruction at a time (the loop deals them between its MFMAs: ten issued in one burst behind the barrier stood 0.5 - 1.6 us in the
+  // texture path's queue with the wave's MFMAs waiting behind them in program order)
+  auto issue_x1 = [&](const Phase& p, int sp, int k, unsigned so) {
+    const int h = p.hb + sp * RPS + row_of(k);
+    const bool ok = p.valid && (unsigned)h < (unsigned)H;
+    const unsigned base = ok ? imgbase + (unsigned)h * rowbytes : OOB;        // scalar select; OOB + xrel is still out of range: the lanes write zeros
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(p.rx, (lds_void_p)(smem + so + (k * NW + wv) * 1024), 16, base + xrel[k], 0, 0, 0);
+  };
   auto issue_x = [&](const Phase& p, int sp, unsigned so) {
 #pragma unroll
-    for (int k = 0; k < NPX; ++k) {
-      const int h = p.hb + sp * RPS + row_of(k);
-      const bool ok = p.valid && (unsigned)h < (unsigned)H;
-      const unsigned base = ok ? imgbase + (unsigned)h * rowbytes + p.choff : OOB;      // scalar select; OOB + xrel is still out of range: the lanes write zeros
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(p.rx, (lds_void_p)(smem + so + (k * NW + wv) * 1024), 16, base + xrel[k], 0, 0, 0);
-    }
+    for (int k = 0; k < NPX; ++k) issue_x1(p, sp, k, so);
   };
-  // The weights of a phase in LDS: [tap column 3][output channel 64][input channel 128] = the image of the pixel tiles (256-byte rows, 16-byte pieces
-  // XOR-swizzled with the row index on the DMA's source side), so a DMA instruction moves four whole 256-byte weight rows (fully coalesced).  The first
+  // The weights of a phase in LDS: [tap column 3][output channel 64][input channel CP] = the image of the pixel tiles (PXB-byte rows, 16-byte pieces
+  // XOR-swizzled with the row index on the DMA's source side), so a DMA instruction moves RPI whole weight rows (fully coalesced).  The first
   // build staged them fragment by fragment - a lane per (output channel, 16 bytes of a 32-byte segment): 32 partly used lines per instruction, and the
   // stamps showed ~30 ns per weight instruction against ~12.5 ns per row instruction in the texture path.
-  static_assert(WPIECES == 3 * 16 && KC * 2 == 256 && NCH == 1, "a tap column = 16 instructions of 4 weight rows");
-  const int wrow0 = 4 * (wv & 3) + (lane >> 4);                               // weight row of instruction idx inside its 16-row group: idx & 3 == wv & 3 for every instruction of the wave
-  const unsigned wsrc = (unsigned)((wrow0 * CP + (((lane & 15) ^ wrow0) * 8)) * 2);
+  constexpr int IP16 = 16 / RPI;                                              // instructions per 16 weight rows (the swizzle's period): idx % IP16 == wv % IP16 for every instruction of the wave
+  const int wrow0 = RPI * (wv % IP16) + lane / PPP;                           // the lane's weight row modulo 16
+  const unsigned wsrc = (unsigned)((wrow0 * CP + (((lane % PPP) ^ swz(wrow0)) * 8)) * 2);
   struct WPhase { __amdgpu_buffer_rsrc_t rw; unsigned base; };
   auto wphase = [&](int ph) {
     WPhase w;
@@ -170,22 +180,15 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
     return w;
   };
   auto issue_w1 = [&](const WPhase& w, int i) {
-    const int idx = i * NW + wv;                                                // tap column idx >> 4, weight rows 4 (idx & 15) ..
-    const unsigned off = w.base + (unsigned)((((idx >> 4) * CP + 4 * ((idx & 15) & ~3)) * CP) * 2);
+    const int idx = i * NW + wv;                                                // tap column idx / (WPIECES / 3), weight rows RPI * (idx % (WPIECES / 3)) ..
+    const int tx = idx / (WPIECES / 3), j = idx % (WPIECES / 3);
+    const unsigned off = w.base + (unsigned)(((tx * CP + 16 * (j / IP16)) * CP) * 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w.rw, (lds_void_p)(sW + idx * 1024), 16, off, 0, 0, 0);
   };
   auto issue_w = [&](int ph) {
     const WPhase w = wphase(ph);
 #pragma unroll
     for (int i = 0; i < WPW; ++i) issue_w1(w, i);
-  };
-  // one DMA instruction at a time (the loop deals them between its MFMAs: ten issued in one burst behind the barrier stood 0.5 - 1.6 us in the
-  // texture path's queue - one 1 KiB instruction per ~10.6 ns and CU - with the wave's MFMAs waiting behind them in program order)
-  auto issue_x1 = [&](const Phase& p, int sp, int k, unsigned so) {
-    const int h = p.hb + sp * RPS + row_of(k);
-    const bool ok = p.valid && (unsigned)h < (unsigned)H;
-    const unsigned base = ok ? imgbase + (unsigned)h * rowbytes + p.choff : OOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(p.rx, (lds_void_p)(smem + so + (k * NW + wv) * 1024), 16, base + xrel[k], 0, 0, 0);
   };
   // BatchNorm (+ ReLU) of a landed stage, in place, on this thread's own DMA pieces (raw LDS accesses: conv_band.hip says why)
   auto tr_stage = [&](const Phase& p, int sp, unsigned so) {
@@ -221,9 +224,9 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
     }
   };
 
-  // this lane's output pixel: stage pixel pt * 32 + pl = row (of the stage) jr, column xo
-  const int qo = pt * 32 + pl, jr = qo / W, xo = qo - jr * W;
-  // MULTI: a member's per-channel statistics, summed over the block (the waves' partials are in sred since the member's epilogue)
+  // this lane's output pixels: tile t of the wave = stage pixel (pg * TPW + t) * 32 + pl = row jr (the same for both tiles: 64 | W), column xo + 32 t
+  const int qo = pg * TPW * 32 + pl, jr = qo / W, xo = qo - jr * W;
+  // a member's per-channel statistics, summed over the block (the waves' partials are in sred since the member's epilogue)
   auto stats_flush = [&](int b) {
     if (tid < 128 && q.stats_mode[b] != 0) {
       const int ch = tid >> 6, ln = tid & 63, idx = ln & 31, khh = ln >> 5;
@@ -234,11 +237,13 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
       unsafeAtomicAdd(&q.stats[b][(size_t)(job & (q.stats_R[b] - 1)) * 2 * CP + st * CP + c], (double)t);
     }
   };
-  f32x16 acc[SPP];
+  f32x16 acc[SPP][TPW];
 #pragma unroll
   for (int r = 0; r < SPP; ++r)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[r][k] = 0.f;
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[r][t][k] = 0.f;
 
   // ---- prologue: the weights of phase 0 (-> registers), stages 0 and 1 -------------------------------------------------------------
   Phase cur = phase(0), nxt = phase(1);
@@ -249,10 +254,16 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   if (bn) tr_stage(cur, 0, 0u);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                              // everyone's pieces of the weights have landed
-  // this wave's weight fragments: row coh * 32 + pl of the tap column's image, k-step ks at e ^ (ks << 5) like the pixel fragments
-  static_assert((R * SLOT) % 256 == 0, "the weight image keeps bits 0 - 7 of its rows clear");
-  const unsigned ew0 = (unsigned)(R * SLOT + (coh * 32 + pl) * 256 + (((pl & 15) >> 1) << 5) + (((kh ^ pl) & 1) << 4));
-  auto wfrag = [&](int tx, int ks) { return *reinterpret_cast<const bf16x8*>(smem + ((ew0 + (unsigned)(tx * 16384)) ^ (unsigned)(ks << 5))); };
+  // Fragment addresses with ONE vector instruction per read: slot = (2 ks + kh) ^ sw = ((ks ^ (sw >> 1)) << 1) | ((kh ^ sw) & 1), so with
+  // e = base + row * PXB + ((sw >> 1) << 5) + (((kh ^ sw) & 1) << 4) the address of k-step ks is e ^ (ks << 5): row * PXB and the bases (multiples of
+  // 256 from LDS address 0: no static LDS in this kernel) leave bits 5 .. to the swizzle.  The same for pixel rows and weight rows.
+  auto frag = [&](unsigned e, int ks) { return *reinterpret_cast<const bf16x8*>(smem + (e ^ (unsigned)(ks << 5))); };
+  auto eaddr = [&](unsigned base, int row) {
+    const int sw = swz(row);
+    return base + (unsigned)(row * PXB + ((sw >> 1) << 5) + (((kh ^ sw) & 1) << 4));
+  };
+  const unsigned ew0 = eaddr((unsigned)(R * SLOT), coh * 32 + pl);           // this wave's weight fragments: row coh * 32 + pl of a tap column's image
+  auto wfrag = [&](int tx, int ks) { return frag(ew0 + (unsigned)(tx * TAPB), ks); };
   bf16x8 wf[3][KS];
 #pragma unroll
   for (int tx = 0; tx < 3; ++tx)
@@ -262,34 +273,27 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
 
   unsigned so_cur = 0, so_nxt = SLOT, so_iss = 2 * SLOT;
   B128_T(0);
-  // The weight buffer is single (two do not fit): the fragments of phase p + 1 are read into the registers of phase p's fragments as the LAST stage
-  // of phase p retires them, tap column by tap column under its MFMAs; every wave has read them when it reaches the barrier of phase p + 1's first
+  // The weight buffer is single (two do not fit at C = 128): the fragments of phase p + 1 are read into the registers of phase p's fragments as the LAST
+  // stage of phase p retires them, k-step by k-step under its MFMAs; every wave has read them when it reaches the barrier of phase p + 1's first
   // stage, which is where the DMAs of phase p + 2 are issued.  They are waited for at the end of that stage (one stage to land, from L2) and made
   // visible by the barrier of the stage that reads them.
-  // Fragment addresses with ONE vector instruction per read: slot = (2 ks + kh) ^ sw = ((ks ^ (sw >> 1)) << 1) | ((kh ^ sw) & 1), so with
-  // e = slot base + pixel * 256 + ((sw >> 1) << 5) + (((kh ^ sw) & 1) << 4) the address of k-step ks is e ^ (ks << 5): pixel * 256 and the slot bases
-  // (multiples of 256 from LDS address 0: no static LDS in this kernel) leave bits 5 - 7 to the swizzle.
-  static_assert(SLOT % 256 == 0, "slot bases keep bits 0 - 7 clear");
-  auto frag = [&](unsigned e, int ks) {
-    return *reinterpret_cast<const bf16x8*>(smem + (e ^ (unsigned)(ks << 5)));
-  };
   for (int ph = 0; ph < nph; ++ph) {
     const int b = ph / PPM;
     const int d = dil_of(b);
-    // b-operand fragment addresses: output pixel (jr, xo), tap column tx reads stage pixel jr * W + xo + (tx - 1) d - or the slot's zero pixel
-    unsigned eoff[3];
+    // b-operand fragment addresses: output pixel (jr, xo + 32 t), tap column tx reads stage pixel jr * W + xo + 32 t + (tx - 1) d - or the slot's zero pixel
+    unsigned eoff[3][TPW];
 #pragma unroll
-    for (int tx = 0; tx < 3; ++tx) {
-      const int xx = xo + (tx - 1) * d;
-      const bool in = (unsigned)xx < (unsigned)W;
-      const int j = jr * W + xx;
-      const int sw = in ? (j & 15) : 0;
-      eoff[tx] = (in ? (unsigned)(j * PXB) : (unsigned)ZOFF) + (unsigned)(((sw >> 1) << 5) + (((kh ^ sw) & 1) << 4));
-    }
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int xx = xo + 32 * t + (tx - 1) * d;
+        const bool in = (unsigned)xx < (unsigned)W;
+        eoff[tx][t] = in ? eaddr(0u, jr * W + xx) : (unsigned)ZOFF + (unsigned)(kh << 4);      // (zero pixel: swizzle 0)
+      }
     const bool last = ph % PPM == PPM - 1;
     // the epilogue's mask source: fetched two stages early (a dependent HBM round trip in front of the epilogue otherwise)
-    uint4 av[SPP][2];
-    const size_t pixg = (size_t)((n_ * H + h0 + jr) * W + xo);         // this lane's pixel in stage 0 of the band; stage sp: + sp * RPS rows
+    uint4 av[SPP][TPW][2];
+    const size_t pixg = (size_t)((n_ * H + h0 + jr) * W + xo);         // tile 0 in stage 0 of the band; tile t: + 32 t, stage sp: + sp * RPS rows
     auto stage = [&](auto spc) {
       constexpr int sp = decltype(spc)::value;
       __builtin_amdgcn_s_barrier();                          // this stage is complete and normalised; every wave is done with the stage before (and, sp = 0, holds its weight fragments)
@@ -305,30 +309,43 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
 #pragma unroll
         for (int r = 0; r < SPP; ++r)
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
-            av[r][g] = auxp ? ldg16(auxp + ((pixg + (size_t)(r * RPS) * W) * CP + co0 + coh * 32 + 16 * g + 8 * kh) * 2) : make_uint4(0, 0, 0, 0);
+          for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+              av[r][t][g] = auxp ? ldg16(auxp + ((pixg + (size_t)(r * RPS) * W + 32 * t) * CP + co0 + coh * 32 + 16 * g + 8 * kh) * 2) : make_uint4(0, 0, 0, 0);
       }
       B128_E(1);
-      const unsigned e0 = so_cur + eoff[0], e1 = so_cur + eoff[1], e2 = so_cur + eoff[2];
-      auto eof = [&](int tx) { return tx == 0 ? e0 : (tx == 1 ? e1 : e2); };
-      const WPhase wn = wphase(ph + 1);
-      // 24 MFMAs in program order, PF fragment reads ahead of the product that consumes them, the stage's DMA instructions dealt between them: stage 0
-      // the WPW weight pieces of the next phase (in FRONT of the rows: the wait at the end of the stage then leaves only the rows in flight) and
-      // the NPX row pieces of the stage two ahead (into the slot the stage before this one has just left), stage 1 its NPX row pieces - and, as a
-      // tap column's fragments retire, the next phase's weight fragments into their registers.  (An LDS-DMA is an LDS write the compiler cannot
-      // tell from the fragment reads' addresses: it keeps both in source order, which is the order wanted here.)
-      constexpr int PF = 4, NI = 3 * KS;
-      constexpr int NDMA = sp == 0 ? WPW + NPX : NPX, DSTEP = sp == 0 ? 2 : 5, D0 = 1;
-      static_assert(D0 + (NDMA - 1) * DSTEP < NI, "every DMA has its MFMA");
-      bf16x8 fr[8];
+      unsigned e[3][TPW];
 #pragma unroll
-      for (int i = 0; i < PF; ++i) fr[i] = frag(eof(i / KS), i % KS);
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) e[tx][t] = so_cur + eoff[tx][t];
+      const WPhase wn = wphase(ph + 1);
+      // 3 KS k-steps of TPW MFMAs in program order, PF fragment reads ahead of the product that consumes them, the stage's DMA instructions dealt between
+      // them: stage 0 the WPW weight pieces of the next phase (in FRONT of the rows: the wait at the end of the stage then leaves only the rows in
+      // flight) and the NPX row pieces of the stage two ahead (into the slot the stage before this one has just left), stage 1 its NPX row pieces -
+      // and, as a k-step's fragment retires, the next phase's weight fragment into its registers.  (An LDS-DMA is an LDS write the compiler cannot
+      // tell from the fragment reads' addresses: it keeps both in source order, which is the order wanted here.)
+      constexpr int NI = 3 * KS, PFK = 4 / TPW;              // k-steps; k-steps of fragment reads in flight (four fragments)
+      constexpr int NDMA = sp == 0 ? WPW + NPX : NPX, D0 = 1, DSTEP = (NI - 1 - D0) / (NDMA > 1 ? NDMA - 1 : 1) < 5 ? (NI - 1 - D0) / (NDMA > 1 ? NDMA - 1 : 1) : 5;
+      static_assert(DSTEP >= 1 && D0 + (NDMA - 1) * DSTEP < NI, "every DMA has its k-step");
+      bf16x8 fr[8][TPW];                                   // ring of 8 k-steps (> PFK: a slot is rewritten only after its product has been issued)
+#pragma unroll
+      for (int i = 0; i < PFK; ++i)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) fr[i][t] = frag(e[i / KS][t], i % KS);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int tx = i / KS, ks = i % KS;
-        if (i + PF < NI) fr[(i + PF) & 7] = frag(eof((i + PF) / KS), (i + PF) % KS);
-        if constexpr (!(RUA_B128_ABLATE & 8)) acc[sp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tx][ks], fr[i & 7], acc[sp], 0, 0, 0);
-        else asm volatile("" :: "v"(fr[i & 7]), "v"(wf[tx][ks]));
+        if (i + PFK < NI) {
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) fr[(i + PFK) & 7][t] = frag(e[(i + PFK) / KS][t], (i + PFK) % KS);
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          if constexpr (!(RUA_B128_ABLATE & 8)) acc[sp][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tx][ks], fr[i & 7][t], acc[sp][t], 0, 0, 0);
+          else asm volatile("" :: "v"(fr[i & 7][t]), "v"(wf[tx][ks]));
+        }
         if constexpr (sp == SPP - 1) wf[tx][ks] = wfrag(tx, ks);   // retired: the next phase's fragment takes its registers
         if (i >= D0 && (i - D0) % DSTEP == 0 && (i - D0) / DSTEP < NDMA) {
           const int j = (i - D0) / DSTEP;
@@ -342,12 +359,12 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
       }
       if constexpr (!(RUA_B128_ABLATE & 8)) {
         // the interleave, spelled out for the scheduler (left alone it sinks every fragment read to one MFMA in front of its use: an LDS round trip per product)
-        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, PFK * TPW, 0);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           constexpr int wfr = sp == SPP - 1 ? 1 : 0;
-          if (i + PF < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1 + wfr, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, TPW, 0);
+          if (i + PFK < NI) __builtin_amdgcn_sched_group_barrier(0x100, TPW + wfr, 0);
           else if (wfr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           if (i >= D0 && (i - D0) % DSTEP == 0 && (i - D0) / DSTEP < NDMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
@@ -367,7 +384,6 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
       B128_T(4);
       B128_E(3);
     };
-    static_assert(SPP == 2, "two stages per phase");
     stage(B128IC<0>{});
     stage(B128IC<1>{});
     if (last) {
@@ -382,44 +398,46 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s1[g][j] = 0.f; s2[g][j] = 0.f; }
 #pragma unroll
-      for (int r = 0; r < SPP; ++r) {
-        float v[2][8];
+      for (int r = 0; r < SPP; ++r)
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int t = 0; t < TPW; ++t) {
+          float v[2][8];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float a = acc[r][(2 * g) * 4 + j], b2 = acc[r][(2 * g + 1) * 4 + j];
-            if (g == 0 && j == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
-            else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
-            v[g][j] = a;
-            v[g][4 + j] = b2;
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float a = acc[r][t][(2 * g) * 4 + j], b2 = acc[r][t][(2 * g + 1) * 4 + j];
+              if (g == 0 && j == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+              else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+              v[g][j] = a;
+              v[g][4 + j] = b2;
+            }
+          unsigned char* yrow = yp + ((pixg + (size_t)(r * RPS) * W + 32 * t) * CP) * 2;
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int cl = coh * 32 + 16 * g + 8 * kh;        // channel inside the block's slice
+            float a8[8];
+            ET<T>::unpack(av[r][t][g], a8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g][j] += tb[cl + j];
+            if (auxp) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[g][j] = (fmaf(tb[64 + cl + j], a8[j], tb[128 + cl + j]) > 0.f) ? v[g][j] : 0.f;
+            }
+            if (smode == 1) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], v[g][j], s2[g][j]); }
+            } else if (smode == 2) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], a8[j], s2[g][j]); }
+            }
+            stg16(yrow + (co0 + cl) * 2, ET<T>::pack(v[g]));
           }
-        unsigned char* yrow = yp + ((pixg + (size_t)(r * RPS) * W) * CP) * 2;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int cl = coh * 32 + 16 * g + 8 * kh;        // channel inside the block's slice
-          float a8[8];
-          ET<T>::unpack(av[r][g], a8);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[g][j] += tb[cl + j];
-          if (auxp) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[g][j] = (fmaf(tb[64 + cl + j], a8[j], tb[128 + cl + j]) > 0.f) ? v[g][j] : 0.f;
-          }
-          if (smode == 1) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], v[g][j], s2[g][j]); }
-          } else if (smode == 2) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s1[g][j] += v[g][j]; s2[g][j] = fmaf(v[g][j], a8[j], s2[g][j]); }
-          }
-          stg16(yrow + (co0 + cl) * 2, ET<T>::pack(v[g]));
+          for (int k = 0; k < 16; ++k) acc[r][t][k] = 0.f;
         }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[r][k] = 0.f;
-      }
       if (smode != 0) {
-        // 32 partial sums per lane -> per-channel sums over the wave's 32 pixels by a transposing butterfly (conv_band64m's), lane l ends with value l
+        // 32 partial sums per lane -> per-channel sums over the wave's 32 pixel columns by a transposing butterfly (conv_band64m's), lane l ends with value l
         float vals[32];
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -459,17 +477,22 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
 // touched 32 partly used lines per instruction and cost ~30 ns each in the texture path against ~12.5 ns for a row instruction; as whole swizzled rows - the
 // form above - the first form went 43 - 46 -> 37 - 39 us and the specialised one lost its reason.)
 
-template <int CP, int W, int KC, int R> __global__ __launch_bounds__(512) void conv_band128m(const Band128K q) { conv_band128_body<CP, W, KC, R>(q); }
+template <int CP, int W> __global__ __launch_bounds__(512) void conv_band128m(const Band128K q) { conv_band128_body<CP, W>(q); }
 
 // ---- host side (called by rua_conv_fwd_group, conv_mfma.hip) -----------------------------------------------------------------------
+static int band128_rows(int C, int W) { return 2 * ((32768 / (C * 2)) / W); }          // rows per band
 bool rua_band128m_ok(const rua_conv_desc* d, int n) {
-  if (!g_tune.conv_band128m || n < 1 || n > RUA_MAX_BRANCH) return false;
+  if (n < 1 || n > RUA_MAX_BRANCH) return false;
   const rua_conv_desc& a = d[0];
-  if (a.dtype != RUA_BF16 || a.W != 64 || a.H % 4 != 0 || (long long)a.N * a.H * a.W < 1024) return false;
+  const int Cc = a.Cout;
+  if (Cc == 128) { if (!(g_tune.conv_band128m & 1) || (a.W != 64 && a.W != 128)) return false; }
+  else if (Cc == 64) { if (!(g_tune.conv_band128m & 2) || (a.W != 64 && a.W != 128 && a.W != 256)) return false; }
+  else return false;
+  if (a.dtype != RUA_BF16 || a.H % band128_rows(Cc, a.W) != 0 || (long long)a.N * a.H * a.W < 1024) return false;
   for (int i = 0; i < n; ++i) {
     const rua_conv_desc& m = d[i];
     const rua_conv_seg& g = m.seg[0];
-    if (m.nseg != 1 || m.dtype != RUA_BF16 || g.taps != 9 || g.up_shift != 0 || g.C != 128 || m.Cout != 128 || m.stride != 1 ||
+    if (m.nseg != 1 || m.dtype != RUA_BF16 || g.taps != 9 || g.up_shift != 0 || g.C != Cc || m.Cout != Cc || m.stride != 1 ||
         m.out_stride != 1 || m.OH != m.H || m.OW != m.W || g.Hs != m.H || g.Ws != m.W || g.dil < 1) return false;
     if (m.N != a.N || m.H != a.H || m.W != a.W || !m.y) return false;
     for (int j = 0; j < i; ++j) if (d[j].y == m.y) return false;               // independent outputs
@@ -478,10 +501,23 @@ bool rua_band128m_ok(const rua_conv_desc* d, int n) {
     if (m.stats_mode != 0 && (!m.stats || m.stats_replicas < 1 || (m.stats_replicas & (m.stats_replicas - 1)))) return false;
     if (m.stats_mode == 2 && m.aux_mode != 2) return false;
     if (m.stats_mode < 0 || m.stats_mode > 2) return false;
-    if (m.in_fold) return false;                                               // (coefficients are given at this level: rua_bn_fwd makes them)
-    if ((m.in_scale != nullptr) != (a.in_scale != nullptr) || (m.in_shift != nullptr) != (m.in_scale != nullptr) || m.in_relu != a.in_relu) return false;
+    if (m.in_fold && Cc != 64) return false;                                   // (C = 128: the coefficients are given - rua_bn_fwd makes them at that level)
+    if ((m.in_fold != nullptr) != (a.in_fold != nullptr) || (m.in_scale != nullptr) != (a.in_scale != nullptr) || m.in_relu != a.in_relu) return false;
+    if (m.in_fold && (m.in_scale || m.in_shift)) return false;
+    if ((m.in_shift != nullptr) != (m.in_scale != nullptr)) return false;
   }
   return true;
+}
+
+template <int CP, int W>
+static int band128_launch(const Band128K& q, hipStream_t st) {
+  constexpr int smem = 3 * (32768 + 256) + 3 * 64 * CP * 2 + (RUA_MAX_BRANCH * 2 * CP + RUA_MAX_BRANCH * 192 + 8 * 64) * 4;
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  static RuaPerDevFlag attr;
+  if (!attr.get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band128m<CP, W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr.get() = true; }
+  hipLaunchKernelGGL((conv_band128m<CP, W>), dim3(q.njobs), dim3(512), smem, st, q);
+  RUA_LAUNCH_CHECK("conv_band128m");
+  return RUA_OK;
 }
 
 int rua_launch_band128m(const rua_conv_desc* d, int n, hipStream_t st) {
@@ -496,24 +532,26 @@ int rua_launch_band128m(const rua_conv_desc* d, int n, hipStream_t st) {
     q.aux[i] = m.aux_mode == 2 ? (const unsigned char*)m.aux : nullptr;
     q.mscale[i] = m.mscale; q.mshift[i] = m.mshift;
     q.stats[i] = m.stats; q.stats_mode[i] = m.stats ? m.stats_mode : 0; q.stats_R[i] = m.stats_replicas > 0 ? m.stats_replicas : 1;
+    if (m.in_fold) {
+      q.f[i] = *m.in_fold;
+      const rua_bn_fold& f = q.f[i];
+      RUA_CHECK_ARG(f.stats && f.replicas >= 1 && f.count > 0 && f.gamma && f.beta && f.scale && f.shift, "rua_conv_fwd_group: incomplete in_fold");
+      RUA_CHECK_ARG((f.moving_mean == nullptr) == (f.moving_var == nullptr), "rua_conv_fwd_group: in_fold needs both moving statistics or neither");
+    }
   }
   for (int i = n; i < RUA_MAX_BRANCH; ++i) { q.d[i] = 1; q.stats_R[i] = 1; }
   const rua_conv_desc& a = d[0];
+  const int Cc = a.Cout;
   q.dbg = g_tune.band_dbg;
   q.stamps = (unsigned long long*)(uintptr_t)g_tune.dbg_ptr;
-  q.has_bn = a.in_scale ? 1 : 0;
+  q.has_fold = a.in_fold ? 1 : 0;
+  q.has_bn = (a.in_fold || a.in_scale) ? 1 : 0;
   q.in_relu = a.in_relu;
   q.N = a.N; q.H = a.H;
-  RUA_CHECK_ARG((size_t)a.N * a.H * a.W * 128 * 2 < 0x7FFFFF00ull, "rua_conv_fwd_group: tensor of 2 GiB or more");
-  q.xbytes = (unsigned)((size_t)a.N * a.H * a.W * 128 * 2);
-  constexpr int CP = 128, R = 3;
-  q.bands = a.H / 4;
-  q.njobs = a.N * q.bands * (CP / 64);
-  constexpr int smem = R * (128 * 256 + 256) + 48 * 1024 + (RUA_MAX_BRANCH * 2 * CP + RUA_MAX_BRANCH * 192 + 8 * 64) * 4;
-  static_assert(smem <= 160 * 1024, "LDS budget");
-  static RuaPerDevFlag attr;
-  if (!attr.get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band128m<128, 64, 128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr.get() = true; }
-  hipLaunchKernelGGL((conv_band128m<128, 64, 128, 3>), dim3(q.njobs), dim3(512), smem, st, q);
-  RUA_LAUNCH_CHECK("conv_band128m");
-  return RUA_OK;
+  RUA_CHECK_ARG((size_t)a.N * a.H * a.W * Cc * 2 < 0x7FFFFF00ull, "rua_conv_fwd_group: tensor of 2 GiB or more");
+  q.xbytes = (unsigned)((size_t)a.N * a.H * a.W * Cc * 2);
+  q.bands = a.H / band128_rows(Cc, a.W);
+  q.njobs = a.N * q.bands * (Cc / 64);
+  if (Cc == 128) return a.W == 64 ? band128_launch<128, 64>(q, st) : band128_launch<128, 128>(q, st);
+  return a.W == 64 ? band128_launch<64, 64>(q, st) : (a.W == 128 ? band128_launch<64, 128>(q, st) : band128_launch<64, 256>(q, st));
 }

@@ -135,15 +135,25 @@ __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
     for (int k = 0; k < NPX; ++k)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(p.rx, (lds_void_p)(smem + so + DMA0 * PXB + (k * NW + wv) * 1024), 16, base + xrel[k], 0, 0, 0);
   };
-  // weight piece idx of kernel row (phase) ph into buffer ph & 1: tap 3 ty + (idx >> 3), k-step (idx >> 1) & 3, output-channel half idx & 1
+  // weight piece idx of kernel row (phase) ph into buffer ph & 1.  Round 5: the buffer holds the kernel row as [tap column 3][output channel 64][input
+  // channel 64] - 128-byte rows with the pixel slots' swizzle (piece ^ ((row >> 1) & 7)) on the DMA's source side -, an instruction moves EIGHT WHOLE
+  // weight rows (coalesced).  Rounds 3 - 4 staged a fragment per lane (32 rows x 32 bytes per instruction: 32 partly used lines, ~30 ns per instruction
+  // in the texture path against ~12.5 ns for a row instruction - measured on conv_band128m, conv_band128.hip).
+  const int wrl = (lane >> 3);                                                // row of the instruction's eight, piece slot lane & 7
   auto issue_w = [&](int ph, int idx) {
     const int b = ph / 3, ty = ph - 3 * b;
     if (idx < WPIECES && ph < 3 * nb) {
       const __amdgpu_buffer_rsrc_t rw = make_rsrc(q.w[b], (unsigned)(9 * C * C * 2));
-      const int t = ty * 3 + (idx >> 3), ks = (idx >> 1) & 3, ch = idx & 1;
-      const unsigned off = (unsigned)(((t * C + ch * 32 + pl) * C + ks * 16 + kh * 8) * 2);
+      const int t = ty * 3 + (idx >> 3), row = 8 * (idx & 7) + wrl;
+      const unsigned off = (unsigned)(((t * C + row) * C + (((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_p)(sW + (ph & 1) * WBUF + idx * 1024), 16, off, 0, 0, 0);
     }
+  };
+  // this wave's fragment of tap column tx, k-step ks: row coh * 32 + pl of the image, piece 2 ks + kh at slot ^ ((row >> 1) & 7)
+  const unsigned wfo = (unsigned)((coh * 32 + pl) * 128);
+  const int wfs = (pl >> 1) & 7;
+  auto wfrag = [&](int buf, int tx, int ks) {
+    return *reinterpret_cast<const bf16x8*>(sW + buf * WBUF + tx * 8192 + wfo + (((2 * ks + kh) ^ wfs) * 16));
   };
   // BatchNorm (+ ReLU) of a landed row, in place, on this thread's own DMA pieces (raw LDS accesses: see conv_band.hip)
   auto tr_valid = [&](const Phase& p, int r) { return bn && p.valid && (unsigned)(p.hb + r) < (unsigned)H; };
@@ -250,11 +260,10 @@ __device__ __forceinline__ void conv_band64_body(const Band64K& q) {
       }
       if (r == 0) {
         // this wave's fragments of the kernel row (its output-channel half): landed long ago (issued two phases back), visible since the barrier
-        const unsigned char* wb = sW + (ph & 1) * WBUF + coh * 1024 + lane * 16;
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) wf[tx][ks] = *reinterpret_cast<const bf16x8*>(wb + ((tx * 4 + ks) * 2) * 1024);
+          for (int ks = 0; ks < 4; ++ks) wf[tx][ks] = wfrag(ph & 1, tx, ks);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else if (r <= 3) {
         issue_w(ph + 2, (r - 1) * NW + wv);              // the kernel row two phases ahead into the buffer every wave has just finished reading

@@ -2294,14 +2294,14 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
   g_group_last_grids = n;
   g_group_last_band = 0;
   g_group_last_chain = 0;
-  if (rua_band64m_ok(d, n)) {                               // the C = 64 level: one row-streaming launch for all members (conv_band64.hip)
-    const int rc = rua_launch_band64m(d, n, st);
-    if (rc == RUA_OK) { g_group_last_grids = 1; g_group_last_band = 1; }
-    return rc;
-  }
-  if (n >= 2 && rua_band128m_ok(d, n)) {                    // the C = 128 level on 64-pixel rows (conv_band128.hip)
+  if (n >= 2 && rua_band128m_ok(d, n)) {                    // C = 128 / C = 64 on whole rows: two-row stages, weights of a kernel row in registers (conv_band128.hip)
     const int rc = rua_launch_band128m(d, n, st);
     if (rc == RUA_OK) { g_group_last_grids = 1; g_group_last_band = 2; }
+    return rc;
+  }
+  if (rua_band64m_ok(d, n)) {                               // the C = 64 level, round-3 form: one row-streaming launch for all members (conv_band64.hip)
+    const int rc = rua_launch_band64m(d, n, st);
+    if (rc == RUA_OK) { g_group_last_grids = 1; g_group_last_band = 1; }
     return rc;
   }
   if (n == 1 || !g_tune.conv_group) {

@@ -1705,18 +1705,29 @@ BAND64M_CASES = [
     (2, 64, 64, [1, 3, 15], "first", 128),            # coefficients given (in_scale / in_shift) + ReLU on load, statistics
     (1, 36, 64, [3, 31, 15, 1], "dgrad", 128),        # 9 bands, four members, a dilation wider than half the row
     (3, 8, 64, [15, 3], "first_scale", 128),          # two bands: every row of the d = 15 member's outer kernel rows is padding
+    (1, 128, 128, [1, 3, 15], "dgrad", 128),          # one row per stage, two-row bands (cfg4's level 3)
+    (1, 64, 64, [1, 3, 15, 31], "first", 64),         # C = 64 on 64-pixel rows (cfg5's level 2): four rows per stage, eight-row bands, in_fold
 ]
 
 
 @pytest.mark.parametrize("case", BAND64M_CASES)
 def test_conv_group_band64_multi(case):
+    try:
+        _band_multi(case)
+    finally:
+        L.lib().set_tuning(conv_band128m=1, conv_band64m=1)      # the defaults, whatever happened
+
+
+def _band_multi(case):
     """rua_conv_fwd_group at C = Cout = 64 -> conv_band64m: the independent 3x3 convolutions of a level-2 ResBlock (model2.py:17-24 first
     convs of every dilation branch; their data gradients) as ONE row-streaming launch, every member with its own normalise-on-load,
     bias, ReLU mask and statistics.  Against float64 convolutions of the bf16-rounded operands (and, for the data-gradient form,
     against the members run one by one on the implicit-GEMM kernel: outputs to bf16 rounding, statistics to fp32 partial-sum order)."""
     N, H, W, dils, kind = case[:5]
     Cs = case[5] if len(case) > 5 else 64
-    key = "conv_band64m" if Cs == 64 else "conv_band128m"
+    L.lib().set_tuning(conv_band128m=3)                       # (default 1: C = 128 only; this test runs the C = 64 form of the kernel too)
+    # C = 64 runs on conv_band128m's two-tiles-per-wave form since round 5 (tuning key conv_band128m bit 1; bit 1 off: conv_band64m, which the second
+    # pass below also exercises), C = 128 on its one-tile form (bit 0)
     dt = L.RUA_BF16
     lib = L.lib()
     rng = np.random.default_rng(H + W + len(dils) + len(kind))
@@ -1782,7 +1793,7 @@ def test_conv_group_band64_multi(case):
     arr, ys, sts, keep = build(True)
     assert lib.raw("rua_conv_group_band_ok")(arr, nb) == 1
     lib.call("rua_conv_fwd_group", arr, nb, stream())
-    assert lib.raw("rua_conv_group_last_band")() == (1 if Cs == 64 else 2) and lib.raw("rua_conv_group_last_grids")() == 1
+    assert lib.raw("rua_conv_group_last_band")() == 2 and lib.raw("rua_conv_group_last_grids")() == 1
     torch.cuda.synchronize()
     if kind == "first" and Cs == 64:                          # every member published its coefficients and moved its moving statistics once
         for b in range(nb):
@@ -1810,17 +1821,18 @@ def test_conv_group_band64_multi(case):
             assert rel_err(stv[:Cs], exp.sum(axis=(0, 1, 2))) < 5 * tol(dt) + 1e-4, b
             assert rel_err(stv[Cs:], s2) < 5 * tol(dt) + 1e-4, b
     if not first:                                              # the same members through the implicit-GEMM kernel, one grid or one by one
-        lib.set_tuning(**{key: 0})
-        try:
-            arr2, ys2, sts2, _ = build(True)
-            lib.call("rua_conv_fwd_group", arr2, nb, stream())
-            assert lib.raw("rua_conv_group_last_band")() == 0
-            torch.cuda.synchronize()
-        finally:
-            lib.set_tuning(**{key: 1})
-        for b in range(nb):
-            assert rel_err(ys[b].float().cpu().numpy(), ys2[b].float().cpu().numpy()) < tol(dt)
-            assert np.allclose(sts[b].cpu().numpy().reshape(R, -1).sum(0), sts2[b].cpu().numpy().reshape(R, -1).sum(0), rtol=1e-3, atol=1e-2)
+        for keys, flag in (([("conv_band128m", 0)], 1 if Cs == 64 else 0), ([("conv_band128m", 0), ("conv_band64m", 0)], 0)):
+            lib.set_tuning(**dict(keys))
+            try:
+                arr2, ys2, sts2, _ = build(True)
+                lib.call("rua_conv_fwd_group", arr2, nb, stream())
+                assert lib.raw("rua_conv_group_last_band")() == flag
+                torch.cuda.synchronize()
+            finally:
+                lib.set_tuning(conv_band128m=3, conv_band64m=1)
+            for b in range(nb):
+                assert rel_err(ys[b].float().cpu().numpy(), ys2[b].float().cpu().numpy()) < tol(dt)
+                assert np.allclose(sts[b].cpu().numpy().reshape(R, -1).sum(0), sts2[b].cpu().numpy().reshape(R, -1).sum(0), rtol=1e-3, atol=1e-2)
 
 
 @pytest.mark.parametrize("N,H,W,Cs,Cout,dil", [(8, 64, 64, 128, 128, 3), (4, 32, 32, 256, 256, 15), (8, 16, 16, 512, 512, 1), (2, 40, 24, 192, 128, 1)])

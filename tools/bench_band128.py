@@ -20,7 +20,7 @@ def main():
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     sweep = torch.zeros(128 << 20, dtype=torch.float32, device=dev)
     ws = torch.zeros(16 << 20, dtype=torch.float32, device=dev)
-    N, HW, Cc, dils = 8, 64, 128, [1, 3, 15]
+    N, HW, Cc, dils = (8, 64, 128, [1, 3, 15]) if os.environ.get("BB_LEVEL", "3") == "3" else (8, 128, 64, [1, 3, 15, 31])    # BB_LEVEL=2: the C = 64 level
     g = torch.Generator(device="cpu").manual_seed(0)
     nb = len(dils)
     xs = [torch.randn((N, HW, HW, Cc), generator=g).to(dev).to(torch.bfloat16) for _ in dils]
@@ -65,7 +65,7 @@ def main():
         t = sorted(e[2 * i].elapsed_time(e[2 * i + 1]) * 1e3 for i in range(reps))
         return t[len(t) // 2], t[0]
 
-    variants = [int(v) for v in os.environ.get("BB_VARIANTS", "1").split(",")]      # conv_band128m forms to time against conv_dmap (1: the kernel; other values: experiment builds)
+    variants = [int(v) for v in os.environ.get("BB_VARIANTS", "3").split(",")]      # values of the tuning key conv_band128m to time against 0 (3: the kernel at both levels; level 2: 1 = conv_band64m)
     for kind in ("first", "dgrad"):
         arr = group(kind)
         outs = {}
@@ -82,7 +82,7 @@ def main():
                 ds = ((outs[v][1][b] - outs[0][1][b]).abs().max() / outs[0][1][b].abs().max()).item()
                 print(f"{kind} member {b} (d = {dils[b]}): band128 form {v} vs conv_dmap: output {dy:.2e} of scale, statistics {ds:.2e}   (band flags {outs[v][2]} / {outs[0][2]})")
         for rnd in range(2):
-            for v, name in [(v, "conv_band128%s" % ("m" if v == 1 else "w")) for v in variants] + [(0, "conv_dmap group")]:
+            for v, name in [(v, "conv_band128m=%d" % v) for v in variants] + [(0, "conv_band128m=0  ")]:
                 lib.set_tuning(conv_band128m=v)
                 for cold in (False, True):
                     med, best = timed(arr, cold)
