@@ -113,7 +113,7 @@ struct RuaTuning {
   int strip_seglen = 0;                 // experiments (tools/bench_conv3x3.py): rows per block of conv_strip, 0 = one round of blocks
   int band_stag = 1;                    // conv_band32s (staggered halves) for full-width BatchNorm + ReLU sums (0: conv_band32; >= 4: that many ring slots)
   int strip_stag = 1;                   // conv_strip32s: full-width strips with the two halves of a block half a stage apart (0: conv_strip32 everywhere)
-  int wgrad_group = 7;                  // 1 wgrad_kernel, 2 wgrad_taps<32>, 4 wgrad_taps<64>, 8 wgrad_dmap (off: three members at once thrash the L2, 27.6 vs 24.6 us each)
+  int wgrad_group = 23;                 // 1 wgrad_kernel, 2 wgrad_taps<32>, 4 wgrad_taps<64>, 8 wgrad_dmap (off: three members at once thrash the L2, 27.6 vs 24.6 us each), 16 wgrad_pw (members with workspaces of their own)
 };
 extern RuaTuning g_tune;
 int rua_cu_count();          // compute units of the current device (queried once per device, cached)

@@ -4059,7 +4059,12 @@ struct WgpK {
   int C, Cout, Hs, Ws, H, W, stride, wshift, hshift, dense, R;
   int M, px_per_wave;
   unsigned abytes, dybytes;
+  int nblk;                         // blocks of this member (= gridDim.x of a launch of its own; a grouped launch has the grid of its largest member)
 };
+struct WgpKG { WgpK k[RUA_MAX_BRANCH]; };
+// rua_conv_wgrad_group: wgrad_pw members (own workspaces: own replicas and tickets) are recorded here and issued as ONE grid per (NCO, NCI) form
+struct WgPwCapture { int n; WgpK k[RUA_MAX_BRANCH]; int form[RUA_MAX_BRANCH]; };
+static thread_local WgPwCapture* g_wg_pw = nullptr;
 constexpr int WG_PW_REPLICAS = 16;
 constexpr int64_t WG_PW_TAIL = (int64_t)WG_PW_REPLICAS * 64 * 64 * 4 + 8192;   // replicas + two ticket pages at the end of the workspace
 
@@ -4071,7 +4076,7 @@ template <int NCO, int NCI> static constexpr int wgrad_pw_smem() {
 }
 
 template <int NCO, int NCI>
-__global__ __launch_bounds__(1024) void wgrad_pw(const WgpK p) {
+__device__ __forceinline__ void wgrad_pw_body(const WgpK& p) {
   constexpr int NW = 16, NT = NW * 64;                           // waves / threads per block
   constexpr int PXW = (NCO + NCI <= 2) ? 32 : 16;                  // pixels per wave iteration
   constexpr int ROWB_D = NCO == 2 ? 192 : 64, ROWB_A = NCI == 2 ? 192 : 64;   // 64 ch + pad / 32 ch: conflict-free tr reads
@@ -4231,9 +4236,9 @@ __global__ __launch_bounds__(1024) void wgrad_pw(const WgpK p) {
   // are 16 counters in one cache line): the group counters sit 256 B apart, the last block of each replica group draws
   // from the top counter (its own page), the last of those finishes.
   if (tid == 0) {
-    const int G = (int)gridDim.x < p.R ? (int)gridDim.x : p.R;
+    const int G = p.nblk < p.R ? p.nblk : p.R;
     const int g = blockIdx.x % p.R;
-    const int gsize = ((int)gridDim.x - g + p.R - 1) / p.R;
+    const int gsize = (p.nblk - g + p.R - 1) / p.R;
     int last = 0;
     int* cg = p.cnt + g * 64;
     int* ctop = p.cnt + WG_PW_REPLICAS * 64;
@@ -4268,6 +4273,14 @@ __global__ __launch_bounds__(1024) void wgrad_pw(const WgpK p) {
       if (o < nel) p.dw[o] += sum;
     }
   }
+}
+template <int NCO, int NCI> __global__ __launch_bounds__(1024) void wgrad_pw(const WgpK p) { wgrad_pw_body<NCO, NCI>(p); }
+// members of unequal size in one grid (blockIdx.y = member): the narrow 1x1 weight gradients of a composite - the sources of a concatenating conv, the
+// branch convs of a PSPPooling - are 2 - 15 us of mostly launch ramp and drain apiece when launched one by one
+template <int NCO, int NCI> __global__ __launch_bounds__(1024) void wgrad_pw_g(const WgpKG g) {
+  const WgpK& p = g.k[blockIdx.y];
+  if ((int)blockIdx.x >= p.nblk) return;
+  wgrad_pw_body<NCO, NCI>(p);
 }
 
 static int64_t wg_taps_bytes(const rua_wgrad_desc* d) { return (int64_t)rua_cu_count() * 9 * 32 * (int64_t)d->C * 4; }   // one block partial of [9][32][C] fp32 per CU
@@ -4311,6 +4324,12 @@ static int launch_wgrad_pw(const rua_wgrad_desc* d, hipStream_t st) {
     if (g_tune.wgpw_r > 0) k.R = g_tune.wgpw_r > WG_PW_REPLICAS ? WG_PW_REPLICAS : g_tune.wgpw_r;
   }
   const unsigned grid = (unsigned)((k.M + ppw * 16 - 1) / (ppw * 16));
+  k.nblk = (int)grid;
+  if (g_wg_pw && g_wg_pw->n < RUA_MAX_BRANCH) {            // a member of a group: recorded, issued by rua_conv_wgrad_group
+    WgPwCapture& c = *g_wg_pw; const int i = c.n++;
+    c.k[i] = k; c.form[i] = (nco - 1) * 2 + (nci - 1);
+    return RUA_OK;
+  }
   constexpr int s11 = wgrad_pw_smem<1, 1>(), s21 = wgrad_pw_smem<2, 1>(), s12 = wgrad_pw_smem<1, 2>(), s22 = wgrad_pw_smem<2, 2>();
   static RuaPerDevFlag attr_;
   bool& attr = attr_.get();
@@ -4539,6 +4558,49 @@ extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream
       if (d[i].dw == d[j].dw) shared = true;
     }
   g_wg_group_last_grids = n;
+  {
+    // all members narrow 1x1 weight gradients (wgrad_pw) with replicas / tickets of their own: one grid per (NCO, NCI) form
+    bool allpw = n >= 2 && (g_tune.wgrad_group & 16);
+    for (int i = 0; i < n && allpw; ++i) allpw = rua_wgrad_kind(d + i) == 3;
+    for (int i = 0; i < n && allpw; ++i)
+      for (int j = i + 1; j < n; ++j) {
+        const char* ti = (const char*)d[i].workspace + d[i].workspace_bytes - WG_PW_TAIL; const char* tj = (const char*)d[j].workspace + d[j].workspace_bytes - WG_PW_TAIL;
+        if (ti < tj + WG_PW_TAIL && tj < ti + WG_PW_TAIL) allpw = false;        // shared replicas: one by one
+        if (d[i].dw == d[j].dw) allpw = false;
+      }
+    if (allpw) {
+      WgPwCapture cap;
+      cap.n = 0;
+      g_wg_pw = &cap;
+      int rc = RUA_OK;
+      for (int i = 0; i < n && rc == RUA_OK; ++i) rc = rua_conv_wgrad(d + i, stream);
+      g_wg_pw = nullptr;
+      if (rc != RUA_OK) return rc;
+      int grids = n - cap.n;
+      constexpr int s11 = wgrad_pw_smem<1, 1>(), s21 = wgrad_pw_smem<2, 1>(), s12 = wgrad_pw_smem<1, 2>(), s22 = wgrad_pw_smem<2, 2>();
+      static RuaPerDevFlag attr_;
+      if (!attr_.get()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pw_g<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, s21);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pw_g<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, s12);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pw_g<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, s22);
+        attr_.get() = true;
+      }
+      for (int form = 0; form < 4; ++form) {
+        WgpKG g; int m = 0; unsigned gx = 0;
+        for (int i = 0; i < cap.n; ++i) if (cap.form[i] == form) { g.k[m++] = cap.k[i]; if ((unsigned)cap.k[i].nblk > gx) gx = (unsigned)cap.k[i].nblk; }
+        if (m == 0) continue;
+        for (int i = m; i < RUA_MAX_BRANCH; ++i) g.k[i] = g.k[0];
+        if (form == 0) hipLaunchKernelGGL((wgrad_pw_g<1, 1>), dim3(gx, m), dim3(1024), s11, st, g);
+        else if (form == 1) hipLaunchKernelGGL((wgrad_pw_g<1, 2>), dim3(gx, m), dim3(1024), s12, st, g);
+        else if (form == 2) hipLaunchKernelGGL((wgrad_pw_g<2, 1>), dim3(gx, m), dim3(1024), s21, st, g);
+        else hipLaunchKernelGGL((wgrad_pw_g<2, 2>), dim3(gx, m), dim3(1024), s22, st, g);
+        RUA_LAUNCH_CHECK("wgrad_pw (group)");
+        ++grids;
+      }
+      g_wg_group_last_grids = grids;
+      return RUA_OK;
+    }
+  }
   if (n == 1 || shared || !g_tune.wgrad_group) {
     for (int i = 0; i < n; ++i) { const int rc = rua_conv_wgrad(d + i, stream); if (rc != RUA_OK) return rc; }
     return RUA_OK;

@@ -778,6 +778,35 @@ class Graph:
         plan.keep.append(arr)
         plan.add("rua_conv_wgrad_group", arr, len(descs))
 
+    def wgrad_pw_group(self, plan: Plan, specs: List[tuple]):
+        """The narrow 1x1 weight gradients of one composite (the sources of a concatenating conv, the branch convs of a PSPPooling: independent, 2 - 15 us
+        apiece and mostly launch ramp + drain) as ONE rua_conv_wgrad_group call.  The library runs them as one grid when every member is a wgrad_pw launch with
+        replicas / tickets of its own - so each member gets a private (zeroed) workspace here; anything else falls back to one launch each, as before."""
+        lib = L.lib()
+        if self.dry or len(specs) < 2 or self.dt != L.RUA_BF16 or not self.e.group_wgrad_pw or len(specs) > L.RUA_MAX_BRANCH:
+            if len(specs) > L.RUA_MAX_BRANCH and not self.dry and self.dt == L.RUA_BF16 and self.e.group_wgrad_pw:
+                self.wgrad_pw_group(plan, specs[:L.RUA_MAX_BRANCH])
+                self.wgrad_pw_group(plan, specs[L.RUA_MAX_BRANCH:])
+                return
+            for sp in specs:
+                self.wgrad(plan, *sp)
+            return
+        descs = [self.wgrad_desc(plan, *sp, may_flush=(i == 0)) for i, sp in enumerate(specs)]
+        if not all(lib.raw("rua_wgrad_kind")(C.byref(d)) == 3 and not d.defer for d in descs):
+            for d in descs:                                    # (descriptors are already recorded for the deferred reductions: launch exactly these)
+                plan.keep.append(d)
+                plan.add("rua_conv_wgrad", C.byref(d))
+            return
+        for d in descs:
+            nbytes = int(lib.raw("rua_wgrad_workspace_bytes")(C.byref(d)))
+            ws = self.alloc(((nbytes + 3) // 4,), torch.float32, zero=True)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        arr = (L.WgradDesc * len(descs))()
+        for i, dsc in enumerate(descs):
+            C.memmove(C.byref(arr, i * C.sizeof(L.WgradDesc)), C.byref(dsc), C.sizeof(L.WgradDesc))
+        plan.keep.append(arr)
+        plan.add("rua_conv_wgrad_group", arr, len(descs))
+
     # -- deferred weight-gradient reductions: the partial sums of many weight gradients (all-taps block partials, K-slice slabs)
     #    are added into dW by ONE batched launch instead of one small launch each (80 of them per cfg3 step).  Under data
     #    parallel the batch is flushed whenever the next weight gradient belongs to another all-reduce bucket, so a bucket's
@@ -1148,9 +1177,11 @@ class Graph:
                 pooled[up] = pd
         grouped = len(segs) > 1 and not self.dry and self.e.group_1x1 and self.dt == L.RUA_BF16
         ddescs = []
+        # the per-source weight gradients: one grid where every member is a wgrad_pw launch (round 5), else one launch each (as a generic group these
+        # unequal, tiny weight gradients measured slower - 18 vs 12 us)
+        self.wgrad_pw_group(Bp, [(t, pooled[up], seg["off"], 1, 1, 1) for (t, up), seg in zip(segs, lay["segs"])])
         for (t, up), seg, tg in zip(segs, lay["segs"], targets):
             d = pooled[up]
-            self.wgrad(Bp, t, d, seg["off"], 1, 1, 1)          # (one launch each: as a group these unequal, tiny weight gradients measured slower - 18 vs 12 us)
             if tg is None:
                 gx, acc = self.gacc(t)
                 dd = self.dgrad_desc(d, self.Wd(seg["dst"]), t.C, 1, 1, gx, acc)
@@ -1227,8 +1258,7 @@ class Graph:
                     self.issue_bn_bwd(Bp, bbs)
                 if bbs is not None and pyramid and bdescs is not None:
                     # the branch convolutions' data gradients as one group (independent: own source gradients)
-                    for (k, p, z, lay, zb, node) in br:
-                        self.wgrad(Bp, p, z.grad, lay["segs"][0]["off"], 1, 1, 1)
+                    self.wgrad_pw_group(Bp, [(p, z.grad, lay["segs"][0]["off"], 1, 1, 1) for (k, p, z, lay, zb, node) in br])
                     dd = []
                     for (k, p, z, lay, zb, node) in br:
                         gx, acc = self.gacc(p)
@@ -1740,6 +1770,7 @@ class Engine:
         self.group_1x1 = os.environ.get("RUA_GROUP_1X1", "1") != "0"       # PSPPooling's branch convolutions and the per-source gradients of concatenating 1x1 convolutions as groups
         self.group_heads = os.environ.get("RUA_GROUP_HEADS", "1") != "0"   # the heads' 3x3 convolutions (and their gradients) grouped across the heads
         self.multi_head = os.environ.get("RUA_MULTI_HEAD", "1") != "0"     # the heads' loss finalisation / d(loss)/d(logits) as one launch each
+        self.group_wgrad_pw = os.environ.get("RUA_GROUP_WGRAD_PW", "1") != "0"   # the narrow 1x1 weight gradients of a composite as one grid (Graph.wgrad_pw_group)
         self.stem_mfma = os.environ.get("RUA_STEM_MFMA", "1") != "0"       # bf16: the stem's weight gradient through rua_stem_fwd_pack / rua_conv_wgrad / rua_stem_bwd_fold
         self.stem_stats = os.environ.get("RUA_STEM_STATS", "1") != "0"     # rua_stem_fwd_stats instead of a rua_col_stats pass over the stem's output
         self._captured: Dict[int, object] = {}

@@ -418,6 +418,57 @@ def test_wgrad_pointwise_kernel(case):
         assert float(ws[-(16 * 64 * 64 + 2048):].abs().max()) == 0.0
 
 
+def test_wgrad_pointwise_group_is_one_grid():
+    """rua_conv_wgrad_group over narrow 1x1 weight gradients with workspaces of their own (round 5: the per-source weight gradients of a concatenating
+    1x1 conv, the branch convs of a PSPPooling - Graph.wgrad_pw_group): members of UNEQUAL size and channel counts run as one wgrad_pw_g grid per
+    (NCO, NCI) form, bit for bit what the members give one by one apart from the replica atomics' order, against the fp64 gradient; replicas and
+    tickets are left zero; members sharing a workspace fall back to one launch each."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(23)
+    members = [(8, 64, 64, 32, 32), (8, 32, 32, 8, 32), (2, 64, 32, 16, 32), (8, 16, 16, 8, 32)]      # N, H, W, C, Cout: four grids of 64 / 4 / 2 / 1 blocks ... one form (1, 1)
+    keep, descs, refs, bases, dws, wss = [], [], [], [], [], []
+    for N, H, W, Cs, Cout in members:
+        a = rng.standard_normal((N, H, W, Cs)).astype(np.float32); dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+        ad, dyd = to_dev(a, dt), to_dev(dy, dt)
+        base = rng.standard_normal((1, Cout, Cs)).astype(np.float32)
+        dw = torch.from_numpy(base).to(dev())
+        d = L.WgradDesc()
+        d.a, d.C, d.Hs, d.Ws = ad.data_ptr(), Cs, H, W
+        d.dy, d.Cout, d.H, d.W = dyd.data_ptr(), Cout, H, W
+        d.N, d.stride, d.dil, d.taps, d.dtype = N, 1, 1, 1, dt
+        d.dw = dw.data_ptr()
+        nbytes = lib.raw("rua_wgrad_workspace_bytes")(C.byref(d))
+        ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev())
+        d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+        assert lib.raw("rua_wgrad_kind")(C.byref(d)) == 3
+        w = torch.zeros((1, Cout, Cs), dtype=torch.float64, requires_grad=True)
+        y = ref_conv_nhwc(rnd(dt, a).double(), w, None, 1, 1, 1)
+        y.backward(rnd(dt, dy).double())
+        keep += [ad, dyd]; descs.append(d); refs.append(w.grad.numpy()); bases.append(base); dws.append(dw); wss.append(ws)
+    arr = (L.WgradDesc * len(descs))()
+    for i, d in enumerate(descs):
+        C.memmove(C.byref(arr, i * C.sizeof(L.WgradDesc)), C.byref(d), C.sizeof(L.WgradDesc))
+    for rep in range(2):                                        # the second call runs on what the first left behind
+        for dw, base in zip(dws, bases):
+            dw.copy_(torch.from_numpy(base))
+        lib.call("rua_conv_wgrad_group", arr, len(descs), stream())
+        assert lib.raw("rua_wgrad_group_last_grids")() == 1
+        torch.cuda.synchronize()
+        for dw, base, ref, ws in zip(dws, bases, refs, wss):
+            assert rel_err(dw.cpu().numpy() - base, ref) < 2e-3
+            assert float(ws[-(16 * 64 * 64 + 2048):].abs().max()) == 0.0
+    # two members on ONE workspace (shared replicas): the library must not put them into one grid
+    arr[1].workspace, arr[1].workspace_bytes = arr[0].workspace, arr[0].workspace_bytes
+    for dw, base in zip(dws, bases):
+        dw.copy_(torch.from_numpy(base))
+    lib.call("rua_conv_wgrad_group", arr, len(descs), stream())
+    assert lib.raw("rua_wgrad_group_last_grids")() == len(descs)
+    torch.cuda.synchronize()
+    for dw, base, ref in zip(dws, bases, refs):
+        assert rel_err(dw.cpu().numpy() - base, ref) < 2e-3
+
+
 @pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
 def test_weight_prep_layouts(dt):
     rng = np.random.default_rng(4)
