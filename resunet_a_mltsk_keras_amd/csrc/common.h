@@ -102,10 +102,10 @@ struct RuaTuning {
   int conv_band64m = 1;                 // the independent 3x3 convs of a C = 64 ResBlock (first convs, data gradients) as ONE conv_band64m launch
   int conv_band64 = 1;                  // ... and of a C = 64 ResBlock (conv_band64)
   long long dbg_ptr = 0;                // diagnostic builds only (-DRUA_B128_STAMPS): device buffer for in-kernel stamps
-  int conv_band128m = 1;                // conv_band128m for the independent 3x3 convs of a ResBlock (first convs, data gradients) as ONE launch: bit 0 at C = 128 (else grouped conv_dmap:
+  int conv_band128m = 5;                // conv_band128m for the independent 3x3 convs of a ResBlock (first convs, data gradients) as ONE launch: bit 0 at C = 128 (else grouped conv_dmap:
                                         // 37 - 43 vs 50 - 58 us, step 6.49 -> 6.39 ms), bit 1 at C = 64 (else conv_band64m; off: level with it launch by launch - 54 / 65 vs 60 / 65 us warm / cold
                                         // for plain first convolutions, 68 / 88 vs 69 / 92 for data gradients - and SLOWER in the step, 6.62 vs 6.53 ms: its in-place BatchNorm pass runs behind
-                                        // the MFMAs of a stage, conv_band64m's between them, and the level-2 first convolutions normalise on load)
+                                        // the MFMAs of a stage, conv_band64m's between them, and the level-2 first convolutions normalise on load), bit 2 at C = 256 on 32-pixel rows (else grouped conv_dmap)
   int conv_band = 1;                    // rua_conv_fwd_sum: the branches' second convs of a C = 32 ResBlock as ONE launch with the sum kept on chip (conv_band32)
   int wgd_ks_slow = 1;                  // wgrad_dmap block order: K slice slowest (blocks that read the same pixels share an XCD's L2)
   int wgrad_rows = 31;                  // bit 0: wgrad_rows32 (the all-taps weight gradient at C = 32 on whole rows, W = 256 / 128, one shared LDS-DMA ring), bit 1: wgrad_rows64 (C = 64, W = 128); 0: wgrad_taps_kernel

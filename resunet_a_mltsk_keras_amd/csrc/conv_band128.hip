@@ -60,21 +60,25 @@ static_assert(sizeof(Band128K) <= 4096, "kernel arguments are limited to 4 KiB")
 
 template <int V> struct B128IC { static constexpr int value = V; };
 
-// CP = C = Cout (128: one pixel tile per wave; 64: two), W = row width (a stage is SPX / W whole rows)
-template <int CP, int W>
+// CP = C = Cout, W = row width (a stage is SPX / W whole rows), KC = input channels staged per phase (CP, or 128 of 256: a kernel row then takes two phases),
+// COS = output channels per block: 64 = two 32-channel tiles over the waves (128: one pixel tile per wave; 64: two), or 32 = ONE tile with the k-steps of a
+// phase split over the two waves that share a pixel tile (C = 256 on 32-pixel rows: 8 images x 4 bands x 8 slices = 256 jobs; the halves are added through LDS
+// in the member epilogue)
+template <int CP, int W, int KC = CP, int COS = 64>
 __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   typedef bf16_t T;
   constexpr int NW = 8, NT = NW * 64, R = 3;
-  constexpr int PXB = CP * 2, PPP = PXB / 16;                                 // bytes / 16-byte pieces per pixel (256 / 16 or 128 / 8)
+  constexpr int PXB = KC * 2, PPP = PXB / 16;                                 // bytes / 16-byte pieces per staged pixel (256 / 16 or 128 / 8)
   constexpr int SLOTB = 32768, SPX = SLOTB / PXB, RPS = SPX / W, SPP = 2, BR = SPP * RPS;     // a stage = 32 KB = 128 or 256 pixels = RPS rows; a band = two stages
-  constexpr int TPW = SPX / 128;                                              // pixel tiles (of 32) per wave: 4 pixel groups x 2 output-channel tiles = 8 waves
+  constexpr int TPW = SPX / 128;                                              // pixel tiles (of 32) per wave: 4 pixel groups x 2 (output-channel tiles or k halves) = 8 waves
   constexpr int ZOFF = SLOTB, SLOT = SLOTB + 256;                             // the stage tile + one zero pixel
   constexpr int NINST = SLOTB / 1024, NPX = NINST / NW, PPI = 64 / PPP;       // DMA instructions per stage / per wave, pixels per instruction
-  constexpr int PPM = 3;                                                      // phases (kernel rows) per member
-  constexpr int KS = CP / 16;                                                 // k-steps per tap
-  constexpr int TAPB = 64 * PXB, WBUF = 3 * TAPB, WPIECES = WBUF / 1024, WPW = WPIECES / NW, RPI = 1024 / PXB;   // weight image [tap column][64 rows][CP]; rows per DMA instruction
-  constexpr int NCS = CP / 64;
-  static_assert((CP == 128 || CP == 64) && SPX % W == 0 && RPS >= 1 && W % (NW * PPI) == 0 && W % 32 == 0, "geometry");
+  constexpr int NCH = CP / KC, PPM = 3 * NCH;                                 // input-channel chunks; phases (kernel row x chunk) per member
+  constexpr int KS = KC / 16, KQ = 64 / COS, KSW = KS / KQ;                   // k-steps per tap and phase; waves sharing a pixel tile (1: they differ in the output-channel tile); k-steps per wave
+  constexpr int TAPB = COS * PXB, WBUF = 3 * TAPB, WPIECES = WBUF / 1024, WPW = WPIECES / NW, RPI = 1024 / PXB;   // weight image [tap column][COS rows][KC]; rows per DMA instruction
+  constexpr int NCS = CP / COS;
+  static_assert((CP == 256 || CP == 128 || CP == 64) && (COS == 64 || COS == 32) && CP % KC == 0 && SPX % W == 0 && RPS >= 1 && W % (NW * PPI) == 0 && W % 32 == 0, "geometry");
+  static_assert(KQ == 1 || TPW == 1, "the k split is for one pixel tile per wave");
   static_assert(NINST % NW == 0 && WPIECES % NW == 0 && SLOT % 256 == 0 && (R * SLOT) % 256 == 0, "geometry");
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -82,11 +86,12 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   float* tab = reinterpret_cast<float*>(sW + WBUF);                           // [nb][2][CP] scale, shift
   float* tabm = tab + RUA_MAX_BRANCH * 2 * CP;                                // [nb][3][64] bias, mask scale, mask shift of the block's output channels
   float* sred = tabm + RUA_MAX_BRANCH * 192;                                  // [8 waves][64] statistics partials of a member
+  float* xbuf = sred + NW * 64;                                               // KQ == 2: [4 pixel tiles][16 registers][64 lanes] - the k halves' accumulators meet here
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pl = lane & 31, kh = lane >> 5;
-  const int pg = wv >> 1, coh = wv & 1;                                       // this wave's pixel group (TPW tiles of the stage) and output-channel tile
+  const int pg = wv >> 1, coh = KQ == 1 ? (wv & 1) : 0, kq = KQ == 1 ? 0 : (wv & 1);   // this wave's pixel group (TPW tiles of the stage), output-channel tile, k half
   const int H = q.H, nb = q.nb;
   auto swz = [](int i) { return PPP == 16 ? (i & 15) : ((i >> 1) & 7); };     // piece slot = piece ^ swz(row or pixel index): 16 pieces per 256-byte bank row, or 8 per half of it
 
@@ -96,13 +101,13 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   const int job = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // consecutive jobs (the slices of one band first) share an XCD's L2
   const int cs = job % NCS, tq = job / NCS;
   const int band = tq % q.bands, n_ = tq / q.bands;
-  const int h0 = band * BR, co0 = cs * 64;
+  const int h0 = band * BR, co0 = cs * COS;
 
 #ifdef RUA_B128_STAMPS
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime();
 #endif
   // ---- per-channel tables (ordinary loads: all consumed before the first LDS-DMA is issued) ------------------------------
-  if (tid < 64)
+  if (tid < COS)
     for (int i = 0; i < nb; ++i) {
       tabm[i * 192 + tid] = q.bias[i] ? q.bias[i][co0 + tid] : 0.f;
       tabm[i * 192 + 64 + tid] = (q.aux[i] && q.mscale[i]) ? q.mscale[i][co0 + tid] : 1.f;
@@ -139,15 +144,16 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   const unsigned rowbytes = (unsigned)(W * CP * 2), imgbase = (unsigned)(n_ * H) * rowbytes;
 
   const int nph = nb * PPM;
-  struct Phase { int hb; bool valid; __amdgpu_buffer_rsrc_t rx; unsigned ca; };
+  struct Phase { int hb; bool valid; __amdgpu_buffer_rsrc_t rx; unsigned ca, choff; };
   auto phase = [&](int ph) {
     Phase p;
-    const int b = ph / PPM, ty = ph - b * PPM;
+    const int b = ph / PPM, pm = ph - b * PPM, ty = pm / NCH, ch = pm - ty * NCH;
     p.valid = ph < nph;
     const int bb = p.valid ? b : 0;
     p.hb = h0 + (ty - 1) * dil_of(bb);
     p.rx = make_rsrc(q.x[bb], q.xbytes);
-    p.ca = smem_a + (unsigned)((unsigned char*)(tab + bb * 2 * CP + psrc * 8) - smem);
+    p.choff = (unsigned)(ch * KC * 2);
+    p.ca = smem_a + (unsigned)((unsigned char*)(tab + bb * 2 * CP + ch * KC + psrc * 8) - smem);
     return p;
   };
   // one DMA instruction at a time (the loop deals them between its MFMAs: ten issued in one burst behind the barrier stood 0.5 - 1.6 us in the
@@ -155,7 +161,7 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   auto issue_x1 = [&](const Phase& p, int sp, int k, unsigned so) {
     const int h = p.hb + sp * RPS + row_of(k);
     const bool ok = p.valid && (unsigned)h < (unsigned)H;
-    const unsigned base = ok ? imgbase + (unsigned)h * rowbytes : OOB;        // scalar select; OOB + xrel is still out of range: the lanes write zeros
+    const unsigned base = ok ? imgbase + (unsigned)h * rowbytes + p.choff : OOB;        // scalar select; OOB + xrel is still out of range: the lanes write zeros
     __builtin_amdgcn_raw_ptr_buffer_load_lds(p.rx, (lds_void_p)(smem + so + (k * NW + wv) * 1024), 16, base + xrel[k], 0, 0, 0);
   };
   auto issue_x = [&](const Phase& p, int sp, unsigned so) {
@@ -174,9 +180,9 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
     WPhase w;
     const bool ok = ph < nph;
     const int pp = ok ? ph : 0;
-    const int b = pp / PPM, ty = pp - b * PPM;
+    const int b = pp / PPM, pm = pp - b * PPM, ty = pm / NCH, ch = pm - ty * NCH;
     w.rw = make_rsrc(q.w[b], ok ? (unsigned)(9 * CP * CP * 2) : 0u);           // past the last phase: every lane out of range (zeros into a dead buffer; the counted waits stay uniform)
-    w.base = (unsigned)((((ty * 3) * CP + co0) * CP) * 2) + wsrc;
+    w.base = (unsigned)((((ty * 3) * CP + co0) * CP + ch * KC) * 2) + wsrc;
     return w;
   };
   auto issue_w1 = [&](const WPhase& w, int i) {
@@ -228,11 +234,16 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   const int qo = pg * TPW * 32 + pl, jr = qo / W, xo = qo - jr * W;
   // a member's per-channel statistics, summed over the block (the waves' partials are in sred since the member's epilogue)
   auto stats_flush = [&](int b) {
-    if (tid < 128 && q.stats_mode[b] != 0) {
+    if (tid < COS * 2 && q.stats_mode[b] != 0) {
       const int ch = tid >> 6, ln = tid & 63, idx = ln & 31, khh = ln >> 5;
       float t = 0.f;
+      if constexpr (KQ == 1) {
 #pragma unroll
-      for (int p4 = 0; p4 < 4; ++p4) t += sred[(p4 * 2 + ch) * 64 + ln];
+        for (int p4 = 0; p4 < 4; ++p4) t += sred[(p4 * 2 + ch) * 64 + ln];
+      } else {                                               // one output-channel tile: all eight waves hold partials of it
+#pragma unroll
+        for (int w8 = 0; w8 < NW; ++w8) t += sred[w8 * 64 + ln];
+      }
       const int st = idx >> 4, c = co0 + ch * 32 + 16 * ((idx >> 3) & 1) + 8 * khh + (idx & 7);
       unsafeAtomicAdd(&q.stats[b][(size_t)(job & (q.stats_R[b] - 1)) * 2 * CP + st * CP + c], (double)t);
     }
@@ -263,12 +274,12 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
     return base + (unsigned)(row * PXB + ((sw >> 1) << 5) + (((kh ^ sw) & 1) << 4));
   };
   const unsigned ew0 = eaddr((unsigned)(R * SLOT), coh * 32 + pl);           // this wave's weight fragments: row coh * 32 + pl of a tap column's image
-  auto wfrag = [&](int tx, int ks) { return frag(ew0 + (unsigned)(tx * TAPB), ks); };
-  bf16x8 wf[3][KS];
+  auto wfrag = [&](int tx, int j) { return frag(ew0 + (unsigned)(tx * TAPB), kq * KSW + j); };      // this wave's k-step j of the tap column
+  bf16x8 wf[3][KSW];
 #pragma unroll
   for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[tx][ks] = wfrag(tx, ks);
+    for (int ks = 0; ks < KSW; ++ks) wf[tx][ks] = wfrag(tx, ks);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   unsigned so_cur = 0, so_nxt = SLOT, so_iss = 2 * SLOT;
@@ -308,11 +319,12 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
         const unsigned char* auxp = q.aux[b];
 #pragma unroll
         for (int r = 0; r < SPP; ++r)
+          if (KQ == 1 || r == kq)                            // (k split: a wave finishes the tile of stage kq only)
 #pragma unroll
-          for (int t = 0; t < TPW; ++t)
+            for (int t = 0; t < TPW; ++t)
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-              av[r][t][g] = auxp ? ldg16(auxp + ((pixg + (size_t)(r * RPS) * W + 32 * t) * CP + co0 + coh * 32 + 16 * g + 8 * kh) * 2) : make_uint4(0, 0, 0, 0);
+              for (int g = 0; g < 2; ++g)
+                av[r][t][g] = auxp ? ldg16(auxp + ((pixg + (size_t)(r * RPS) * W + 32 * t) * CP + co0 + coh * 32 + 16 * g + 8 * kh) * 2) : make_uint4(0, 0, 0, 0);
       }
       B128_E(1);
       unsigned e[3][TPW];
@@ -326,20 +338,20 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
       // flight) and the NPX row pieces of the stage two ahead (into the slot the stage before this one has just left), stage 1 its NPX row pieces -
       // and, as a k-step's fragment retires, the next phase's weight fragment into its registers.  (An LDS-DMA is an LDS write the compiler cannot
       // tell from the fragment reads' addresses: it keeps both in source order, which is the order wanted here.)
-      constexpr int NI = 3 * KS, PFK = 4 / TPW;              // k-steps; k-steps of fragment reads in flight (four fragments)
+      constexpr int NI = 3 * KSW, PFK = 4 / TPW;             // this wave's k-steps; k-steps of fragment reads in flight (four fragments)
       constexpr int NDMA = sp == 0 ? WPW + NPX : NPX, D0 = 1, DSTEP = (NI - 1 - D0) / (NDMA > 1 ? NDMA - 1 : 1) < 5 ? (NI - 1 - D0) / (NDMA > 1 ? NDMA - 1 : 1) : 5;
       static_assert(DSTEP >= 1 && D0 + (NDMA - 1) * DSTEP < NI, "every DMA has its k-step");
       bf16x8 fr[8][TPW];                                   // ring of 8 k-steps (> PFK: a slot is rewritten only after its product has been issued)
 #pragma unroll
       for (int i = 0; i < PFK; ++i)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) fr[i][t] = frag(e[i / KS][t], i % KS);
+        for (int t = 0; t < TPW; ++t) fr[i][t] = frag(e[i / KSW][t], kq * KSW + i % KSW);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int tx = i / KS, ks = i % KS;
+        const int tx = i / KSW, ks = i % KSW;
         if (i + PFK < NI) {
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) fr[(i + PFK) & 7][t] = frag(e[(i + PFK) / KS][t], (i + PFK) % KS);
+          for (int t = 0; t < TPW; ++t) fr[(i + PFK) & 7][t] = frag(e[(i + PFK) / KSW][t], kq * KSW + (i + PFK) % KSW);
         }
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
@@ -392,6 +404,27 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
       unsigned char* yp = q.ym[b];
       const int smode = q.stats_mode[b];
       const float* tb = tabm + b * 192;
+      if constexpr (KQ == 2) {
+        // the two k halves of a pixel tile meet: wave kq = 1 hands its stage-0 accumulator to wave kq = 0 and takes that wave's stage-1 accumulator
+        // (each wave then finishes ONE of the two tiles: the epilogue's work stays on eight waves)
+        float* xb = xbuf + pg * 1024 + lane;
+        if (kq == 1) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) xb[k * 64] = acc[0][0][k];
+        }
+        __syncthreads();
+        if (kq == 0) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[0][0][k] += xb[k * 64];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) xb[k * 64] = acc[1][0][k];
+        }
+        __syncthreads();
+        if (kq == 1) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[1][0][k] += xb[k * 64];
+        }
+      }
       float s1[2][8], s2[2][8];
 #pragma unroll
       for (int g = 0; g < 2; ++g)
@@ -401,6 +434,11 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
       for (int r = 0; r < SPP; ++r)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
+          if (KQ == 2 && r != kq) {                          // the partner finishes this tile
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[r][t][k] = 0.f;
+            continue;
+          }
           float v[2][8];
 #pragma unroll
           for (int g = 0; g < 2; ++g)
@@ -477,16 +515,17 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
 // touched 32 partly used lines per instruction and cost ~30 ns each in the texture path against ~12.5 ns for a row instruction; as whole swizzled rows - the
 // form above - the first form went 43 - 46 -> 37 - 39 us and the specialised one lost its reason.)
 
-template <int CP, int W> __global__ __launch_bounds__(512) void conv_band128m(const Band128K q) { conv_band128_body<CP, W>(q); }
+template <int CP, int W, int KC, int COS> __global__ __launch_bounds__(512) void conv_band128m(const Band128K q) { conv_band128_body<CP, W, KC, COS>(q); }
 
 // ---- host side (called by rua_conv_fwd_group, conv_mfma.hip) -----------------------------------------------------------------------
-static int band128_rows(int C, int W) { return 2 * ((32768 / (C * 2)) / W); }          // rows per band
+static int band128_rows(int C, int W) { return 2 * ((32768 / ((C > 128 ? 128 : C) * 2)) / W); }          // rows per band (two stages of 32 KB of <= 128 staged channels)
 bool rua_band128m_ok(const rua_conv_desc* d, int n) {
   if (n < 1 || n > RUA_MAX_BRANCH) return false;
   const rua_conv_desc& a = d[0];
   const int Cc = a.Cout;
   if (Cc == 128) { if (!(g_tune.conv_band128m & 1) || (a.W != 64 && a.W != 128)) return false; }
   else if (Cc == 64) { if (!(g_tune.conv_band128m & 2) || (a.W != 64 && a.W != 128 && a.W != 256)) return false; }
+  else if (Cc == 256) { if (!(g_tune.conv_band128m & 4) || a.W != 32) return false; }
   else return false;
   if (a.dtype != RUA_BF16 || a.H % band128_rows(Cc, a.W) != 0 || (long long)a.N * a.H * a.W < 1024) return false;
   for (int i = 0; i < n; ++i) {
@@ -501,7 +540,7 @@ bool rua_band128m_ok(const rua_conv_desc* d, int n) {
     if (m.stats_mode != 0 && (!m.stats || m.stats_replicas < 1 || (m.stats_replicas & (m.stats_replicas - 1)))) return false;
     if (m.stats_mode == 2 && m.aux_mode != 2) return false;
     if (m.stats_mode < 0 || m.stats_mode > 2) return false;
-    if (m.in_fold && Cc != 64) return false;                                   // (C = 128: the coefficients are given - rua_bn_fwd makes them at that level)
+    if (m.in_fold && Cc != 64) return false;                                   // (C >= 128: the coefficients are given - rua_bn_fwd makes them at those levels)
     if ((m.in_fold != nullptr) != (a.in_fold != nullptr) || (m.in_scale != nullptr) != (a.in_scale != nullptr) || m.in_relu != a.in_relu) return false;
     if (m.in_fold && (m.in_scale || m.in_shift)) return false;
     if ((m.in_shift != nullptr) != (m.in_scale != nullptr)) return false;
@@ -509,13 +548,13 @@ bool rua_band128m_ok(const rua_conv_desc* d, int n) {
   return true;
 }
 
-template <int CP, int W>
+template <int CP, int W, int KC, int COS>
 static int band128_launch(const Band128K& q, hipStream_t st) {
-  constexpr int smem = 3 * (32768 + 256) + 3 * 64 * CP * 2 + (RUA_MAX_BRANCH * 2 * CP + RUA_MAX_BRANCH * 192 + 8 * 64) * 4;
+  constexpr int smem = 3 * (32768 + 256) + 3 * COS * KC * 2 + (RUA_MAX_BRANCH * 2 * CP + RUA_MAX_BRANCH * 192 + 8 * 64 + (COS == 32 ? 4 * 1024 : 0)) * 4;
   static_assert(smem <= 160 * 1024, "LDS budget");
   static RuaPerDevFlag attr;
-  if (!attr.get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band128m<CP, W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr.get() = true; }
-  hipLaunchKernelGGL((conv_band128m<CP, W>), dim3(q.njobs), dim3(512), smem, st, q);
+  if (!attr.get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band128m<CP, W, KC, COS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr.get() = true; }
+  hipLaunchKernelGGL((conv_band128m<CP, W, KC, COS>), dim3(q.njobs), dim3(512), smem, st, q);
   RUA_LAUNCH_CHECK("conv_band128m");
   return RUA_OK;
 }
@@ -551,7 +590,8 @@ int rua_launch_band128m(const rua_conv_desc* d, int n, hipStream_t st) {
   RUA_CHECK_ARG((size_t)a.N * a.H * a.W * Cc * 2 < 0x7FFFFF00ull, "rua_conv_fwd_group: tensor of 2 GiB or more");
   q.xbytes = (unsigned)((size_t)a.N * a.H * a.W * Cc * 2);
   q.bands = a.H / band128_rows(Cc, a.W);
-  q.njobs = a.N * q.bands * (Cc / 64);
-  if (Cc == 128) return a.W == 64 ? band128_launch<128, 64>(q, st) : band128_launch<128, 128>(q, st);
-  return a.W == 64 ? band128_launch<64, 64>(q, st) : (a.W == 128 ? band128_launch<64, 128>(q, st) : band128_launch<64, 256>(q, st));
+  q.njobs = a.N * q.bands * (Cc == 256 ? 8 : Cc / 64);
+  if (Cc == 256) return band128_launch<256, 32, 128, 32>(q, st);
+  if (Cc == 128) return a.W == 64 ? band128_launch<128, 64, 128, 64>(q, st) : band128_launch<128, 128, 128, 64>(q, st);
+  return a.W == 64 ? band128_launch<64, 64, 64, 64>(q, st) : (a.W == 128 ? band128_launch<64, 128, 64, 64>(q, st) : band128_launch<64, 256, 64, 64>(q, st));
 }

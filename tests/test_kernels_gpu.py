@@ -1741,6 +1741,7 @@ def test_fill_zero_is_a_kernel_and_exact_at_the_edges(offset, nbytes):
     lib.call("rua_fill_zero", buf.data_ptr(), 0, stream())           # zero bytes: nothing launched, no error
 
 
+BAND128M_DEFAULT = 5                                  # RuaTuning::conv_band128m (csrc/common.h)
 BAND64M_CASES = [
     # N, H, W, dilations, kind: "first" = the branches' first convs (shared input, per-branch BatchNorm on load, bias, statistics sum v / sum v^2),
     #                           "dgrad" = their data gradients (own inputs, ReLU mask from an aux tensor, statistics sum g / sum g * aux)
@@ -1758,6 +1759,12 @@ BAND64M_CASES = [
     (3, 8, 64, [15, 3], "first_scale", 128),          # two bands: every row of the d = 15 member's outer kernel rows is padding
     (1, 128, 128, [1, 3, 15], "dgrad", 128),          # one row per stage, two-row bands (cfg4's level 3)
     (1, 64, 64, [1, 3, 15, 31], "first", 64),         # C = 64 on 64-pixel rows (cfg5's level 2): four rows per stage, eight-row bands, in_fold
+    # C = Cout = 256 on 32-pixel rows (the level-4 ResBlock): 128 of the 256 input channels per phase, 32-channel output slices, the k-steps of a phase split
+    # over two waves whose accumulators meet in the member epilogue; d = 15 on 32 x 32: most of the outer kernel rows and columns are padding
+    (8, 32, 32, [1, 3, 15], "first_plain", 256),
+    (8, 32, 32, [1, 3, 15], "dgrad", 256),
+    (2, 32, 32, [3, 15], "first", 256),
+    (2, 16, 32, [15, 1, 3, 5], "dgrad", 256),         # two bands per image, four members
 ]
 
 
@@ -1766,7 +1773,7 @@ def test_conv_group_band64_multi(case):
     try:
         _band_multi(case)
     finally:
-        L.lib().set_tuning(conv_band128m=1, conv_band64m=1)      # the defaults, whatever happened
+        L.lib().set_tuning(conv_band128m=BAND128M_DEFAULT, conv_band64m=1)      # the defaults, whatever happened
 
 
 def _band_multi(case):
@@ -1776,7 +1783,7 @@ def _band_multi(case):
     against the members run one by one on the implicit-GEMM kernel: outputs to bf16 rounding, statistics to fp32 partial-sum order)."""
     N, H, W, dils, kind = case[:5]
     Cs = case[5] if len(case) > 5 else 64
-    L.lib().set_tuning(conv_band128m=3)                       # (default 1: C = 128 only; this test runs the C = 64 form of the kernel too)
+    L.lib().set_tuning(conv_band128m=7)                       # every form of the kernel (bits: 1 C = 128, 2 C = 64, 4 C = 256), whatever the defaults are
     # C = 64 runs on conv_band128m's two-tiles-per-wave form since round 5 (tuning key conv_band128m bit 1; bit 1 off: conv_band64m, which the second
     # pass below also exercises), C = 128 on its one-tile form (bit 0)
     dt = L.RUA_BF16
@@ -1880,7 +1887,7 @@ def _band_multi(case):
                 assert lib.raw("rua_conv_group_last_band")() == flag
                 torch.cuda.synchronize()
             finally:
-                lib.set_tuning(conv_band128m=3, conv_band64m=1)
+                lib.set_tuning(conv_band128m=7, conv_band64m=1)
             for b in range(nb):
                 assert rel_err(ys[b].float().cpu().numpy(), ys2[b].float().cpu().numpy()) < tol(dt)
                 assert np.allclose(sts[b].cpu().numpy().reshape(R, -1).sum(0), sts2[b].cpu().numpy().reshape(R, -1).sum(0), rtol=1e-3, atol=1e-2)

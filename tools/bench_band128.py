@@ -20,7 +20,7 @@ def main():
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     sweep = torch.zeros(128 << 20, dtype=torch.float32, device=dev)
     ws = torch.zeros(16 << 20, dtype=torch.float32, device=dev)
-    N, HW, Cc, dils = (8, 64, 128, [1, 3, 15]) if os.environ.get("BB_LEVEL", "3") == "3" else (8, 128, 64, [1, 3, 15, 31])    # BB_LEVEL=2: the C = 64 level
+    N, HW, Cc, dils = {"3": (8, 64, 128, [1, 3, 15]), "2": (8, 128, 64, [1, 3, 15, 31]), "4": (8, 32, 256, [1, 3, 15])}[os.environ.get("BB_LEVEL", "3")]    # the level of the network
     g = torch.Generator(device="cpu").manual_seed(0)
     nb = len(dils)
     xs = [torch.randn((N, HW, HW, Cc), generator=g).to(dev).to(torch.bfloat16) for _ in dils]
@@ -65,7 +65,7 @@ def main():
         t = sorted(e[2 * i].elapsed_time(e[2 * i + 1]) * 1e3 for i in range(reps))
         return t[len(t) // 2], t[0]
 
-    variants = [int(v) for v in os.environ.get("BB_VARIANTS", "3").split(",")]      # values of the tuning key conv_band128m to time against 0 (3: the kernel at both levels; level 2: 1 = conv_band64m)
+    variants = [int(v) for v in os.environ.get("BB_VARIANTS", "7").split(",")]      # values of the tuning key conv_band128m to time against 0 (3: the kernel at both levels; level 2: 1 = conv_band64m)
     for kind in ("first", "dgrad"):
         arr = group(kind)
         outs = {}
@@ -87,7 +87,7 @@ def main():
                 for cold in (False, True):
                     med, best = timed(arr, cold)
                     print(f"{kind:6s} {name:16s} {'cold' if cold else 'warm'}: median {med:6.1f} us, best {best:6.1f} us  = {flops / med / 1e6:6.1f} TFLOP/s", flush=True)
-    lib.set_tuning(conv_band128m=1)
+    lib.set_tuning(conv_band128m=5)
 
 
 if __name__ == "__main__":
