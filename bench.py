@@ -362,6 +362,47 @@ def profile_kernels(eng, g, dtype):
     return out
 
 
+def d6_ceiling_probe(batch, reps=30):
+    """The north star's sub-metric, priced: what the SAME row-streaming kernel family does on the d6 block's product - 4 members x [B x 256 x 256
+    pixels x 288] . [288 x 32], model2.py:15-34,102 - when everything the training-mode BatchNorm barrier hangs on it is taken away: no normalise-on-load,
+    no bias, no statistics, no epilogue stream - row DMA + MFMA + the output store only (the plain form of conv_strip32s, one grouped launch).  The block is
+    two such grids (first and second convolutions, 38.65 GFLOP each at batch 8), so 2 x this probe is a CEILING for the block on this kernel family, and
+    the probe against 38.65 us (= 40 % of the dense bf16 peak per grid) says whether the 40 % target is within the family's reach at C = 32."""
+    from resunet_a_mltsk_keras_amd import _lib as L
+    lib = L.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N, HW, Cc, dils = batch, 256, 32, [1, 3, 15, 31]
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn((N, HW, HW, Cc), generator=g).to(dev).to(torch.bfloat16)
+    ws = [(torch.randn((9, Cc, Cc), generator=g) / (3 * Cc ** 0.5)).to(dev).to(torch.bfloat16) for _ in dils]
+    ys = [torch.empty((N, HW, HW, Cc), device=dev, dtype=torch.bfloat16) for _ in dils]
+    arr = (L.ConvDesc * len(dils))()
+    for b, dl in enumerate(dils):
+        d = arr[b]
+        d.nseg = 1
+        sg = d.seg[0]
+        sg.x, sg.w, sg.C, sg.Hs, sg.Ws, sg.up_shift, sg.dil, sg.taps = x.data_ptr(), ws[b].data_ptr(), Cc, HW, HW, 0, dl, 9
+        d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, HW, HW, Cc, 1, L.RUA_BF16
+        d.y, d.out_stride, d.OH, d.OW = ys[b].data_ptr(), 1, HW, HW
+    ev_new, ev_rec, ev_us, ev_del = (lib.raw("rua_prof_event_" + n) for n in ("create", "record", "elapsed_us", "destroy"))
+    for _ in range(3):
+        lib.call("rua_conv_fwd_group", arr, len(dils), s)
+    grids = lib.raw("rua_conv_group_last_grids")()
+    a, b_ = C.c_void_p(ev_new()), C.c_void_p(ev_new())
+    ev_rec(a, s)
+    for _ in range(reps):
+        lib.call("rua_conv_fwd_group", arr, len(dils), s)
+    ev_rec(b_, s)
+    v = C.c_double()
+    lib.check(ev_us(a, b_, C.byref(v)), "rua_prof_event_elapsed_us")
+    ev_del(a); ev_del(b_)
+    us = v.value / reps
+    gflop = len(dils) * 2.0 * N * HW * HW * Cc * Cc * 9 / 1e9
+    return {"probe_us_per_grid": round(us, 1), "gflop_per_grid": round(gflop, 2), "grids_per_launch": int(grids),
+            "what": "plain conv_strip32s group: row DMA + MFMA + output store, no BatchNorm / bias / statistics / epilogue stream; back to back, operands warm"}
+
+
 def host_cores():
     """CPU share actually available: affinity mask capped by the cgroup quota (os.cpu_count() reports the host)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -667,6 +708,20 @@ def main():
                                            "hbm": {"bound": "hbm", "tensor_pass_bytes": round(by), "achieved_gb_s": round(by / sec / 1e9, 1),
                                                    "peak_gb_s": HBM_PEAK_GBS, "frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4),
                                                    "note": "bytes = every tensor each launch of the block reads or writes, once per launch"}}
+        try:                                                    # the stripped ceiling probe of the d6 block (VERDICT r4 next#2a)
+            pr = d6_ceiling_probe(B)
+            tgt = pr["gflop_per_grid"] / (0.40 * peak * 1e3) * 1e6                 # us per grid at 40 % of the peak
+            pr["us_per_grid_at_40pct"] = round(tgt, 1)
+            pr["ceiling_us"] = round(2 * pr["probe_us_per_grid"], 1)
+            pr["ceiling_frac"] = round(2 * pr["gflop_per_grid"] * 1e9 / (pr["ceiling_us"] * 1e-6) / 1e12 / peak, 4)
+            pr["target_40pct_within_reach_of_this_kernel_family"] = bool(pr["probe_us_per_grid"] <= tgt)
+            if "d6_block" in out["roofline"]:
+                out["roofline"]["d6_block"]["ceiling_probe"] = pr
+            out["roofline"]["d6_block_ceiling_us"] = pr["ceiling_us"]
+            out["roofline"]["d6_block_ceiling_frac"] = pr["ceiling_frac"]
+            out["roofline"]["d6_block_40pct_reachable"] = pr["target_40pct_within_reach_of_this_kernel_family"]
+        except Exception as exc:                                # diagnostics only: never lose the headline line
+            log(f"d6 ceiling probe failed: {type(exc).__name__}: {exc}")
         out["roofline"]["resblocks"] = lv
         # every other composite of the step (stem, stride-2 convs, PSPPooling, upsample + combine, heads, losses): microseconds only
         comp = {}

@@ -825,9 +825,9 @@ extern "C" int rua_conv_fwd_sum(const rua_conv_desc* d, int n, void* stream) {
   const int smem = R * (sw + 64) * 64 + 18 * 1024 + nw * 1024 + (4 * 64 + 32) * 4;
   RUA_CHECK_ARG(smem <= 160 * 1024 && smem >= nw * 2 * 2 * 32 * 8, "conv_band: %d bytes of LDS", smem);
   const bool fullw = q.strips == 1;
-  static thread_local bool attr[4] = {false, false, false, false};
+  static RuaPerDevFlag attr[4];                         // per device (a hipFuncSetAttribute is): not per thread
 #define RUA_BAND_GO(NW_, FW_, SLOT_) do { \
-    if (!attr[SLOT_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band32<NW_, 8, 4, FW_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[SLOT_] = true; } \
+    if (!attr[SLOT_].get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band32<NW_, 8, 4, FW_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[SLOT_].get() = true; } \
     hipLaunchKernelGGL((conv_band32<NW_, 8, 4, FW_>), dim3(q.njobs), dim3(NW_ * 64), smem, st, q); } while (0)
   if (g_tune.band_stag && fullw && q.has_bn && q.in_relu) {
     // conv_band32s: R slots by tuning key (band_stag = number of ring slots; 1 = the default of the shape)
@@ -843,7 +843,8 @@ extern "C" int rua_conv_fwd_sum(const rua_conv_desc* d, int n, void* stream) {
     else RUA_BANDS_GO(4, 7, 2);
 #undef RUA_BANDS_GO
   } else if (nw == 8 && fullw && (q.dbg & 8)) {                 // experiment: the 6-slot ring (4 rows in flight instead of 2)
-    static thread_local bool a6 = false;
+    static RuaPerDevFlag a6f;
+    bool& a6 = a6f.get();
     const int smem6 = 6 * (sw + 64) * 64 + 18 * 1024 + nw * 1024 + (4 * 64 + 32) * 4;
     if (!a6) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band32<8, 8, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a6 = true; }
     hipLaunchKernelGGL((conv_band32<8, 8, 6, true>), dim3(q.njobs), dim3(512), smem6, st, q);

@@ -486,12 +486,12 @@ int rua_launch_band64(const rua_conv_desc* d, int n, hipStream_t st) {
   q.njobs = a.N * q.strips * q.bands;
   const int smem = R * 192 * 128 + 2 * 24 * 1024 + (4 * 128 + 64 + 4 * 192 + 8 * 64) * 4;
   static_assert(4 * 192 * 128 + 2 * 24 * 1024 + (4 * 128 + 64 + 4 * 192 + 8 * 64) * 4 <= 160 * 1024, "LDS budget");
-  static thread_local bool attr[2] = {false, false};
+  static RuaPerDevFlag attr[2];
   if (q.strips == 1) {
-    if (!attr[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64<BR, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
+    if (!attr[0].get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64<BR, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0].get() = true; }
     hipLaunchKernelGGL((conv_band64<BR, R, true>), dim3(q.njobs), dim3(512), smem, st, q);
   } else {
-    if (!attr[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64<BR, R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1] = true; }
+    if (!attr[1].get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64<BR, R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1].get() = true; }
     hipLaunchKernelGGL((conv_band64<BR, R, false>), dim3(q.njobs), dim3(512), smem, st, q);
   }
   RUA_LAUNCH_CHECK("conv_band64");
@@ -554,12 +554,12 @@ int rua_launch_band64m(const rua_conv_desc* d, int n, hipStream_t st) {
   q.bands = a.H / BR;
   q.njobs = a.N * q.strips * q.bands;
   const int smem = R * 192 * 128 + 2 * 24 * 1024 + (4 * 128 + 64 + 4 * 192 + 8 * 64) * 4;
-  static thread_local bool attr[2] = {false, false};
+  static RuaPerDevFlag attr[2];
   if (q.strips == 1) {
-    if (!attr[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64m<BR, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
+    if (!attr[0].get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64m<BR, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0].get() = true; }
     hipLaunchKernelGGL((conv_band64m<BR, R, true>), dim3(q.njobs), dim3(512), smem, st, q);
   } else {
-    if (!attr[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64m<BR, R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1] = true; }
+    if (!attr[1].get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band64m<BR, R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1].get() = true; }
     hipLaunchKernelGGL((conv_band64m<BR, R, false>), dim3(q.njobs), dim3(512), smem, st, q);
   }
   RUA_LAUNCH_CHECK("conv_band64m");

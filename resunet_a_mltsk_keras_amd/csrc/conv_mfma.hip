@@ -2257,9 +2257,9 @@ static int issue_group(const ConvGroupCapture& c, const int* idx, int m, F1 sing
   if (m == 1) {
     hipLaunchKernelGGL(single, dim3(c.grid[idx[0]]), dim3(threads), c.smem[idx[0]], st, c.k[idx[0]]);
   } else {
-    static thread_local bool attr[8] = {false};
+    static RuaPerDevFlag attr[8];                        // per device, not per thread (the instantiations of this template are per kernel pair)
     const int slot = c.kind[idx[0]];
-    if (!attr[slot]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grouped), hipFuncAttributeMaxDynamicSharedMemorySize, smem_attr); attr[slot] = true; }
+    if (!attr[slot].get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grouped), hipFuncAttributeMaxDynamicSharedMemorySize, smem_attr); attr[slot].get() = true; }
     KG g;
     for (int i = 0; i < m; ++i) g.k[i] = c.k[idx[i]];
     hipLaunchKernelGGL(grouped, dim3(c.grid[idx[0]], m), dim3(threads), c.smem[idx[0]], st, g);
@@ -2279,8 +2279,8 @@ static bool chain_ok(const ConvGroupCapture& c, const int* idx, int m) {
 }
 template <typename FC>
 static int issue_chain(const ConvGroupCapture& c, const int* idx, int m, FC kern, int smem, int slot, hipStream_t st) {
-  static thread_local bool attr[2] = {false, false};
-  if (!attr[slot]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr[slot] = true; }
+  static RuaPerDevFlag attr[2];
+  if (!attr[slot].get()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr[slot].get() = true; }
   ConvKG g;
   for (int i = 0; i < m; ++i) g.k[i] = c.k[idx[i]];
   hipLaunchKernelGGL(kern, dim3(c.grid[idx[0]]), dim3(256), smem, st, g, m);
@@ -4026,7 +4026,8 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
     c.post[i] = d->defer ? 0 : 1; c.part[i] = k.scratch; c.dw[i] = d->dw; c.CC[i] = CC; c.parts[i] = gx; c.rblocks[i] = rblocks; c.ndw[i] = 0;
     return RUA_OK;
   }
-  static thread_local bool attr32 = false, attr64 = false;
+  static RuaPerDevFlag attr32f, attr64f;
+  bool& attr32 = attr32f.get(); bool& attr64 = attr64f.get();
   if (rows_kind) launch_rows32(rows_kind, false, dim3(gx), (int)smem, st, &k, nullptr);
   else if (CC == 32) {
     if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr32 = true; }
@@ -4619,15 +4620,16 @@ extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream
     int idx[RUA_MAX_BRANCH], m = 0; unsigned gx = 0; int smem = 0;
     for (int j = i; j < cap.n; ++j)
       if (!done[j] && cap.kind[j] == cap.kind[i]) { idx[m++] = j; done[j] = true; if (cap.gx[j] > gx) gx = cap.gx[j]; if (cap.smem[j] > smem) smem = cap.smem[j]; }
-    static thread_local bool attr[4] = {false, false, false, false};
+    static RuaPerDevFlag attrf[4];
+    bool* attr[4] = {&attrf[0].get(), &attrf[1].get(), &attrf[2].get(), &attrf[3].get()};
     const int kd = cap.kind[i];
     if (kd == 0) {
       if (m == 1) hipLaunchKernelGGL((wgrad_kernel<bf16_t>), dim3(gx), dim3(256), 0, st, cap.g[idx[0]]);
       else { WgKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.g[idx[q]]; hipLaunchKernelGGL(wgrad_kernel_g, dim3(gx, m), dim3(256), 0, st, g); }
     } else if (kd == 3) {
-      if (!attr[3]) {
+      if (!*attr[3]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap_g), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr[3] = true;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dmap_g), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); *attr[3] = true;
       }
       if (m == 1) hipLaunchKernelGGL(wgrad_dmap, dim3(gx), dim3(256), smem, st, cap.d[idx[0]]);
       else { WgdKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.d[idx[q]]; hipLaunchKernelGGL(wgrad_dmap_g, dim3((gx + 7) / 8 * 8, m), dim3(256), smem, st, g); }
@@ -4638,12 +4640,12 @@ extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream
       else launch_rows32(kd, true, dim3(gx, gyr, m), smem, st, nullptr, &g);
     } else {
       const int gy = kd == 1 ? 1 : 2;
-      if (!attr[kd]) {
+      if (!*attr[kd]) {
         if (kd == 1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel_g<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         else { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel_g<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-        attr[kd] = true;
+        *attr[kd] = true;
       }
       WgtKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.t[idx[q]];
       if (m == 1) { if (kd == 1) hipLaunchKernelGGL((wgrad_taps_kernel<32>), dim3(gx, gy), dim3(768), smem, st, g.k[0]);

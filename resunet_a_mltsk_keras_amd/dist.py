@@ -53,6 +53,9 @@ class GradReducer:
         self.fired = [False] * len(buckets)
         self.measure = False                     # bench.py: bracket the wait for the collectives with events on the launch stream
         self._exposed: List[Tuple[object, object]] = []
+        self._holes: List[Tuple[object, object]] = []    # measure: event pairs around every collective's ISSUE on the launch stream
+        self.n_coll = 0                          # collectives issued since begin()
+        self.n_coll_last = 0                     # ... of the last finished step
 
     def exposed_ms(self) -> Optional[float]:
         """Mean time per step the LAUNCH stream stood waiting for gradient all-reduces (what the backward did not hide), from the
@@ -63,9 +66,21 @@ class GradReducer:
         self._exposed = []
         return float(sum(ms) / len(ms))
 
+    def hole_us(self) -> Optional[float]:
+        """Mean time per step between the two launch-stream events that bracket the ISSUE of each gradient all-reduce, summed over the step's
+        collectives (what a collective costs the launch stream even when its transfer is hidden: DESIGN section 6); None if nothing was measured."""
+        if not self._holes or not self._steps_measured:
+            return None
+        us = sum(a.elapsed_time(b) for a, b in self._holes) * 1e3 / self._steps_measured
+        self._holes, self._steps_measured = [], 0
+        return float(us)
+
+    _steps_measured = 0
+
     def begin(self):
         self.works = []
         self.fired = [False] * len(self.buckets)
+        self.n_coll = 0
 
     def ready(self, i: int):
         """Bucket i is final on the current stream: launch its all-reduce (async)."""
@@ -79,6 +94,11 @@ class GradReducer:
             dist.all_reduce(h, group=self.group)
             view.copy_(h)
             return
+        self.n_coll += 1
+        pair = None
+        if self.measure and self.cuda:
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record(torch.cuda.current_stream(self.flat.device))
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.flat.device))
@@ -87,6 +107,9 @@ class GradReducer:
                 self.works.append(dist.all_reduce(view, group=self.group, async_op=True))
         else:
             self.works.append(dist.all_reduce(view, group=self.group, async_op=True))
+        if pair is not None:
+            pair[1].record(torch.cuda.current_stream(self.flat.device))
+            self._holes.append(pair)
 
     def finish(self):
         """Every bucket reduced and visible to the current stream."""
@@ -96,6 +119,9 @@ class GradReducer:
         if self.measure and self.cuda and not self.host_staged:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(torch.cuda.current_stream(self.flat.device))
+        self.n_coll_last = self.n_coll
+        if self.measure:
+            self._steps_measured += 1
         for w in self.works:
             w.wait()
         if self.side is not None:
@@ -125,7 +151,14 @@ class DataParallel:
         # bucket's hook overlaps it with the rest of the backward.  A second stream of ours in between cost 0.3 ms per step on
         # one GPU (10.42 vs 10.14 ms: event record + wait + stream switch per bucket) for nothing.
         side = os.environ.get("RUA_DP_SIDE_STREAM", "0") == "1"
-        self.reducer = GradReducer(eng.G[:eng.params.n], self.buckets, group, use_side_stream=overlap and side, host_staged=self.host_staged)
+        # The BatchNorm moving statistics (~50 k floats, mean-aggregated like MirroredStrategy's mirrored variables) ride in the FIRST gradient bucket:
+        # the gradient arena has room for a copy of them behind the last parameter, the bucket that ends there (the deepest layers: complete first) is
+        # extended over it - one collective less per step (each costs the launch stream ~20 - 26 us even when its transfer is hidden).
+        n, ns = eng.params.n, eng.params.ns
+        self.fold_state = os.environ.get("RUA_DP_FOLD_STATE", "1") != "0" and eng.G.numel() >= n + ns and ns > 0
+        if self.fold_state:
+            self.buckets[0] = (self.buckets[0][0], n + ns)
+        self.reducer = GradReducer(eng.G[:n + ns] if self.fold_state else eng.G[:n], self.buckets, group, use_side_stream=overlap and side, host_staged=self.host_staged)
         self._bcast(eng.P); self._bcast(eng.S)
         eng.params_changed()
         # Room for RCCL's kernels: several launchers size their grid at exactly one block per CU; with a bucket's all-reduce in flight
@@ -189,7 +222,10 @@ class DataParallel:
         """BN moving statistics are final once the forward has been issued: their (small) all-reduce starts here and hides
         behind the backward instead of standing between the last gradient bucket and the optimizer."""
         self._s_work = None
-        if self.overlap and not self.host_staged:
+        if self.fold_state:                                   # a copy behind the last gradient: reduced with the first bucket
+            n, ns = eng.params.n, eng.params.ns
+            eng.G[n:n + ns].copy_(eng.S[:ns])
+        elif self.overlap and not self.host_staged:
             self._s_work = dist.all_reduce(eng.S, group=self.group, async_op=True)
 
     def reduce_gradients(self, eng):
@@ -198,7 +234,12 @@ class DataParallel:
         S = eng.S
         work = getattr(self, "_s_work", None)
         self._s_work = None
-        if self.host_staged:
+        self.collectives_last = self.reducer.n_coll_last + (0 if self.fold_state else 1)
+        if self.fold_state:
+            n, ns = eng.params.n, eng.params.ns
+            S[:ns].copy_(eng.G[n:n + ns])
+            S[:ns].div_(self.world)
+        elif self.host_staged:
             h = S.cpu(); dist.all_reduce(h, group=self.group); S.copy_(h / self.world)
         elif work is not None:
             work.wait()
@@ -230,6 +271,7 @@ def dp_report(dp: "DataParallel", ms_per_step: float, device=None) -> dict:
     bucket sizes, the exposed all-reduce time, the ranks' own step times."""
     per_rank = gather_floats(ms_per_step, dp.group, device)
     exposed = dp.reducer.exposed_ms()
+    hole = dp.reducer.hole_us() if hasattr(dp.reducer, "hole_us") else None
     exp_all = gather_floats(-1.0 if exposed is None else exposed, dp.group, device)
     return {
         "rccl_ranks": comm_ranks(dp.group, device),
@@ -240,4 +282,9 @@ def dp_report(dp: "DataParallel", ms_per_step: float, device=None) -> dict:
         "ms_per_step_min": round(min(per_rank), 3), "ms_per_step_max": round(max(per_rank), 3),
         "ms_per_step_per_rank": [round(v, 3) for v in per_rank],
         "cu_reserve": dp.cu_reserve, "overlap": bool(dp.overlap),
+        # collectives the step issues (gradient buckets [+ the BatchNorm state when it does not ride in the first bucket]; the 16 result scalars only when
+        # results are fetched) and what their ISSUE costs the launch stream (event pairs around each all-reduce call), per step
+        "collectives_per_step": getattr(dp, "collectives_last", None),
+        "state_in_first_bucket": bool(getattr(dp, "fold_state", False)),
+        "launch_stream_hole_us": None if hole is None else round(hole, 1),
     }

@@ -1728,7 +1728,7 @@ class Engine:
         if L.lib().raw("rua_device_info")(C.byref(cu), None, None, 0) == 0 and cu.value > 0:
             self.cu_count = cu.value
         z = lambda n, dt=torch.float32: torch.zeros(max(n, 16), dtype=dt, device=self.dev)
-        self.P, self.G, self.M1, self.V1, self.S = z(ps.n), z(ps.n), z(ps.n), z(ps.n), z(ps.ns)
+        self.P, self.G, self.M1, self.V1, self.S = z(ps.n), z(ps.n + ps.ns + 16), z(ps.n), z(ps.n), z(ps.ns)      # G: room behind the last gradient for the BatchNorm state's ride in the first all-reduce bucket (dist.py)
         tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
         self.Wf, self.Wd = z(ps.n, tdt), z(ps.n, tdt)
         # first-writer overwrite of the gradient arena: in a whole step every weight gradient has ONE producer and the optimizer left the arena zero, so the kernels

@@ -44,6 +44,7 @@ def _worker(rank, world, port, n, out):
     for i in [2, 0, 2, len(buckets) - 1]:                                    # out of order, repeated: fires once each
         red.ready(i)
     red.finish()                                                              # fires the rest, waits for all
+    assert red.n_coll_last == len(buckets)                                    # one collective per bucket, however often ready() was called
     gathered = [torch.zeros(n) for _ in range(world)]
     dist.all_gather(gathered, mine)
     exp = sum(gathered)
@@ -144,6 +145,8 @@ def _report_worker(rank, world, port, out):
     ok = ok and rep["bucket_mb"] == [round(2000 * 4 / 2**20, 2), round(1000 * 4 / 2**20, 2)]
     ok = ok and rep["allreduce_exposed_ms"] is None and rep["cu_reserve"] == 8 and rep["overlap"] is True    # nothing measured on the CPU
     ok = ok and gather_floats(float(rank)) == [0.0, 1.0]
+    # round 5: the collectives a step issues, whether the BatchNorm state rides in the first bucket, what issuing costs the launch stream (nothing measured on the CPU)
+    ok = ok and rep["collectives_per_step"] is None and rep["state_in_first_bucket"] is False and rep["launch_stream_hole_us"] is None
     out[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -1203,6 +1203,16 @@ def test_wgrad_deferred_batched_reduction_is_bit_identical():
                                    (6, 128, 128, 32, [1, 3, 15, 31]), (8, 32, 32, 256, [1, 3, 15]), (3, 24, 40, 128, [1, 15]),
                                    (32, 64, 64, 64, [1, 3, 15, 31]), (5, 64, 64, 64, [1, 15])])     # C = 64 off the 128-pixel rows: conv_igemm_g
 def test_conv_group_equals_separate_launches(shape):
+    # (C = 128 / 256 groups run on conv_band128m since round 5 - test_conv_group_band64_multi compares that kernel with these members one by one;
+    # this test keeps its subject, the grouped grids of the members' own kernels: conv_band128m off)
+    L.lib().set_tuning(conv_band128m=0)
+    try:
+        _group_equals_separate(shape)
+    finally:
+        L.lib().set_tuning(conv_band128m=BAND128M_DEFAULT)
+
+
+def _group_equals_separate(shape):
     """rua_conv_fwd_group: the dilation branches of a ResBlock in one call.  Members on the same kernel (conv_dmap at the
     64x64x128 level, conv_strip at 256x256x32) share ONE grid, the 128x128x64 level runs as ONE conv_band64m launch; members the launcher cannot group
     (split-K at 16x16x512) run one by one.  Either way the results are bit-identical to separate rua_conv_fwd calls."""
