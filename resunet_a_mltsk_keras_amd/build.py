@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("RUA_BUILD_OUT") or os.path.join(HERE, "librua_hip.so")      # RUA_BUILD_OUT / RUA_BUILD_FLAGS: experiment builds (A/B through RUA_LIB_PATH)
-SOURCES = ["conv_mfma.hip", "conv_strip.hip", "conv_band.hip", "conv_band64.hip", "conv_band128.hip", "elementwise.hip", "small_conv.hip", "loss_optim.hip", "capi.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_strip.hip", "conv_band.hip", "conv_band64.hip", "conv_band128.hip", "conv_img2.hip", "elementwise.hip", "small_conv.hip", "loss_optim.hip", "capi.cpp"]
 # per-file flags.  conv_strip: without the SLP vectorizer - it packed the per-lane statistics sums into v_pk_add_f32 / v_pk_fma_f32 on
 # register pairs it first had to assemble with v_mov_b32 (32 per two row stages); the scalar forms issue in the MFMA shadows
 FILE_FLAGS = {"conv_strip.hip": ["-fno-slp-vectorize"]}

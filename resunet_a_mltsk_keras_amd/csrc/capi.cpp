@@ -108,7 +108,7 @@ static const TuneKey* tune_table(int* n) {
     {"wgpw_r", &g_tune.wgpw_r, nullptr}, {"wgd_blocks", &g_tune.wgd_blocks, nullptr}, {"wgrad_dmap", &g_tune.wgrad_dmap, nullptr},
     {"wgd_mintiles", &g_tune.wgd_mintiles, nullptr}, {"wgrad_blocks", &g_tune.wgrad_blocks, nullptr}, {"bn_grid", &g_tune.bn_grid, nullptr},
     {"tani_vec", &g_tune.tani_vec, nullptr}, {"metrics_blocks", &g_tune.metrics_blocks, nullptr}, {"stem_blocks", &g_tune.stem_blocks, nullptr},
-    {"head_blocks", &g_tune.head_blocks, nullptr}, {"conv_img", &g_tune.conv_img, nullptr}, {"conv_strip", &g_tune.conv_strip, nullptr}, {"wgrad_slabs", &g_tune.wgrad_slabs, nullptr}, {"strip_narrow_maxd", &g_tune.strip_narrow_maxd, nullptr}, {"conv_group", &g_tune.conv_group, nullptr}, {"wgrad_group", &g_tune.wgrad_group, nullptr}, {"wgd_ks_slow", &g_tune.wgd_ks_slow, nullptr}, {"head_fwd2", &g_tune.head_fwd2, nullptr}, {"head_fwd3", &g_tune.head_fwd3, nullptr}, {"head_fwd3_bpc", &g_tune.head_fwd3_bpc, nullptr}, {"stem_reg", &g_tune.stem_reg, nullptr}, {"stats_blocks", &g_tune.stats_blocks, nullptr}, {"conv_band", &g_tune.conv_band, nullptr}, {"conv_band64", &g_tune.conv_band64, nullptr}, {"conv_band64m", &g_tune.conv_band64m, nullptr}, {"strip_group_share", &g_tune.strip_group_share, nullptr}, {"band_dbg", &g_tune.band_dbg, nullptr}, {"fill_kernel", &g_tune.fill_kernel, nullptr}, {"bn_regs", &g_tune.bn_regs, nullptr}, {"wgrad_taps_share", &g_tune.wgrad_taps_share, nullptr}, {"wgrad_kernel_share", &g_tune.wgrad_kernel_share, nullptr}, {"dmap_group_bm128", &g_tune.dmap_group_bm128, nullptr}, {"dmap_chain", &g_tune.dmap_chain, nullptr}, {"epi_fast", &g_tune.epi_fast, nullptr}, {"dmap_spread", &g_tune.dmap_spread, nullptr}, {"bn_bwd_group", &g_tune.bn_bwd_group, nullptr}, {"conv_small", &g_tune.conv_small, nullptr}, {"strip_stag", &g_tune.strip_stag, nullptr}, {"cu_reserve", &g_tune.cu_reserve, nullptr}, {"wgrad_rows", &g_tune.wgrad_rows, nullptr}, {"strip_seglen", &g_tune.strip_seglen, nullptr}, {"band_stag", &g_tune.band_stag, nullptr}, {"conv_band128m", &g_tune.conv_band128m, nullptr}, {"dbg_ptr", nullptr, &g_tune.dbg_ptr},
+    {"head_blocks", &g_tune.head_blocks, nullptr}, {"conv_img", &g_tune.conv_img, nullptr}, {"conv_strip", &g_tune.conv_strip, nullptr}, {"wgrad_slabs", &g_tune.wgrad_slabs, nullptr}, {"strip_narrow_maxd", &g_tune.strip_narrow_maxd, nullptr}, {"conv_group", &g_tune.conv_group, nullptr}, {"wgrad_group", &g_tune.wgrad_group, nullptr}, {"wgd_ks_slow", &g_tune.wgd_ks_slow, nullptr}, {"head_fwd2", &g_tune.head_fwd2, nullptr}, {"head_fwd3", &g_tune.head_fwd3, nullptr}, {"head_fwd3_bpc", &g_tune.head_fwd3_bpc, nullptr}, {"stem_reg", &g_tune.stem_reg, nullptr}, {"stats_blocks", &g_tune.stats_blocks, nullptr}, {"conv_band", &g_tune.conv_band, nullptr}, {"conv_band64", &g_tune.conv_band64, nullptr}, {"conv_band64m", &g_tune.conv_band64m, nullptr}, {"strip_group_share", &g_tune.strip_group_share, nullptr}, {"band_dbg", &g_tune.band_dbg, nullptr}, {"fill_kernel", &g_tune.fill_kernel, nullptr}, {"bn_regs", &g_tune.bn_regs, nullptr}, {"wgrad_taps_share", &g_tune.wgrad_taps_share, nullptr}, {"wgrad_kernel_share", &g_tune.wgrad_kernel_share, nullptr}, {"dmap_group_bm128", &g_tune.dmap_group_bm128, nullptr}, {"dmap_chain", &g_tune.dmap_chain, nullptr}, {"epi_fast", &g_tune.epi_fast, nullptr}, {"dmap_spread", &g_tune.dmap_spread, nullptr}, {"bn_bwd_group", &g_tune.bn_bwd_group, nullptr}, {"conv_small", &g_tune.conv_small, nullptr}, {"strip_stag", &g_tune.strip_stag, nullptr}, {"cu_reserve", &g_tune.cu_reserve, nullptr}, {"wgrad_rows", &g_tune.wgrad_rows, nullptr}, {"strip_seglen", &g_tune.strip_seglen, nullptr}, {"band_stag", &g_tune.band_stag, nullptr}, {"conv_band128m", &g_tune.conv_band128m, nullptr}, {"conv_img2", &g_tune.conv_img2, nullptr}, {"dbg_ptr", nullptr, &g_tune.dbg_ptr},
   };
   *n = (int)(sizeof(t) / sizeof(t[0]));
   return t;

@@ -84,6 +84,7 @@ struct RuaTuning {
   int head_fwd3 = 1;                    // bf16 heads with Cin = 32: the MFMA form, a lane per pixel (0: head_fwd2)
   int head_fwd3_bpc = 0;                // its blocks per CU over the batch (0: 2)
   int head_fwd2 = 1;                    // heads with Cin = 32: the register-weights kernel (0: the LDS-weights one)
+  int conv_img2 = 1;                    // conv_img2 (round 5): the 3x3 convolutions of the 8 x 8 / 16 x 16 levels with whole images resident, coalesced weight rows, weights in registers, K split by input chunks + conv_splitk_finish (0: conv_dmap)
   int conv_img = 0;                     // 1: conv_img - the 3x3 convolutions of the 8 x 8 / 16 x 16 levels with a whole image resident in LDS instead of conv_dmap + split K (measured level: 28 - 29 us either way)
   int conv_small = 4096;                // conv_small serves 1x1 convolutions of at most this many output pixels (0: off)
   int bn_bwd_group = 1;                 // rua_bn_bwd_group: the one-branch BatchNorm backwards of a ResBlock in one grid
@@ -256,6 +257,10 @@ int rua_launch_band64m(const rua_conv_desc* d, int n, hipStream_t st);
 // conv_band128.hip
 bool rua_band128m_ok(const rua_conv_desc* d, int n);   // independent members at C = Cout = 128 on 64-pixel rows as one conv_band128m launch
 int rua_launch_band128m(const rua_conv_desc* d, int n, hipStream_t st);
+// conv_img2.hip
+int rua_pick_img2(const rua_conv_desc* d);             // K slices (0: not this kernel)
+int rua_launch_conv_img2(ConvK& k, const rua_conv_desc* d, int KS, hipStream_t st);
+int rua_splitk_finish_bf16(const ConvK& k, hipStream_t st);   // conv_mfma.hip: conv_splitk_finish over the K slices' slabs
 // conv_strip.hip
 bool rua_pick_strip(const rua_conv_desc* d);
 int rua_launch_conv_strip(const ConvK& k, const rua_conv_desc* d, hipStream_t st);

@@ -528,6 +528,12 @@ template <typename T> static void launch_splitk_finish(const ConvK& k, hipStream
   else hipLaunchKernelGGL((conv_splitk_finish<T, 32>), dim3((unsigned)(((k.M + 31) / 32) * nbn)), dim3(256), 0, st, k);
 }
 
+int rua_splitk_finish_bf16(const ConvK& k, hipStream_t st) {
+  launch_splitk_finish<bf16_t>(k, st);
+  RUA_LAUNCH_CHECK("conv_splitk_finish");
+  return RUA_OK;
+}
+
 // =========================================================================================
 // conv_dma<BM,BN>: the bf16 production kernel.  Same GEMM view, tiles, unit table and epilogue as conv_igemm, but the
 // A / B stage tiles are written by LDS-DMA (buffer_load ... lds: no VGPR staging, no ds_write; out-of-range lanes
@@ -2165,6 +2171,10 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
   if (pick_small(d)) {
     g_last_ksplit = 1;
     return launch_conv_small(k, st);
+  }
+  if (const int img2_ks = rua_pick_img2(d)) {                // the two deepest levels (round 5, conv_img2.hip)
+    g_last_ksplit = img2_ks;
+    return rua_launch_conv_img2(k, d, img2_ks, st);
   }
   if (const int img_ks = pick_img(d)) {
     g_last_ksplit = img_ks;
@@ -4906,6 +4916,7 @@ extern "C" int rua_conv_kernel_id(const rua_conv_desc* d) {
   if (pick_halo(d)) return 3;
   if (pick_pw(d)) return 4;
   if (pick_small(d)) return 6;
+  if (rua_pick_img2(d)) return 8;
   if (pick_img(d)) return 7;
   if (pick_dmap(d)) return 2;
   return pick_dma(d, pick_bn(d, (long long)d->N * d->H * d->W)) ? 1 : 0;
