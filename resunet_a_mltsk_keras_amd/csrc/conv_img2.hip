@@ -12,6 +12,9 @@
 //   * K is split over blocks by input-channel chunks (8 x 2 x 16 = 256 blocks at 8 x 8 x 1024, 4 x 8 x 8 at 16 x 16 x 512): every block stores its fp32 partial tile
 //     into its slice's slab, conv_splitk_finish (conv_mfma.hip) sums the slabs in a fixed order and runs the shared epilogue (bias, mask, statistics, store) - the
 //     same finisher, slab layout and bit-reproducibility as the split-K path it replaces.
+// (Measured and not kept: TWO weight images - the input tile + 2 x 48 KB are exactly the 160 KB, so the zero pixel went and a tap that leaves the image read its own
+// pixel and was cleared by a per-lane mask, four v_and per fragment - with the weights of phase p + 2 issued in phase p: 28.8 vs 25.8 us per convolution, step
+// -0.047 vs -0.07 ms.  The ANDs sit between a fragment read and its MFMA.)
 #include "common.h"
 
 struct Img2K {
