@@ -78,7 +78,7 @@ struct RuaTuning {
   int bn_grid = 0, tani_vec = 1, metrics_blocks = 0, stem_blocks = 0, head_blocks = 0;
   int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0, strip_group_share = 1;
   // grouped launches of a ResBlock's dilation branches, one bit per kernel family (0: every member launches on its own)
-  int conv_group = 31;                  // 1 conv_strip, 2 conv_igemm<bf16,256,64>, 4 conv_dmap<128,128>, 8 conv_dmap<64,128>, 16 conv_small (unequal grids)
+  int conv_group = 63;                  // 1 conv_strip, 2 conv_igemm<bf16,256,64>, 4 conv_dmap<128,128>, 8 conv_dmap<64,128>, 16 conv_small (unequal grids), 32 conv_pw with K <= 32 (unequal grids)
   int stats_blocks = 0;                 // col_stats grid cap (0: 1024)
   int stem_reg = 1;                     // stem with Cin <= 8: weights in registers, next pixel prefetched (0: the LDS-weights kernel)
   int head_fwd3 = 1;                    // bf16 heads with Cin = 32: the MFMA form, a lane per pixel (0: head_fwd2)

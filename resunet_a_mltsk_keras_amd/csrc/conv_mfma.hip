@@ -1480,10 +1480,16 @@ template <int BM, int BN, int ROWB> static int launch_conv_dmap(const ConvK& k, 
 // mask, ReLU, statistics) and 16-byte stores.  Statistics stay in registers over all tiles of a wave and leave through
 // shuffles -> LDS -> one fp64 atomic per channel and block, like everywhere else.
 struct PwStep { const unsigned char* x; const unsigned char* w; unsigned xbytes, wbytes; int C, kofs, up, Hs, Ws, dense; };
-template <int KS> struct PwK { ConvK c; PwStep st[KS]; int px_per_wave, wsh, hsh; };
+template <int KS> struct PwK { ConvK c; PwStep st[KS]; int px_per_wave, wsh, hsh, nblk; };
+// members of a group (rua_conv_fwd_group: the four branch convolutions of the top-level PSPPooling, the per-source data gradients of a concatenating 1x1
+// conv): recorded by the launcher, issued as ONE grid (blockIdx.y = member, grids of unequal size) - each was a launch of 8 - 15 us, half of it ramp and drain
+struct PwGroupCapture { int n; PwK<2> k[RUA_MAX_BRANCH]; bool dense[RUA_MAX_BRANCH]; };
+static thread_local PwGroupCapture* g_pw_group = nullptr;
+template <int KS> struct PwKG { PwK<KS> k[RUA_MAX_BRANCH]; };
+static_assert(sizeof(PwKG<2>) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 
 template <int KS, bool DENSE>
-__global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_pw(const PwK<KS> q) {      // >= 3 waves per SIMD for K <= 64
+__device__ __forceinline__ void conv_pw_body(const PwK<KS>& q) {
   const ConvK& p = q.c;
   __shared__ float tab[3 * 32];                       // bias sum, mask scale, mask shift per output channel
   __shared__ float sred[4 * 64 * 33 + 4 * 64];        // statistics fold: [wave][value row][33] + [wave][64]
@@ -1646,6 +1652,14 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_pw(const PwK<KS> 
     }
   }
 }
+template <int KS, bool DENSE>
+__global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_pw(const PwK<KS> q) { conv_pw_body<KS, DENSE>(q); }      // >= 3 waves per SIMD for K <= 64
+template <int KS, bool DENSE>
+__global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_pw_g(const PwKG<KS> g) {
+  const PwK<KS>& q = g.k[blockIdx.y];
+  if ((int)blockIdx.x >= q.nblk) return;
+  conv_pw_body<KS, DENSE>(q);
+}
 
 static int pw_steps(const rua_conv_desc* d) {             // 16-channel k-steps of all segments; 0: not a conv_pw shape
   int n = 0;
@@ -1695,8 +1709,15 @@ template <int KS> static int launch_conv_pw(const ConvK& k, const rua_conv_desc*
   ppw = (ppw + 31) / 32 * 32;
   q.px_per_wave = (int)ppw;
   const unsigned grid = (unsigned)((k.M + ppw * 4 - 1) / (ppw * 4));
+  q.nblk = (int)grid;
   bool all_dense = true;
   for (int i = 0; i < KS; ++i) all_dense = all_dense && (q.st[i].dense || q.st[i].C == 0);
+  if constexpr (KS == 2) {
+    if (g_pw_group && g_pw_group->n < RUA_MAX_BRANCH) {      // a member of a group: recorded, issued by rua_conv_fwd_group
+      g_pw_group->dense[g_pw_group->n] = all_dense; g_pw_group->k[g_pw_group->n++] = q;
+      return RUA_OK;
+    }
+  }
   if (all_dense) hipLaunchKernelGGL((conv_pw<KS, true>), dim3(grid), dim3(256), 0, st, q);
   else hipLaunchKernelGGL((conv_pw<KS, false>), dim3(grid), dim3(256), 0, st, q);
   RUA_LAUNCH_CHECK("conv_pw");
@@ -2321,13 +2342,28 @@ extern "C" int rua_conv_fwd_group(const rua_conv_desc* d, int n, void* stream) {
   ConvGroupCapture cap;
   cap.n = 0;
   cap.members = n;
+  PwGroupCapture pwc;
+  pwc.n = 0;
   rua_strip_group_reset();                                  // nothing stale from a group that failed half-way
   g_conv_group = &cap;
+  g_pw_group = (g_tune.conv_group & 32) ? &pwc : nullptr;
   int rc = RUA_OK;
   for (int i = 0; i < n && rc == RUA_OK; ++i) rc = rua_conv_fwd(d + i, stream);      // non-groupable members launch right here
   g_conv_group = nullptr;
+  g_pw_group = nullptr;
   if (rc != RUA_OK) { rua_strip_group_reset(); return rc; }  // captured members are dropped, not issued by the next group
-  int grids = n - cap.n - rua_strip_group_pending();        // members no launcher captured were launched one by one above
+  int grids = n - cap.n - pwc.n - rua_strip_group_pending();        // members no launcher captured were launched one by one above
+  for (int dense = 0; dense < 2; ++dense) {                 // conv_pw members: one grid per addressing form
+    PwKG<2> g; int m = 0; unsigned gx = 0;
+    for (int i = 0; i < pwc.n; ++i) if ((int)pwc.dense[i] == dense) { g.k[m++] = pwc.k[i]; if ((unsigned)pwc.k[i].nblk > gx) gx = (unsigned)pwc.k[i].nblk; }
+    if (m == 0) continue;
+    for (int i = m; i < RUA_MAX_BRANCH; ++i) g.k[i] = g.k[0];
+    if (m == 1) { if (dense) hipLaunchKernelGGL((conv_pw<2, true>), dim3(gx), dim3(256), 0, st, g.k[0]); else hipLaunchKernelGGL((conv_pw<2, false>), dim3(gx), dim3(256), 0, st, g.k[0]); }
+    else if (dense) hipLaunchKernelGGL((conv_pw_g<2, true>), dim3(gx, m), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((conv_pw_g<2, false>), dim3(gx, m), dim3(256), 0, st, g);
+    RUA_LAUNCH_CHECK("conv_pw (group)");
+    ++grids;
+  }
   rc = rua_strip_group_flush(st, &grids);
   if (rc != RUA_OK) return rc;
   bool done[RUA_MAX_BRANCH] = {false};

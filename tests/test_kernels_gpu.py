@@ -418,6 +418,50 @@ def test_wgrad_pointwise_kernel(case):
         assert float(ws[-(16 * 64 * 64 + 2048):].abs().max()) == 0.0
 
 
+def test_conv_pointwise_group_members_share_a_grid():
+    """rua_conv_fwd_group over narrow 1x1 convolutions of UNEQUAL size (round 5: the branch convolutions of the top-level PSPPooling, model2.py:47-68, and the per-source
+    data gradients of its fuse conv): the conv_pw members (>= 65 536 pixels) run as ONE conv_pw_g grid, the smaller ones on their own kernels - every member bit for bit
+    what a launch of its own gives (statistics: fp64 atomics of the same per-block sums)."""
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(31)
+    shapes = [(8, 256, 256), (8, 128, 128), (8, 64, 64), (8, 32, 32)]
+    Cs, Cout = 32, 8
+    keep, descs = [], []
+    for N, H, W in shapes:
+        x = to_dev(rng.standard_normal((N, H, W, Cs)).astype(np.float32), dt)
+        w = to_dev((rng.standard_normal((1, Cout, Cs)) / np.sqrt(Cs)).astype(np.float32), dt)
+        bias = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32)).to(dev())
+        y = torch.zeros((N, H, W, Cout), dtype=torch.bfloat16, device=dev())
+        stats = torch.zeros(8 * 2 * Cout, dtype=torch.float64, device=dev())
+        d = L.ConvDesc()
+        d.nseg = 1
+        sg = d.seg[0]
+        sg.x, sg.w, sg.C, sg.Hs, sg.Ws, sg.up_shift, sg.dil, sg.taps = x.data_ptr(), w.data_ptr(), Cs, H, W, 0, 1, 1
+        d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cout, 1, dt
+        d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+        d.bias = bias.data_ptr()
+        d.stats, d.stats_mode, d.stats_replicas = stats.data_ptr(), 1, 8
+        keep.append((x, w, bias, y, stats)); descs.append(d)
+    npw = sum(1 for d in descs if lib.raw("rua_conv_kernel_id")(C.byref(d)) == 4)
+    assert npw == 2                                            # the 256 x 256 and 128 x 128 members
+    sep = []
+    for d, kp in zip(descs, keep):
+        lib.call("rua_conv_fwd", C.byref(d), stream())
+        torch.cuda.synchronize()
+        sep.append((kp[3].clone(), kp[4].clone()))
+        kp[3].zero_(); kp[4].zero_()
+    arr = (L.ConvDesc * len(descs))()
+    for i, d in enumerate(descs):
+        C.memmove(C.byref(arr, i * C.sizeof(L.ConvDesc)), C.byref(d), C.sizeof(L.ConvDesc))
+    lib.call("rua_conv_fwd_group", arr, len(descs), stream())
+    torch.cuda.synchronize()
+    assert lib.raw("rua_conv_group_last_grids")() <= len(descs) - (npw - 1)
+    for (yy, st), kp in zip(sep, keep):
+        assert torch.equal(kp[3], yy)
+        assert np.allclose(kp[4].cpu().numpy().reshape(8, -1).sum(0), st.cpu().numpy().reshape(8, -1).sum(0), rtol=1e-12, atol=1e-9)
+
+
 def test_wgrad_pointwise_group_is_one_grid():
     """rua_conv_wgrad_group over narrow 1x1 weight gradients with workspaces of their own (round 5: the per-source weight gradients of a concatenating
     1x1 conv, the branch convs of a PSPPooling - Graph.wgrad_pw_group): members of UNEQUAL size and channel counts run as one wgrad_pw_g grid per
