@@ -780,7 +780,7 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
     if (br.replicas > rmax) rmax = br.replicas;
   }
   size_t smem = (size_t)(d->nb * 5 + 2) * d->C * 4;
-  RUA_CHECK_ARG(smem <= 64 * 1024, "rua_bn_bwd: coefficient table too large");
+  RUA_CHECK_ARG(smem <= 160 * 1024, "rua_bn_bwd: coefficient table too large");      // (5 nb + 2) C floats: nb = 4 up to C = 1861, nb = 1 up to C = 5851
   const int CG = d->C / vec;
   if (d->skip_stats) {
     RUA_CHECK_ARG(d->dskip && d->skip_replicas >= 1 && (d->skip_replicas & (d->skip_replicas - 1)) == 0 && CG <= 256 && 256 % CG == 0,
@@ -801,8 +801,10 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int nbk = (CG <= 256 && 256 % CG == 0 && g_tune.bn_regs) ? d->nb : 0;
   const bool mk = d->masked != 0;
-#define RUA_BN_BWD_GO(T_, NB_, MK_) do { if (d->dx_stats) hipLaunchKernelGGL((bn_bwd_kernel<T_, NB_, MK_, true>), dim3(g), dim3(256), smem, st, *d, pieces, CG); \
-                                         else hipLaunchKernelGGL((bn_bwd_kernel<T_, NB_, MK_, false>), dim3(g), dim3(256), smem, st, *d, pieces, CG); } while (0)
+  // a table beyond 64 KB (wider variants than the shipped configurations) needs the kernel's dynamic-LDS limit raised: a rare path, set per launch
+#define RUA_BN_BWD_GO1(T_, NB_, MK_, DX_) do { if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)bn_bwd_kernel<T_, NB_, MK_, DX_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+                                               hipLaunchKernelGGL((bn_bwd_kernel<T_, NB_, MK_, DX_>), dim3(g), dim3(256), smem, st, *d, pieces, CG); } while (0)
+#define RUA_BN_BWD_GO(T_, NB_, MK_) do { if (d->dx_stats) RUA_BN_BWD_GO1(T_, NB_, MK_, true); else RUA_BN_BWD_GO1(T_, NB_, MK_, false); } while (0)
 #define RUA_BN_BWD_SW(T_) switch (nbk * 2 + (mk ? 1 : 0)) { \
     case 2: RUA_BN_BWD_GO(T_, 1, false); break; case 3: RUA_BN_BWD_GO(T_, 1, true); break; \
     case 4: RUA_BN_BWD_GO(T_, 2, false); break; case 5: RUA_BN_BWD_GO(T_, 2, true); break; \
@@ -812,6 +814,7 @@ extern "C" int rua_bn_bwd(const rua_bn_bwd_desc* d, void* stream) {
   if (d->dtype == RUA_BF16) { RUA_BN_BWD_SW(bf16_t) } else { RUA_BN_BWD_SW(float) }
 #undef RUA_BN_BWD_SW
 #undef RUA_BN_BWD_GO
+#undef RUA_BN_BWD_GO1
   RUA_LAUNCH_CHECK("rua_bn_bwd");
   return RUA_OK;
 }

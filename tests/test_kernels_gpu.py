@@ -641,13 +641,15 @@ def test_bn_stats_apply_backward(dt):
     assert rel_err(dx.float().cpu().numpy(), xr.grad.numpy()) < tol(dt)
 
 
+@pytest.mark.parametrize("Cc", [32, 2048])
 @pytest.mark.parametrize("dt", [L.RUA_F32, L.RUA_BF16])
-def test_bn_fused_forward_backward_two_branches(dt):
+def test_bn_fused_forward_backward_two_branches(dt, Cc):
     """rua_bn_fwd / rua_bn_bwd: finalize folded into the launch, two branches sharing one input (the ResBlock case),
-    skip gradient added, moving statistics and parameter gradients updated by block 0."""
+    skip gradient added, moving statistics and parameter gradients updated by block 0.  C = 2048: the backward's coefficient
+    table of (5 nb + 2) C floats is 96 KB, beyond the default 64 KB of dynamic LDS."""
     rng = np.random.default_rng(16)
     lib = L.lib()
-    M, Cc, R = 640, 32, 4
+    M, R = 640, 4
     x = (rng.standard_normal((M, Cc)) * 1.5 + 0.3).astype(np.float32)
     xd = to_dev(x, dt)
     f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev())
