@@ -1262,12 +1262,13 @@ def test_wgrad_deferred_batched_reduction_is_bit_identical():
                                    (32, 64, 64, 64, [1, 3, 15, 31]), (5, 64, 64, 64, [1, 15])])     # C = 64 off the 128-pixel rows: conv_igemm_g
 def test_conv_group_equals_separate_launches(shape):
     # (C = 128 / 256 groups run on conv_band128m since round 5 - test_conv_group_band64_multi compares that kernel with these members one by one;
-    # this test keeps its subject, the grouped grids of the members' own kernels: conv_band128m off)
-    L.lib().set_tuning(conv_band128m=0)
+    # this test keeps its subject, the grouped grids of the members' own kernels: conv_band128m off; and conv_img2 - which a conv on its own takes at
+    # 16 x 16 x 512, d = 1, and a member of a group does not - off, so that "one by one" means the same kernel)
+    L.lib().set_tuning(conv_band128m=0, conv_img2=0)
     try:
         _group_equals_separate(shape)
     finally:
-        L.lib().set_tuning(conv_band128m=BAND128M_DEFAULT)
+        L.lib().set_tuning(conv_band128m=BAND128M_DEFAULT, conv_img2=1)
 
 
 def _group_equals_separate(shape):
