@@ -69,6 +69,16 @@ def measured_traffic(kernel, args):
     return round(sum(v["bytes_per_launch"] * v["launches_seen"] for v in fam) / n) if n else None
 
 
+def wg_taps_name(d, grouped):
+    """The kernel behind rua_wgrad_kind() == 1 as rocprofv3 names it (csrc/conv_mfma.hip::launch_wgrad_taps)."""
+    g = "_g" if grouped else ""
+    if d.C in (128, 256):
+        return f"wgrad_rowsx{g}<{1 if d.C == 256 else 0}>"
+    if d.C == 64 and d.W == 128:
+        return f"wgrad_rows64{g}"
+    return f"wgrad_taps_kernel{g}<{d.C}>"
+
+
 def rocprof_prefixes(name):
     """rocprofv3 kernel-name prefixes of the template instantiations a bench kernel name folds together (conv_halo<32> =
     conv_halo<32,2> + conv_halo<32,3>, ...; conv_strip<32> = conv_strip32<8,true,5> + conv_strip32<8,false,7> + the round-4
@@ -83,6 +93,8 @@ def rocprof_prefixes(name):
         return (name, "wgrad_rows32<")
     if name == "wgrad_taps_kernel_g<32>":
         return (name, "wgrad_rows32_g<")
+    if name in ("wgrad_rows64", "wgrad_rows64_g"):
+        return (name + "<",)
     return (name[:-1] + ",",)
 
 
@@ -247,7 +259,7 @@ def profile_kernels(eng, g, dtype):
                 e1 = mark()
                 d0 = arr[0]
                 wk = lib.raw("rua_wgrad_kind")(C.byref(d0))
-                kn = (f"wgrad_kernel_g", f"wgrad_taps_kernel_g<{d0.C}>", "wgrad_dmap_g", "wgrad_pw")[wk]
+                kn = (f"wgrad_kernel_g", wg_taps_name(d0, True), "wgrad_dmap_g", "wgrad_pw")[wk]
                 grids = lib.raw("rua_wgrad_group_last_grids")()
                 nl = 1
                 if grids == n:                              # this kernel family is not grouped: n launches of the plain kernel
@@ -273,7 +285,7 @@ def profile_kernels(eng, g, dtype):
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "") + (" splitk" if two else "")
                     fl, tag, second = conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags), f"conv_splitk_finish<{tname}>"
                 else:
-                    wk = lib.raw("rua_wgrad_kind")(C.byref(d)); kn = (f"wgrad_kernel<{tname}>", f"wgrad_taps_kernel<{d.C}>", "wgrad_dmap", "wgrad_pw")[wk]
+                    wk = lib.raw("rua_wgrad_kind")(C.byref(d)); kn = (f"wgrad_kernel<{tname}>", wg_taps_name(d, False), "wgrad_dmap", "wgrad_pw")[wk]
                     ik = lib.raw("rua_wgrad_img_kind")(C.byref(d)) if wk == 0 else 0
                     if ik:
                         kn = f"wgrad_img<{d.W}>" if ik == 1 else "wgrad_imgs"

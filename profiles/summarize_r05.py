@@ -103,6 +103,8 @@ def rocprof_prefixes(name):            # bench.py::rocprof_prefixes (kept in ste
         return (name, "wgrad_rows32<")
     if name == "wgrad_taps_kernel_g<32>":
         return (name, "wgrad_rows32_g<")
+    if name in ("wgrad_rows64", "wgrad_rows64_g"):
+        return (name + "<",)
     return (name[:-1] + ",",)
 
 

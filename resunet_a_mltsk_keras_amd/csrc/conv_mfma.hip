@@ -3585,6 +3585,8 @@ __global__ __launch_bounds__(768) void wgrad_rows128_g(const WgtKG g) {       //
   wgrad_rows128_body(p, (int)blockIdx.y);
 }
 
+#include "wgrad_rowsx.inc"
+
 // wgrad_img<W> (round 4): the 3x3 weight gradients of the two deepest levels (16 x 16 x 512 and 8 x 8 x 1024, dilation 1: model2.py:109-112 and their decoder mirror).  The generic
 // wgrad_kernel cuts dW into 64 x 64 tiles per TAP - 2 304 blocks at 8 x 8 x 1024, each staging all 512 pixels of its two operand slices through registers and LDS again, 64 pixels
 // and two barriers at a time: ~0.3 GB of L2 -> LDS traffic per launch, 22 - 28 us for 9.66 GFLOP.  Here a block owns a 64 x 64 tile of dW for ALL NINE taps over a chunk of 512
@@ -3918,7 +3920,7 @@ static thread_local WgGroupCapture* g_wg_group = nullptr;
 
 // wgrad_rows32 variants: kind 4 + 2 * (NPG == 2) + (no BatchNorm on load)
 static void launch_rows32(int kind, bool grouped, dim3 grid, int smem, hipStream_t st, const WgtK* one, const WgtKG* many) {
-  static RuaPerDevFlag attr_[14];
+  static RuaPerDevFlag attr_[18];
   bool& attr = attr_[(kind - 4) * 2 + (grouped ? 1 : 0)].get();
 #define RUA_ROWS_GO(NPG_, BN_) do { \
     if (grouped) { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows32_g<NPG_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
@@ -3930,6 +3932,11 @@ static void launch_rows32(int kind, bool grouped, dim3 grid, int smem, hipStream
                    hipLaunchKernelGGL((wgrad_rows64_g<BN_>), grid, dim3(768), smem, st, *many); } \
     else { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows64<BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
            hipLaunchKernelGGL((wgrad_rows64<BN_>), grid, dim3(768), smem, st, *one); } } while (0)
+#define RUA_ROWSX_GO(MODE_) do { \
+    if (grouped) { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rowsx_g<MODE_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+                   hipLaunchKernelGGL((wgrad_rowsx_g<MODE_>), grid, dim3(768), smem, st, *many); } \
+    else { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rowsx<MODE_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+           hipLaunchKernelGGL((wgrad_rowsx<MODE_>), grid, dim3(768), smem, st, *one); } } while (0)
   switch (kind) {
     case 4: RUA_ROWS_GO(4, true); break;
     case 5: RUA_ROWS_GO(4, false); break;
@@ -3937,6 +3944,8 @@ static void launch_rows32(int kind, bool grouped, dim3 grid, int smem, hipStream
     case 7: RUA_ROWS_GO(2, false); break;
     case 8: RUA_ROWS64_GO(true); break;                  // C = 64, 128-pixel rows
     case 9: RUA_ROWS64_GO(false); break;
+    case 11: RUA_ROWSX_GO(0); break;                     // the slot-stream form (wgrad_rowsx.inc): C = 128 on 64-pixel rows (grid.y = 2) ...
+    case 12: RUA_ROWSX_GO(1); break;                     // ... and C = 256 on 32-pixel rows, two images per stage (grid.y = 4 output-channel slices x 2 input-channel halves)
     default:                                             // 10: C = 128, 64-pixel rows (grid.y = output-channel slice)
       if (grouped) { if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows128_g), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
                      hipLaunchKernelGGL(wgrad_rows128_g, grid, dim3(768), smem, st, *many); }
@@ -3944,6 +3953,7 @@ static void launch_rows32(int kind, bool grouped, dim3 grid, int smem, hipStream
              hipLaunchKernelGGL(wgrad_rows128, grid, dim3(768), smem, st, *one); }
       break;
   }
+#undef RUA_ROWSX_GO
 #undef RUA_ROWS64_GO
 #undef RUA_ROWS_GO
 }
@@ -3955,6 +3965,39 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   k.H = d->H; k.W = d->W; k.N = d->N; k.dil = d->dil;
   k.in_scale = d->in_scale; k.in_shift = d->in_shift; k.in_relu = d->in_relu;
   const long long M = (long long)d->N * d->H * d->W;
+  if (CC == 256 || (CC == 128 && (g_tune.wgrad_rows & 64))) {
+    // wgrad_rowsx: gx blocks per grid row share the slot stream of the member evenly; grid.y = (output-channel slice, input-channel half); a block leaves two
+    // partials [9][32][C] (or its 128 columns of them), so C / 32 x gx of them <= one per CU - the workspace contract of the all-taps kernels
+    const int ncu_ = rua_cu_count();
+    const int gy_ = CC == 256 ? 8 : 2;
+    const int share_ = (g_tune.wgrad_taps_share && d->group_members > 1) ? d->group_members : 1;
+    int gx_ = ncu_ / share_ / gy_;
+    if (gx_ > ncu_ / (CC / 32)) gx_ = ncu_ / (CC / 32);
+    const long long U_ = (long long)(CC == 256 ? d->N / 2 : d->N) * (d->H + d->dil);
+    if (gx_ > U_ / 4) gx_ = (int)(U_ / 4);               // >= 4 slots behind a block's three-row fill
+    if (gx_ < 1) gx_ = 1;
+    k.NPG = 1; k.strips = 1; k.halo = 0; k.halo4 = 0; k.group_bytes = 0; k.nchains = 0; k.spc = 0; k.seglen = 0; k.njobs = 0; k.jpw = 0;
+    k.gx = gx_; k.nworkers = gx_;
+    k.abytes = (unsigned)((size_t)M * CC * 2); k.dybytes = k.abytes;
+    const size_t smem_ = (size_t)32 * 256 + 5 * (size_t)96 * 256 + 3 * (size_t)64 * 128;
+    const int rblocks_ = rua_div_up(9 * CC * CC / 4, TAPS_RED_COLS);
+    const int kd_ = CC == 256 ? 12 : 11;
+    note_pending(1, gx_, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks_);
+    if (g_wgrad_dry) return RUA_OK;
+    if (g_wg_group && (g_tune.wgrad_group & 4) && g_wg_group->n < RUA_MAX_BRANCH) {
+      WgGroupCapture& c = *g_wg_group; const int i = c.n++;
+      c.kind[i] = kd_; c.gx[i] = gx_; c.smem[i] = (int)smem_; c.t[i] = k;
+      c.post[i] = d->defer ? 0 : 1; c.part[i] = k.scratch; c.dw[i] = d->dw; c.CC[i] = CC; c.parts[i] = gx_; c.rblocks[i] = rblocks_; c.ndw[i] = 0;
+      return RUA_OK;
+    }
+    launch_rows32(kd_, false, dim3(gx_, gy_), (int)smem_, st, &k, nullptr);
+    RUA_LAUNCH_CHECK("wgrad_rowsx");
+    if (d->defer) return RUA_OK;
+    record_mid_event(st);
+    hipLaunchKernelGGL(wgrad_taps_reduce, dim3(rblocks_), dim3(256), 0, st, (const float*)k.scratch, d->dw, CC, gx_);
+    RUA_LAUNCH_CHECK("wgrad_taps_reduce");
+    return RUA_OK;
+  }
   if (CC == 128) {
     // wgrad_rows128: blocks (x) per output-channel slice (y = 2); a block leaves two partials (the halves of its slice), the scratch holds ncu of them
     const int ncu_ = rua_cu_count();
@@ -4450,13 +4493,19 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
   return RUA_OK;
 }
 
+// wgrad_rowsx<1>: C = Cout = 256 on 32-pixel rows, an even number of images (the level-4 ResBlock), dilation <= 16 (the zeros between the two rows of a slot)
+static bool wgrad_rows256_ok(const rua_wgrad_desc* d) {
+  return (g_tune.wgrad_rows & 32) && d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->C == 256 && d->Cout == 256 && d->W == 32 && d->N % 2 == 0 && d->N >= 2 &&
+         d->Hs == d->H && d->Ws == d->W && d->dil >= 1 && d->dil <= 16 && !d->in_scale && d->workspace && d->workspace_bytes >= wg_taps_bytes(d) &&
+         (long long)d->N * d->H * d->W * d->C * 2 < (1ll << 31);
+}
 extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
   if (!d) return RUA_ERR_ARG;
   if (pick_wgrad_pw(d)) return 3;
   {
     const int on = g_tune.wgrad_dmap;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (on && d->dtype == RUA_BF16 && (d->taps == 9 || d->taps == 1) && d->stride == 1 && d->C % 128 == 0 && d->Cout % 128 == 0 &&
+    if (on && !wgrad_rows256_ok(d) && d->dtype == RUA_BF16 && (d->taps == 9 || d->taps == 1) && d->stride == 1 && d->C % 128 == 0 && d->Cout % 128 == 0 &&
         d->Hs == d->H && d->Ws == d->W && pow2(d->H) && pow2(d->W) && d->dil >= 1 &&
         ((long long)d->N * d->H * d->W + 64 * 64) * (d->C > d->Cout ? d->C : d->Cout) * 2 < (1ll << 31)) {
       // measured per level of the reference network (us, wgrad_dmap vs wgrad_kernel): 64x64x128 33.1 / 32.5 (9 tiles: the
@@ -4469,6 +4518,7 @@ extern "C" int rua_wgrad_kind(const rua_wgrad_desc* d) {
     }
   }
   const bool rows128 = (g_tune.wgrad_rows & 4) && d->C == 128 && d->W == 64 && !d->in_scale;      // wgrad_rows128 (the level-3 ResBlock)
+  if (wgrad_rows256_ok(d)) return 1;
   const bool ok = d->dtype == RUA_BF16 && d->taps == 9 && d->stride == 1 && d->C == d->Cout && (d->C == 32 || d->C == 64 || rows128) &&
                   d->W % 64 == 0 && d->Hs == d->H && d->Ws == d->W && d->dil >= 1 && d->dil <= 31 && d->workspace &&
                   d->workspace_bytes >= wg_taps_bytes(d) && (long long)d->N * d->H * d->W * d->C * 2 < (1ll << 31);
@@ -4681,7 +4731,7 @@ extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream
       else { WgdKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.d[idx[q]]; hipLaunchKernelGGL(wgrad_dmap_g, dim3((gx + 7) / 8 * 8, m), dim3(256), smem, st, g); }
     } else if (kd >= 4) {
       WgtKG g; for (int q = 0; q < m; ++q) g.k[q] = cap.t[idx[q]];
-      const unsigned gyr = kd == 10 ? 2u : 1u;             // wgrad_rows128: grid.y = output-channel slice
+      const unsigned gyr = kd == 12 ? 8u : (kd == 10 || kd == 11) ? 2u : 1u;     // wgrad_rows128 / wgrad_rowsx: grid.y = output-channel slice (x input-channel half)
       if (m == 1) launch_rows32(kd, false, dim3(gx, gyr), smem, st, &g.k[0], nullptr);
       else launch_rows32(kd, true, dim3(gx, gyr, m), smem, st, nullptr, &g);
     } else {

@@ -332,6 +332,51 @@ def test_wgrad_all_taps_kernel(case):
     assert rel_err(outs[0] - base, w.grad.numpy()) < 2e-3
 
 
+WGRAD_ROWS_DEFAULT = 127                                       # csrc/common.h: Tuning::wgrad_rows
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 128, 1), (1, 64, 64, 128, 15), (3, 40, 64, 128, 3), (8, 64, 64, 128, 31), (1, 7, 64, 128, 3),     # C = 128 on 64-pixel rows
+                                  (8, 32, 32, 256, 1), (8, 32, 32, 256, 3), (8, 32, 32, 256, 15), (2, 32, 32, 256, 15), (4, 20, 32, 256, 16), (6, 48, 32, 256, 7),
+                                  (2, 3, 32, 256, 1)])                                                                                            # C = 256 on 32-pixel rows, image pairs
+def test_wgrad_row_stream_kernel(case):
+    """wgrad_rowsx (round 5): the whole-row weight gradient with the rows of all images and dilation chains dealt to the blocks as ONE stream of slots (a chain's rows +
+    one separator row of zeros), at C = 128 on 64-pixel rows and - two images per stage, a 128-channel half of the input per block - at C = 256 on 32-pixel rows
+    (the level-4 ResBlock; was wgrad_dmap).  Deterministic block partials, adds into dW, matches autograd; short images and dilations up to the zero gap of a slot."""
+    N, H, W, Cc, dil = case
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(113)
+    a = rng.standard_normal((N, H, W, Cc)).astype(np.float32)
+    dy = rng.standard_normal((N, H, W, Cc)).astype(np.float32)
+    ad, dyd = to_dev(a, dt), to_dev(dy, dt)
+    base = rng.standard_normal((9, Cc, Cc)).astype(np.float32)
+    dw = torch.from_numpy(base).to(dev())
+    d = L.WgradDesc()
+    d.a, d.C, d.Hs, d.Ws = ad.data_ptr(), Cc, H, W
+    d.dy, d.Cout, d.H, d.W = dyd.data_ptr(), Cc, H, W
+    d.N, d.stride, d.dil, d.taps, d.dtype = N, 1, dil, 9, dt
+    d.dw = dw.data_ptr()
+    lib.set_tuning(wgrad_rows=127)
+    try:
+        ws = torch.empty(lib.raw("rua_wgrad_workspace_bytes")(C.byref(d)) // 4, dtype=torch.float32, device=dev())
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        assert lib.raw("rua_wgrad_kind")(C.byref(d)) == 1
+        outs = []
+        for rep in range(2):
+            dw.copy_(torch.from_numpy(base))
+            ws.uniform_(-1e3, 1e3)                              # partials need no initialisation
+            lib.call("rua_conv_wgrad", C.byref(d), stream())
+            torch.cuda.synchronize()
+            outs.append(dw.cpu().numpy().copy())
+    finally:
+        lib.set_tuning(wgrad_rows=WGRAD_ROWS_DEFAULT)
+    assert np.array_equal(outs[0], outs[1])                    # deterministic (no atomics)
+    w = torch.zeros((9, Cc, Cc), dtype=torch.float64, requires_grad=True)
+    y = ref_conv_nhwc(rnd(dt, a).double(), w, None, dil, 9, 1)
+    y.backward(rnd(dt, dy).double())
+    assert rel_err(outs[0] - base, w.grad.numpy()) < 2e-3
+
+
 @pytest.mark.parametrize("case", [(8, 8, 1024, 1024), (8, 16, 512, 512), (2, 16, 128, 64), (16, 8, 64, 128), (8, 8, 64, 64), (24, 8, 128, 128), (4, 16, 64, 192),
                                   (4, 16, 512, 256), (6, 16, 256, 512), (10, 16, 384, 352), (16, 8, 512, 256), (24, 8, 256, 544)])      # 16 x 16, > 512 pixels, >= 128 tiles of 32 x 32: wgrad_imgs (streamed chunks, no K slices)
 def test_wgrad_whole_image_kernel(case):
@@ -1211,8 +1256,8 @@ def test_wgrad_deferred_batched_reduction_is_bit_identical():
     dt = L.RUA_BF16
     lib = L.lib()
     rng = np.random.default_rng(77)
-    cases = [(2, 64, 64, 32, 32, 1, 3, 9), (1, 128, 64, 64, 64, 1, 15, 9), (4, 32, 32, 256, 256, 1, 3, 9), (2, 16, 16, 128, 256, 1, 1, 1),
-             (2, 64, 64, 32, 8, 1, 1, 1)]                                    # all-taps x2, wgrad_dmap, generic with K split, wgrad_pw (nothing pending)
+    cases = [(2, 64, 64, 32, 32, 1, 3, 9), (1, 128, 64, 64, 64, 1, 15, 9), (5, 32, 32, 256, 256, 1, 3, 9), (2, 16, 16, 128, 256, 1, 1, 1),
+             (2, 64, 64, 32, 8, 1, 1, 1), (4, 32, 32, 256, 256, 1, 3, 9)]    # all-taps x2, wgrad_dmap (an odd number of images: not wgrad_rowsx), generic with K split, wgrad_pw (nothing pending), wgrad_rowsx<1>
     descs, keep, imm = [], [], []
     for (N, H, W, Cs, Cout, stride, dil, taps) in cases:
         a = to_dev(rng.standard_normal((N, H, W, Cs)).astype(np.float32), dt)
@@ -1239,7 +1284,7 @@ def test_wgrad_deferred_batched_reduction_is_bit_identical():
         lib.call("rua_conv_wgrad", C.byref(d), stream())
         if r.kind:
             recs.append(r)
-    assert kinds == [1, 1, 2, 2, 0]
+    assert kinds == [1, 1, 2, 2, 0, 1]
     table = (L.WgradPending * len(recs))()
     blocks = 0
     for i, r in enumerate(recs):
@@ -1979,6 +2024,7 @@ def test_conv_dmap_issue_forms_are_bit_identical(N, H, W, Cs, Cout, dil):
     ws = torch.zeros(8 << 20, dtype=torch.float32, device=dev())
     res = {}
     try:
+        lib.set_tuning(conv_img2=0)                          # (16 x 16 x 512, d = 1 is conv_img2's by default since round 5: the subject here is conv_dmap)
         for form in (0, 1, 2, 6):
             lib.set_tuning(dmap_spread=form)
             outs = []
@@ -2003,7 +2049,7 @@ def test_conv_dmap_issue_forms_are_bit_identical(N, H, W, Cs, Cout, dil):
                 outs.append((y, stats.cpu().numpy().reshape(8, -1).sum(0)))
             res[form] = outs
     finally:
-        lib.set_tuning(dmap_spread=1)
+        lib.set_tuning(dmap_spread=1, conv_img2=1)
     exp = ref_conv_nhwc(rnd(dt, x.float().cpu().numpy()), rnd(dt, w.float().cpu().numpy()), None, dil, 9).numpy() + bias.cpu().numpy().astype(np.float64)
     assert rel_err(res[0][0][0].float().cpu().numpy(), exp) < tol(dt)
     for form in (1, 2, 6):
