@@ -21,6 +21,7 @@ extern "C" {
 #define RUA_BF16 1
 #define RUA_MAX_SEG 6
 #define RUA_MAX_BRANCH 4
+#define RUA_MAX_WGRAD_GROUP 8   /* members of one rua_conv_wgrad_group call (both convolutions of every branch of a ResBlock) */
 
 #define RUA_OK 0
 #define RUA_ERR_ARG (-1)      /* shape/alignment precondition violated */
@@ -195,7 +196,7 @@ int rua_wgrad_plan(const rua_wgrad_desc* d, rua_wgrad_pending* out);
  * block_begin, total_blocks = sum of their `blocks` */
 int rua_wgrad_reduce_batch(const rua_wgrad_pending* items_dev, int n_items, int total_blocks, void* stream);
 int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream);
-/* n (<= RUA_MAX_BRANCH) INDEPENDENT weight gradients - the dilation branches of a ResBlock (model2.py:26-31) - with the results of n
+/* n (<= RUA_MAX_WGRAD_GROUP) INDEPENDENT weight gradients - the dilation branches of a ResBlock (model2.py:26-31), first and second convolutions - with the results of n
  * rua_conv_wgrad calls; members on the same kernel run as ONE grid.  Members must not share dw or partial-sum workspace (a group
  * that does runs member by member). */
 int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream);

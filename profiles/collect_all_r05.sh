@@ -5,6 +5,7 @@ python3 tools/step_trace.py > profiles/r05/step_trace.txt 2> gpurun_out/step_tra
 python3 profiles/gap_analysis.py $(ls gpurun_out/r05prof/trace/*/*_kernel_trace.csv | head -1) > profiles/r05/launch_gaps.txt 2> gpurun_out/gap.err || exit 12
 python3 tools/bench_band128.py > profiles/r05/bench_band128.txt 2> gpurun_out/bb.err || exit 13
 BB_LEVEL=4 python3 tools/bench_band128.py > profiles/r05/bench_band128_level4.txt 2> gpurun_out/bb4.err || exit 14
+python3 tools/bench_wgrad_rows.py > profiles/r05/bench_wgrad_rows.txt 2> gpurun_out/bwr.err || exit 20
 BL_LEVELS=5,6 python3 tools/bench_conv_levels.py > profiles/r05/bench_conv_levels56.txt 2> gpurun_out/bl.err || exit 15
 python3 bench.py --force-dp --steps 30 --warmup 10 --no-cpu-baseline --no-also > profiles/r05/bench_force_dp.json 2> gpurun_out/force_dp.err || exit 16
 RUA_LIB_PATH=$PWD/scratch/stamps.so python3 tools/band128_phases.py first > profiles/r05/band128_phases.txt 2> gpurun_out/phases.err || exit 18

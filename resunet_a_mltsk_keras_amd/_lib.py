@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RUA_LIB_PATH") or os.path.join(HERE, "librua_hip.so")   # RUA_LIB_PATH: experiment builds only
 
 RUA_F32, RUA_BF16 = 0, 1
-RUA_MAX_SEG, RUA_MAX_BRANCH = 6, 4
+RUA_MAX_SEG, RUA_MAX_BRANCH, RUA_MAX_WGRAD_GROUP = 6, 4, 8
 LOSS_TANIMOTO, LOSS_WCE, LOSS_CE_LOGITS, LOSS_BCE_LOGITS, LOSS_MSE = 0, 1, 2, 3, 4
 ACT_NONE, ACT_SOFTMAX, ACT_SIGMOID = 0, 1, 2
 

@@ -2545,7 +2545,7 @@ __device__ __forceinline__ void wgrad_kernel_body(const WgK& p) {
 template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) { wgrad_kernel_body<T>(p); }
 // grouped launch (rua_conv_wgrad_group): the weight gradients of the dilation branches of a ResBlock in ONE grid; blockIdx.y picks
 // the member, blocks beyond a member's own grid leave at once
-struct WgKG { WgK k[RUA_MAX_BRANCH]; };
+struct WgKG { WgK k[RUA_MAX_WGRAD_GROUP]; };
 static_assert(sizeof(WgKG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 __global__ __launch_bounds__(256) void wgrad_kernel_g(const WgKG g) {
   const WgK& p = g.k[blockIdx.y];
@@ -2777,7 +2777,7 @@ __device__ __forceinline__ void wgrad_dmap_body(const WgdK& p, const int nwg) {
       }
 }
 __global__ __launch_bounds__(256) void wgrad_dmap(const WgdK p) { wgrad_dmap_body(p, (int)gridDim.x); }
-struct WgdKG { WgdK k[RUA_MAX_BRANCH]; };
+struct WgdKG { WgdK k[RUA_MAX_WGRAD_GROUP]; };
 static_assert(sizeof(WgdKG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 __global__ __launch_bounds__(256) void wgrad_dmap_g(const WgdKG g) {
   const WgdK& p = g.k[blockIdx.y];
@@ -3004,7 +3004,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgtK& p) {
   }
 }
 template <int CC> __global__ __launch_bounds__(768) void wgrad_taps_kernel(const WgtK p) { wgrad_taps_body<CC>(p); }
-struct WgtKG { WgtK k[RUA_MAX_BRANCH]; };
+struct WgtKG { WgtK k[RUA_MAX_WGRAD_GROUP]; };
 static_assert(sizeof(WgtKG) <= 4096, "grouped launch: kernel arguments are limited to 4 KiB");
 template <int CC> __global__ __launch_bounds__(768) void wgrad_taps_kernel_g(const WgtKG g) {      // blockIdx.z = member
   const WgtK& p = g.k[blockIdx.z];
@@ -3910,11 +3910,11 @@ __global__ __launch_bounds__(256) void wgrad_taps_reduce(const float* __restrict
 // rua_conv_wgrad_group: the launchers below record instead of launching while g_wg_group is set
 struct WgGroupCapture {
   int n;
-  int kind[RUA_MAX_BRANCH];                 // 0 wgrad_kernel<bf16>, 1 wgrad_taps<32>, 2 wgrad_taps<64>, 3 wgrad_dmap
-  unsigned gx[RUA_MAX_BRANCH]; int smem[RUA_MAX_BRANCH];
-  WgK g[RUA_MAX_BRANCH]; WgdK d[RUA_MAX_BRANCH]; WgtK t[RUA_MAX_BRANCH];
-  int post[RUA_MAX_BRANCH];                 // reduction the member wants right after its grid (not deferred): 0 none, 1 block partials, 2 slabs
-  const float* part[RUA_MAX_BRANCH]; float* dw[RUA_MAX_BRANCH]; long long ndw[RUA_MAX_BRANCH]; int parts[RUA_MAX_BRANCH], CC[RUA_MAX_BRANCH], rblocks[RUA_MAX_BRANCH];
+  int kind[RUA_MAX_WGRAD_GROUP];                 // 0 wgrad_kernel<bf16>, 1 wgrad_taps<32>, 2 wgrad_taps<64>, 3 wgrad_dmap
+  unsigned gx[RUA_MAX_WGRAD_GROUP]; int smem[RUA_MAX_WGRAD_GROUP];
+  WgK g[RUA_MAX_WGRAD_GROUP]; WgdK d[RUA_MAX_WGRAD_GROUP]; WgtK t[RUA_MAX_WGRAD_GROUP];
+  int post[RUA_MAX_WGRAD_GROUP];                 // reduction the member wants right after its grid (not deferred): 0 none, 1 block partials, 2 slabs
+  const float* part[RUA_MAX_WGRAD_GROUP]; float* dw[RUA_MAX_WGRAD_GROUP]; long long ndw[RUA_MAX_WGRAD_GROUP]; int parts[RUA_MAX_WGRAD_GROUP], CC[RUA_MAX_WGRAD_GROUP], rblocks[RUA_MAX_WGRAD_GROUP];
 };
 static thread_local WgGroupCapture* g_wg_group = nullptr;
 
@@ -3984,7 +3984,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
     const int kd_ = CC == 256 ? 12 : 11;
     note_pending(1, gx_, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks_);
     if (g_wgrad_dry) return RUA_OK;
-    if (g_wg_group && (g_tune.wgrad_group & 4) && g_wg_group->n < RUA_MAX_BRANCH) {
+    if (g_wg_group && (g_tune.wgrad_group & 4) && g_wg_group->n < RUA_MAX_WGRAD_GROUP) {
       WgGroupCapture& c = *g_wg_group; const int i = c.n++;
       c.kind[i] = kd_; c.gx[i] = gx_; c.smem[i] = (int)smem_; c.t[i] = k;
       c.post[i] = d->defer ? 0 : 1; c.part[i] = k.scratch; c.dw[i] = d->dw; c.CC[i] = CC; c.parts[i] = gx_; c.rblocks[i] = rblocks_; c.ndw[i] = 0;
@@ -4022,7 +4022,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
     const int rblocks_ = rua_div_up(9 * CC * CC / 4, TAPS_RED_COLS);
     note_pending(1, gx_, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks_);
     if (g_wgrad_dry) return RUA_OK;
-    if (g_wg_group && (g_tune.wgrad_group & 4) && g_wg_group->n < RUA_MAX_BRANCH) {
+    if (g_wg_group && (g_tune.wgrad_group & 4) && g_wg_group->n < RUA_MAX_WGRAD_GROUP) {
       WgGroupCapture& c = *g_wg_group; const int i = c.n++;
       c.kind[i] = 10; c.gx[i] = gx_; c.smem[i] = (int)smem_; c.t[i] = k;
       c.post[i] = d->defer ? 0 : 1; c.part[i] = k.scratch; c.dw[i] = d->dw; c.CC[i] = CC; c.parts[i] = gx_; c.rblocks[i] = rblocks_; c.ndw[i] = 0;
@@ -4109,7 +4109,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   const int rblocks = rua_div_up(9 * CC * CC / 4, TAPS_RED_COLS);
   note_pending(1, gx, (long long)9 * CC * CC, (const float*)k.scratch, d->dw, CC, rblocks);
   if (g_wgrad_dry) return RUA_OK;
-  if (g_wg_group && (g_tune.wgrad_group & (CC == 32 ? 2 : 4)) && g_wg_group->n < RUA_MAX_BRANCH) {
+  if (g_wg_group && (g_tune.wgrad_group & (CC == 32 ? 2 : 4)) && g_wg_group->n < RUA_MAX_WGRAD_GROUP) {
     WgGroupCapture& c = *g_wg_group; const int i = c.n++;
     c.kind[i] = rows_kind ? rows_kind : (CC == 32 ? 1 : 2); c.gx[i] = gx; c.smem[i] = (int)smem; c.t[i] = k;
     c.post[i] = d->defer ? 0 : 1; c.part[i] = k.scratch; c.dw[i] = d->dw; c.CC[i] = CC; c.parts[i] = gx; c.rblocks[i] = rblocks; c.ndw[i] = 0;
@@ -4478,7 +4478,7 @@ static int launch_wgrad_dmap(const rua_wgrad_desc* d, hipStream_t st) {
   k.ks_slow = g_tune.wgd_ks_slow;
   if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + SLAB_RED_COLS - 1) / SLAB_RED_COLS));
   if (g_wgrad_dry) return RUA_OK;
-  if (g_wg_group && (g_tune.wgrad_group & 8) && g_wg_group->n < RUA_MAX_BRANCH) {
+  if (g_wg_group && (g_tune.wgrad_group & 8) && g_wg_group->n < RUA_MAX_WGRAD_GROUP) {
     WgGroupCapture& c = *g_wg_group; const int i = c.n++;
     c.kind[i] = 3; c.gx[i] = (unsigned)(tiles * k.ksplit); c.smem[i] = 96 * 1024; c.d[i] = k;
     c.post[i] = (k.slabs && !d->defer) ? 2 : 0; c.part[i] = k.slabs; c.dw[i] = d->dw; c.ndw[i] = ndw; c.parts[i] = k.ksplit; c.CC[i] = 0; c.rblocks[i] = 0;
@@ -4625,7 +4625,7 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (k.slabs) note_pending(2, k.ksplit, ndw, k.slabs, d->dw, 0, (int)((ndw / 4 + SLAB_RED_COLS - 1) / SLAB_RED_COLS));
   if (g_wgrad_dry) return RUA_OK;
-  if (g_wg_group && (g_tune.wgrad_group & 1) && g_wg_group->n < RUA_MAX_BRANCH && d->dtype == RUA_BF16) {
+  if (g_wg_group && (g_tune.wgrad_group & 1) && g_wg_group->n < RUA_MAX_WGRAD_GROUP && d->dtype == RUA_BF16) {
     WgGroupCapture& c = *g_wg_group; const int i = c.n++;
     c.kind[i] = 0; c.gx[i] = (unsigned)grid; c.smem[i] = 0; c.g[i] = k;
     c.post[i] = (k.slabs && !d->defer) ? 2 : 0; c.part[i] = k.slabs; c.dw[i] = d->dw; c.ndw[i] = ndw; c.parts[i] = k.ksplit; c.CC[i] = 0; c.rblocks[i] = 0;
@@ -4645,7 +4645,7 @@ extern "C" int rua_conv_wgrad(const rua_wgrad_desc* d, void* stream) {
 static thread_local int g_wg_group_last_grids = 0;
 extern "C" int rua_wgrad_group_last_grids(void) { return g_wg_group_last_grids; }
 extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream) {
-  RUA_CHECK_ARG(d && n >= 1 && n <= RUA_MAX_BRANCH, "rua_conv_wgrad_group: 1..%d members", RUA_MAX_BRANCH);
+  RUA_CHECK_ARG(d && n >= 1 && n <= RUA_MAX_WGRAD_GROUP, "rua_conv_wgrad_group: 1..%d members", RUA_MAX_WGRAD_GROUP);
   hipStream_t st = (hipStream_t)stream;
   bool shared = false;
   for (int i = 0; i < n; ++i)
@@ -4710,10 +4710,10 @@ extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream
   g_wg_group = nullptr;
   if (rc != RUA_OK) return rc;
   int grids = n - cap.n;
-  bool done[RUA_MAX_BRANCH] = {false};
+  bool done[RUA_MAX_WGRAD_GROUP] = {false};
   for (int i = 0; i < cap.n; ++i) {
     if (done[i]) continue;
-    int idx[RUA_MAX_BRANCH], m = 0; unsigned gx = 0; int smem = 0;
+    int idx[RUA_MAX_WGRAD_GROUP], m = 0; unsigned gx = 0; int smem = 0;
     for (int j = i; j < cap.n; ++j)
       if (!done[j] && cap.kind[j] == cap.kind[i]) { idx[m++] = j; done[j] = true; if (cap.gx[j] > gx) gx = cap.gx[j]; if (cap.smem[j] > smem) smem = cap.smem[j]; }
     static RuaPerDevFlag attrf[4];

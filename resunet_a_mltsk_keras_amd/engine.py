@@ -767,9 +767,9 @@ class Graph:
             for sp in specs:
                 self.wgrad(plan, *sp)
             return
-        if len(specs) > L.RUA_MAX_BRANCH:
-            self.wgrad_group(plan, specs[:L.RUA_MAX_BRANCH])
-            self.wgrad_group(plan, specs[L.RUA_MAX_BRANCH:])
+        if len(specs) > L.RUA_MAX_WGRAD_GROUP:
+            self.wgrad_group(plan, specs[:L.RUA_MAX_WGRAD_GROUP])
+            self.wgrad_group(plan, specs[L.RUA_MAX_WGRAD_GROUP:])
             return
         descs = [self.wgrad_desc(plan, *sp, may_flush=(i == 0), group=len(specs)) for i, sp in enumerate(specs)]
         arr = (L.WgradDesc * len(descs))()
@@ -777,6 +777,15 @@ class Graph:
             C.memmove(C.byref(arr, i * C.sizeof(L.WgradDesc)), C.byref(dsc), C.sizeof(L.WgradDesc))
         plan.keep.append(arr)
         plan.add("rua_conv_wgrad_group", arr, len(descs))
+
+    def wgrad_now_or_later(self, plan: Plan, specs: List[tuple]) -> List[tuple]:
+        """The weight gradients of a ResBlock's SECOND convolutions: issued here - or returned, to ride in ONE group with the first convolutions' (whose
+        dy exists three launches later).  Twice the members per grid = half the blocks per member: half the block partials to write and to reduce
+        (levels 3 - 4: 24 MB per member) and half the ring fills per row of work.  Engine.merge_wgrad holds the channel counts that do."""
+        if self.dry or len(specs) < 2 or 2 * len(specs) > L.RUA_MAX_WGRAD_GROUP or specs[0][0].C not in self.e.merge_wgrad:
+            self.wgrad_group(plan, specs)
+            return []
+        return specs
 
     def wgrad_pw_group(self, plan: Plan, specs: List[tuple]):
         """The narrow 1x1 weight gradients of one composite (the sources of a concatenating conv, the branch convs of a PSPPooling: independent, 2 - 15 us
@@ -935,9 +944,10 @@ class Graph:
             if not v2:
                 self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])      # (model2: summed by the final bn_bwd, which reads dO as the skip gradient)
             if sum2:                                           # y1_b normalised on load by the weight gradient too
-                self.wgrad_group(Bp, [(y, dO, l[3]["segs"][0]["off"], 1, d, 9, c2) for d, l, y, c2 in zip(dils, lay, y1, coef2)])
+                w2 = [(y, dO, l[3]["segs"][0]["off"], 1, d, 9, c2) for d, l, y, c2 in zip(dils, lay, y1, coef2)]
             else:
-                self.wgrad_group(Bp, [(a_2, dO, l[3]["segs"][0]["off"], 1, d, 9, None) for d, l, a_2 in zip(dils, lay, a2)])
+                w2 = [(a_2, dO, l[3]["segs"][0]["off"], 1, d, 9, None) for d, l, a_2 in zip(dils, lay, a2)]
+            w2 = self.wgrad_now_or_later(Bp, w2)
             g2s = [self.like(x) for _ in dils]
             s2s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
             self.conv_group(Bp, [self.dgrad_desc(dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
@@ -945,7 +955,7 @@ class Graph:
             dy1s = [self.like(x) for _ in dils]
             self.bn_bwd_group(Bp, [(g2, c2, l[2], s2, y, dy1, cnt) for l, y, c2, g2, s2, dy1 in zip(lay, y1, coef2, g2s, s2s, dy1s)])
             # no bias gradient launch: the output of a BN backward sums to zero per channel, so d b1 == 0 exactly
-            self.wgrad_group(Bp, [(a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9, None) for d, l, a_1, dy1 in zip(dils, lay, a1, dy1s)])
+            self.wgrad_group(Bp, w2 + [(a_1, dy1, l[1]["segs"][0]["off"], 1, d, 9, None) for d, l, a_1, dy1 in zip(dils, lay, a1, dy1s)])
             g1s = g2s                                          # g2 is dead after its bn_bwd: reuse the storage
             s1s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
             self.conv_group(Bp, [self.dgrad_desc(dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
@@ -1065,14 +1075,14 @@ class Graph:
             dO = out.grad
             if not v2:
                 self.bias_grad(Bp, dO, [l[3]["bias"] for l in lay])
-            self.wgrad_group(Bp, [(y, dO, l[3]["segs"][0]["off"], 1, d, 9, c2) for d, l, y, c2 in zip(dils, lay, y1, coef2)])
+            w2 = self.wgrad_now_or_later(Bp, [(y, dO, l[3]["segs"][0]["off"], 1, d, 9, c2) for d, l, y, c2 in zip(dils, lay, y1, coef2)])
             g2s = [self.like(x) for _ in dils]
             s2s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
             self.conv_group(Bp, [self.dgrad_desc(dO, self.Wd(l[3]["segs"][0]["dst"]), nf, d, 9, g2, 0, mask=(y, c2.scale, c2.shift), stats2=s2)
                                  for d, l, y, c2, g2, s2 in zip(dils, lay, y1, coef2, g2s, s2s)])
             dy1s = [self.like(x) for _ in dils]
             self.bn_bwd_group(Bp, [(g2, c2, l[2], s2, y, dy1, cnt) for l, y, c2, g2, s2, dy1 in zip(lay, y1, coef2, g2s, s2s, dy1s)])
-            self.wgrad_group(Bp, [(x, dy1, l[1]["segs"][0]["off"], 1, d, 9, c1) for d, l, c1, dy1 in zip(dils, lay, coef1, dy1s)])
+            self.wgrad_group(Bp, w2 + [(x, dy1, l[1]["segs"][0]["off"], 1, d, 9, c1) for d, l, c1, dy1 in zip(dils, lay, coef1, dy1s)])
             g1s = g2s
             s1s = [self.stat(nf, (cnt + 127) // 128) for _ in dils]
             self.conv_group(Bp, [self.dgrad_desc(dy1, self.Wd(l[1]["segs"][0]["dst"]), nf, d, 9, g1, 0, mask=(x, c1.scale, c1.shift), stats2=s1)
@@ -1770,6 +1780,7 @@ class Engine:
         self.group_1x1 = os.environ.get("RUA_GROUP_1X1", "1") != "0"       # PSPPooling's branch convolutions and the per-source gradients of concatenating 1x1 convolutions as groups
         self.group_heads = os.environ.get("RUA_GROUP_HEADS", "1") != "0"   # the heads' 3x3 convolutions (and their gradients) grouped across the heads
         self.multi_head = os.environ.get("RUA_MULTI_HEAD", "1") != "0"     # the heads' loss finalisation / d(loss)/d(logits) as one launch each
+        self.merge_wgrad = {int(v) for v in os.environ.get("RUA_MERGE_WGRAD", "32,64,128,256").split(",") if v}     # channel counts whose ResBlocks issue both weight-gradient groups as one (Graph.wgrad_now_or_later)
         self.group_wgrad_pw = os.environ.get("RUA_GROUP_WGRAD_PW", "1") != "0"   # the narrow 1x1 weight gradients of a composite as one grid (Graph.wgrad_pw_group)
         self.stem_mfma = os.environ.get("RUA_STEM_MFMA", "1") != "0"       # bf16: the stem's weight gradient through rua_stem_fwd_pack / rua_conv_wgrad / rua_stem_bwd_fold
         self.stem_stats = os.environ.get("RUA_STEM_STATS", "1") != "0"     # rua_stem_fwd_stats instead of a rua_col_stats pass over the stem's output
