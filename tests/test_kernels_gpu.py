@@ -1398,7 +1398,8 @@ def _group_equals_separate(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 256, 32, [1, 3, 15, 31], True), (4, 128, 128, 64, [1, 3, 15, 31], False), (8, 32, 32, 256, [1, 3, 15], False),
-                                   (8, 64, 64, 128, [1, 3, 15], False), (4, 32, 32, 64, [1, 3, 15], False)])
+                                   (8, 64, 64, 128, [1, 3, 15], False), (4, 32, 32, 64, [1, 3, 15], False),
+                                   (8, 32, 32, 256, [1, 3, 15, 15, 3, 1], False), (2, 128, 128, 64, [1, 3, 15, 31, 31, 15, 3, 1], False)])   # both convolutions of every branch: up to RUA_MAX_WGRAD_GROUP members
 def test_wgrad_group_equals_separate_launches(shape):
     """rua_conv_wgrad_group: the weight gradients of the dilation branches of a ResBlock in one call (wgrad_taps<32> with BatchNorm
     on load, wgrad_taps<64>, wgrad_dmap, wgrad_kernel with K slabs): ONE grid, results bit-identical to separate calls - both with
