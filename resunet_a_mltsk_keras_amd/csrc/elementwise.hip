@@ -24,8 +24,8 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
   // replica (block % R).  Same-address fp64 atomics serialise at ~180 ns each (measured), so the launcher keeps the grid
   // at <= 512 blocks and the caller sizes R for <= ~16 adds per address.
   constexpr int VEC = ET<T>::VEC;
-  __shared__ float sred[4 * 64 * 2 * VEC];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ float sred[256 * (2 * VEC + 1)];
+  const int tid = threadIdx.x;
   const int CGA = p.CG;                                  // pieces per row (power of two)
   const int CG = CGA < 256 ? CGA : 256;                  // pieces handled by one block (blockIdx.y picks the 256-piece slab)
   const int cp0 = blockIdx.y * CG;
@@ -82,25 +82,22 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const StatsK p) {
       }
     }
   }
-  // lanes l and l ^ o (o = CG, 2CG, .. < 64) hold the same piece
+  // The 256 / CG threads that share a piece meet in an LDS tile [thread][2 VEC + 1] and ONE thread per (piece, value) sums its column with independent reads.
+  // (Until round 5: wave shuffles first - at C = 32 64 dependent ds_bpermute per wave at the end of every block, the LDS-pipe tail of the round-4 heads:
+  // rua_col_stats2 on 2 x 33.5 MB took 28.6 us.)
+  constexpr int TW = 2 * VEC + 1;
+  float* mine = sred + tid * TW;
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    for (int o = CG; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
-  }
-  const int lpw = CG < 64 ? CG : 64;                     // distinct pieces held by one wave
-  if (lane < lpw) {
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) { sred[((wid * 64 + lane) * 2) * VEC + j] = s1[j]; sred[((wid * 64 + lane) * 2 + 1) * VEC + j] = s2[j]; }
-  }
+  for (int j = 0; j < VEC; ++j) { mine[j] = s1[j]; mine[VEC + j] = s2[j]; }
   __syncthreads();
   double* st = p.stats + (size_t)(blockIdx.x & (p.R - 1)) * 2 * p.C;
   for (int t = tid; t < CG * 2 * VEC; t += 256) {
     const int cpi = t / (2 * VEC), k = t % (2 * VEC);     // piece, (which sum, channel in piece)
-    float acc = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w)                          // waves whose lane (cpi % 64) holds piece cpi
-      if (((w * 64 + (cpi & 63)) & (CG - 1)) == cpi) acc += sred[((w * 64 + (cpi & 63)) * 2) * VEC + k];
-    unsafeAtomicAdd(&st[(k / VEC) * p.C + (cp0 + cpi) * VEC + (k % VEC)], (double)acc);
+    float a0 = 0.f, a1 = 0.f;
+    int rr = cpi;
+    for (; rr + CG < 256; rr += 2 * CG) { a0 += sred[rr * TW + k]; a1 += sred[(rr + CG) * TW + k]; }
+    if (rr < 256) a0 += sred[rr * TW + k];
+    unsafeAtomicAdd(&st[(k / VEC) * p.C + (cp0 + cpi) * VEC + (k % VEC)], (double)(a0 + a1));
   }
 }
 
