@@ -1478,7 +1478,7 @@ class Graph:
         self.conv_group(F, [fdesc(s1, lay["seg2"], s2), fdesc(d1, lay["dist2"], d2)])
         self.cur_tag = F.scope = None
         if tr:
-            def phase(convs):                              # [(x, y, layer)]: weight gradients, then data gradients, of independent convolutions
+            def phase(convs, carried=(), later=False):      # [(x, y, layer)]: weight gradients, then data gradients, of independent convolutions
                 Bp = self.bwd
                 for x, y, ly in convs:
                     assert not (y.masked_w and y.plain_w), "mixed masked / unmasked writers of a ReLU output's gradient"
@@ -1487,7 +1487,9 @@ class Graph:
                         Bp.add("rua_relu_mask", y.grad.ptr, y.ptr, y.t.numel(), self.dt)
                     if not y.bias_done:
                         self.bias_grad(Bp, y.grad, [ly["bias"]])
-                self.wgrad_group(Bp, [(x, y.grad, ly["segs"][0]["off"], 1, 1, 9, None) for x, y, ly in convs])
+                wg = list(carried) + [(x, y.grad, ly["segs"][0]["off"], 1, 1, 9, None) for x, y, ly in convs]
+                if not later:                               # (later: these ride in the next phase's group - as the two groups of a ResBlock do, wgrad_now_or_later)
+                    self.wgrad_group(Bp, wg)
                 descs, sums = [], []
                 for x, y, ly in convs:
                     gx, acc = self.gacc(x, masked=x.relu_out)
@@ -1500,12 +1502,14 @@ class Graph:
                 for sx, x in sums:
                     self.stats_to_grads(Bp, sx, x.C, x.bias_offs)
                     x.bias_done = True
+                return wg if later else []
 
             def back():
                 Bp = self.bwd
                 Bp.scope = "heads_conv"
-                phase([(s1, s2, lay["seg2"]), (x_psp, b1, lay["bound1"]), (d1, d2, lay["dist2"])])
-                phase([(x_psp, s1, lay["seg1"]), (x_comb, d1, lay["dist1"])])
+                merge = (not self.dry) and 1 in self.e.merge_wgrad            # (1: the heads)
+                wg = phase([(s1, s2, lay["seg2"]), (x_psp, b1, lay["bound1"]), (d1, d2, lay["dist2"])], later=merge)
+                phase([(x_psp, s1, lay["seg1"]), (x_comb, d1, lay["dist1"])], carried=wg)
                 Bp.scope = None
             self.back_steps.append(back)
         self.tagged("head_seg", self.head, s2, Cc, L.ACT_SOFTMAX, "seg", "seg3", lay["seg3"])
@@ -1780,7 +1784,7 @@ class Engine:
         self.group_1x1 = os.environ.get("RUA_GROUP_1X1", "1") != "0"       # PSPPooling's branch convolutions and the per-source gradients of concatenating 1x1 convolutions as groups
         self.group_heads = os.environ.get("RUA_GROUP_HEADS", "1") != "0"   # the heads' 3x3 convolutions (and their gradients) grouped across the heads
         self.multi_head = os.environ.get("RUA_MULTI_HEAD", "1") != "0"     # the heads' loss finalisation / d(loss)/d(logits) as one launch each
-        self.merge_wgrad = {int(v) for v in os.environ.get("RUA_MERGE_WGRAD", "32,64,128,256").split(",") if v}     # channel counts whose ResBlocks issue both weight-gradient groups as one (Graph.wgrad_now_or_later)
+        self.merge_wgrad = {int(v) for v in os.environ.get("RUA_MERGE_WGRAD", "1,32,64,128,256").split(",") if v}     # channel counts whose ResBlocks issue both weight-gradient groups as one (Graph.wgrad_now_or_later)
         self.group_wgrad_pw = os.environ.get("RUA_GROUP_WGRAD_PW", "1") != "0"   # the narrow 1x1 weight gradients of a composite as one grid (Graph.wgrad_pw_group)
         self.stem_mfma = os.environ.get("RUA_STEM_MFMA", "1") != "0"       # bf16: the stem's weight gradient through rua_stem_fwd_pack / rua_conv_wgrad / rua_stem_bwd_fold
         self.stem_stats = os.environ.get("RUA_STEM_STATS", "1") != "0"     # rua_stem_fwd_stats instead of a rua_col_stats pass over the stem's output
