@@ -22,7 +22,9 @@ def main():
     variants = [int(v) for v in os.environ.get("BW_VARIANTS", "31,127").split(",")]
     default = lib.get_tuning("wgrad_rows")
     for level in os.environ.get("BW_LEVELS", "3,4").split(","):
-        N, HW, Cc, dils = {"3": (8, 64, 128, [1, 3, 15]), "4": (8, 32, 256, [1, 3, 15])}[level]
+        N, HW, Cc, dils = {"1": (8, 256, 32, [1, 3, 15, 31]), "2": (8, 128, 64, [1, 3, 15, 31]), "3": (8, 64, 128, [1, 3, 15]), "4": (8, 32, 256, [1, 3, 15])}[level]
+        if os.environ.get("BW_DILS"):                        # (what the short chains of the large dilations cost: BW_DILS=1,1,1,1 against the default)
+            dils = [int(v) for v in os.environ["BW_DILS"].split(",")]
         g = torch.Generator(device="cpu").manual_seed(0)
         nb = len(dils)
         a = torch.randn((N, HW, HW, Cc), generator=g).to(dev).to(torch.bfloat16)
