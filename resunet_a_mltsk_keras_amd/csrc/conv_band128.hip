@@ -341,6 +341,26 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
       constexpr int NI = 3 * KSW, PFK = 4 / TPW;             // this wave's k-steps; k-steps of fragment reads in flight (four fragments)
       constexpr int NDMA = sp == 0 ? WPW + NPX : NPX, D0 = 1, DSTEP = (NI - 1 - D0) / (NDMA > 1 ? NDMA - 1 : 1) < 5 ? (NI - 1 - D0) / (NDMA > 1 ? NDMA - 1 : 1) : 5;
       static_assert(DSTEP >= 1 && D0 + (NDMA - 1) * DSTEP < NI, "every DMA has its k-step");
+      // A stage whose rows ALL lie outside the image multiplies zeros (d = 15 on 32 rows: the upper kernel row of the two top bands, the lower one of the two
+      // bottom bands - a quarter of that member's stages): its DMAs (out of range: zero fill), waits and barriers stay, its fragment reads and MFMAs do not.
+      const int hs_ = cur.hb + sp * RPS;
+      const bool dead = CP == 256 && (q.dbg & 32) == 0 && (hs_ + RPS <= 0 || hs_ >= H);      // (C = 128: the second loop body costs 30 spilled registers - and scratch traffic would be counted by the vmcnt waits)
+      if (dead) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int tx = i / KSW, ks = i % KSW;
+          if constexpr (sp == SPP - 1) wf[tx][ks] = wfrag(tx, ks);
+          if (i >= D0 && (i - D0) % DSTEP == 0 && (i - D0) / DSTEP < NDMA) {
+            const int j = (i - D0) / DSTEP;
+            if constexpr (sp == 0) {
+              if (j < WPW) { if constexpr (!(RUA_B128_ABLATE & 16)) issue_w1(wn, j); }
+              else if constexpr (!(RUA_B128_ABLATE & 4)) issue_x1(nxt, sp, j - WPW, so_iss);
+            } else {
+              if constexpr (!(RUA_B128_ABLATE & 4)) issue_x1(nxt, sp, j, so_iss);
+            }
+          }
+        }
+      } else {
       bf16x8 fr[8][TPW];                                   // ring of 8 k-steps (> PFK: a slot is rewritten only after its product has been issued)
 #pragma unroll
       for (int i = 0; i < PFK; ++i)
@@ -380,6 +400,7 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
           else if (wfr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           if (i >= D0 && (i - D0) % DSTEP == 0 && (i - D0) / DSTEP < NDMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
+      }
       }
       B128_T(3);
       B128_E(2);
