@@ -109,7 +109,7 @@ struct RuaTuning {
                                         // the MFMAs of a stage, conv_band64m's between them, and the level-2 first convolutions normalise on load), bit 2 at C = 256 on 32-pixel rows (else grouped conv_dmap)
   int conv_band = 1;                    // rua_conv_fwd_sum: the branches' second convs of a C = 32 ResBlock as ONE launch with the sum kept on chip (conv_band32)
   int wgd_ks_slow = 1;                  // wgrad_dmap block order: K slice slowest (blocks that read the same pixels share an XCD's L2)
-  int wgrad_rows = 127;                 // bit 0: wgrad_rows32 (the all-taps weight gradient at C = 32 on whole rows, W = 256 / 128, one shared LDS-DMA ring), bit 1: wgrad_rows64 (C = 64, W = 128), bit 2: wgrad_rows128, bits 3 - 4: wgrad_img / wgrad_imgs, bit 5: wgrad_rowsx<1> (C = 256 on 32-pixel rows, was wgrad_dmap), bit 6: wgrad_rowsx<0> instead of wgrad_rows128; 0: wgrad_taps_kernel
+  int wgrad_rows = 127;                 // bit 0: wgrad_rows32 (the all-taps weight gradient at C = 32 on whole rows, W = 256 / 128, one shared LDS-DMA ring), bit 1: wgrad_rows64 (C = 64, W = 128), bit 2: wgrad_rows128, bits 3 - 4: wgrad_img / wgrad_imgs, bit 5: wgrad_rowsx<1> (C = 256 on 32-pixel rows, was wgrad_dmap), bit 6: wgrad_rowsx<0> instead of wgrad_rows128, bit 7 (off): wgrad_rows32 / wgrad_rows64 deal their rows as a slot stream too (WgSlots) - measured: level 2 48 - 50 -> 46 - 50 us per group, level 1 55 - 59 -> 56 - 59 (at d = 1 the cursor work costs the stage loop 10 %, what the short chains of d = 31 gain); 0: wgrad_taps_kernel
   int cu_reserve = 0;                   // CUs the one-round grids leave free (rua_cu_count() = CUs - cu_reserve): room for RCCL's kernels under data parallel
   int strip_seglen = 0;                 // experiments (tools/bench_conv3x3.py): rows per block of conv_strip, 0 = one round of blocks
   int band_stag = 1;                    // conv_band32s (staggered halves) for full-width BatchNorm + ReLU sums (0: conv_band32; >= 4: that many ring slots)

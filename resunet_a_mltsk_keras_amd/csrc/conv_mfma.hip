@@ -2804,6 +2804,7 @@ struct WgtK {
   int njobs, nworkers, jpw;                // (chain, segment) jobs, pixel groups in the grid, jobs per group
   unsigned abytes, dybytes;
   const float* in_scale; const float* in_shift; int in_relu;      // a is read as [relu](in_scale * a + in_shift) (zero padding stays zero)
+  int sx;                                  // wgrad_rows32 / wgrad_rows64: the rows as ONE stream of slots (WgSlots) instead of (chain, segment) jobs
 };
 
 template <int CC>
@@ -3012,6 +3013,30 @@ template <int CC> __global__ __launch_bounds__(768) void wgrad_taps_kernel_g(con
   wgrad_taps_body<CC>(p);
 }
 
+// The rows of all images and dilation chains (h = r, r + d, ... of one image) as ONE sequence of slots: a chain's rows followed by one separator (a row of zeros: the
+// lower neighbour of the chain's last row and the upper neighbour of the next chain's first).  A block that owns slots [u0, u1) streams them through its ring
+// without draining it between chains; a (chain, segment) job refilled the window per job - at d = 31 a chain of a 256-row image has 8 rows, the fill three.
+// (wgrad_rowsx.inc has the same machinery inline, for image pairs.)  All of it wave-uniform: scalar registers.
+struct SlotCur { int p, r, i; };             // image, chain, position in the chain (i == rows of the chain: its separator)
+struct WgSlots {
+  int H, d, NP, nyb, R1, per;
+  __device__ __forceinline__ void init(int H_, int d_, int NP_) { H = H_; d = d_; NP = NP_; nyb = (H + d - 1) / d; R1 = H - (nyb - 1) * d; per = H + d; }
+  __device__ __forceinline__ int rows_of(int r) const { return nyb - (r >= R1 ? 1 : 0); }      // chains r < R1 have nyb rows, the others nyb - 1
+  __device__ __forceinline__ SlotCur decode(int u) const {
+    SlotCur c;
+    if (u < 0) { c.p = -1; c.r = d - 1; c.i = rows_of(d - 1); return c; }      // the separator in front of slot 0
+    c.p = u / per;
+    int rem = u - c.p * per;
+    const int big = R1 * (nyb + 1);
+    if (rem < big) { c.r = rem / (nyb + 1); c.i = rem - c.r * (nyb + 1); }
+    else { rem -= big; const int q = rem / nyb; c.r = R1 + q; c.i = rem - q * nyb; }
+    return c;
+  }
+  __device__ __forceinline__ void adv(SlotCur& c) const { if (++c.i > rows_of(c.r)) { c.i = 0; if (++c.r == d) { c.r = 0; ++c.p; } } }
+  __device__ __forceinline__ bool is_row(const SlotCur& c) const { return c.p >= 0 && c.p < NP && c.i < rows_of(c.r); }
+  __device__ __forceinline__ int grow(const SlotCur& c) const { return c.p * H + c.r + c.i * d; }      // row index over all images
+};
+
 // wgrad_rows32<NPG, BN> (round 4): the all-taps weight gradient at C = Cout = 32 for rows that are exactly 64 * NPG pixels wide (the
 // d6 residual atrous block at 256 x 256: NPG = 4; 128 x 128: NPG = 2), rebuilt like conv_strip32s around what the round-3 census of
 // wgrad_taps_kernel<32> showed - 190 - 300 instructions per wave and 64-pixel stage around its 12 MFMAs, three waves per SIMD:
@@ -3026,7 +3051,7 @@ template <int CC> __global__ __launch_bounds__(768) void wgrad_taps_kernel_g(con
 //     under the MFMAs of k-step k.
 // Same jobs (chain segments, several per block), same block partial and deterministic reduction as wgrad_taps_kernel.
 // vmcnt: every wave issues exactly KDMA vector-memory operations per stage (row pieces, dy pieces, dummy stores).
-template <int NPG, bool BN>
+template <int NPG, bool BN, bool SX>
 __device__ __forceinline__ void wgrad_rows32_body(const WgtK& p) {
   constexpr int C = 32, NW = 3 * NPG, NT = NW * 64, SW = 64 * NPG, PADPX = 32;
   constexpr int SLOT = (SW + PADPX) * 64, DSLOT = SW * 64, R = 6, RD = 3;
@@ -3080,12 +3105,23 @@ __device__ __forceinline__ void wgrad_rows32_body(const WgtK& p) {
     }
   };
   auto xrow_ok = [&](int rho) { const int h = r_ + (i0 + rho) * d; return nit > 0 && rho <= nit && h >= 0 && h < H; };
+  WgSlots G; SlotCur cxi = {0, 0, 0}, cdi = {0, 0, 0}, ctr = {0, 0, 0}, ccm = {0, 0, 0}; int sn = 0;      // SX: the slot cursors of the four streams - row fetched, dy row fetched, row normalised, row multiplied
+  if constexpr (SX) {
+    G.init(H, d, p.N);
+    const long long U = (long long)p.N * G.per;
+    const int u0 = (int)(U * (long long)blockIdx.x / p.gx), u1 = (int)(U * (long long)(blockIdx.x + 1) / p.gx);
+    sn = u1 - u0;
+    cxi = G.decode(u0 - 1); ctr = cxi; cdi = G.decode(u0); ccm = cdi;
+  }
   auto xslot = [&](int rho) { return (unsigned)(((rho + 1 + R) % R) * SLOT); };
   auto dslot = [&](int j) { return (unsigned)(((j + RD) % RD) * DSLOT); };
   // the stage's DMA operations of this wave: piece pi = k NW + wv: < NPS a piece of input row xr, < 2 NPS a piece of dy row dr, else a dummy
   auto issue = [&](int xr, int dr) {
-    const unsigned xbase = xrow_ok(xr) ? (unsigned)(n_ * H + r_ + (i0 + xr) * d) * rowbytes : OOB;
-    const unsigned dbase = (dr >= 0 && dr < nit) ? (unsigned)(n_ * H + r_ + (i0 + dr) * d) * rowbytes : OOB;
+    const bool xok_ = SX ? (xr <= sn && G.is_row(cxi)) : xrow_ok(xr);
+    const bool dok_ = SX ? (dr >= 0 && dr < sn && G.is_row(cdi)) : (dr >= 0 && dr < nit);
+    const unsigned xbase = xok_ ? (unsigned)(SX ? G.grow(cxi) : n_ * H + r_ + (i0 + xr) * d) * rowbytes : OOB;
+    const unsigned dbase = dok_ ? (unsigned)(SX ? G.grow(cdi) : n_ * H + r_ + (i0 + dr) * d) * rowbytes : OOB;
+    if constexpr (SX) { G.adv(cxi); if (dr >= 0) G.adv(cdi); }      // (the streams are visited in order: every call is the next row of its stream)
     const unsigned xs = xslot(xr), ds = dslot(dr);
 #pragma unroll
     for (int k = 0; k < KDMA; ++k) {
@@ -3098,7 +3134,9 @@ __device__ __forceinline__ void wgrad_rows32_body(const WgtK& p) {
   // BatchNorm + ReLU of input row rho in place, on this wave's own pieces of it (piece pi = k NW + wv < NPS)
   auto transform = [&](int rho) {
     if constexpr (BN) {
-      const unsigned ca = (tab_a + (xrow_ok(rho) ? 0u : 64u * 4u)) + (unsigned)((lane & 3) * 32);
+      const bool tok_ = SX ? (rho <= sn && G.is_row(ctr)) : xrow_ok(rho);
+      if constexpr (SX) G.adv(ctr);
+      const unsigned ca = (tab_a + (tok_ ? 0u : 64u * 4u)) + (unsigned)((lane & 3) * 32);
       const unsigned xs = sx_a + xslot(rho) + lrel;
 #pragma unroll
       for (int k = 0; k < KDMA; ++k) {
@@ -3160,8 +3198,9 @@ __device__ __forceinline__ void wgrad_rows32_body(const WgtK& p) {
     }
   };
 
-  for (int jb = 0; jb < p.jpw; ++jb) {
-    enter_job((int)blockIdx.x + jb * p.gx);
+  const int njb_ = SX ? 1 : p.jpw;
+  for (int jb = 0; jb < njb_; ++jb) {
+    if constexpr (SX) nit = sn; else enter_job((int)blockIdx.x + jb * p.gx);
     // ---- window fill: input rows -1 .. 3 and dy rows 0, 1 in flight, all landed; rows -1, 0, 1 normalised -------------------------
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // the previous job's last stage is done with the rings
@@ -3175,6 +3214,9 @@ __device__ __forceinline__ void wgrad_rows32_body(const WgtK& p) {
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * KDMA) : "memory");      // the operations of stage it - 2 (input row it + 2) are done
       const unsigned da = sd_a + dslot(it) + fbase;
       const unsigned xa = sx_a + xslot(it + ty - 1) + fbase;
+      const bool mul_ = !SX || G.is_row(ccm);             // (SX: a separator slot has nothing to multiply)
+      if constexpr (SX) G.adv(ccm);
+      if (mul_) {
       Frags fa, fb;
       read_frags(da, xa, 0, fa);
       read_frags(da, xa, 1, fb);
@@ -3184,6 +3226,7 @@ __device__ __forceinline__ void wgrad_rows32_body(const WgtK& p) {
       read_frags(da, xa, 3, fb);
       wait_frags(fa, 1); mfma3(fa);
       wait_frags(fb, 0); mfma3(fb);
+      }
       transform(it + 2);
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" :: "n"(KDMA) : "memory");   // stage it - 1's operations (dy row it + 1) are done; this wave's LDS writes too
     }
@@ -3213,11 +3256,11 @@ __device__ __forceinline__ void wgrad_rows32_body(const WgtK& p) {
       }
   }
 }
-template <int NPG, bool BN> __global__ __launch_bounds__(NPG * 192) void wgrad_rows32(const WgtK p) { wgrad_rows32_body<NPG, BN>(p); }
+template <int NPG, bool BN> __global__ __launch_bounds__(NPG * 192) void wgrad_rows32(const WgtK p) { if (p.sx) wgrad_rows32_body<NPG, BN, true>(p); else wgrad_rows32_body<NPG, BN, false>(p); }
 template <int NPG, bool BN> __global__ __launch_bounds__(NPG * 192) void wgrad_rows32_g(const WgtKG g) {       // blockIdx.z = member
   const WgtK& p = g.k[blockIdx.z];
   if ((int)blockIdx.x >= p.gx) return;
-  wgrad_rows32_body<NPG, BN>(p);
+  if (p.sx) wgrad_rows32_body<NPG, BN, true>(p); else wgrad_rows32_body<NPG, BN, false>(p);
 }
 
 // wgrad_rows64<BN> (round 4): wgrad_rows32's scheme at C = Cout = 64 for rows of exactly 128 pixels (the level-2 ResBlock at 128 x 128, model2.py:15-34,104).
@@ -3228,7 +3271,7 @@ template <int NPG, bool BN> __global__ __launch_bounds__(NPG * 192) void wgrad_r
 // the four pixel rows of a transposing read on two banks: the 16-byte chunks of a pixel are XOR-swizzled with bit 1 of the pixel index (chunk ^ 4), applied on
 // the DMA's SOURCE side (the LDS destination of a DMA is lane-linear) and in the fragment / coefficient addresses.
 // Same jobs, same block partials (one per output-channel half) and deterministic reduction as wgrad_taps_kernel<64>.
-template <bool BN>
+template <bool BN, bool SX>
 __device__ __forceinline__ void wgrad_rows64_body(const WgtK& p) {
   constexpr int C = 64, NPG = 2, NW = 6 * NPG, NT = NW * 64, SW = 64 * NPG, PADPX = 32, PXB = C * 2;
   constexpr int SLOT = (SW + PADPX) * PXB, DSLOT = SW * PXB, R = 5, RD = 3;
@@ -3289,11 +3332,22 @@ __device__ __forceinline__ void wgrad_rows64_body(const WgtK& p) {
     }
   };
   auto xrow_ok = [&](int rho) { const int h = r_ + (i0 + rho) * d; return nit > 0 && rho <= nit && h >= 0 && h < H; };
+  WgSlots G; SlotCur cxi = {0, 0, 0}, cdi = {0, 0, 0}, ctr = {0, 0, 0}, ccm = {0, 0, 0}; int sn = 0;      // SX: the slot cursors of the four streams - row fetched, dy row fetched, row normalised, row multiplied
+  if constexpr (SX) {
+    G.init(H, d, p.N);
+    const long long U = (long long)p.N * G.per;
+    const int u0 = (int)(U * (long long)blockIdx.x / p.gx), u1 = (int)(U * (long long)(blockIdx.x + 1) / p.gx);
+    sn = u1 - u0;
+    cxi = G.decode(u0 - 1); ctr = cxi; cdi = G.decode(u0); ccm = cdi;
+  }
   auto xslot = [&](int rho) { return (unsigned)(((rho + 1 + R) % R) * SLOT); };
   auto dslot = [&](int j) { return (unsigned)(((j + RD) % RD) * DSLOT); };
   auto issue = [&](int xr, int dr) {
-    const unsigned xbase = xrow_ok(xr) ? (unsigned)(n_ * H + r_ + (i0 + xr) * d) * rowbytes : OOB;
-    const unsigned dbase = (dr >= 0 && dr < nit) ? (unsigned)(n_ * H + r_ + (i0 + dr) * d) * rowbytes : OOB;
+    const bool xok_ = SX ? (xr <= sn && G.is_row(cxi)) : xrow_ok(xr);
+    const bool dok_ = SX ? (dr >= 0 && dr < sn && G.is_row(cdi)) : (dr >= 0 && dr < nit);
+    const unsigned xbase = xok_ ? (unsigned)(SX ? G.grow(cxi) : n_ * H + r_ + (i0 + xr) * d) * rowbytes : OOB;
+    const unsigned dbase = dok_ ? (unsigned)(SX ? G.grow(cdi) : n_ * H + r_ + (i0 + dr) * d) * rowbytes : OOB;
+    if constexpr (SX) { G.adv(cxi); if (dr >= 0) G.adv(cdi); }      // (the streams are visited in order: every call is the next row of its stream)
     const unsigned xs = xslot(xr), ds = dslot(dr);
 #pragma unroll
     for (int k = 0; k < KDMA; ++k) {
@@ -3306,7 +3360,9 @@ __device__ __forceinline__ void wgrad_rows64_body(const WgtK& p) {
   // BatchNorm + ReLU of input row rho in place, on this wave's own pieces of it (piece pi = k NW + wv < NPS); the piece of lane l holds the channels of chunk gchunk
   auto transform = [&](int rho) {
     if constexpr (BN) {
-      const unsigned ca = (tab_a + (xrow_ok(rho) ? 0u : 128u * 4u)) + (unsigned)(gchunk * 32);
+      const bool tok_ = SX ? (rho <= sn && G.is_row(ctr)) : xrow_ok(rho);
+      if constexpr (SX) G.adv(ctr);
+      const unsigned ca = (tab_a + (tok_ ? 0u : 128u * 4u)) + (unsigned)(gchunk * 32);
       const unsigned xs = sx_a + xslot(rho) + lrel;
 #pragma unroll
       for (int k = 0; k < KDMA; ++k) {
@@ -3372,8 +3428,9 @@ __device__ __forceinline__ void wgrad_rows64_body(const WgtK& p) {
     }
   };
 
-  for (int jb = 0; jb < p.jpw; ++jb) {
-    enter_job((int)blockIdx.x + jb * p.gx);
+  const int njb_ = SX ? 1 : p.jpw;
+  for (int jb = 0; jb < njb_; ++jb) {
+    if constexpr (SX) nit = sn; else enter_job((int)blockIdx.x + jb * p.gx);
     // ---- window fill: input rows -1 .. 2 and dy rows 0, 1 in flight, all landed; rows -1, 0, 1 normalised ---------------------------
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // the previous job's last stage is done with the rings
@@ -3387,6 +3444,9 @@ __device__ __forceinline__ void wgrad_rows64_body(const WgtK& p) {
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KDMA) : "memory");          // the operations of stage it - 1 (input row it + 2, dy row it + 1) are done
       const unsigned da = sd_a + dslot(it);
       const unsigned xa = sx_a + xslot(it + ty - 1);
+      const bool mul_ = !SX || G.is_row(ccm);             // (SX: a separator slot has nothing to multiply)
+      if constexpr (SX) G.adv(ccm);
+      if (mul_) {
       Frags fa, fb;
       read_frags(da, xa, 0, fa);
       read_frags(da, xa, 1, fb);
@@ -3396,6 +3456,7 @@ __device__ __forceinline__ void wgrad_rows64_body(const WgtK& p) {
       read_frags(da, xa, 3, fb);
       wait_frags(fa, 1); mfma6(fa);
       wait_frags(fb, 0); mfma6(fb);
+      }
       transform(it + 2);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // this wave's LDS writes are done before the barrier publishes them
     }
@@ -3426,11 +3487,11 @@ __device__ __forceinline__ void wgrad_rows64_body(const WgtK& p) {
     }
   }
 }
-template <bool BN> __global__ __launch_bounds__(768) void wgrad_rows64(const WgtK p) { wgrad_rows64_body<BN>(p); }
+template <bool BN> __global__ __launch_bounds__(768) void wgrad_rows64(const WgtK p) { if (p.sx) wgrad_rows64_body<BN, true>(p); else wgrad_rows64_body<BN, false>(p); }
 template <bool BN> __global__ __launch_bounds__(768) void wgrad_rows64_g(const WgtKG g) {       // blockIdx.z = member
   const WgtK& p = g.k[blockIdx.z];
   if ((int)blockIdx.x >= p.gx) return;
-  wgrad_rows64_body<BN>(p);
+  if (p.sx) wgrad_rows64_body<BN, true>(p); else wgrad_rows64_body<BN, false>(p);
 }
 
 // wgrad_rows128 (round 4): the same scheme one level down - C = Cout = 128 on 64-pixel rows (the level-3 ResBlock at 64 x 64, model2.py:105-106; its input is a
@@ -3963,7 +4024,7 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
   WgtK k;
   k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.scratch = (float*)d->workspace; k.dw = d->dw;
   k.H = d->H; k.W = d->W; k.N = d->N; k.dil = d->dil;
-  k.in_scale = d->in_scale; k.in_shift = d->in_shift; k.in_relu = d->in_relu;
+  k.in_scale = d->in_scale; k.in_shift = d->in_shift; k.in_relu = d->in_relu; k.sx = 0;
   const long long M = (long long)d->N * d->H * d->W;
   if (CC == 256 || (CC == 128 && (g_tune.wgrad_rows & 64))) {
     // wgrad_rowsx: gx blocks per grid row share the slot stream of the member evenly; grid.y = (output-channel slice, input-channel half); a block leaves two
@@ -4081,6 +4142,10 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
     k.spc = (ny + k.seglen - 1) / k.seglen;
     k.njobs = k.nchains * k.spc;
     gx = k.njobs < blocks ? k.njobs : blocks;
+    if (g_tune.wgrad_rows & 128) {                       // the slot stream (WgSlots): every block an equal share of the rows + separators
+      const long long U_ = (long long)d->N * (d->H + d->dil);
+      k.sx = 1; gx = (int)(U_ / 4 < blocks ? (U_ / 4 > 0 ? U_ / 4 : 1) : blocks);
+    }
     k.gx = gx; k.nworkers = gx;
     k.jpw = (k.njobs + gx - 1) / gx;
     smem = (size_t)32 * 64 + 6 * (size_t)(d->W + 32) * 64 + 3 * (size_t)d->W * 64 + 128 * 4;
@@ -4102,6 +4167,10 @@ static int launch_wgrad_taps(const rua_wgrad_desc* d, hipStream_t st) {
     k.spc = (ny + k.seglen - 1) / k.seglen;
     k.njobs = k.nchains * k.spc;
     gx = k.njobs < blocks ? k.njobs : blocks;
+    if (g_tune.wgrad_rows & 128) {
+      const long long U_ = (long long)d->N * (d->H + d->dil);
+      k.sx = 1; gx = (int)(U_ / 4 < blocks ? (U_ / 4 > 0 ? U_ / 4 : 1) : blocks);
+    }
     k.gx = gx; k.nworkers = gx;
     k.jpw = (k.njobs + gx - 1) / gx;
     smem = (size_t)32 * 128 + 5 * (size_t)(128 + 32) * 128 + 3 * (size_t)128 * 128 + 256 * 4;

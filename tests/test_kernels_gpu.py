@@ -298,12 +298,23 @@ def test_conv_wgrad(case, dt):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 32, 1), (1, 128, 64, 32, 3), (2, 64, 128, 32, 15), (1, 64, 64, 32, 31),
+                                  (2, 40, 256, 32, 31), (1, 256, 256, 32, 15), (3, 7, 128, 32, 3), (8, 16, 256, 32, 1),      # full-width rows at C = 32: wgrad_rows32
                                   (2, 64, 64, 64, 1), (1, 64, 128, 64, 15), (1, 128, 64, 64, 31), (3, 64, 64, 64, 3),
                                   (2, 128, 128, 64, 31), (1, 128, 128, 64, 1), (3, 40, 128, 64, 3),      # C = 64 on 128-pixel rows: wgrad_rows64
                                   (2, 64, 64, 128, 1), (1, 64, 64, 128, 15), (3, 40, 64, 128, 3), (8, 64, 64, 128, 31)])  # C = 128 on 64-pixel rows: wgrad_rows128
-def test_wgrad_all_taps_kernel(case):
+@pytest.mark.parametrize("rows", [127, 255])
+def test_wgrad_all_taps_kernel(case, rows):
     """Top-level weight gradient (C = Cout in {32, 64}, W % 64 == 0, bf16): all nine taps from one LDS halo,
-    deterministic partial reduction; must add into dW and match autograd."""
+    deterministic partial reduction; must add into dW and match autograd.  rows = the tuning key wgrad_rows: bit 7 deals the rows of wgrad_rows32 / wgrad_rows64
+    (full-width rows at C = 32 / 64) as one stream of slots instead of (chain, segment) jobs."""
+    L.lib().set_tuning(wgrad_rows=rows)
+    try:
+        _wgrad_all_taps(case)
+    finally:
+        L.lib().set_tuning(wgrad_rows=WGRAD_ROWS_DEFAULT)
+
+
+def _wgrad_all_taps(case):
     N, H, W, Cc, dil = case
     dt = L.RUA_BF16
     rng = np.random.default_rng(13)
