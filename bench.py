@@ -280,7 +280,7 @@ def profile_kernels(eng, g, dtype):
                 if name == "rua_conv_fwd":
                     bm_, bn_ = lib.raw('rua_conv_tile_bm')(C.byref(d)), lib.raw('rua_conv_tile_bn')(C.byref(d))
                     two = fired
-                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", dmap_name(bm_, bn_, False), f"conv_halo<{d.Cout}>", "conv_pw", f"conv_strip<{d.Cout}>", "conv_small<2>", f"conv_img<{d.W},{1 if d.H * d.W * d.seg[0].C * 2 <= 131072 else 2}>", f"conv_img2<{d.W}>")[kid]
+                    kid = lib.raw("rua_conv_kernel_id")(C.byref(d)); kn = (f"conv_igemm<{tname},{bm_},{bn_}>", f"conv_dma<{bm_},{bn_}>", dmap_name(bm_, bn_, False), f"conv_halo<{d.Cout}>", "conv_pw", f"conv_strip<{d.Cout}>", "conv_small<2>", f"conv_img<{d.W},{1 if d.H * d.W * d.seg[0].C * 2 <= 131072 else 2}>", f"conv_img2<{d.W}>", f"conv_band128m<{d.Cout}> (sum)")[kid]
                     kk = sum(d.seg[i].taps * d.seg[i].C for i in range(d.nseg))
                     flags = ("stats" if d.stats_mode else "") + (f" aux{d.aux_mode}" if d.aux_mode else "") + (" acc" if d.accumulate else "") + (" splitk" if two else "")
                     fl, tag, second = conv_flops(d), (d.N * d.H * d.W, d.Cout, kk, d.seg[0].dil, flags), f"conv_splitk_finish<{tname}>"

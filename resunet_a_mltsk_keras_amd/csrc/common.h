@@ -103,10 +103,12 @@ struct RuaTuning {
   int conv_band64m = 1;                 // the independent 3x3 convs of a C = 64 ResBlock (first convs, data gradients) as ONE conv_band64m launch
   int conv_band64 = 1;                  // ... and of a C = 64 ResBlock (conv_band64)
   long long dbg_ptr = 0;                // diagnostic builds only (-DRUA_B128_STAMPS): device buffer for in-kernel stamps
-  int conv_band128m = 5;                // conv_band128m for the independent 3x3 convs of a ResBlock (first convs, data gradients) as ONE launch: bit 0 at C = 128 (else grouped conv_dmap:
+  int conv_band128m = 13;               // conv_band128m for the independent 3x3 convs of a ResBlock (first convs, data gradients) as ONE launch: bit 0 at C = 128 (else grouped conv_dmap:
                                         // 37 - 43 vs 50 - 58 us, step 6.49 -> 6.39 ms), bit 1 at C = 64 (else conv_band64m; off: level with it launch by launch - 54 / 65 vs 60 / 65 us warm / cold
                                         // for plain first convolutions, 68 / 88 vs 69 / 92 for data gradients - and SLOWER in the step, 6.62 vs 6.53 ms: its in-place BatchNorm pass runs behind
-                                        // the MFMAs of a stage, conv_band64m's between them, and the level-2 first convolutions normalise on load), bit 2 at C = 256 on 32-pixel rows (else grouped conv_dmap)
+                                        // the MFMAs of a stage, conv_band64m's between them, and the level-2 first convolutions normalise on load), bit 2 at C = 256 on 32-pixel rows (else grouped conv_dmap),
+                                        // bit 3: a rua_conv_fwd of several 3x3 segments at those channel counts (the summed second convolutions of levels 3 - 4) in the same form with the sum kept on chip
+                                        // (else conv_dmap_chain: 40 -> 32 us at level 3, 50 -> 44 at level 4, step -0.024 ms)
   int conv_band = 1;                    // rua_conv_fwd_sum: the branches' second convs of a C = 32 ResBlock as ONE launch with the sum kept on chip (conv_band32)
   int wgd_ks_slow = 1;                  // wgrad_dmap block order: K slice slowest (blocks that read the same pixels share an XCD's L2)
   int wgrad_rows = 127;                 // bit 0: wgrad_rows32 (the all-taps weight gradient at C = 32 on whole rows, W = 256 / 128, one shared LDS-DMA ring), bit 1: wgrad_rows64 (C = 64, W = 128), bit 2: wgrad_rows128, bits 3 - 4: wgrad_img / wgrad_imgs, bit 5: wgrad_rowsx<1> (C = 256 on 32-pixel rows, was wgrad_dmap), bit 6: wgrad_rowsx<0> instead of wgrad_rows128, bit 7 (off): wgrad_rows32 / wgrad_rows64 deal their rows as a slot stream too (WgSlots) - measured: level 2 48 - 50 -> 46 - 50 us per group, level 1 55 - 59 -> 56 - 59 (at d = 1 the cursor work costs the stage loop 10 %, what the short chains of d = 31 gain); 0: wgrad_taps_kernel
@@ -257,6 +259,8 @@ int rua_launch_band64m(const rua_conv_desc* d, int n, hipStream_t st);
 // conv_band128.hip
 bool rua_band128m_ok(const rua_conv_desc* d, int n);   // independent members at C = Cout = 128 on 64-pixel rows as one conv_band128m launch
 int rua_launch_band128m(const rua_conv_desc* d, int n, hipStream_t st);
+bool rua_band128_sum_ok(const rua_conv_desc* d);         // rua_conv_fwd with several 3x3 segments (the summed second convolutions of a level-3 / level-4 ResBlock) in conv_band128m's form
+int rua_launch_band128_sum(const rua_conv_desc* d, hipStream_t st);
 // conv_img2.hip
 int rua_pick_img2(const rua_conv_desc* d);             // K slices (0: not this kernel)
 int rua_launch_conv_img2(ConvK& k, const rua_conv_desc* d, int KS, hipStream_t st);

@@ -37,6 +37,7 @@ struct Band128K {
   int d[RUA_MAX_BRANCH];
   int has_fold, has_bn, in_relu, nb;
   int N, H, bands, njobs;
+  int sum;                                  // 1: the members are the segments of ONE convolution (rua_conv_fwd with several 3x3 segments: the summed second convolutions of a ResBlock) - the accumulators run over all members, one epilogue (bias sum, residual from aux) after the last
   unsigned xbytes;
   int dbg;                                  // experiments (tuning key band_dbg): 2 no BatchNorm pass
   unsigned long long* stamps;               // RUA_B128_STAMPS builds: [njobs][8] section cycle sums (tuning key dbg_ptr), else null
@@ -109,7 +110,7 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
   // ---- per-channel tables (ordinary loads: all consumed before the first LDS-DMA is issued) ------------------------------
   if (tid < COS)
     for (int i = 0; i < nb; ++i) {
-      tabm[i * 192 + tid] = q.bias[i] ? q.bias[i][co0 + tid] : 0.f;
+      tabm[i * 192 + tid] = (q.bias[i] ? q.bias[i][co0 + tid] : 0.f) + ((q.sum && i > 0) ? tabm[(i - 1) * 192 + tid] : 0.f);      // (sum: the last member's row holds the sum of the biases)
       tabm[i * 192 + 64 + tid] = (q.aux[i] && q.mscale[i]) ? q.mscale[i][co0 + tid] : 1.f;
       tabm[i * 192 + 128 + tid] = (q.aux[i] && q.mshift[i]) ? q.mshift[i][co0 + tid] : 0.f;
     }
@@ -301,7 +302,7 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
         const bool in = (unsigned)xx < (unsigned)W;
         eoff[tx][t] = in ? eaddr(0u, jr * W + xx) : (unsigned)ZOFF + (unsigned)(kh << 4);      // (zero pixel: swizzle 0)
       }
-    const bool last = ph % PPM == PPM - 1;
+    const bool last = ph % PPM == PPM - 1 && (!q.sum || b == nb - 1);      // the phase behind which a member's (sum: the only) epilogue runs
     // the epilogue's mask source: fetched two stages early (a dependent HBM round trip in front of the epilogue otherwise)
     uint4 av[SPP][TPW][2];
     const size_t pixg = (size_t)((n_ * H + h0 + jr) * W + xo);         // tile 0 in stage 0 of the band; tile t: + 32 t, stage sp: + sp * RPS rows
@@ -480,8 +481,13 @@ __device__ __forceinline__ void conv_band128_body(const Band128K& q) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[g][j] += tb[cl + j];
             if (auxp) {
+              if (q.sum) {                                   // the residual
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[g][j] = (fmaf(tb[64 + cl + j], a8[j], tb[128 + cl + j]) > 0.f) ? v[g][j] : 0.f;
+                for (int j = 0; j < 8; ++j) v[g][j] += a8[j];
+              } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[g][j] = (fmaf(tb[64 + cl + j], a8[j], tb[128 + cl + j]) > 0.f) ? v[g][j] : 0.f;
+              }
             }
             if (smode == 1) {
 #pragma unroll
@@ -615,4 +621,47 @@ int rua_launch_band128m(const rua_conv_desc* d, int n, hipStream_t st) {
   if (Cc == 256) return band128_launch<256, 32, 128, 32>(q, st);
   if (Cc == 128) return a.W == 64 ? band128_launch<128, 64, 128, 64>(q, st) : band128_launch<128, 128, 128, 64>(q, st);
   return a.W == 64 ? band128_launch<64, 64, 64, 64>(q, st) : (a.W == 128 ? band128_launch<64, 128, 64, 64>(q, st) : band128_launch<64, 256, 64, 64>(q, st));
+}
+
+// The summed second convolutions of a level-3 / level-4 ResBlock (model2.py:26-31: out = x + sum_b conv_b(a2_b); rua_conv_fwd with one 3x3 segment per branch; was
+// conv_dmap_chain, K x 3) in conv_band128m's form: the accumulators run over the members, ONE epilogue (the sum of the biases, the residual) - tuning key conv_band128m, bit 3.
+bool rua_band128_sum_ok(const rua_conv_desc* d) {
+  if (!(g_tune.conv_band128m & 8) || d->nseg < 2 || d->nseg > RUA_MAX_BRANCH || d->dtype != RUA_BF16) return false;
+  const int Cc = d->Cout;
+  if (Cc == 128) { if (!(g_tune.conv_band128m & 1) || (d->W != 64 && d->W != 128)) return false; }
+  else if (Cc == 256) { if (!(g_tune.conv_band128m & 4) || d->W != 32) return false; }
+  else return false;
+  if (d->H % band128_rows(Cc, d->W) != 0 || (long long)d->N * d->H * d->W < 1024 || !d->y) return false;
+  if (d->stride != 1 || d->out_stride != 1 || d->OH != d->H || d->OW != d->W || d->accumulate || d->out_relu) return false;
+  if (d->in_scale || d->in_shift || d->in_fold) return false;
+  if (!(d->aux_mode == 0 || (d->aux_mode == 1 && d->aux))) return false;
+  if (d->stats_mode != 0 && d->stats) return false;
+  for (int i = 0; i < d->nseg; ++i) {
+    const rua_conv_seg& g = d->seg[i];
+    if (g.taps != 9 || g.up_shift != 0 || g.C != Cc || g.Hs != d->H || g.Ws != d->W || g.dil < 1 || !g.x || !g.w) return false;
+  }
+  for (int i = d->nseg - 1; i < 3; ++i) if (d->bias_more[i]) return false;      // at most one bias per segment
+  return (size_t)d->N * d->H * d->W * Cc * 2 < 0x7FFFFF00ull;
+}
+
+int rua_launch_band128_sum(const rua_conv_desc* d, hipStream_t st) {
+  Band128K q;
+  memset(&q, 0, sizeof(q));
+  const int n = d->nseg, Cc = d->Cout;
+  q.nb = n; q.sum = 1;
+  for (int i = 0; i < n; ++i) {
+    q.x[i] = (const unsigned char*)d->seg[i].x; q.w[i] = (const unsigned char*)d->seg[i].w; q.d[i] = d->seg[i].dil;
+    q.bias[i] = i == 0 ? d->bias : d->bias_more[i - 1];
+    q.ym[i] = (unsigned char*)d->y; q.stats_R[i] = 1;
+  }
+  q.aux[n - 1] = d->aux_mode == 1 ? (const unsigned char*)d->aux : nullptr;
+  for (int i = n; i < RUA_MAX_BRANCH; ++i) { q.d[i] = 1; q.stats_R[i] = 1; }
+  q.dbg = g_tune.band_dbg;
+  q.stamps = nullptr;
+  q.N = d->N; q.H = d->H;
+  q.xbytes = (unsigned)((size_t)d->N * d->H * d->W * Cc * 2);
+  q.bands = d->H / band128_rows(Cc, d->W);
+  q.njobs = d->N * q.bands * (Cc == 256 ? 8 : Cc / 64);
+  if (Cc == 256) return band128_launch<256, 32, 128, 32>(q, st);
+  return d->W == 64 ? band128_launch<128, 64, 128, 64>(q, st) : band128_launch<128, 128, 128, 64>(q, st);
 }

@@ -2197,6 +2197,10 @@ extern "C" int rua_conv_fwd(const rua_conv_desc* d, void* stream) {
     g_last_ksplit = img2_ks;
     return rua_launch_conv_img2(k, d, img2_ks, st);
   }
+  if (!g_conv_group && rua_band128_sum_ok(d)) {              // several 3x3 segments at C = 128 / 256 (the summed second convolutions of levels 3 - 4): conv_band128m, the sum on chip
+    g_last_ksplit = 1;
+    return rua_launch_band128_sum(d, st);
+  }
   if (const int img_ks = pick_img(d)) {
     g_last_ksplit = img_ks;
     return launch_conv_img(k, d, img_ks, st);
@@ -5072,6 +5076,7 @@ extern "C" int rua_conv_kernel_id(const rua_conv_desc* d) {
   if (pick_pw(d)) return 4;
   if (pick_small(d)) return 6;
   if (rua_pick_img2(d)) return 8;
+  if (!g_conv_group && rua_band128_sum_ok(d)) return 9;
   if (pick_img(d)) return 7;
   if (pick_dmap(d)) return 2;
   return pick_dma(d, pick_bn(d, (long long)d->N * d->H * d->W)) ? 1 : 0;

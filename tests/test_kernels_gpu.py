@@ -1735,6 +1735,56 @@ BAND_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [(8, 64, 64, 128, [1, 3, 15], True), (2, 64, 64, 128, [1, 15], False), (8, 32, 32, 256, [1, 3, 15], True), (4, 32, 32, 256, [15, 3], True),
+                                  (1, 64, 128, 128, [3, 1, 15, 31], True)])
+def test_conv_segments_sum_on_band128(case):
+    """rua_conv_fwd with one 3x3 segment per dilation branch (model2.py:26-31 at levels 3 - 4: out = x + sum_b (bias_b + conv_b(a2_b)), the inputs materialised BatchNorm
+    outputs) as ONE conv_band128m launch with the accumulators kept over the members (tuning key conv_band128m, bit 3; rua_conv_kernel_id = 9) - against float64 on the
+    bf16-rounded operands and against the K-concatenated conv_dmap form it replaces."""
+    N, H, W, Cs, dils, res = case
+    dt = L.RUA_BF16
+    lib = L.lib()
+    rng = np.random.default_rng(H + Cs + len(dils))
+    nb = len(dils)
+    xs = [rng.standard_normal((N, H, W, Cs)).astype(np.float32) for _ in dils]
+    ws = [(rng.standard_normal((9, Cs, Cs)) / np.sqrt(9 * Cs * nb)).astype(np.float32) for _ in dils]
+    biases = [rng.standard_normal(Cs).astype(np.float32) for _ in dils]
+    aux = rng.standard_normal((N, H, W, Cs)).astype(np.float32)
+    xd = [to_dev(a, dt) for a in xs]; wd = [to_dev(a, dt) for a in ws]
+    bd = [torch.from_numpy(a).to(dev()) for a in biases]
+    ad = to_dev(aux, dt)
+    wsb = torch.zeros(8 << 20, dtype=torch.float32, device=dev())
+    outs = {}
+    try:
+        for form in (13, 5):
+            lib.set_tuning(conv_band128m=form)
+            y = torch.full((N, H, W, Cs), 7.0, dtype=torch.bfloat16, device=dev())
+            d = L.ConvDesc()
+            d.nseg = nb
+            for b in range(nb):
+                sg = d.seg[b]
+                sg.x, sg.w, sg.C, sg.Hs, sg.Ws, sg.up_shift, sg.dil, sg.taps = xd[b].data_ptr(), wd[b].data_ptr(), Cs, H, W, 0, dils[b], 9
+            d.N, d.H, d.W, d.Cout, d.stride, d.dtype = N, H, W, Cs, 1, dt
+            d.y, d.out_stride, d.OH, d.OW = y.data_ptr(), 1, H, W
+            d.bias = bd[0].data_ptr()
+            for b in range(1, nb):
+                d.bias_more[b - 1] = bd[b].data_ptr()
+            if res:
+                d.aux, d.aux_mode = ad.data_ptr(), 1
+            d.workspace, d.workspace_bytes = wsb.data_ptr(), wsb.numel() * 4
+            assert (lib.raw("rua_conv_kernel_id")(C.byref(d)) == 9) == (form == 13)
+            lib.call("rua_conv_fwd", C.byref(d), stream())
+            torch.cuda.synchronize()
+            outs[form] = y.float().cpu().numpy()
+    finally:
+        lib.set_tuning(conv_band128m=BAND128M_DEFAULT)
+    exp = sum(ref_conv_nhwc(rnd(dt, xs[b]), rnd(dt, ws[b]), None, dils[b], 9).numpy() + biases[b].astype(np.float64) for b in range(nb))
+    if res:
+        exp = exp + rnd(dt, aux).numpy()
+    assert rel_err(outs[13], exp) < tol(dt)
+    assert rel_err(outs[13], outs[5]) < tol(dt)
+
+
 @pytest.mark.parametrize("case", BAND_CASES)
 def test_conv_sum_band_kernel(case):
     """rua_conv_fwd_sum -> conv_band32 (model2.py:26-31: out = x_input + sum of the branches' second convolutions, every branch
@@ -1867,7 +1917,7 @@ def test_fill_zero_is_a_kernel_and_exact_at_the_edges(offset, nbytes):
     lib.call("rua_fill_zero", buf.data_ptr(), 0, stream())           # zero bytes: nothing launched, no error
 
 
-BAND128M_DEFAULT = 5                                  # RuaTuning::conv_band128m (csrc/common.h)
+BAND128M_DEFAULT = 13                                 # RuaTuning::conv_band128m (csrc/common.h)
 BAND64M_CASES = [
     # N, H, W, dilations, kind: "first" = the branches' first convs (shared input, per-branch BatchNorm on load, bias, statistics sum v / sum v^2),
     #                           "dgrad" = their data gradients (own inputs, ReLU mask from an aux tensor, statistics sum g / sum g * aux)

@@ -87,7 +87,7 @@ def main():
                 for cold in (False, True):
                     med, best = timed(arr, cold)
                     print(f"{kind:6s} {name:16s} {'cold' if cold else 'warm'}: median {med:6.1f} us, best {best:6.1f} us  = {flops / med / 1e6:6.1f} TFLOP/s", flush=True)
-    lib.set_tuning(conv_band128m=5)
+    lib.set_tuning(conv_band128m=13)
 
 
 if __name__ == "__main__":
