@@ -74,7 +74,7 @@ struct RuaTuning {
   long long conv_pw_minm = 65536;
   int conv_pw_blocks = 0, conv_halo = 1, halo64_maxd = 0 /* conv_halo<64> at d = 1 was 28 vs 34 us alone, but as the 4th member of the
                                                               grouped conv_igemm grid the d = 1 branch costs less: +0.35 % on the step */, conv_dmap = 1, dmap_target = 0, dmap_fused_finish = 0, dmap_rowb = 64, dmap_bm64 = 1;
-  int wgrad_pw = 1, wgpw_blocks = 0, wgpw_r = 0, wgd_blocks = 0, wgrad_dmap = 1, wgd_mintiles = 10 /* 9 took the 64x64x128 level too: a wash alone, -0.55 % in the step since its K slabs (28 x 0.6 MB) */, wgrad_blocks = 0;
+  int wgrad_pw = 3 /* bit 1 (round 5): block partials + the batched reduction instead of replicas, tickets and a finishing block */, wgpw_blocks = 0, wgpw_r = 0, wgd_blocks = 0, wgrad_dmap = 1, wgd_mintiles = 10 /* 9 took the 64x64x128 level too: a wash alone, -0.55 % in the step since its K slabs (28 x 0.6 MB) */, wgrad_blocks = 0;
   int bn_grid = 0, tani_vec = 1, metrics_blocks = 0, stem_blocks = 0, head_blocks = 0;
   int conv_strip = 1, wgrad_slabs = 1, strip_narrow_maxd = 0, strip_group_share = 1;
   // grouped launches of a ResBlock's dilation branches, one bit per kernel family (0: every member launches on its own)

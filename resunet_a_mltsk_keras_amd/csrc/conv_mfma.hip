@@ -4223,10 +4223,11 @@ struct WgpK {
   int M, px_per_wave;
   unsigned abytes, dybytes;
   int nblk;                         // blocks of this member (= gridDim.x of a launch of its own; a grouped launch has the grid of its largest member)
+  float* slabs;                     // round 5: block b stores its sum as partial [b][Cout][C] here (summed in a fixed order by wgrad_slab_reduce / rua_wgrad_reduce_batch); null: replicas + tickets
 };
 struct WgpKG { WgpK k[RUA_MAX_BRANCH]; };
 // rua_conv_wgrad_group: wgrad_pw members (own workspaces: own replicas and tickets) are recorded here and issued as ONE grid per (NCO, NCI) form
-struct WgPwCapture { int n; WgpK k[RUA_MAX_BRANCH]; int form[RUA_MAX_BRANCH]; };
+struct WgPwCapture { int n; WgpK k[RUA_MAX_BRANCH]; int form[RUA_MAX_BRANCH]; int post[RUA_MAX_BRANCH]; };      // post: the member's partials are summed right behind the grid (not deferred)
 static thread_local WgPwCapture* g_wg_pw = nullptr;
 constexpr int WG_PW_REPLICAS = 16;
 constexpr int64_t WG_PW_TAIL = (int64_t)WG_PW_REPLICAS * 64 * 64 * 4 + 8192;   // replicas + two ticket pages at the end of the workspace
@@ -4381,8 +4382,21 @@ __device__ __forceinline__ void wgrad_pw_body(const WgpK& p) {
   // would write back this XCD's whole L2), and the last block reads the replicas with atomic exchanges (read and reset
   // in one round trip, all R in flight), which needs no acquire fence either.
   const float* s0 = reinterpret_cast<const float*>(smem);
-  float* rep = p.rep + (size_t)(blockIdx.x % p.R) * nel;
   constexpr int NPT = NCO * NCI;                                   // elements per thread at the full tile width
+  if (p.slabs) {
+    // Round 5: the block's sum leaves as ONE partial with plain stores and the kernel ends here - the atomics, the two ticket round trips and the finishing
+    // block below were 5 - 8 us of dependent latency behind 6 - 11 us of streaming; the partials (<= 16 KB a block) are summed with every other pending
+    // weight gradient by rua_wgrad_reduce_batch, in a fixed order: the narrow 1x1 weight gradients are bit-reproducible now as well.
+    float* part = p.slabs + (size_t)blockIdx.x * nel;
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) {
+      const int o = tid + e * NT;
+      const int co = o / p.C, ci = o - co * p.C;
+      if (o < nel) { const float* q = s0 + co * RW + ci; part[o] = (q[0] + q[SLOT]) + (q[2 * SLOT] + q[3 * SLOT]); }
+    }
+    return;
+  }
+  float* rep = p.rep + (size_t)(blockIdx.x % p.R) * nel;
   float olds[NPT];
 #pragma unroll
   for (int e = 0; e < NPT; ++e) {                                  // unrolled: all of a thread's adds are in flight together
@@ -4455,13 +4469,12 @@ static bool pick_wgrad_pw(const rua_wgrad_desc* d) {
   const bool dense = d->stride == 1 && d->Hs == d->H && d->Ws == d->W;
   return on && d->dtype == RUA_BF16 && d->taps == 1 && d->C <= 64 && d->Cout <= 64 && d->C % 8 == 0 && d->Cout % 8 == 0 &&
          (dense || (pow2(d->H) && pow2(d->W))) && M >= 2048 && d->workspace &&
-         d->workspace_bytes >= wg_taps_bytes(d) + WG_PW_TAIL && M * d->Cout * 2 < (1ll << 31) &&
+         d->workspace_bytes >= WG_PW_TAIL && M * d->Cout * 2 < (1ll << 31) &&
          (long long)d->N * d->Hs * d->Ws * d->C * 2 < (1ll << 31) &&
          (long long)(d->H - 1) * d->stride < d->Hs && (long long)(d->W - 1) * d->stride < d->Ws;
 }
 
 static int launch_wgrad_pw(const rua_wgrad_desc* d, hipStream_t st) {
-  if (g_wgrad_dry) return RUA_OK;                       // reduces inside its own launch: nothing pending
   WgpK k;
   k.a = (const unsigned char*)d->a; k.dy = (const unsigned char*)d->dy; k.dw = d->dw;
   char* tail = (char*)d->workspace + d->workspace_bytes - WG_PW_TAIL;
@@ -4488,9 +4501,16 @@ static int launch_wgrad_pw(const rua_wgrad_desc* d, hipStream_t st) {
   }
   const unsigned grid = (unsigned)((k.M + ppw * 16 - 1) / (ppw * 16));
   k.nblk = (int)grid;
+  // block partials in front of the tail (tuning key wgrad_pw, bit 1) where the workspace holds one per block; else replicas + tickets (nothing pending)
+  const long long nel = (long long)d->Cout * d->C;
+  // (a call that reduces right away keeps the replicas unless bit 2 is set: one block walking 256 partials of a 2 KB dW - the stem's - takes 10 us longer than the tickets)
+  const bool slab = (g_tune.wgrad_pw & 2) && (d->defer || (g_tune.wgrad_pw & 4)) && (long long)grid * nel * 4 <= (long long)d->workspace_bytes - WG_PW_TAIL;
+  k.slabs = slab ? (float*)d->workspace : nullptr;
+  if (slab) note_pending(2, (int)grid, nel, k.slabs, d->dw, 0, (int)((nel / 4 + SLAB_RED_COLS - 1) / SLAB_RED_COLS));
+  if (g_wgrad_dry) return RUA_OK;
   if (g_wg_pw && g_wg_pw->n < RUA_MAX_BRANCH) {            // a member of a group: recorded, issued by rua_conv_wgrad_group
     WgPwCapture& c = *g_wg_pw; const int i = c.n++;
-    c.k[i] = k; c.form[i] = (nco - 1) * 2 + (nci - 1);
+    c.k[i] = k; c.form[i] = (nco - 1) * 2 + (nci - 1); c.post[i] = (slab && !d->defer) ? 1 : 0;
     return RUA_OK;
   }
   constexpr int s11 = wgrad_pw_smem<1, 1>(), s21 = wgrad_pw_smem<2, 1>(), s12 = wgrad_pw_smem<1, 2>(), s22 = wgrad_pw_smem<2, 2>();
@@ -4507,6 +4527,7 @@ static int launch_wgrad_pw(const rua_wgrad_desc* d, hipStream_t st) {
   else if (nco == 1 && nci == 2) hipLaunchKernelGGL((wgrad_pw<1, 2>), dim3(grid), dim3(1024), s12, st, k);
   else hipLaunchKernelGGL((wgrad_pw<2, 2>), dim3(grid), dim3(1024), s22, st, k);
   RUA_LAUNCH_CHECK("wgrad_pw");
+  if (slab && !d->defer) { record_mid_event(st); return launch_slab_reduce(k.slabs, d->dw, nel, (int)grid, st); }
   return RUA_OK;
 }
 
@@ -4768,6 +4789,8 @@ extern "C" int rua_conv_wgrad_group(const rua_wgrad_desc* d, int n, void* stream
         ++grids;
       }
       g_wg_group_last_grids = grids;
+      for (int i = 0; i < cap.n; ++i)
+        if (cap.post[i]) { rc = launch_slab_reduce(cap.k[i].slabs, cap.k[i].dw, (long long)cap.k[i].Cout * cap.k[i].C, cap.k[i].nblk, st); if (rc != RUA_OK) return rc; }
       return RUA_OK;
     }
   }

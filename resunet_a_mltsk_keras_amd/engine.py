@@ -730,7 +730,7 @@ class Graph:
         return d
 
     def wgrad_desc(self, plan: Plan, a: Ten, dy: Ten, dw_off: int, stride: int, dil: int, taps: int, in_bn: Optional["Coef"] = None,
-                   may_flush: bool = True, group: int = 0):
+                   may_flush: bool = True, group: int = 0, defer_ok: bool = True):
         d = L.WgradDesc()
         d.group_members = group                            # members of the rua_conv_wgrad_group call this descriptor belongs to
         d.a, d.C, d.Hs, d.Ws = a.ptr, a.C, a.H, a.W
@@ -740,7 +740,7 @@ class Graph:
         d.N, d.stride, d.dil, d.taps, d.dtype = dy.N, stride, dil, taps, self.dt
         if not self.dry and self.e.wgrad_overwrite:
             d.overwrite_dev = self.e.ow_flag.data_ptr()    # whole steps store dW instead of adding to the zeroed arena (Engine._set_overwrite)
-        defer = (not self.dry) and self.e.defer_reduce and plan is self.bwd
+        defer = (not self.dry) and self.e.defer_reduce and plan is self.bwd and defer_ok
         if defer and may_flush:                             # before G(): a flush is a launch of its own and must not count as this one
             bucket = self.e.dist.bucket_of(dw_off) if self.e.dist is not None else 0
             if self.pending and (bucket != self.pending_bucket or self.pending_bytes > self.e.flush_bytes):
@@ -801,12 +801,14 @@ class Graph:
                 self.wgrad(plan, *sp)
             return
         descs = [self.wgrad_desc(plan, *sp, may_flush=(i == 0)) for i, sp in enumerate(specs)]
-        if not all(lib.raw("rua_wgrad_kind")(C.byref(d)) == 3 and not d.defer for d in descs):
+        if not all(lib.raw("rua_wgrad_kind")(C.byref(d)) == 3 for d in descs):
             for d in descs:                                    # (descriptors are already recorded for the deferred reductions: launch exactly these)
                 plan.keep.append(d)
                 plan.add("rua_conv_wgrad", C.byref(d))
             return
         for d in descs:
+            if d.defer:                                        # block partials, summed by the next rua_wgrad_reduce_batch: _defer_wgrad gave it a private workspace
+                continue
             nbytes = int(lib.raw("rua_wgrad_workspace_bytes")(C.byref(d)))
             ws = self.alloc(((nbytes + 3) // 4,), torch.float32, zero=True)
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -1619,8 +1621,7 @@ class Graph:
                 Bp = self.bwd
                 if pack:
                     tmp = self.alloc((w0 * 16,), torch.float32, zero=True)          # [Cout][16]: zero before every launch (the fold leaves it so)
-                    d = self.wgrad_desc(Bp, xpack, c1.grad, stem["segs"][0]["off"], 1, 1, 1)
-                    assert d.defer == 0, "the packed stem weight gradient must reduce inside its own launch (wgrad_pw)"
+                    d = self.wgrad_desc(Bp, xpack, c1.grad, stem["segs"][0]["off"], 1, 1, 1, defer_ok=False)      # the fold reads tmp right behind the call: its partials are summed by the call itself
                     d.dw = tmp.data_ptr()
                     Bp.keep.append(d)
                     Bp.add("rua_conv_wgrad", C.byref(d))

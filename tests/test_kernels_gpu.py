@@ -440,10 +440,20 @@ PW_CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode", [7, 1])
 @pytest.mark.parametrize("case", PW_CASES)
-def test_wgrad_pointwise_kernel(case):
-    """Narrow 1x1 weight gradients (C, Cout <= 64, bf16: wgrad_pw): per-wave streaming, replica accumulators and a ticket in
-    the tail of the workspace, which must be zero before the first call and is left zero by every call."""
+def test_wgrad_pointwise_kernel(case, mode):
+    """Narrow 1x1 weight gradients (C, Cout <= 64, bf16: wgrad_pw): per-wave streaming; the block sums leave as partials in front of the workspace's tail and are
+    summed in a fixed order (tuning key wgrad_pw: bit 1, round 5 - for deferred reductions, the engine's case; bit 2: for calls that reduce right away too, as here) - or, = 1, through replica accumulators and a ticket in the tail of the workspace, which must be
+    zero before the first call and is left zero by every call."""
+    L.lib().set_tuning(wgrad_pw=mode)
+    try:
+        _wgrad_pointwise(case, mode)
+    finally:
+        L.lib().set_tuning(wgrad_pw=3)
+
+
+def _wgrad_pointwise(case, mode):
     N, Hs, Ws, Cs, Cout, stride = case
     H, W = Hs // stride, Ws // stride
     dt = L.RUA_BF16
@@ -466,12 +476,16 @@ def test_wgrad_pointwise_kernel(case):
     w = torch.zeros((1, Cout, Cs), dtype=torch.float64, requires_grad=True)
     y = ref_conv_nhwc(rnd(dt, a).double(), w, None, 1, 1, stride)
     y.backward(rnd(dt, dy).double())
+    outs = []
     for rep in range(2):                                        # the second call runs on what the first left behind
         dw.copy_(torch.from_numpy(base))
         L.lib().call("rua_conv_wgrad", C.byref(d), stream())
         torch.cuda.synchronize()
-        assert rel_err(dw.cpu().numpy() - base, w.grad.numpy()) < 2e-3
+        outs.append(dw.cpu().numpy().copy())
+        assert rel_err(outs[-1] - base, w.grad.numpy()) < 2e-3
         assert float(ws[-(16 * 64 * 64 + 2048):].abs().max()) == 0.0
+    if mode == 7:
+        assert np.array_equal(outs[0], outs[1])                # block partials, fixed order: bit-reproducible
 
 
 def test_conv_pointwise_group_members_share_a_grid():
@@ -1295,7 +1309,7 @@ def test_wgrad_deferred_batched_reduction_is_bit_identical():
         lib.call("rua_conv_wgrad", C.byref(d), stream())
         if r.kind:
             recs.append(r)
-    assert kinds == [1, 1, 2, 2, 0, 1]
+    assert kinds == [1, 1, 2, 2, 2, 1]                                       # (wgrad_pw leaves block partials since round 5: bit-reproducible like the rest)
     table = (L.WgradPending * len(recs))()
     blocks = 0
     for i, r in enumerate(recs):
@@ -1307,10 +1321,11 @@ def test_wgrad_deferred_batched_reduction_is_bit_identical():
     torch.cuda.synchronize()
     for i, d in enumerate(descs):
         got = keep[5 * i + 3].cpu().numpy()
-        if kinds[i]:
-            assert np.array_equal(got, imm[i]), i
-        else:                                                                 # wgrad_pw adds through replica atomics: equal up to their order
+        assert kinds[i] != 0
+        if i == 4:                                                            # wgrad_pw: the immediate call went through replica atomics, the deferred one through block partials
             assert np.allclose(got, imm[i], rtol=1e-5, atol=1e-4), i
+        else:
+            assert np.array_equal(got, imm[i]), i
 
 
 @pytest.mark.parametrize("shape", [(8, 64, 64, 128, [1, 3, 15]), (2, 256, 256, 32, [1, 3, 15, 31]), (4, 128, 128, 64, [3, 15, 31]), (8, 16, 16, 512, [1, 3]),
