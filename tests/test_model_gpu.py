@@ -592,4 +592,4 @@ def test_cfg3_bf16_training_tracks_fp32_over_200_steps_on_varying_batches():
     assert end(b) < BF16_TRAIN_GAP and step(b) < BF16_TRAIN_STEP_GAP, (end(b), step(b), end(a2), step(a2))
 
 
-BF16_TRAIN_GAP, BF16_TRAIN_STEP_GAP = 0.07, 0.16     # absolute caps = 1.5x the largest gaps ever measured (round 4: 4.6e-2 at the end, 1.05e-1 at the worst step; round 5: 3.8e-3 / 4.1e-2)
+BF16_TRAIN_GAP, BF16_TRAIN_STEP_GAP = 0.09, 0.18     # absolute caps = 2x / 1.7x the largest gaps ever measured (round 4: 4.6e-2 at the end, 1.05e-1 at the worst step; round 5, six builds: 0.4 - 4.5e-2 / 4.1 - 9.3e-2, with either sign - and the fp32 pair 0.3 - 2.5e-2 / 3.9 - 7.0e-2: a draw of a chaotic quantity, so the cap leaves room)
