@@ -19,7 +19,7 @@ def main():
     lib = L.lib()
     dev = torch.device("cuda", 0)
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    N, HW, Cc, dils = {"3": (8, 64, 128, [1, 3, 15]), "4": (8, 32, 256, [1, 3, 15])}[os.environ.get("BP_LEVEL", "3")]      # BP_LEVEL=4: conv_band128m<256,32,128,32>
+    N, HW, Cc, dils = {"3": (8, 64, 128, [1, 3, 15]), "4": (8, 32, 256, [1, 3, 15]), "2": (8, 128, 64, [1, 3, 15, 31])}[os.environ.get("BP_LEVEL", "3")]      # BP_LEVEL=4: conv_band128m<256,32,128,32>
     nb = len(dils)
     g = torch.Generator(device="cpu").manual_seed(0)
     xs = [torch.randn((N, HW, HW, Cc), generator=g).to(dev).to(torch.bfloat16) for _ in dils]
@@ -44,7 +44,7 @@ def main():
             d.bias, d.stats_mode = bias[b].data_ptr(), 1
         else:
             d.aux, d.aux_mode, d.mscale, d.mshift, d.stats_mode = aux[b].data_ptr(), 2, msc[b].data_ptr(), msh[b].data_ptr(), 2
-    njobs = N * (HW // 4) * 2 if Cc == 128 else N * (HW // 8) * 8
+    njobs = N * (HW // 4) * 2 if Cc == 128 else (N * (HW // 8) * 8 if Cc == 256 else N * (HW // 4))
     stamps = torch.zeros(njobs * 8 + njobs * 8 * 2 * 4 * 2, dtype=torch.int64, device=dev)
     lib.set_tuning(dbg_ptr=stamps.data_ptr(), conv_band128m=form)
     for _ in range(20):
