@@ -562,7 +562,7 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other BASELINE configurations (N = 1 line)")
     ap.add_argument("--also-steps", type=int, default=10)
     ap.add_argument("--no-overlap", action="store_true")
-    ap.add_argument("--bucket-mb", type=float, default=25.0)
+    ap.add_argument("--bucket-mb", type=float, default=50.0)
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (RCCL group of one rank) on one GPU")
     args = ap.parse_args()
 
